@@ -1,0 +1,1701 @@
+/* pf_oracle.c -- TEST INFRASTRUCTURE ONLY (see pf_oracle.h).
+ *
+ * Plain-C restatement of the reference's assembly + CG path.  Compile with -ffp-contract=off so that the
+ * floating-point operation order written here is the one executed (the linear assembler's sparsity pattern
+ * depends on which local values are exactly < 1e-30 in magnitude, Assembler.cpp:170-173).
+ */
+#include "pf_oracle.h"
+#include "pf_quad_tables.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small helpers                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+
+void pfo_csc_free(pfo_csc *m)
+{
+	if (!m)
+		return;
+	free(m->outer);
+	free(m->inner);
+	free(m->values);
+	m->outer = NULL;
+	m->inner = NULL;
+	m->values = NULL;
+	m->nnz = 0;
+}
+
+int pfo_n_loc(int kind)
+{
+	switch (kind)
+	{
+	case PFO_P1TET:
+		return 4;
+	case PFO_P2TET:
+		return 10;
+	case PFO_Q1HEX:
+		return 8;
+	case PFO_Q2HEX:
+		return 27;
+	}
+	return -1;
+}
+
+int pfo_order_of(int kind)
+{
+	return (kind == PFO_P1TET || kind == PFO_Q1HEX) ? 1 : 2;
+}
+
+static int is_hex(int kind) { return kind == PFO_Q1HEX || kind == PFO_Q2HEX; }
+
+/* utils/ElasticityUtils.cpp:203-214 */
+double pfo_lambda_from_E_nu(double E, double nu) { return (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu)); }
+double pfo_mu_from_E_nu(double E, double nu) { return E / (2.0 * (1.0 + nu)); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* quadrature                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* quadrature/TetQuadrature.cpp:31-43 : table lookup, then weights /= 6 */
+int pfo_tet_quadrature(int order, pfo_quad *q)
+{
+	const double *p = NULL, *w = NULL;
+	int n = 0;
+	switch (order)
+	{
+	case 1:
+		p = pf_tet_pts_1, w = pf_tet_wts_1, n = PF_TET_NPTS_1;
+		break;
+	case 2:
+		p = pf_tet_pts_2, w = pf_tet_wts_2, n = PF_TET_NPTS_2;
+		break;
+	case 3:
+		p = pf_tet_pts_3, w = pf_tet_wts_3, n = PF_TET_NPTS_3;
+		break;
+	case 4:
+		p = pf_tet_pts_4, w = pf_tet_wts_4, n = PF_TET_NPTS_4;
+		break;
+	case 5:
+		p = pf_tet_pts_5, w = pf_tet_wts_5, n = PF_TET_NPTS_5;
+		break;
+	default:
+		return -1;
+	}
+	q->n_pts = n;
+	for (int k = 0; k < n; ++k)
+	{
+		q->pts[k][0] = p[3 * k + 0];
+		q->pts[k][1] = p[3 * k + 1];
+		q->pts[k][2] = p[3 * k + 2];
+		q->w[k] = w[k] / 6;
+	}
+	return 0;
+}
+
+/* quadrature/LineQuadrature.cpp:4707-4734.  The two std::sort calls there compare doubles that were
+ * converted to int indices (all 0), so the comparator is always false and the table order is kept.
+ * weights /= 2 ; points = points/2 + 1*0.5 ; weights /= weights.sum() */
+int pfo_line_quadrature(int order, pfo_quad *q)
+{
+	const double *p = NULL, *w = NULL;
+	switch (order)
+	{
+	case 1:
+		p = pf_line_pts_1, w = pf_line_wts_1;
+		break;
+	case 2:
+		p = pf_line_pts_2, w = pf_line_wts_2;
+		break;
+	case 3:
+		p = pf_line_pts_3, w = pf_line_wts_3;
+		break;
+	case 4:
+		p = pf_line_pts_4, w = pf_line_wts_4;
+		break;
+	case 5:
+		p = pf_line_pts_5, w = pf_line_wts_5;
+		break;
+	default:
+		return -1;
+	}
+	q->n_pts = order;
+	double sum = 0;
+	for (int k = 0; k < order; ++k)
+	{
+		q->w[k] = w[k] / 2;
+		q->pts[k][0] = p[k] / 2 + 1.0 * 0.5;
+		q->pts[k][1] = 0;
+		q->pts[k][2] = 0;
+	}
+	/* Eigen's sum() of a dynamic vector is a plain left-to-right redux for these sizes (<= 5 entries,
+	 * packets of 2 doubles would pair (w0+w2)+(w1+w3)...; with so few entries the difference is at most
+	 * 1 ulp of a number equal to 1 -- parity unpinned) */
+	for (int k = 0; k < order; ++k)
+		sum += q->w[k];
+	for (int k = 0; k < order; ++k)
+		q->w[k] /= sum;
+	return 0;
+}
+
+/* quadrature/HexQuadrature.cpp:17-45 : tensor product, index (i*n+j)*n+k, point (x_k,y_j,z_i) */
+int pfo_hex_quadrature(int order, pfo_quad *q)
+{
+	pfo_quad l;
+	if (pfo_line_quadrature(order, &l))
+		return -1;
+	const int n = l.n_pts;
+	if (n * n * n > PFO_MAX_PTS)
+		return -1;
+	q->n_pts = n * n * n;
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j < n; ++j)
+			for (int k = 0; k < n; ++k)
+			{
+				const int index = (i * n + j) * n + k;
+				q->pts[index][0] = l.pts[k][0];
+				q->pts[index][1] = l.pts[j][0];
+				q->pts[index][2] = l.pts[i][0];
+				q->w[index] = l.w[i] * l.w[j] * l.w[k];
+			}
+	return 0;
+}
+
+/* basis/FEBasis3d.cpp:1467 (hex), :1506 (tet): real_order = max(quadrature_order, 2(p-1)+1) */
+int pfo_element_quadrature(int kind, int quad_order, pfo_quad *q)
+{
+	const int p = pfo_order_of(kind);
+	int real_order = (p - 1) * 2 + 1;
+	if (quad_order > real_order)
+		real_order = quad_order;
+	return is_hex(kind) ? pfo_hex_quadrature(real_order, q) : pfo_tet_quadrature(real_order, q);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* shape functions                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* One factor of a Q basis expression as the reference's generator printed it; evaluated in place. */
+enum
+{
+	F_X,     /* t            */
+	F_XM1,   /* (t - 1)      */
+	F_2XM1,  /* (2.0*t - 1.0)*/
+	F_4XM3,  /* (4.0*t - 3.0)*/
+	F_4XM1,  /* (4.0*t - 1.0)*/
+	F_16XM12,
+	F_16XM4,
+	F_64XM48,
+	F_64XM16,
+	F_END
+};
+
+static double qfac(int code, double t)
+{
+	switch (code)
+	{
+	case F_X:
+		return t;
+	case F_XM1:
+		return t - 1;
+	case F_2XM1:
+		return 2.0 * t - 1.0;
+	case F_4XM3:
+		return 4.0 * t - 3.0;
+	case F_4XM1:
+		return 4.0 * t - 1.0;
+	case F_16XM12:
+		return 16.0 * t - 12.0;
+	case F_16XM4:
+		return 16.0 * t - 4.0;
+	case F_64XM48:
+		return 64.0 * t - 48.0;
+	case F_64XM16:
+		return 64.0 * t - 16.0;
+	}
+	return 0;
+}
+
+/* A Q expression: coef * f0 * f1 * ... evaluated left to right.  Each factor = (axis<<4)|code.
+ * The factor order of every expression is the one printed in autogen/auto_q_bases.cpp:1067-1871. */
+typedef struct
+{
+	double coef;
+	unsigned char f[7];
+} qexpr;
+#define X(c) ((0 << 4) | (c))
+#define Y(c) ((1 << 4) | (c))
+#define Z(c) ((2 << 4) | (c))
+#define E_ 0xff
+
+static double qeval(const qexpr *e, const double *pt)
+{
+	double r = e->coef;
+	int first = 1;
+	for (int k = 0; k < 7 && e->f[k] != E_; ++k)
+	{
+		const double v = qfac(e->f[k] & 15, pt[e->f[k] >> 4]);
+		/* coef is +-1, +-4, +-16, +-64: "c * f0" ; a leading "-x" is coef=-1 times x (exact) */
+		r = first ? (e->coef * v) : (r * v);
+		first = 0;
+	}
+	return r;
+}
+
+/* autogen/auto_q_bases.cpp:1067-1110 (values), :1115-1260 (gradients) */
+static const qexpr q1_val[8] = {
+	{-1.0, {X(F_XM1), Y(F_XM1), Z(F_XM1), E_}},
+	{1.0, {X(F_X), Y(F_XM1), Z(F_XM1), E_}},
+	{-1.0, {X(F_X), Y(F_X), Z(F_XM1), E_}},
+	{1.0, {Y(F_X), X(F_XM1), Z(F_XM1), E_}},
+	{1.0, {Z(F_X), X(F_XM1), Y(F_XM1), E_}},
+	{-1.0, {X(F_X), Z(F_X), Y(F_XM1), E_}},
+	{1.0, {X(F_X), Y(F_X), Z(F_X), E_}},
+	{-1.0, {Y(F_X), Z(F_X), X(F_XM1), E_}},
+};
+static const qexpr q1_grad[8][3] = {
+	{{-1.0, {Y(F_XM1), Z(F_XM1), E_}}, {-1.0, {X(F_XM1), Z(F_XM1), E_}}, {-1.0, {X(F_XM1), Y(F_XM1), E_}}},
+	{{1.0, {Y(F_XM1), Z(F_XM1), E_}}, {1.0, {X(F_X), Z(F_XM1), E_}}, {1.0, {X(F_X), Y(F_XM1), E_}}},
+	{{-1.0, {Y(F_X), Z(F_XM1), E_}}, {-1.0, {X(F_X), Z(F_XM1), E_}}, {-1.0, {X(F_X), Y(F_X), E_}}},
+	{{1.0, {Y(F_X), Z(F_XM1), E_}}, {1.0, {X(F_XM1), Z(F_XM1), E_}}, {1.0, {Y(F_X), X(F_XM1), E_}}},
+	{{1.0, {Z(F_X), Y(F_XM1), E_}}, {1.0, {Z(F_X), X(F_XM1), E_}}, {1.0, {X(F_XM1), Y(F_XM1), E_}}},
+	{{-1.0, {Z(F_X), Y(F_XM1), E_}}, {-1.0, {X(F_X), Z(F_X), E_}}, {-1.0, {X(F_X), Y(F_XM1), E_}}},
+	{{1.0, {Y(F_X), Z(F_X), E_}}, {1.0, {X(F_X), Z(F_X), E_}}, {1.0, {X(F_X), Y(F_X), E_}}},
+	{{-1.0, {Y(F_X), Z(F_X), E_}}, {-1.0, {Z(F_X), X(F_XM1), E_}}, {-1.0, {Y(F_X), X(F_XM1), E_}}},
+};
+
+/* Q2: tensor products of the 1-D quadratic Lagrange factors on nodes {0, 1/2, 1}; local node order from
+ * the node table auto_q_bases.cpp:1873-1903.  Values and gradients (auto_q_bases.cpp:1277-1871) are the
+ * same polynomials; here the three 1-D factors are formed first and multiplied x*y*z, whereas the
+ * reference's generated expressions multiply their factors in the printer's order, so results can differ
+ * in the last bit (value parity ~1 ulp; the exact-zero pattern of a Q2 stiffness matrix is therefore
+ * pinned only against this restatement). */
+static const signed char q2_node[27][3] = {
+	/* lattice position of each local node in units of 1/2 (auto_q_bases.cpp:1873-1903) */
+	{0, 0, 0}, {2, 0, 0}, {2, 2, 0}, {0, 2, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2},
+	{1, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 1, 0}, {0, 0, 1}, {2, 0, 1}, {2, 2, 1}, {0, 2, 1},
+	{1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {0, 1, 1}, {2, 1, 1}, {1, 0, 1}, {1, 2, 1},
+	{1, 1, 0}, {1, 1, 2}, {1, 1, 1}};
+
+/* 1-D factors: l0(t) = (t-1)(2t-1), l2(t) = t(2t-1), l1(t) = -4 t (t-1);
+ *              l0' = 4t-3,          l2' = 4t-1,      l1' = -4(2t-1)                      */
+static double q2_l(int a, double t)
+{
+	switch (a)
+	{
+	case 0:
+		return (t - 1) * (2.0 * t - 1.0);
+	case 2:
+		return t * (2.0 * t - 1.0);
+	default:
+		return -4.0 * t * (t - 1);
+	}
+}
+static double q2_dl(int a, double t)
+{
+	switch (a)
+	{
+	case 0:
+		return 4.0 * t - 3.0;
+	case 2:
+		return 4.0 * t - 1.0;
+	default:
+		return -4.0 * (2.0 * t - 1.0);
+	}
+}
+
+void pfo_basis_nodes(int kind, double *nodes)
+{
+	static const double p1[4][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+	static const double p2[10][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {.5, 0, 0}, {.5, .5, 0}, {0, .5, 0}, {0, 0, .5}, {.5, 0, .5}, {0, .5, .5}};
+	static const double q1[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+	switch (kind)
+	{
+	case PFO_P1TET: /* auto_p_bases.cpp:1080-1087 */
+		memcpy(nodes, p1, sizeof(p1));
+		break;
+	case PFO_P2TET: /* auto_p_bases.cpp:1328-1341 */
+		memcpy(nodes, p2, sizeof(p2));
+		break;
+	case PFO_Q1HEX: /* auto_q_bases.cpp:1262-1275 */
+		memcpy(nodes, q1, sizeof(q1));
+		break;
+	case PFO_Q2HEX:
+		for (int i = 0; i < 27; ++i)
+			for (int c = 0; c < 3; ++c)
+				nodes[3 * i + c] = q2_node[i][c] / 2.0;
+		break;
+	}
+}
+
+void pfo_basis_value(int kind, int li, const double *pt, double *val)
+{
+	const double x = pt[0], y = pt[1], z = pt[2];
+	switch (kind)
+	{
+	case PFO_P1TET: /* auto_p_bases.cpp:967-999 */
+		switch (li)
+		{
+		case 0:
+			*val = -x - y - z + 1;
+			break;
+		case 1:
+			*val = x;
+			break;
+		case 2:
+			*val = y;
+			break;
+		case 3:
+			*val = z;
+			break;
+		}
+		break;
+	case PFO_P2TET: /* auto_p_bases.cpp:1089-1151 */
+		switch (li)
+		{
+		case 0:
+			*val = (x + y + z - 1) * (2 * x + 2 * y + 2 * z - 1);
+			break;
+		case 1:
+			*val = x * (2 * x - 1);
+			break;
+		case 2:
+			*val = y * (2 * y - 1);
+			break;
+		case 3:
+			*val = z * (2 * z - 1);
+			break;
+		case 4:
+			*val = -4 * x * (x + y + z - 1);
+			break;
+		case 5:
+			*val = 4 * x * y;
+			break;
+		case 6:
+			*val = -4 * y * (x + y + z - 1);
+			break;
+		case 7:
+			*val = -4 * z * (x + y + z - 1);
+			break;
+		case 8:
+			*val = 4 * x * z;
+			break;
+		case 9:
+			*val = 4 * y * z;
+			break;
+		}
+		break;
+	case PFO_Q1HEX:
+		*val = qeval(&q1_val[li], pt);
+		break;
+	case PFO_Q2HEX: /* auto_q_bases.cpp:1277-1418: tensor product of the 1-D factors (value parity to ~1 ulp) */
+		*val = q2_l(q2_node[li][0], x) * q2_l(q2_node[li][1], y) * q2_l(q2_node[li][2], z);
+		break;
+	}
+}
+
+void pfo_basis_grad(int kind, int li, const double *pt, double *g)
+{
+	const double x = pt[0], y = pt[1], z = pt[2];
+	switch (kind)
+	{
+	case PFO_P1TET: /* auto_p_bases.cpp:1000-1078 */
+	{
+		static const double t[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+		g[0] = t[li][0], g[1] = t[li][1], g[2] = t[li][2];
+		break;
+	}
+	case PFO_P2TET: /* auto_p_bases.cpp:1152-1326 */
+		switch (li)
+		{
+		case 0:
+			g[0] = g[1] = g[2] = 4 * x + 4 * y + 4 * z - 3;
+			break;
+		case 1:
+			g[0] = 4 * x - 1, g[1] = 0, g[2] = 0;
+			break;
+		case 2:
+			g[0] = 0, g[1] = 4 * y - 1, g[2] = 0;
+			break;
+		case 3:
+			g[0] = 0, g[1] = 0, g[2] = 4 * z - 1;
+			break;
+		case 4:
+			g[0] = 4 * (-2 * x - y - z + 1), g[1] = -4 * x, g[2] = -4 * x;
+			break;
+		case 5:
+			g[0] = 4 * y, g[1] = 4 * x, g[2] = 0;
+			break;
+		case 6:
+			g[0] = -4 * y, g[1] = 4 * (-x - 2 * y - z + 1), g[2] = -4 * y;
+			break;
+		case 7:
+			g[0] = -4 * z, g[1] = -4 * z, g[2] = 4 * (-x - y - 2 * z + 1);
+			break;
+		case 8:
+			g[0] = 4 * z, g[1] = 0, g[2] = 4 * x;
+			break;
+		case 9:
+			g[0] = 0, g[1] = 4 * z, g[2] = 4 * y;
+			break;
+		}
+		break;
+	case PFO_Q1HEX:
+		for (int c = 0; c < 3; ++c)
+			g[c] = qeval(&q1_grad[li][c], pt);
+		break;
+	case PFO_Q2HEX: /* auto_q_bases.cpp:1420-1871 */
+	{
+		const int a = q2_node[li][0], b = q2_node[li][1], c = q2_node[li][2];
+		g[0] = q2_dl(a, x) * q2_l(b, y) * q2_l(c, z);
+		g[1] = q2_l(a, x) * q2_dl(b, y) * q2_l(c, z);
+		g[2] = q2_l(a, x) * q2_l(b, y) * q2_dl(c, z);
+		break;
+	}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* 3x3 dense pieces done by Eigen 3.4.0 in the reference (un-vendored; restated; parity unpinned)    */
+/* ------------------------------------------------------------------------------------------------ */
+
+#define M(m, r, c) ((m)[3 * (r) + (c)])
+
+/* Eigen/src/LU/Determinant.h: bruteforce_det3_helper(m,0,1,2) - helper(m,1,0,2) + helper(m,2,0,1),
+ * helper(m,a,b,c) = m(0,a) * (m(1,b)*m(2,c) - m(1,c)*m(2,b)) */
+static double det3_eigen(const double *m)
+{
+	const double h0 = M(m, 0, 0) * (M(m, 1, 1) * M(m, 2, 2) - M(m, 1, 2) * M(m, 2, 1));
+	const double h1 = M(m, 0, 1) * (M(m, 1, 0) * M(m, 2, 2) - M(m, 1, 2) * M(m, 2, 0));
+	const double h2 = M(m, 0, 2) * (M(m, 1, 0) * M(m, 2, 1) - M(m, 1, 1) * M(m, 2, 0));
+	return h0 - h1 + h2;
+}
+
+static double cof3(const double *m, int i, int j)
+{
+	const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+	return M(m, i1, j1) * M(m, i2, j2) - M(m, i1, j2) * M(m, i2, j1);
+}
+
+/* Eigen/src/LU/InverseImpl.h compute_inverse<.,.,3>: cofactors of column 0, det = sum(cof .* col0),
+ * invdet = 1/det, inverse(r,c) = cofactor<c,r> * invdet */
+static void inv3_eigen(const double *m, double *inv)
+{
+	const double c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+	const double det = (c0 * M(m, 0, 0) + c1 * M(m, 1, 0)) + c2 * M(m, 2, 0);
+	const double invdet = 1.0 / det;
+	M(inv, 0, 0) = c0 * invdet;
+	M(inv, 0, 1) = c1 * invdet;
+	M(inv, 0, 2) = c2 * invdet;
+	M(inv, 1, 0) = cof3(m, 0, 1) * invdet;
+	M(inv, 1, 1) = cof3(m, 1, 1) * invdet;
+	M(inv, 1, 2) = cof3(m, 2, 1) * invdet;
+	M(inv, 2, 0) = cof3(m, 0, 2) * invdet;
+	M(inv, 2, 1) = cof3(m, 1, 2) * invdet;
+	M(inv, 2, 2) = cof3(m, 2, 2) * invdet;
+}
+
+/* utils/MatrixUtils.hpp:16-30 */
+double pfo_determinant3(const double *m)
+{
+	return M(m, 0, 0) * (M(m, 1, 1) * M(m, 2, 2) - M(m, 1, 2) * M(m, 2, 1)) - M(m, 0, 1) * (M(m, 1, 0) * M(m, 2, 2) - M(m, 1, 2) * M(m, 2, 0)) + M(m, 0, 2) * (M(m, 1, 0) * M(m, 2, 1) - M(m, 1, 1) * M(m, 2, 0));
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ElementAssemblyValues::compute + finalize3d                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* assembler/ElementAssemblyValues.cpp:205-351 and :94-133.  Local2Global lists have size 1, val 1.0. */
+void pfo_compute_vals(const pfo_mesh *mesh, int64_t e, const pfo_quad *quad, pfo_vals *v)
+{
+	const int n_loc = pfo_n_loc(mesh->kind);
+	const int n_g = pfo_n_loc(mesh->gkind);
+	const int m = quad->n_pts;
+	v->n_pts = m;
+	v->n_loc = n_loc;
+	v->quad = *quad;
+
+	for (int j = 0; j < n_loc; ++j)
+		for (int k = 0; k < m; ++k)
+		{
+			pfo_basis_value(mesh->kind, j, quad->pts[k], &v->val[j][k]);
+			pfo_basis_grad(mesh->kind, j, quad->pts[k], v->grad[j][k]);
+		}
+
+	for (int k = 0; k < m; ++k)
+	{
+		double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (int j = 0; j < n_g; ++j)
+		{
+			double gg[3];
+			pfo_basis_grad(mesh->gkind, j, quad->pts[k], gg);
+			const double *node = mesh->xyz + 3 * (int64_t)mesh->gconn[e * n_g + j];
+			const double gval = 1.0; /* Local2Global.val */
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c)
+					M(tmp, r, c) += gg[r] * node[c] * gval;
+		}
+		v->det[k] = det3_eigen(tmp);
+		double inv[9];
+		inv3_eigen(tmp, inv);
+		for (int r = 0; r < 3; ++r)
+			for (int c = 0; c < 3; ++c)
+				M(v->jac_it[k], r, c) = M(inv, c, r);
+		for (int j = 0; j < n_loc; ++j)
+			for (int c = 0; c < 3; ++c)
+			{
+				const double *g = v->grad[j][k];
+				const double *jt = v->jac_it[k];
+				v->grad_t_m[j][k][c] = (g[0] * M(jt, 0, c) + g[1] * M(jt, 1, c)) + g[2] * M(jt, 2, c);
+			}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* local assemblers                                                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* assembler/Laplacian.cpp:7-18 */
+void pfo_local_laplacian(const pfo_vals *v, int i, int j, const double *da, double *res1)
+{
+	double res = 0;
+	for (int k = 0; k < v->n_pts; ++k)
+	{
+		const double *gi = v->grad_t_m[i][k], *gj = v->grad_t_m[j][k];
+		const double dot = (gi[0] * gj[0] + gi[1] * gj[1]) + gi[2] * gj[2];
+		res += dot * da[k];
+	}
+	*res1 = res;
+}
+
+/* assembler/LinearElasticity.cpp:21-54 ; res index jj*size+ii */
+void pfo_local_linear_elasticity(const pfo_vals *v, int i, int j, const double *da, double lambda, double mu, double *res)
+{
+	for (int c = 0; c < 9; ++c)
+		res[c] = 0;
+	for (int k = 0; k < v->n_pts; ++k)
+	{
+		const double *gi = v->grad_t_m[i][k], *gj = v->grad_t_m[j][k];
+		double outer[9]; /* column-major 3x3: outer[col*3+row] = gi[row]*gj[col] */
+		for (int col = 0; col < 3; ++col)
+			for (int row = 0; row < 3; ++row)
+				outer[col * 3 + row] = gi[row] * gj[col];
+		const double dot = (gi[0] * gj[0] + gi[1] * gj[1]) + gi[2] * gj[2];
+		double res_k[9];
+		for (int ii = 0; ii < 3; ++ii)
+			for (int jj = 0; jj < 3; ++jj)
+			{
+				res_k[jj * 3 + ii] = outer[ii * 3 + jj] * mu + outer[jj * 3 + ii] * lambda;
+				if (ii == jj)
+					res_k[jj * 3 + ii] += mu * dot;
+			}
+		for (int c = 0; c < 9; ++c)
+			res[c] += res_k[c] * da[k];
+	}
+}
+
+/* F = local_disp^T * grad(p) * jac_it(p) + I ; local_disp is n_loc x 3 (row i = displacement of basis i).
+ * NeoHookeanElasticity.cpp:402 / :491 (dense products).  F row-major. */
+static void def_grad_at(const pfo_vals *v, int p, const double *local_disp, double *F)
+{
+	double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; /* local_disp^T * grad : A(d,c) = sum_i u_i[d] grad_i[c] */
+	for (int d = 0; d < 3; ++d)
+		for (int c = 0; c < 3; ++c)
+		{
+			double s = 0;
+			for (int i = 0; i < v->n_loc; ++i)
+				s += local_disp[3 * i + d] * v->grad[i][p][c];
+			M(A, d, c) = s;
+		}
+	const double *jt = v->jac_it[p];
+	for (int d = 0; d < 3; ++d)
+		for (int c = 0; c < 3; ++c)
+		{
+			double s = 0;
+			for (int a = 0; a < 3; ++a)
+				s += M(A, d, a) * M(jt, a, c);
+			M(F, d, c) = s + (d == c ? 1.0 : 0.0);
+		}
+}
+
+/* NeoHookeanElasticity.cpp:250-331 : sum_p da_p [ mu/2 (tr(F^T F) - 3 - 2 ln J) + lambda/2 ln^2 J ] */
+double pfo_local_neohookean_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu)
+{
+	double energy = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9];
+		def_grad_at(v, p, local_disp, F);
+		const double log_det_j = log(pfo_determinant3(F));
+		double tr = 0;
+		for (int k = 0; k < 9; ++k)
+			tr += F[k] * F[k];
+		const double val = mu / 2 * (tr - 3 - 2 * log_det_j) + lambda / 2 * log_det_j * log_det_j;
+		energy += val * da[p];
+	}
+	return energy;
+}
+
+/* LinearElasticity.cpp:96-169 : sum_p da_p [ mu tr(eps^T eps) + lambda/2 tr(eps)^2 ], eps = sym(grad u) */
+double pfo_local_linear_elasticity_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu)
+{
+	double energy = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9];
+		def_grad_at(v, p, local_disp, F);
+		for (int d = 0; d < 3; ++d)
+			M(F, d, d) -= 1.0; /* grad u */
+		double s = 0, tr = 0;
+		for (int a = 0; a < 3; ++a)
+		{
+			tr += (M(F, a, a) + M(F, a, a)) / 2;
+			for (int b = 0; b < 3; ++b)
+			{
+				const double eab = (M(F, a, b) + M(F, b, a)) / 2;
+				s += eab * eab;
+			}
+		}
+		energy += (mu * s + lambda / 2 * tr * tr) * da[p];
+	}
+	return energy;
+}
+
+static void cross3(const double *x, const double *y, double *z)
+{
+	z[0] = x[1] * y[2] - x[2] * y[1];
+	z[1] = x[2] * y[0] - x[0] * y[2];
+	z[2] = x[0] * y[1] - x[1] * y[0];
+}
+
+/* delJ_delF: columns cross(v,w), cross(w,u), cross(u,v) with u,v,w the columns of F
+ * (NeoHookeanElasticity.cpp:422-432). Row-major output. */
+static void delJ_delF3(const double *F, double *dJ)
+{
+	double u[3], vv[3], w[3], c0[3], c1[3], c2[3];
+	for (int r = 0; r < 3; ++r)
+		u[r] = M(F, r, 0), vv[r] = M(F, r, 1), w[r] = M(F, r, 2);
+	cross3(vv, w, c0);
+	cross3(w, u, c1);
+	cross3(u, vv, c2);
+	for (int r = 0; r < 3; ++r)
+		M(dJ, r, 0) = c0[r], M(dJ, r, 1) = c1[r], M(dJ, r, 2) = c2[r];
+}
+
+/* NeoHookeanElasticity.cpp:364-453 ; G is n_loc x 3 flattened node-major (G_T.data()) */
+void pfo_local_neohookean_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G)
+{
+	const int n = v->n_loc;
+	for (int k = 0; k < 3 * n; ++k)
+		G[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9], dJ[9], T[9];
+		def_grad_at(v, p, local_disp, F);
+		const double J = det3_eigen(F);
+		const double log_det_j = log(J);
+		delJ_delF3(F, dJ);
+		/* gradient_temp = mu F - mu (1/J) dJ + lambda lnJ (1/J) dJ */
+		for (int k = 0; k < 9; ++k)
+			T[k] = mu * F[k] - mu * (1 / J) * dJ[k] + lambda * log_det_j * (1 / J) * dJ[k];
+		const double *jt = v->jac_it[p];
+		for (int i = 0; i < n; ++i)
+		{
+			double dFdU[3]; /* (grad * jac_it).row(i) */
+			for (int c = 0; c < 3; ++c)
+			{
+				double s = 0;
+				for (int a = 0; a < 3; ++a)
+					s += v->grad[i][p][a] * M(jt, a, c);
+				dFdU[c] = s;
+			}
+			/* gradient(i,d) = sum_c dFdU(i,c) * T^T(c,d) = sum_c dFdU[c] * T(d,c) */
+			for (int d = 0; d < 3; ++d)
+			{
+				double s = 0;
+				for (int c = 0; c < 3; ++c)
+					s += dFdU[c] * M(T, d, c);
+				G[3 * i + d] += s * da[p];
+			}
+		}
+	}
+}
+
+/* hat(x), NeoHookeanElasticity.cpp:333-348 */
+static void hat3(const double *x, double *h)
+{
+	for (int k = 0; k < 9; ++k)
+		h[k] = 0;
+	M(h, 0, 1) = -x[2];
+	M(h, 0, 2) = x[1];
+	M(h, 1, 0) = x[2];
+	M(h, 1, 2) = -x[0];
+	M(h, 2, 0) = -x[1];
+	M(h, 2, 1) = x[0];
+}
+
+/* NeoHookeanElasticity.cpp:455-565.  vec() is Eigen's column-major flattening: index(r,c) = c*3 + r.
+ * H is (3n x 3n) row-major, row/col index = i*3 + d. */
+void pfo_local_neohookean_hessian(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H)
+{
+	const int n = v->n_loc;
+	const int N = 3 * n;
+	for (int k = 0; k < N * N; ++k)
+		H[k] = 0;
+	double *B = (double *)malloc(sizeof(double) * 9 * N);  /* delF_delU_tensor 9 x N */
+	double *HB = (double *)malloc(sizeof(double) * 9 * N); /* hessian_temp * B */
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9], dJ[9];
+		def_grad_at(v, p, local_disp, F);
+		const double J = det3_eigen(F);
+		const double log_det_j = log(J);
+		delJ_delF3(F, dJ);
+		double u[3], vv[3], w[3];
+		for (int r = 0; r < 3; ++r)
+			u[r] = M(F, r, 0), vv[r] = M(F, r, 1), w[r] = M(F, r, 2);
+
+		double d2[81];
+		for (int k = 0; k < 81; ++k)
+			d2[k] = 0;
+		double hu[9], hv[9], hw[9];
+		hat3(u, hu), hat3(vv, hv), hat3(w, hw);
+#define D2(r, c) d2[(r)*9 + (c)]
+		for (int r = 0; r < 3; ++r)
+			for (int c = 0; c < 3; ++c)
+			{
+				D2(0 + r, 6 + c) = M(hv, r, c);
+				D2(6 + r, 0 + c) = -M(hv, r, c);
+				D2(0 + r, 3 + c) = -M(hw, r, c);
+				D2(3 + r, 0 + c) = M(hw, r, c);
+				D2(3 + r, 6 + c) = -M(hu, r, c);
+				D2(6 + r, 3 + c) = M(hu, r, c);
+			}
+		double gj[9]; /* vec(delJ_delF), column-major */
+		for (int r = 0; r < 3; ++r)
+			for (int c = 0; c < 3; ++c)
+				gj[c * 3 + r] = M(dJ, r, c);
+		double ht[81];
+		const double c1 = (mu + lambda * (1 - log_det_j)) / (J * J);
+		const double c2 = (lambda * log_det_j - mu) / (J);
+		for (int r = 0; r < 9; ++r)
+			for (int c = 0; c < 9; ++c)
+				ht[r * 9 + c] = (r == c ? mu : 0.0) + c1 * (gj[r] * gj[c]) + c2 * D2(r, c);
+#undef D2
+		/* column (i*3+j) of B = vec( e_j (x) (grad.row(i) * jac_it) ) : temp(j, :) = dFdU_i */
+		const double *jt = v->jac_it[p];
+		for (int k = 0; k < 9 * N; ++k)
+			B[k] = 0;
+		for (int i = 0; i < n; ++i)
+		{
+			double dFdU[3];
+			for (int c = 0; c < 3; ++c)
+			{
+				double s = 0;
+				for (int a = 0; a < 3; ++a)
+					s += v->grad[i][p][a] * M(jt, a, c);
+				dFdU[c] = s;
+			}
+			for (int j = 0; j < 3; ++j)
+				for (int c = 0; c < 3; ++c)
+					B[(c * 3 + j) * N + (i * 3 + j)] = dFdU[c];
+		}
+		for (int r = 0; r < 9; ++r)
+			for (int c = 0; c < N; ++c)
+			{
+				double s = 0;
+				for (int k = 0; k < 9; ++k)
+					s += ht[r * 9 + k] * B[k * N + c];
+				HB[r * N + c] = s;
+			}
+		for (int r = 0; r < N; ++r)
+			for (int c = 0; c < N; ++c)
+			{
+				double s = 0;
+				for (int k = 0; k < 9; ++k)
+					s += B[k * N + r] * HB[k * N + c];
+				H[r * N + c] += s * da[p];
+			}
+	}
+	free(B);
+	free(HB);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* triplets -> CSC  (Eigen::SparseMatrix::setFromTriplets: duplicates summed in insertion order,     */
+/* explicit zeros kept, inner indices ascending)                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct
+{
+	int32_t r, c;
+	double v;
+} trip;
+
+typedef struct
+{
+	trip *t;
+	int64_t n, cap;
+} tripvec;
+
+static void tv_push(tripvec *tv, int32_t r, int32_t c, double v)
+{
+	if (tv->n == tv->cap)
+	{
+		tv->cap = tv->cap ? tv->cap * 2 : (1 << 16);
+		tv->t = (trip *)realloc(tv->t, sizeof(trip) * tv->cap);
+	}
+	tv->t[tv->n].r = r;
+	tv->t[tv->n].c = c;
+	tv->t[tv->n].v = v;
+	tv->n++;
+}
+
+/* Eigen/src/SparseCore/SparseMatrix.h set_from_triplets: pass 1 builds the transposed (row-major) matrix
+ * by counting + insertion in triplet order, collapses duplicates per row in insertion order, pass 2
+ * transposes back, which sorts inner indices. */
+static int trips_to_csc(int32_t n, const trip *t, int64_t nt, pfo_csc *out)
+{
+	int64_t *rptr = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+	for (int64_t k = 0; k < nt; ++k)
+		rptr[t[k].r + 1]++;
+	for (int32_t r = 0; r < n; ++r)
+		rptr[r + 1] += rptr[r];
+	int32_t *rc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nt ? nt : 1));
+	double *rv = (double *)malloc(sizeof(double) * (size_t)(nt ? nt : 1));
+	int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+	memcpy(cur, rptr, sizeof(int64_t) * ((size_t)n + 1));
+	for (int64_t k = 0; k < nt; ++k)
+	{
+		const int64_t pos = cur[t[k].r]++;
+		rc[pos] = t[k].c;
+		rv[pos] = t[k].v;
+	}
+	/* collapse duplicates row by row, first occurrence keeps its place */
+	int64_t *wi = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+	for (int32_t c = 0; c < n; ++c)
+		wi[c] = -1;
+	int64_t *ccount = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+	int64_t count = 0;
+	int64_t *rstart = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+	for (int32_t r = 0; r < n; ++r)
+	{
+		const int64_t start = count;
+		rstart[r] = start;
+		for (int64_t k = rptr[r]; k < rptr[r + 1]; ++k)
+		{
+			const int32_t c = rc[k];
+			if (wi[c] >= start)
+				rv[wi[c]] += rv[k];
+			else
+			{
+				rv[count] = rv[k];
+				rc[count] = c;
+				wi[c] = count;
+				++count;
+				ccount[c + 1]++;
+			}
+		}
+	}
+	rstart[n] = count;
+	out->n = n;
+	out->nnz = count;
+	out->outer = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+	out->inner = (int32_t *)malloc(sizeof(int32_t) * (size_t)(count ? count : 1));
+	out->values = (double *)malloc(sizeof(double) * (size_t)(count ? count : 1));
+	for (int32_t c = 0; c < n; ++c)
+		ccount[c + 1] += ccount[c];
+	for (int32_t c = 0; c <= n; ++c)
+		out->outer[c] = (int32_t)ccount[c];
+	memcpy(cur, ccount, sizeof(int64_t) * ((size_t)n + 1));
+	for (int32_t r = 0; r < n; ++r)
+		for (int64_t k = rstart[r]; k < rstart[r + 1]; ++k)
+		{
+			const int64_t pos = cur[rc[k]]++;
+			out->inner[pos] = r;
+			out->values[pos] = rv[k];
+		}
+	free(rptr), free(rc), free(rv), free(cur), free(wi), free(ccount), free(rstart);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* global assemblers                                                                                */
+/* ------------------------------------------------------------------------------------------------ */
+
+static int block_size(const pfo_material *mat) { return mat->model == PFO_LAPLACIAN ? 1 : mat->dim; }
+
+typedef struct
+{
+	const pfo_mesh *mesh;
+	const pfo_material *mat;
+	const double *x;
+	int64_t e0, e1;
+	tripvec tv;
+	double scalar;
+	double *vec;
+	int mode; /* 0 linear, 1 energy, 2 grad, 3 hessian */
+} job;
+
+static void gather_local_disp(const pfo_mesh *mesh, int64_t e, int n_loc, const double *x, double *ld)
+{
+	/* NeoHookeanElasticity.cpp:371-383 ; global list of size 1 with val 1.0 */
+	for (int i = 0; i < n_loc; ++i)
+		for (int d = 0; d < 3; ++d)
+			ld[3 * i + d] = 0 + 1.0 * x[(int64_t)mesh->conn[e * n_loc + i] * 3 + d];
+}
+
+static void *job_run(void *arg)
+{
+	job *jb = (job *)arg;
+	const pfo_mesh *mesh = jb->mesh;
+	const pfo_material *mat = jb->mat;
+	const int n_loc = pfo_n_loc(mesh->kind);
+	const int size = block_size(mat);
+	pfo_quad quad;
+	pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad);
+	pfo_vals *v = (pfo_vals *)malloc(sizeof(pfo_vals));
+	double da[PFO_MAX_PTS];
+	double *H = (double *)malloc(sizeof(double) * 81 * 81);
+	double ld[3 * PFO_MAX_LOC], G[3 * PFO_MAX_LOC];
+
+	for (int64_t e = jb->e0; e < jb->e1; ++e)
+	{
+		pfo_compute_vals(mesh, e, &quad, v);
+		for (int k = 0; k < quad.n_pts; ++k)
+			da[k] = v->det[k] * quad.w[k];
+		const int32_t *idx = mesh->conn + e * n_loc;
+
+		if (jb->mode == 0)
+		{
+			/* Assembler.cpp:149-199 */
+			for (int i = 0; i < n_loc; ++i)
+				for (int j = 0; j <= i; ++j)
+				{
+					double sv[9];
+					if (mat->model == PFO_LAPLACIAN)
+						pfo_local_laplacian(v, i, j, da, sv);
+					else
+						pfo_local_linear_elasticity(v, i, j, da, mat->lambda, mat->mu, sv);
+					for (int n = 0; n < size; ++n)
+						for (int m = 0; m < size; ++m)
+						{
+							const double local_value = sv[n * size + m];
+							if (fabs(local_value) < 1e-30)
+								continue;
+							const int32_t gi = idx[i] * size + m;
+							const int32_t gj = idx[j] * size + n;
+							tv_push(&jb->tv, gi, gj, local_value * 1.0 * 1.0);
+							if (j < i)
+								tv_push(&jb->tv, gj, gi, local_value * 1.0 * 1.0);
+						}
+				}
+		}
+		else
+		{
+			gather_local_disp(mesh, e, n_loc, jb->x, ld);
+			if (jb->mode == 1)
+			{
+				/* Assembler.cpp:657-668 */
+				const double val = mat->model == PFO_NEOHOOKEAN ? pfo_local_neohookean_energy(v, da, ld, mat->lambda, mat->mu) : pfo_local_linear_elasticity_energy(v, da, ld, mat->lambda, mat->mu);
+				jb->scalar += val;
+			}
+			else if (jb->mode == 2)
+			{
+				/* Assembler.cpp:465-492 */
+				pfo_local_neohookean_grad(v, da, ld, mat->lambda, mat->mu, G);
+				for (int j = 0; j < n_loc; ++j)
+					for (int m = 0; m < size; ++m)
+					{
+						const double local_value = G[j * size + m];
+						if (fabs(local_value) < 1e-30)
+							continue;
+						jb->vec[(int64_t)idx[j] * size + m] += local_value * 1.0;
+					}
+			}
+			else
+			{
+				/* Assembler.cpp:550-616 : every entry, order (i, j, n, m) */
+				pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+				const int N = n_loc * size;
+				for (int i = 0; i < n_loc; ++i)
+					for (int j = 0; j < n_loc; ++j)
+						for (int n = 0; n < size; ++n)
+							for (int m = 0; m < size; ++m)
+							{
+								const double local_value = H[(i * size + m) * N + (j * size + n)];
+								tv_push(&jb->tv, idx[i] * size + m, idx[j] * size + n, local_value * 1.0 * 1.0);
+							}
+			}
+		}
+	}
+	free(v);
+	free(H);
+	return NULL;
+}
+
+/* Static contiguous chunks per thread: utils/par_for.cpp:10-26 (the reference's TBB blocked_range is
+ * also contiguous per task).  Thread-local storages are merged in thread order afterwards. */
+static void run_jobs(job *jobs, int nt)
+{
+	if (nt == 1)
+	{
+		job_run(&jobs[0]);
+		return;
+	}
+	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nt);
+	for (int t = 0; t < nt; ++t)
+		pthread_create(&th[t], NULL, job_run, &jobs[t]);
+	for (int t = 0; t < nt; ++t)
+		pthread_join(th[t], NULL);
+	free(th);
+}
+
+static job *make_jobs(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int mode, int *nt_io, int64_t vec_len)
+{
+	int nt = *nt_io < 1 ? 1 : *nt_io;
+	if (nt > mesh->n_el)
+		nt = mesh->n_el > 0 ? (int)mesh->n_el : 1;
+	*nt_io = nt;
+	job *jobs = (job *)calloc(nt, sizeof(job));
+	const int64_t chunk = (mesh->n_el + nt - 1) / nt;
+	for (int t = 0; t < nt; ++t)
+	{
+		jobs[t].mesh = mesh;
+		jobs[t].mat = mat;
+		jobs[t].x = x;
+		jobs[t].mode = mode;
+		jobs[t].e0 = t * chunk < mesh->n_el ? t * chunk : mesh->n_el;
+		jobs[t].e1 = (t + 1) * chunk < mesh->n_el ? (t + 1) * chunk : mesh->n_el;
+		if (vec_len)
+			jobs[t].vec = (double *)calloc((size_t)vec_len, sizeof(double)); /* LocalThreadVecStorage(rhs.size()), Assembler.cpp:442 */
+	}
+	return jobs;
+}
+
+static int merge_trips(job *jobs, int nt, int32_t n, pfo_csc *out)
+{
+	/* Assembler.cpp:235-301 : concatenate the thread-local triplets, then setFromTriplets */
+	int64_t total = 0;
+	for (int t = 0; t < nt; ++t)
+		total += jobs[t].tv.n;
+	trip *all;
+	if (nt == 1)
+		all = jobs[0].tv.t;
+	else
+	{
+		all = (trip *)malloc(sizeof(trip) * (size_t)(total ? total : 1));
+		int64_t off = 0;
+		for (int t = 0; t < nt; ++t)
+		{
+			memcpy(all + off, jobs[t].tv.t, sizeof(trip) * (size_t)jobs[t].tv.n);
+			off += jobs[t].tv.n;
+			free(jobs[t].tv.t);
+		}
+	}
+	const int rc = trips_to_csc(n, all, total, out);
+	free(all);
+	return rc;
+}
+
+/* assembler/Assembler.cpp:100-317 */
+int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_threads, pfo_csc *out)
+{
+	if (mat->model != PFO_LAPLACIAN && mat->model != PFO_LINEAR_ELASTICITY)
+		return -1;
+	int nt = n_threads;
+	job *jobs = make_jobs(mesh, mat, NULL, 0, &nt, 0);
+	run_jobs(jobs, nt);
+	const int rc = merge_trips(jobs, nt, (int32_t)(mesh->n_nodes * block_size(mat)), out);
+	free(jobs);
+	return rc;
+}
+
+/* assembler/Assembler.cpp:638-678 */
+double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads)
+{
+	int nt = n_threads;
+	job *jobs = make_jobs(mesh, mat, x, 1, &nt, 0);
+	run_jobs(jobs, nt);
+	double res = 0;
+	for (int t = 0; t < nt; ++t)
+		res += jobs[t].scalar;
+	free(jobs);
+	return res;
+}
+
+/* assembler/Assembler.cpp:427-504 */
+int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, double *rhs)
+{
+	if (mat->model != PFO_NEOHOOKEAN)
+		return -1;
+	const int64_t N = mesh->n_nodes * block_size(mat);
+	int nt = n_threads;
+	job *jobs = make_jobs(mesh, mat, x, 2, &nt, N);
+	run_jobs(jobs, nt);
+	for (int64_t k = 0; k < N; ++k)
+		rhs[k] = 0;
+	for (int t = 0; t < nt; ++t)
+	{
+		for (int64_t k = 0; k < N; ++k)
+			rhs[k] += jobs[t].vec[k];
+		free(jobs[t].vec);
+	}
+	free(jobs);
+	return 0;
+}
+
+/* assembler/Assembler.cpp:506-636, first (pattern-building) pass: triplets of every local entry */
+int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
+{
+	if (mat->model != PFO_NEOHOOKEAN)
+		return -1;
+	int nt = n_threads;
+	job *jobs = make_jobs(mesh, mat, x, 3, &nt, 0);
+	run_jobs(jobs, nt);
+	const int rc = merge_trips(jobs, nt, (int32_t)(mesh->n_nodes * block_size(mat)), out);
+	free(jobs);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* SpareMatrixCache (utils/MatrixUtils.cpp:32-357)                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct
+{
+	int32_t col;
+	int64_t index;
+} mapent;
+
+struct pfo_cache
+{
+	int64_t size;
+	tripvec entries;     /* entries_                                                   */
+	pfo_csc mat;         /* mat_ (only used before the mapping exists)                  */
+	int has_mat;
+	/* mapping_[row] = list of (col, value index) */
+	mapent **mapping;
+	int32_t *mapping_len;
+	int64_t mapping_rows; /* 0 = empty */
+	int32_t *inner_index, *outer_index;
+	double *values;
+	int64_t n_values;
+	const pfo_cache *main_cache;
+	/* second cache */
+	int32_t **second_cache;
+	int64_t *second_cache_len;
+	int64_t second_cache_n;
+	/* second_cache_entries_ : per element list of (i,j) */
+	int32_t **sce;
+	int64_t *sce_len, *sce_cap;
+	int64_t sce_n;
+	int current_e, current_e_index;
+};
+
+static const pfo_cache *cache_main(const pfo_cache *c) { return c->main_cache ? c->main_cache : c; }
+int64_t pfo_cache_mapping_size(const pfo_cache *c) { return cache_main(c)->mapping_rows; }
+
+pfo_cache *pfo_cache_create(int64_t size)
+{
+	pfo_cache *c = (pfo_cache *)calloc(1, sizeof(pfo_cache));
+	c->size = size;
+	c->current_e = -1;
+	c->current_e_index = -1;
+	return c;
+}
+
+/* copy constructor -> init(other): MatrixUtils.cpp:73-90 */
+pfo_cache *pfo_cache_clone(const pfo_cache *other)
+{
+	pfo_cache *c = pfo_cache_create(other->size);
+	c->main_cache = other->main_cache ? other->main_cache : other;
+	c->n_values = other->n_values;
+	c->values = (double *)calloc((size_t)(c->n_values ? c->n_values : 1), sizeof(double));
+	return c;
+}
+
+void pfo_cache_destroy(pfo_cache *c)
+{
+	if (!c)
+		return;
+	free(c->entries.t);
+	if (c->has_mat)
+		pfo_csc_free(&c->mat);
+	for (int64_t r = 0; r < c->mapping_rows; ++r)
+		free(c->mapping[r]);
+	free(c->mapping);
+	free(c->mapping_len);
+	free(c->inner_index);
+	free(c->outer_index);
+	free(c->values);
+	for (int64_t e = 0; e < c->second_cache_n; ++e)
+		free(c->second_cache[e]);
+	free(c->second_cache);
+	free(c->second_cache_len);
+	for (int64_t e = 0; e < c->sce_n; ++e)
+		free(c->sce[e]);
+	free(c->sce);
+	free(c->sce_len);
+	free(c->sce_cap);
+	free(c);
+}
+
+/* MatrixUtils.cpp:92-98 */
+void pfo_cache_set_zero(pfo_cache *c)
+{
+	if (c->has_mat)
+	{
+		pfo_csc_free(&c->mat);
+		c->has_mat = 0;
+	}
+	for (int64_t k = 0; k < c->n_values; ++k)
+		c->values[k] = 0;
+}
+
+/* MatrixUtils.cpp:108-151 */
+void pfo_cache_add_value(pfo_cache *c, int e, int i, int j, double value)
+{
+	const pfo_cache *mc = cache_main(c);
+	if (mc->mapping_rows == 0)
+	{
+		tv_push(&c->entries, i, j, value);
+		if (c->sce_n <= e)
+		{
+			const int64_t nn = e + 1;
+			c->sce = (int32_t **)realloc(c->sce, sizeof(int32_t *) * nn);
+			c->sce_len = (int64_t *)realloc(c->sce_len, sizeof(int64_t) * nn);
+			c->sce_cap = (int64_t *)realloc(c->sce_cap, sizeof(int64_t) * nn);
+			for (int64_t k = c->sce_n; k < nn; ++k)
+				c->sce[k] = NULL, c->sce_len[k] = 0, c->sce_cap[k] = 0;
+			c->sce_n = nn;
+		}
+		if (c->sce_len[e] == c->sce_cap[e])
+		{
+			c->sce_cap[e] = c->sce_cap[e] ? 2 * c->sce_cap[e] : 16;
+			c->sce[e] = (int32_t *)realloc(c->sce[e], sizeof(int32_t) * 2 * c->sce_cap[e]);
+		}
+		c->sce[e][2 * c->sce_len[e]] = i;
+		c->sce[e][2 * c->sce_len[e] + 1] = j;
+		c->sce_len[e]++;
+	}
+	else
+	{
+		if (e != c->current_e)
+		{
+			c->current_e = e;
+			c->current_e_index = 0;
+		}
+		c->values[mc->second_cache[e][c->current_e_index]] += value;
+		c->current_e_index++;
+	}
+}
+
+/* sparse a += b for two CSC matrices with sorted inner indices (Eigen's operator+= result pattern is the
+ * sorted union) */
+static void csc_add_inplace(pfo_csc *a, const pfo_csc *b)
+{
+	const int32_t n = a->n;
+	int32_t *outer = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+	int32_t *inner = (int32_t *)malloc(sizeof(int32_t) * (size_t)(a->nnz + b->nnz + 1));
+	double *vals = (double *)malloc(sizeof(double) * (size_t)(a->nnz + b->nnz + 1));
+	int64_t cnt = 0;
+	for (int32_t c = 0; c < n; ++c)
+	{
+		outer[c] = (int32_t)cnt;
+		int32_t ia = a->outer[c], ib = b->outer[c];
+		const int32_t ea = a->outer[c + 1], eb = b->outer[c + 1];
+		while (ia < ea || ib < eb)
+		{
+			if (ib >= eb || (ia < ea && a->inner[ia] < b->inner[ib]))
+				inner[cnt] = a->inner[ia], vals[cnt] = a->values[ia], ++ia;
+			else if (ia >= ea || b->inner[ib] < a->inner[ia])
+				inner[cnt] = b->inner[ib], vals[cnt] = b->values[ib], ++ib;
+			else
+				inner[cnt] = a->inner[ia], vals[cnt] = a->values[ia] + b->values[ib], ++ia, ++ib;
+			++cnt;
+		}
+	}
+	outer[n] = (int32_t)cnt;
+	free(a->outer), free(a->inner), free(a->values);
+	a->outer = outer, a->inner = inner, a->values = vals, a->nnz = cnt;
+}
+
+/* MatrixUtils.cpp:153-169 */
+void pfo_cache_prune(pfo_cache *c)
+{
+	if (cache_main(c)->mapping_rows != 0)
+		return;
+	pfo_csc tmp;
+	trips_to_csc((int32_t)c->size, c->entries.t, c->entries.n, &tmp);
+	if (!c->has_mat)
+	{
+		c->mat = tmp;
+		c->has_mat = 1;
+	}
+	else
+	{
+		csc_add_inplace(&c->mat, &tmp);
+		pfo_csc_free(&tmp);
+	}
+	c->entries.n = 0;
+}
+
+/* MatrixUtils.cpp:319-357 */
+void pfo_cache_add(pfo_cache *c, const pfo_cache *o)
+{
+	if (cache_main(c)->mapping_rows == 0 || cache_main(o)->mapping_rows == 0)
+	{
+		if (o->has_mat)
+		{
+			if (!c->has_mat)
+			{
+				trips_to_csc((int32_t)c->size, NULL, 0, &c->mat);
+				c->has_mat = 1;
+			}
+			csc_add_inplace(&c->mat, &o->mat);
+		}
+		for (int64_t e = 0; e < o->sce_n; ++e)
+			for (int64_t k = 0; k < o->sce_len[e]; ++k)
+			{
+				/* append to second_cache_entries_[e] */
+				if (c->sce_n <= e)
+				{
+					const int64_t nn = e + 1;
+					c->sce = (int32_t **)realloc(c->sce, sizeof(int32_t *) * nn);
+					c->sce_len = (int64_t *)realloc(c->sce_len, sizeof(int64_t) * nn);
+					c->sce_cap = (int64_t *)realloc(c->sce_cap, sizeof(int64_t) * nn);
+					for (int64_t q = c->sce_n; q < nn; ++q)
+						c->sce[q] = NULL, c->sce_len[q] = 0, c->sce_cap[q] = 0;
+					c->sce_n = nn;
+				}
+				if (c->sce_len[e] == c->sce_cap[e])
+				{
+					c->sce_cap[e] = c->sce_cap[e] ? 2 * c->sce_cap[e] : 16;
+					c->sce[e] = (int32_t *)realloc(c->sce[e], sizeof(int32_t) * 2 * c->sce_cap[e]);
+				}
+				c->sce[e][2 * c->sce_len[e]] = o->sce[e][2 * k];
+				c->sce[e][2 * c->sce_len[e] + 1] = o->sce[e][2 * k + 1];
+				c->sce_len[e]++;
+			}
+	}
+	else
+	{
+		for (int64_t k = 0; k < o->n_values; ++k)
+			c->values[k] += o->values[k];
+	}
+}
+
+static void csc_copy(const pfo_csc *src, pfo_csc *dst)
+{
+	dst->n = src->n;
+	dst->nnz = src->nnz;
+	dst->outer = (int32_t *)malloc(sizeof(int32_t) * ((size_t)src->n + 1));
+	dst->inner = (int32_t *)malloc(sizeof(int32_t) * (size_t)(src->nnz ? src->nnz : 1));
+	dst->values = (double *)malloc(sizeof(double) * (size_t)(src->nnz ? src->nnz : 1));
+	memcpy(dst->outer, src->outer, sizeof(int32_t) * ((size_t)src->n + 1));
+	memcpy(dst->inner, src->inner, sizeof(int32_t) * (size_t)src->nnz);
+	memcpy(dst->values, src->values, sizeof(double) * (size_t)src->nnz);
+}
+
+/* MatrixUtils.cpp:171-264 */
+int pfo_cache_get_matrix(pfo_cache *c, int compute_mapping, pfo_csc *out)
+{
+	pfo_cache_prune(c);
+	const pfo_cache *mc = cache_main(c);
+	if (mc->mapping_rows == 0)
+	{
+		if (!c->has_mat)
+		{
+			trips_to_csc((int32_t)c->size, NULL, 0, &c->mat);
+			c->has_mat = 1;
+		}
+		if (compute_mapping && c->size > 0)
+		{
+			const pfo_csc *m = &c->mat;
+			c->n_values = m->nnz;
+			c->values = (double *)calloc((size_t)(m->nnz ? m->nnz : 1), sizeof(double));
+			c->inner_index = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m->nnz ? m->nnz : 1));
+			c->outer_index = (int32_t *)malloc(sizeof(int32_t) * ((size_t)m->n + 1));
+			memcpy(c->inner_index, m->inner, sizeof(int32_t) * (size_t)m->nnz);
+			memcpy(c->outer_index, m->outer, sizeof(int32_t) * ((size_t)m->n + 1));
+			c->mapping_rows = m->n;
+			c->mapping = (mapent **)calloc((size_t)m->n, sizeof(mapent *));
+			c->mapping_len = (int32_t *)calloc((size_t)m->n, sizeof(int32_t));
+			for (int64_t k = 0; k < m->nnz; ++k)
+				c->mapping_len[m->inner[k]]++;
+			for (int32_t r = 0; r < m->n; ++r)
+			{
+				c->mapping[r] = (mapent *)malloc(sizeof(mapent) * (size_t)(c->mapping_len[r] ? c->mapping_len[r] : 1));
+				c->mapping_len[r] = 0;
+			}
+			int64_t index = 0;
+			for (int32_t i = 0; i < m->n; ++i) /* i = outer (column) */
+				for (int32_t ii = m->outer[i]; ii < m->outer[i + 1]; ++ii)
+				{
+					const int32_t j = m->inner[ii]; /* row */
+					mapent *me = &c->mapping[j][c->mapping_len[j]++];
+					me->col = i;
+					me->index = index;
+					++index;
+				}
+			/* second cache: value index of the k-th add_value call of element e */
+			c->second_cache_n = c->sce_n;
+			c->second_cache = (int32_t **)calloc((size_t)(c->sce_n ? c->sce_n : 1), sizeof(int32_t *));
+			c->second_cache_len = (int64_t *)calloc((size_t)(c->sce_n ? c->sce_n : 1), sizeof(int64_t));
+			for (int64_t e = 0; e < c->sce_n; ++e)
+			{
+				c->second_cache[e] = (int32_t *)malloc(sizeof(int32_t) * (size_t)(c->sce_len[e] ? c->sce_len[e] : 1));
+				c->second_cache_len[e] = c->sce_len[e];
+				for (int64_t k = 0; k < c->sce_len[e]; ++k)
+				{
+					const int32_t i = c->sce[e][2 * k], j = c->sce[e][2 * k + 1];
+					int64_t idx = -1;
+					for (int32_t q = 0; q < c->mapping_len[i]; ++q)
+						if (c->mapping[i][q].col == j)
+						{
+							idx = c->mapping[i][q].index;
+							break;
+						}
+					if (idx < 0)
+						return -2;
+					c->second_cache[e][k] = (int32_t)idx;
+				}
+				free(c->sce[e]);
+				c->sce[e] = NULL;
+			}
+			c->sce_n = 0;
+		}
+		csc_copy(&c->mat, out);
+	}
+	else
+	{
+		out->n = (int32_t)c->size;
+		out->nnz = c->n_values;
+		out->outer = (int32_t *)malloc(sizeof(int32_t) * ((size_t)c->size + 1));
+		out->inner = (int32_t *)malloc(sizeof(int32_t) * (size_t)(c->n_values ? c->n_values : 1));
+		out->values = (double *)malloc(sizeof(double) * (size_t)(c->n_values ? c->n_values : 1));
+		memcpy(out->outer, mc->outer_index, sizeof(int32_t) * ((size_t)c->size + 1));
+		memcpy(out->inner, mc->inner_index, sizeof(int32_t) * (size_t)c->n_values);
+		memcpy(out->values, c->values, sizeof(double) * (size_t)c->n_values);
+		c->current_e = -1;
+		c->current_e_index = -1;
+	}
+	for (int64_t k = 0; k < c->n_values; ++k)
+		c->values[k] = 0;
+	return 0;
+}
+
+/* NLAssembler::assemble_hessian with a caller-owned cache (Assembler.cpp:527-632), single thread */
+int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, const double *x, pfo_cache *cache, pfo_csc *out)
+{
+	const int n_loc = pfo_n_loc(mesh->kind);
+	const int size = block_size(mat);
+	pfo_cache_set_zero(cache);
+	pfo_cache *local = pfo_cache_clone(cache); /* LocalThreadMatStorage(buffer_size, mat_cache) */
+	if (cache_main(cache)->mapping_rows == 0)
+	{
+		/* first time: the clone has no mapping to share, it acts as a fresh cache */
+		local->main_cache = NULL;
+	}
+	pfo_quad quad;
+	pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad);
+	pfo_vals *v = (pfo_vals *)malloc(sizeof(pfo_vals));
+	double da[PFO_MAX_PTS], ld[3 * PFO_MAX_LOC];
+	double *H = (double *)malloc(sizeof(double) * 81 * 81);
+	const int N = n_loc * size;
+	for (int64_t e = 0; e < mesh->n_el; ++e)
+	{
+		pfo_compute_vals(mesh, e, &quad, v);
+		for (int k = 0; k < quad.n_pts; ++k)
+			da[k] = v->det[k] * quad.w[k];
+		gather_local_disp(mesh, e, n_loc, x, ld);
+		pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+		const int32_t *idx = mesh->conn + e * n_loc;
+		for (int i = 0; i < n_loc; ++i)
+			for (int j = 0; j < n_loc; ++j)
+				for (int n = 0; n < size; ++n)
+					for (int m = 0; m < size; ++m)
+						pfo_cache_add_value(local, (int)e, idx[i] * size + m, idx[j] * size + n, H[(i * size + m) * N + (j * size + n)] * 1.0 * 1.0);
+	}
+	pfo_cache_prune(local);
+	pfo_cache_add(cache, local);
+	local->main_cache = cache; /* so destroy does not free shared data */
+	pfo_cache_destroy(local);
+	free(v);
+	free(H);
+	return pfo_cache_get_matrix(cache, 1, out);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* full_to_reduced_matrix (utils/MatrixUtils.cpp:408-469)                                           */
+/* ------------------------------------------------------------------------------------------------ */
+
+int pfo_full_to_reduced_matrix(const pfo_csc *full, const int32_t *removed_vars, int64_t n_removed, pfo_csc *reduced)
+{
+	const int32_t full_size = full->n;
+	int32_t *indices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(full_size ? full_size : 1));
+	int32_t index = 0;
+	int64_t kk = 0;
+	for (int32_t i = 0; i < full_size; ++i)
+	{
+		if (kk < n_removed && removed_vars[kk] == i)
+		{
+			++kk;
+			indices[i] = -1;
+		}
+		else
+			indices[i] = index++;
+	}
+	tripvec tv = {0};
+	for (int32_t k = 0; k < full_size; ++k)
+	{
+		if (indices[k] < 0)
+			continue;
+		for (int32_t it = full->outer[k]; it < full->outer[k + 1]; ++it)
+		{
+			const int32_t row = full->inner[it];
+			if (indices[row] < 0)
+				continue;
+			tv_push(&tv, indices[row], indices[k], full->values[it]);
+		}
+	}
+	const int rc = trips_to_csc(index, tv.t, tv.n, reduced);
+	free(tv.t);
+	free(indices);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* CG (Eigen 3.4.0 IterativeLinearSolvers/ConjugateGradient.h, DiagonalPreconditioner) -- parity      */
+/* unpinned: the Eigen/polysolve sources are not in the reference tree and it has no CG goldens.     */
+/* ------------------------------------------------------------------------------------------------ */
+
+void pfo_spmv(const pfo_csc *A, const double *x, double *y)
+{
+	for (int32_t r = 0; r < A->n; ++r)
+		y[r] = 0;
+	for (int32_t c = 0; c < A->n; ++c)
+	{
+		const double xc = x[c];
+		for (int32_t k = A->outer[c]; k < A->outer[c + 1]; ++k)
+			y[A->inner[k]] += A->values[k] * xc;
+	}
+}
+
+static double dot(const double *a, const double *b, int64_t n)
+{
+	double s = 0;
+	for (int64_t k = 0; k < n; ++k)
+		s += a[k] * b[k];
+	return s;
+}
+
+int pfo_cg(const pfo_csc *A, const double *b, double *x, int precond_jacobi, int max_iter, double tol, int *iters_out, double *error_out)
+{
+	const int64_t n = A->n;
+	double *invdiag = (double *)malloc(sizeof(double) * (size_t)n);
+	double *residual = (double *)malloc(sizeof(double) * (size_t)n);
+	double *p = (double *)malloc(sizeof(double) * (size_t)n);
+	double *z = (double *)malloc(sizeof(double) * (size_t)n);
+	double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
+	/* DiagonalPreconditioner::factorize: invdiag = 1/diag if diag != 0 else 1 */
+	for (int64_t k = 0; k < n; ++k)
+		invdiag[k] = 1.0;
+	if (precond_jacobi)
+		for (int32_t c = 0; c < A->n; ++c)
+			for (int32_t k = A->outer[c]; k < A->outer[c + 1]; ++k)
+				if (A->inner[k] == c && A->values[k] != 0)
+					invdiag[c] = 1.0 / A->values[k];
+
+	int iters = 0;
+	double tol_error = 0;
+	pfo_spmv(A, x, tmp);
+	for (int64_t k = 0; k < n; ++k)
+		residual[k] = b[k] - tmp[k];
+	const double rhsNorm2 = dot(b, b, n);
+	if (rhsNorm2 == 0)
+	{
+		for (int64_t k = 0; k < n; ++k)
+			x[k] = 0;
+		goto done;
+	}
+	{
+		const double considerAsZero = DBL_MIN;
+		double threshold = tol * tol * rhsNorm2;
+		if (threshold < considerAsZero)
+			threshold = considerAsZero;
+		double residualNorm2 = dot(residual, residual, n);
+		if (residualNorm2 < threshold)
+		{
+			tol_error = sqrt(residualNorm2 / rhsNorm2);
+			goto done;
+		}
+		for (int64_t k = 0; k < n; ++k)
+			p[k] = invdiag[k] * residual[k];
+		double absNew = dot(residual, p, n);
+		int i = 0;
+		while (i < max_iter)
+		{
+			pfo_spmv(A, p, tmp);
+			const double alpha = absNew / dot(p, tmp, n);
+			for (int64_t k = 0; k < n; ++k)
+				x[k] += alpha * p[k];
+			for (int64_t k = 0; k < n; ++k)
+				residual[k] -= alpha * tmp[k];
+			residualNorm2 = dot(residual, residual, n);
+			if (residualNorm2 < threshold)
+				break;
+			for (int64_t k = 0; k < n; ++k)
+				z[k] = invdiag[k] * residual[k];
+			const double absOld = absNew;
+			absNew = dot(residual, z, n);
+			const double beta = absNew / absOld;
+			for (int64_t k = 0; k < n; ++k)
+				p[k] = z[k] + beta * p[k];
+			i++;
+		}
+		tol_error = sqrt(residualNorm2 / rhsNorm2);
+		iters = i;
+	}
+done:
+	*iters_out = iters;
+	*error_out = tol_error;
+	free(invdiag), free(residual), free(p), free(z), free(tmp);
+	return 0;
+}
+
+/* polysolve dirichlet_solve (un-vendored; restated from its documented behaviour, parity unpinned):
+ * g = b restricted to the Dirichlet dofs; b -= A g on the free dofs; rows and columns of the Dirichlet
+ * dofs are replaced by the identity; b keeps the Dirichlet values.  Call site:
+ * state/StateSolveLinear.cpp:27-29. */
+int pfo_dirichlet_modify(pfo_csc *A, double *b, const int32_t *boundary_nodes, int64_t n_boundary)
+{
+	const int32_t n = A->n;
+	char *is_b = (char *)calloc((size_t)(n ? n : 1), 1);
+	double *g = (double *)calloc((size_t)(n ? n : 1), sizeof(double));
+	double *Ag = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+	for (int64_t k = 0; k < n_boundary; ++k)
+	{
+		is_b[boundary_nodes[k]] = 1;
+		g[boundary_nodes[k]] = b[boundary_nodes[k]];
+	}
+	pfo_spmv(A, g, Ag);
+	for (int32_t r = 0; r < n; ++r)
+		if (!is_b[r])
+			b[r] -= Ag[r];
+	for (int32_t c = 0; c < n; ++c)
+		for (int32_t k = A->outer[c]; k < A->outer[c + 1]; ++k)
+		{
+			const int32_t r = A->inner[k];
+			if (is_b[r] || is_b[c])
+				A->values[k] = (r == c) ? 1.0 : 0.0;
+		}
+	free(is_b), free(g), free(Ag);
+	return 0;
+}

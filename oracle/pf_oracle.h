@@ -1,0 +1,140 @@
+/* pf_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement, in plain C, of the reference's (xDarkLemon/polyfem) element-assembly + CG hot path.
+ * It is the parity checker for the HIP library and the timed "cpu_baseline"; nothing in the product path
+ * (polyfem_amd/, include/) may call, link or import it.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the reference root).
+ * Arithmetic that lives in un-vendored third-party code (Eigen 3.4.0 dense 3x3 inverse/determinant,
+ * Eigen::ConjugateGradient, polysolve dirichlet_solve) is restated from its published algorithm and is
+ * marked "parity unpinned": the reference holds no golden vectors for it.
+ */
+#ifndef PF_ORACLE_H
+#define PF_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element kinds: number of local bases 4 / 10 / 8 / 27 */
+enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3 };
+/* local assemblers */
+enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2 };
+
+#define PFO_MAX_PTS 64
+#define PFO_MAX_LOC 27
+
+typedef struct
+{
+	int n_pts;
+	double pts[PFO_MAX_PTS][3];
+	double w[PFO_MAX_PTS];
+} pfo_quad;
+
+/* per-element evaluation (reference: assembler::ElementAssemblyValues) */
+typedef struct
+{
+	int n_pts, n_loc;
+	double val[PFO_MAX_LOC][PFO_MAX_PTS];          /* basis value at each point */
+	double grad[PFO_MAX_LOC][PFO_MAX_PTS][3];      /* reference-space gradient  */
+	double grad_t_m[PFO_MAX_LOC][PFO_MAX_PTS][3];  /* physical gradient          */
+	double det[PFO_MAX_PTS];
+	double jac_it[PFO_MAX_PTS][9];                 /* row-major 3x3 (J^{-1})^T   */
+	pfo_quad quad;
+} pfo_vals;
+
+typedef struct
+{
+	int kind;      /* basis kind                       */
+	int gkind;     /* geometry basis kind (P1TET for tets, Q1HEX for hexes unless isoparametric) */
+	int64_t n_el;
+	int64_t n_nodes;  /* number of global bases (scalar) */
+	int64_t n_gnodes;
+	const int32_t *conn;   /* n_el x n_loc  global basis index per local basis (Local2Global.index) */
+	const int32_t *gconn;  /* n_el x n_gloc geometry node index                                      */
+	const double *xyz;     /* n_gnodes x 3  geometry node positions (Local2Global.node)               */
+	int quad_order;        /* -1: reference default max(-1, 2(p-1)+1)                                 */
+} pfo_mesh;
+
+typedef struct
+{
+	int model;
+	int dim;          /* problem dimension (3) ; block size is 1 for the Laplacian, dim otherwise */
+	double lambda, mu; /* uniform Lame parameters */
+} pfo_material;
+
+/* compressed column storage with int32 indices = Eigen::SparseMatrix<double, ColMajor, int> */
+typedef struct
+{
+	int32_t n;
+	int64_t nnz;
+	int32_t *outer; /* n+1 */
+	int32_t *inner; /* nnz, ascending inside a column */
+	double *values;
+} pfo_csc;
+
+void pfo_csc_free(pfo_csc *m);
+
+int pfo_n_loc(int kind);
+int pfo_order_of(int kind);
+double pfo_lambda_from_E_nu(double E, double nu); /* 3-D */
+double pfo_mu_from_E_nu(double E, double nu);
+
+int pfo_tet_quadrature(int order, pfo_quad *q);
+int pfo_line_quadrature(int order, pfo_quad *q);
+int pfo_hex_quadrature(int order, pfo_quad *q);
+int pfo_element_quadrature(int kind, int quad_order, pfo_quad *q);
+
+void pfo_basis_value(int kind, int local_index, const double *pt, double *val);
+void pfo_basis_grad(int kind, int local_index, const double *pt, double *g3);
+void pfo_basis_nodes(int kind, double *nodes /* n_loc x 3 */);
+
+double pfo_determinant3(const double *m /* row-major 3x3 */);
+
+void pfo_compute_vals(const pfo_mesh *mesh, int64_t e, const pfo_quad *quad, pfo_vals *vals);
+
+/* local assemblers */
+void pfo_local_laplacian(const pfo_vals *v, int i, int j, const double *da, double *res1);
+void pfo_local_linear_elasticity(const pfo_vals *v, int i, int j, const double *da, double lambda, double mu, double *res9);
+double pfo_local_neohookean_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu);
+void pfo_local_neohookean_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G);
+void pfo_local_neohookean_hessian(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H);
+double pfo_local_linear_elasticity_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu);
+
+/* global assemblers; n_threads > 1 uses thread-local storages merged like the reference does */
+int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_threads, pfo_csc *out);
+double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads);
+int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, double *rhs);
+int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out);
+
+/* SpareMatrixCache restatement */
+typedef struct pfo_cache pfo_cache;
+pfo_cache *pfo_cache_create(int64_t size);
+pfo_cache *pfo_cache_clone(const pfo_cache *other);
+void pfo_cache_destroy(pfo_cache *c);
+void pfo_cache_set_zero(pfo_cache *c);
+void pfo_cache_add_value(pfo_cache *c, int e, int i, int j, double value);
+void pfo_cache_prune(pfo_cache *c);
+void pfo_cache_add(pfo_cache *c, const pfo_cache *o); /* operator+= */
+int pfo_cache_get_matrix(pfo_cache *c, int compute_mapping, pfo_csc *out);
+int64_t pfo_cache_mapping_size(const pfo_cache *c);
+int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, const double *x, pfo_cache *cache, pfo_csc *out);
+
+/* Dirichlet reduction */
+int pfo_full_to_reduced_matrix(const pfo_csc *full, const int32_t *removed_vars, int64_t n_removed, pfo_csc *reduced);
+
+/* sparse helpers */
+void pfo_spmv(const pfo_csc *A, const double *x, double *y);
+
+/* Eigen::ConjugateGradient with DiagonalPreconditioner (parity unpinned) */
+int pfo_cg(const pfo_csc *A, const double *b, double *x, int precond_jacobi, int max_iter, double tol, int *iters, double *error);
+
+/* polysolve::dirichlet_solve system modification (parity unpinned): A,b modified in place */
+int pfo_dirichlet_modify(pfo_csc *A, double *b, const int32_t *boundary_nodes, int64_t n_boundary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,300 @@
+"""ctypes binding of the CPU oracle (oracle/pf_oracle.c).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+bench.py's cpu_baseline leg and __graft_entry__.smoke() as the checker, never by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpf_oracle.so")
+
+P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN = 0, 1, 2
+MAX_PTS, MAX_LOC = 64, 27
+
+
+class Quad(C.Structure):
+    _fields_ = [("n_pts", C.c_int), ("pts", C.c_double * 3 * MAX_PTS), ("w", C.c_double * MAX_PTS)]
+
+
+class Vals(C.Structure):
+    _fields_ = [
+        ("n_pts", C.c_int), ("n_loc", C.c_int),
+        ("val", C.c_double * MAX_PTS * MAX_LOC),
+        ("grad", C.c_double * 3 * MAX_PTS * MAX_LOC),
+        ("grad_t_m", C.c_double * 3 * MAX_PTS * MAX_LOC),
+        ("det", C.c_double * MAX_PTS),
+        ("jac_it", C.c_double * 9 * MAX_PTS),
+        ("quad", Quad),
+    ]
+
+
+class MeshS(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("gkind", C.c_int), ("n_el", C.c_int64), ("n_nodes", C.c_int64), ("n_gnodes", C.c_int64),
+        ("conn", C.POINTER(C.c_int32)), ("gconn", C.POINTER(C.c_int32)), ("xyz", C.POINTER(C.c_double)),
+        ("quad_order", C.c_int),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [("model", C.c_int), ("dim", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double)]
+
+
+class Csc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("nnz", C.c_int64), ("outer", C.POINTER(C.c_int32)),
+                ("inner", C.POINTER(C.c_int32)), ("values", C.POINTER(C.c_double))]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "pf_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.pfo_assemble_energy.restype = C.c_double
+        L.pfo_determinant3.restype = C.c_double
+        L.pfo_lambda_from_E_nu.restype = C.c_double
+        L.pfo_mu_from_E_nu.restype = C.c_double
+        L.pfo_lambda_from_E_nu.argtypes = [C.c_double, C.c_double]
+        L.pfo_mu_from_E_nu.argtypes = [C.c_double, C.c_double]
+        L.pfo_local_neohookean_energy.restype = C.c_double
+        L.pfo_cache_create.restype = C.c_void_p
+        L.pfo_cache_clone.restype = C.c_void_p
+        L.pfo_cache_mapping_size.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def lame(E: float, nu: float):
+    L = lib()
+    return L.pfo_lambda_from_E_nu(E, nu), L.pfo_mu_from_E_nu(E, nu)
+
+
+def quadrature(kind: int, quad_order: int = -1):
+    q = Quad()
+    rc = lib().pfo_element_quadrature(kind, quad_order, C.byref(q))
+    assert rc == 0
+    n = q.n_pts
+    pts = np.array([[q.pts[k][c] for c in range(3)] for k in range(n)])
+    w = np.array([q.w[k] for k in range(n)])
+    return pts, w
+
+
+def tet_quadrature(order: int):
+    q = Quad()
+    assert lib().pfo_tet_quadrature(order, C.byref(q)) == 0
+    n = q.n_pts
+    return np.array([[q.pts[k][c] for c in range(3)] for k in range(n)]), np.array([q.w[k] for k in range(n)])
+
+
+def line_quadrature(order: int):
+    q = Quad()
+    assert lib().pfo_line_quadrature(order, C.byref(q)) == 0
+    n = q.n_pts
+    return np.array([q.pts[k][0] for k in range(n)]), np.array([q.w[k] for k in range(n)])
+
+
+def basis_value(kind: int, li: int, pt) -> float:
+    p = (C.c_double * 3)(*pt)
+    v = C.c_double()
+    lib().pfo_basis_value(kind, li, p, C.byref(v))
+    return v.value
+
+
+def basis_grad(kind: int, li: int, pt):
+    p = (C.c_double * 3)(*pt)
+    g = (C.c_double * 3)()
+    lib().pfo_basis_grad(kind, li, p, g)
+    return np.array(list(g))
+
+
+def basis_nodes(kind: int):
+    n = lib().pfo_n_loc(kind)
+    out = np.zeros((n, 3))
+    lib().pfo_basis_nodes(kind, _dp(out))
+    return out
+
+
+def determinant3(m) -> float:
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(9))
+    return lib().pfo_determinant3(_dp(a))
+
+
+class OMesh:
+    """Keeps the numpy arrays alive next to the C struct."""
+
+    def __init__(self, mesh):
+        self.conn = np.ascontiguousarray(mesh.conn, dtype=np.int32)
+        self.gconn = np.ascontiguousarray(mesh.gconn, dtype=np.int32)
+        self.xyz = np.ascontiguousarray(mesh.xyz, dtype=np.float64)
+        self.n_nodes = int(mesh.n_nodes)
+        self.s = MeshS(mesh.kind, mesh.gkind, self.conn.shape[0], mesh.n_nodes, self.xyz.shape[0],
+                       _ip(self.conn), _ip(self.gconn), _dp(self.xyz), mesh.quad_order)
+
+
+def _csc_to_numpy(m: Csc, free: bool = True):
+    n, nnz = m.n, m.nnz
+    outer = np.ctypeslib.as_array(m.outer, shape=(n + 1,)).copy()
+    inner = np.ctypeslib.as_array(m.inner, shape=(max(nnz, 1),))[:nnz].copy()
+    values = np.ctypeslib.as_array(m.values, shape=(max(nnz, 1),))[:nnz].copy()
+    if free:
+        lib().pfo_csc_free(C.byref(m))
+    return outer, inner, values
+
+
+def _numpy_to_csc(outer, inner, values):
+    outer = np.ascontiguousarray(outer, dtype=np.int32)
+    inner = np.ascontiguousarray(inner, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    m = Csc(outer.size - 1, inner.size, _ip(outer), _ip(inner), _dp(values))
+    return m, (outer, inner, values)
+
+
+def compute_vals(mesh, e: int, quad_order: int = -1):
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    q = Quad()
+    assert lib().pfo_element_quadrature(om.s.kind, quad_order, C.byref(q)) == 0
+    v = Vals()
+    lib().pfo_compute_vals(C.byref(om.s), C.c_int64(e), C.byref(q), C.byref(v))
+    n_loc, m = v.n_loc, v.n_pts
+    val = np.ctypeslib.as_array(v.val).reshape(MAX_LOC, MAX_PTS)[:n_loc, :m].copy()
+    grad = np.ctypeslib.as_array(v.grad).reshape(MAX_LOC, MAX_PTS, 3)[:n_loc, :m].copy()
+    gtm = np.ctypeslib.as_array(v.grad_t_m).reshape(MAX_LOC, MAX_PTS, 3)[:n_loc, :m].copy()
+    det = np.ctypeslib.as_array(v.det)[:m].copy()
+    jac_it = np.ctypeslib.as_array(v.jac_it).reshape(MAX_PTS, 3, 3)[:m].copy()
+    w = np.array([q.w[k] for k in range(m)])
+    return dict(val=val, grad=grad, grad_t_m=gtm, det=det, jac_it=jac_it, w=w)
+
+
+def assemble_linear(mesh, model: int, lam: float, mu: float, n_threads: int = 1):
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat = Material(model, 3, lam, mu)
+    out = Csc()
+    rc = lib().pfo_assemble_linear(C.byref(om.s), C.byref(mat), n_threads, C.byref(out))
+    assert rc == 0
+    return _csc_to_numpy(out)
+
+
+def assemble_energy(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1) -> float:
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat = Material(model, 3, lam, mu)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return lib().pfo_assemble_energy(C.byref(om.s), C.byref(mat), _dp(x), n_threads)
+
+
+def assemble_gradient(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1):
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat = Material(model, 3, lam, mu)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    rhs = np.zeros(om.n_nodes * 3)
+    rc = lib().pfo_assemble_gradient(C.byref(om.s), C.byref(mat), _dp(x), n_threads, _dp(rhs))
+    assert rc == 0
+    return rhs
+
+
+def assemble_hessian(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1):
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat = Material(model, 3, lam, mu)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = Csc()
+    rc = lib().pfo_assemble_hessian(C.byref(om.s), C.byref(mat), _dp(x), n_threads, C.byref(out))
+    assert rc == 0
+    return _csc_to_numpy(out)
+
+
+class Cache:
+    """utils::SpareMatrixCache restatement."""
+
+    def __init__(self, size: int = 0, _ptr=None):
+        self.p = C.c_void_p(_ptr if _ptr is not None else lib().pfo_cache_create(C.c_int64(size)))
+
+    def clone(self):
+        return Cache(_ptr=lib().pfo_cache_clone(self.p))
+
+    def add_value(self, e, i, j, v):
+        lib().pfo_cache_add_value(self.p, int(e), int(i), int(j), C.c_double(v))
+
+    def prune(self):
+        lib().pfo_cache_prune(self.p)
+
+    def get_matrix(self, compute_mapping: bool = True):
+        out = Csc()
+        rc = lib().pfo_cache_get_matrix(self.p, int(compute_mapping), C.byref(out))
+        assert rc == 0
+        return _csc_to_numpy(out)
+
+    def mapping_size(self) -> int:
+        return lib().pfo_cache_mapping_size(self.p)
+
+    def __del__(self):
+        try:
+            lib().pfo_cache_destroy(self.p)
+        except Exception:
+            pass
+
+
+def assemble_hessian_cached(mesh, model, lam, mu, x, cache: Cache):
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat = Material(model, 3, lam, mu)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = Csc()
+    rc = lib().pfo_assemble_hessian_cached(C.byref(om.s), C.byref(mat), _dp(x), cache.p, C.byref(out))
+    assert rc == 0
+    return _csc_to_numpy(out)
+
+
+def full_to_reduced_matrix(csc, removed_vars):
+    m, keep = _numpy_to_csc(*csc)
+    rv = np.ascontiguousarray(removed_vars, dtype=np.int32)
+    out = Csc()
+    rc = lib().pfo_full_to_reduced_matrix(C.byref(m), _ip(rv), C.c_int64(rv.size), C.byref(out))
+    assert rc == 0
+    return _csc_to_numpy(out)
+
+
+def spmv(csc, x):
+    m, keep = _numpy_to_csc(*csc)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().pfo_spmv(C.byref(m), _dp(x), _dp(y))
+    return y
+
+
+def cg(csc, b, x0=None, jacobi: bool = True, max_iter: int = 1000, tol: float = 1e-12):
+    m, keep = _numpy_to_csc(*csc)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+    iters, err = C.c_int(), C.c_double()
+    lib().pfo_cg(C.byref(m), _dp(b), _dp(x), int(jacobi), int(max_iter), C.c_double(tol), C.byref(iters), C.byref(err))
+    return x, iters.value, err.value
+
+
+def dirichlet_modify(csc, b, boundary_nodes):
+    outer, inner, values = (np.array(a, copy=True) for a in csc)
+    m, keep = _numpy_to_csc(outer, inner, values)
+    b = np.array(b, dtype=np.float64, copy=True)
+    bn = np.ascontiguousarray(boundary_nodes, dtype=np.int32)
+    lib().pfo_dirichlet_modify(C.byref(m), _dp(b), _ip(bn), C.c_int64(bn.size))
+    return keep, b
