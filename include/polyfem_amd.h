@@ -1,0 +1,171 @@
+/* polyfem_amd.h -- C ABI of the MI355X (gfx950) element-assembly + CG engine.
+ *
+ * This is the drop-in boundary for PolyFEM's assembly / Krylov hot path.  The reference has no FFI for it;
+ * the seam is the C++ member templates of `polyfem::assembler::Assembler<L>` / `NLAssembler<L>`
+ * (src/polyfem/assembler/Assembler.hpp:26-113) and the polysolve `LinearSolver` interface
+ * (call sites src/polyfem/solver/SparseNewtonDescentSolver.tpp:128-155, src/polyfem/state/StateSolveLinear.cpp:14-68).
+ * Each entry point names the reference interface it replaces.  A C++ shim with the reference's own signatures
+ * sits on top of this header (include/polyfem_amd/assembler.hpp).
+ *
+ * Conventions
+ *   - plain pointers and sizes; no exceptions cross the ABI; every call returns PFX_OK (0) or a negative code,
+ *     pfx_last_error() gives the text.
+ *   - one context per GPU and per host thread; the context owns all device memory.
+ *   - pointers are HOST pointers unless the function name ends in `_dev`; `_dev` functions take device
+ *     pointers, enqueue on the context's stream and do not synchronise.
+ *   - vectors are node-major interleaved: x[node*dim + c] (src/polyfem/assembler/NeoHookeanElasticity.cpp:380).
+ *   - indices are int32 for columns (reference: utils/Types.hpp:16-20) and int64 for row offsets.
+ */
+#ifndef POLYFEM_AMD_H
+#define POLYFEM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfx_ctx pfx_ctx;
+typedef int pfx_status;
+
+enum
+{
+	PFX_OK = 0,
+	PFX_ERR_ARG = -1,     /* bad argument / call order          */
+	PFX_ERR_HIP = -2,     /* HIP runtime error                  */
+	PFX_ERR_UNSUPPORTED = -3,
+	PFX_ERR_NUMERIC = -4, /* non-finite energy, J <= 0 ...      */
+	PFX_ERR_SIZE = -5     /* index width / capacity exceeded    */
+};
+
+/* element kinds: local node order of autogen/auto_p_bases.cpp:1080-1087,1328-1341 and
+ * autogen/auto_q_bases.cpp:1262-1275,1873-1903; geometry map is P1 (tets) / Q1 (hexes). */
+enum
+{
+	PFX_P1TET = 0,
+	PFX_P2TET = 1,
+	PFX_Q1HEX = 2,
+	PFX_Q2HEX = 3
+};
+
+/* local assemblers: Laplacian.cpp:7-18, LinearElasticity.cpp:21-54, NeoHookeanElasticity.cpp:250-565 */
+enum
+{
+	PFX_LAPLACIAN = 0,
+	PFX_LINEAR_ELASTICITY = 1,
+	PFX_NEOHOOKEAN = 2
+};
+
+enum
+{
+	PFX_PRECOND_IDENTITY = 0,
+	PFX_PRECOND_JACOBI = 1 /* Eigen::DiagonalPreconditioner, polysolve's default for Eigen::ConjugateGradient */
+};
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device`.  Replaces State::sending_data_to_GPU's role of owning the device
+ * copies (src/polyfem/state/StateSolveNonlinear.cpp:169-300). */
+pfx_status pfx_create(pfx_ctx **ctx, int device);
+void pfx_destroy(pfx_ctx *ctx);
+const char *pfx_last_error(const pfx_ctx *ctx);
+/* Use an existing hipStream_t (e.g. the caller's RCCL/compute stream); NULL = the context's own stream. */
+pfx_status pfx_set_stream(pfx_ctx *ctx, void *hip_stream);
+pfx_status pfx_synchronize(pfx_ctx *ctx);
+
+/* ---- mesh / material ------------------------------------------------------------------------------------------ */
+
+/* Flattened std::vector<ElementBases> bases / gbases (basis/ElementBases.hpp:16-104): conn[e*n_loc + j] =
+ * bases[e].bases[j].global()[0].index, gconn[e*n_gloc + j] = geometry node of gbases[e].bases[j],
+ * geom_xyz[3*g + c] = Local2Global.node.  Only conforming bases (global().size()==1, val==1) are accepted.
+ * quad_order: -1 = the reference default max(-1, 2(p-1)+1) (basis/FEBasis3d.cpp:1467,1506). */
+pfx_status pfx_set_mesh(pfx_ctx *ctx, int elem_kind, int64_t n_el, int64_t n_nodes, int64_t n_gnodes,
+						const int32_t *conn, const int32_t *gconn, const double *geom_xyz, int quad_order);
+
+/* Uniform Lame parameters (LameParameters::lambda_mu with constant expressions, utils/ElasticityUtils.cpp:490-517).
+ * dim = 3.  The block size of the system is 1 for the Laplacian and dim otherwise. */
+pfx_status pfx_set_material(pfx_ctx *ctx, int model, int dim, double lambda, double mu);
+
+/* ---- sparsity pattern (utils::SpareMatrixCache, utils/MatrixUtils.cpp:108-264) --------------------------------- */
+
+/* Builds, on the device, the structural pattern of the global matrix (every (n_loc*dim)^2 entry of every
+ * element, which is what NLAssembler::assemble_hessian inserts, Assembler.cpp:573-616) and the element ->
+ * entry map that later assemblies reuse.  nnz receives the number of scalar entries. */
+pfx_status pfx_build_pattern(pfx_ctx *ctx, int64_t *nnz);
+/* The pattern as scalar CSR (== Eigen's CSC arrays of the structurally symmetric matrix): row_ptr has
+ * n_nodes*dim+1 entries, col_idx nnz entries ascending within a row. */
+pfx_status pfx_get_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx);
+/* Current values in the order of pfx_get_pattern (explicit zeros included). */
+pfx_status pfx_get_values(pfx_ctx *ctx, double *values);
+
+/* ---- assembly ------------------------------------------------------------------------------------------------- */
+
+/* Assembler<L>::assemble (Assembler.cpp:100-317) for L = Laplacian / LinearElasticity: stiffness values are
+ * left on the device in the structural pattern; entries the reference never inserts (|local value| < 1e-30 in
+ * every element, Assembler.cpp:170-173) are remembered in a mask. */
+pfx_status pfx_assemble_linear(pfx_ctx *ctx);
+/* The matrix exactly as the reference's setFromTriplets leaves it: masked entries dropped. Call with
+ * row_ptr == NULL to get only *nnz. */
+pfx_status pfx_get_linear_csr(pfx_ctx *ctx, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values);
+
+/* NLAssembler<L>::assemble -> energy (Assembler.cpp:638-678) */
+pfx_status pfx_energy(pfx_ctx *ctx, const double *u, double *energy);
+/* NLAssembler<L>::assemble_grad (Assembler.cpp:427-504); g has n_nodes*dim entries */
+pfx_status pfx_gradient(pfx_ctx *ctx, const double *u, double *g);
+/* NLAssembler<L>::assemble_hessian (Assembler.cpp:506-636); values (may be NULL = keep on device) in
+ * pfx_get_pattern order.  project_to_psd != 0 is not supported yet (returns PFX_ERR_UNSUPPORTED). */
+pfx_status pfx_hessian(pfx_ctx *ctx, const double *u, int project_to_psd, double *values);
+
+/* Device-resident variants: d_u, d_energy (1 double), d_g are device pointers. */
+pfx_status pfx_energy_dev(pfx_ctx *ctx, const double *d_u, double *d_energy);
+pfx_status pfx_gradient_dev(pfx_ctx *ctx, const double *d_u, double *d_g);
+pfx_status pfx_hessian_dev(pfx_ctx *ctx, const double *d_u);
+
+/* ---- Dirichlet handling --------------------------------------------------------------------------------------- */
+
+/* Sorted list of constrained dofs.  Afterwards the solver works on the reduced system of
+ * utils::full_to_reduced_matrix (utils/MatrixUtils.cpp:408-469) without re-building a matrix. n == 0 clears. */
+pfx_status pfx_set_dirichlet(pfx_ctx *ctx, const int32_t *sorted_dofs, int64_t n);
+/* The reduced matrix itself (for hand-back / parity); row_ptr == NULL returns only *nnz and *n_reduced. */
+pfx_status pfx_get_reduced_csr(pfx_ctx *ctx, int64_t *n_reduced, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values);
+
+/* ---- Krylov solve (polysolve::LinearSolver, solver "Eigen::ConjugateGradient") -------------------------------- */
+
+/* y = A x on the current device matrix (full size, Dirichlet rows/cols act as identity when set). */
+pfx_status pfx_spmv(pfx_ctx *ctx, const double *x, double *y);
+pfx_status pfx_spmv_dev(pfx_ctx *ctx, const double *d_x, double *d_y);
+
+/* LinearSolver::analyzePattern + factorize + solve(b, x) for the CG solver: x_inout holds the initial guess
+ * (solveWithGuess) and receives the solution.  b and x are FULL size; constrained dofs are ignored on input
+ * and returned as 0.  Stopping rule of Eigen::ConjugateGradient: ||r||^2 < max(tol^2 ||b||^2, DBL_MIN);
+ * iters/rel_res are what getInfo() reports ("solver_iter", "solver_error"). */
+pfx_status pfx_cg(pfx_ctx *ctx, const double *b, double *x_inout, int precond, int max_iter, double tol,
+				  int *iters, double *rel_res);
+pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x_inout, int precond, int max_iter, double tol,
+					  int *iters, double *rel_res);
+
+/* polysolve::dirichlet_solve (call site state/StateSolveLinear.cpp:27-29): b holds the Dirichlet values at
+ * the constrained dofs set with pfx_set_dirichlet; solves the modified system and returns the full-size x. */
+pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol,
+							   int *iters, double *rel_res);
+
+/* ---- introspection for benchmarks ----------------------------------------------------------------------------- */
+
+typedef struct
+{
+	int64_t n_el, n_nodes, n_dofs, n_blocks, nnz;
+	int n_loc, n_pts, dim;
+	int64_t bytes_device; /* device memory held by the context */
+} pfx_info;
+pfx_status pfx_get_info(pfx_ctx *ctx, pfx_info *info);
+
+/* Average duration (ms) of the launches of one named kernel family since the last reset, measured with HIP events
+ * on the context's stream when timing is enabled.  Families: "local", "gather", "spmv", "cg_update", "cg_dir". */
+pfx_status pfx_timing_enable(pfx_ctx *ctx, int on);
+pfx_status pfx_timing_get(pfx_ctx *ctx, const char *family, double *avg_ms, int64_t *launches);
+pfx_status pfx_timing_reset(pfx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

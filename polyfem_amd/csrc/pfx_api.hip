@@ -1,0 +1,634 @@
+// pfx_api.hip -- the extern "C" entry points declared in include/polyfem_amd.h: context management, uploads and
+// the host-side sequencing of the kernels.  Reference call sites are cited in the header.
+#include "pfx_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace
+{
+	__global__ void k_set_fixed(const int32_t *__restrict__ dofs, int64_t n, uint8_t *__restrict__ fixed)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			fixed[dofs[k]] = 1;
+	}
+
+	// g = b on constrained dofs, 0 elsewhere
+	__global__ void k_dirichlet_lift(const double *__restrict__ b, const uint8_t *__restrict__ fixed, int64_t n, double *__restrict__ g)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			g[k] = fixed[k] ? b[k] : 0.0;
+	}
+
+	// rhs = b - A g on free dofs (constrained entries are ignored by the solver)
+	__global__ void k_dirichlet_rhs(const double *__restrict__ b, const double *__restrict__ Ag, const uint8_t *__restrict__ fixed, int64_t n, double *__restrict__ rhs)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			rhs[k] = fixed[k] ? 0.0 : b[k] - Ag[k];
+	}
+
+	__global__ void k_dirichlet_fill(const double *__restrict__ b, const uint8_t *__restrict__ fixed, int64_t n, double *__restrict__ x)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			if (fixed[k])
+				x[k] = b[k];
+	}
+
+	inline int grid_for(int64_t n, int block = 256)
+	{
+		int64_t g = (n + block - 1) / block;
+		if (g > 256 * 16)
+			g = 256 * 16;
+		if (g < 1)
+			g = 1;
+		return (int)g;
+	}
+
+	template <typename T>
+	void free_dev(T *&p)
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+	}
+
+	void release_pattern(pfx_ctx *ctx)
+	{
+		free_dev(ctx->d_node_ptr);
+		free_dev(ctx->d_node_col);
+		free_dev(ctx->d_blk_ptr);
+		free_dev(ctx->d_blk_src);
+		free_dev(ctx->d_ne_ptr);
+		free_dev(ctx->d_ne_src);
+		free_dev(ctx->d_values);
+		free_dev(ctx->d_mask);
+		free_dev(ctx->d_kloc);
+		free_dev(ctx->d_gloc);
+		free_dev(ctx->d_eloc);
+		free_dev(ctx->d_fixed);
+		free_dev(ctx->d_dirichlet);
+		free_dev(ctx->d_work);
+		free_dev(ctx->d_u);
+		free_dev(ctx->d_vec);
+		ctx->n_blocks = ctx->nnz = 0;
+		ctx->n_dirichlet = 0;
+		ctx->have_mask = false;
+	}
+
+	pfx_status need_pattern(pfx_ctx *ctx)
+	{
+		if (!ctx->d_node_ptr)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_build_pattern must be called first");
+		return PFX_OK;
+	}
+
+	pfx_status ensure_staging(pfx_ctx *ctx)
+	{
+		const int64_t n = ctx->n_dofs();
+		if (!ctx->d_u && pfx_alloc(ctx, &ctx->d_u, n))
+			return PFX_ERR_HIP;
+		if (!ctx->d_vec && pfx_alloc(ctx, &ctx->d_vec, n + 1))
+			return PFX_ERR_HIP;
+		return PFX_OK;
+	}
+
+	pfx_status check_flag(pfx_ctx *ctx)
+	{
+		int h = 0;
+		PFX_HIP(hipMemcpyAsync(&h, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		if (h)
+		{
+			PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream));
+			PFX_FAIL(PFX_ERR_NUMERIC, "non-positive deformation-gradient determinant in at least one element (energy is not finite)");
+		}
+		return PFX_OK;
+	}
+
+	void resolve_timers(pfx_ctx *ctx)
+	{
+		if (ctx->ev_pending.empty())
+			return;
+		(void)hipStreamSynchronize(ctx->stream);
+		for (auto &pp : ctx->ev_pending)
+		{
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, pp.e0, pp.e1) == hipSuccess)
+			{
+				auto &t = ctx->timers[pp.family];
+				t.total_ms += ms;
+				t.launches += 1;
+			}
+			ctx->ev_free.push_back(pp.e0);
+			ctx->ev_free.push_back(pp.e1);
+		}
+		ctx->ev_pending.clear();
+	}
+} // namespace
+
+extern "C"
+{
+
+	pfx_status pfx_create(pfx_ctx **out, int device)
+	{
+		if (!out)
+			return PFX_ERR_ARG;
+		*out = nullptr;
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+			return PFX_ERR_HIP;
+		if (hipSetDevice(device) != hipSuccess)
+			return PFX_ERR_HIP;
+		pfx_ctx *ctx = new (std::nothrow) pfx_ctx();
+		if (!ctx)
+			return PFX_ERR_ARG;
+		ctx->device = device;
+		if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+		{
+			delete ctx;
+			return PFX_ERR_HIP;
+		}
+		ctx->own_stream = true;
+		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * 3 * 1024) != hipSuccess)
+		{
+			delete ctx;
+			return PFX_ERR_HIP;
+		}
+		(void)hipMemset(ctx->d_flag, 0, sizeof(int));
+		*out = ctx;
+		return PFX_OK;
+	}
+
+	void pfx_destroy(pfx_ctx *ctx)
+	{
+		if (!ctx)
+			return;
+		(void)hipSetDevice(ctx->device);
+		(void)hipStreamSynchronize(ctx->stream);
+		release_pattern(ctx);
+		free_dev(ctx->d_conn);
+		free_dev(ctx->d_gconn);
+		free_dev(ctx->d_xyz);
+		free_dev(ctx->d_tab);
+		free_dev(ctx->d_flag);
+		free_dev(ctx->d_partials);
+		free_dev(ctx->d_cgstate);
+		resolve_timers(ctx);
+		for (auto e : ctx->ev_free)
+			(void)hipEventDestroy(e);
+		if (ctx->own_stream)
+			(void)hipStreamDestroy(ctx->stream);
+		delete ctx;
+	}
+
+	const char *pfx_last_error(const pfx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+	pfx_status pfx_set_stream(pfx_ctx *ctx, void *hip_stream)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		if (hip_stream)
+		{
+			if (ctx->own_stream)
+				(void)hipStreamDestroy(ctx->stream);
+			ctx->stream = (hipStream_t)hip_stream;
+			ctx->own_stream = false;
+		}
+		else if (!ctx->own_stream)
+		{
+			PFX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+			ctx->own_stream = true;
+		}
+		return PFX_OK;
+	}
+
+	pfx_status pfx_synchronize(pfx_ctx *ctx)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_mesh(pfx_ctx *ctx, int elem_kind, int64_t n_el, int64_t n_nodes, int64_t n_gnodes,
+							const int32_t *conn, const int32_t *gconn, const double *geom_xyz, int quad_order)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (elem_kind < PFX_P1TET || elem_kind > PFX_Q2HEX)
+			PFX_FAIL(PFX_ERR_ARG, "unknown element kind");
+		if (n_el <= 0 || n_nodes <= 0 || n_gnodes <= 0 || !conn || !gconn || !geom_xyz)
+			PFX_FAIL(PFX_ERR_ARG, "empty mesh or null pointer");
+		if (n_nodes >= ((int64_t)1 << 31) / 3)
+			PFX_FAIL(PFX_ERR_SIZE, "n_nodes*dim must fit the reference's 32-bit column index");
+		PFX_HIP(hipSetDevice(ctx->device));
+		pfx_fill_tables(elem_kind, quad_order, &ctx->h_tab);
+		if (ctx->h_tab.n_pts == 0)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "quadrature order not available for this element kind");
+		const int n_loc = ctx->h_tab.n_loc, n_gloc = ctx->h_tab.n_gloc;
+		// the kernels index device arrays with these values: validate them on the host
+		for (int64_t k = 0; k < n_el * n_loc; ++k)
+			if (conn[k] < 0 || conn[k] >= n_nodes)
+				PFX_FAIL(PFX_ERR_ARG, "conn entry out of range");
+		for (int64_t k = 0; k < n_el * n_gloc; ++k)
+			if (gconn[k] < 0 || gconn[k] >= n_gnodes)
+				PFX_FAIL(PFX_ERR_ARG, "gconn entry out of range");
+		release_pattern(ctx);
+		ctx->kind = elem_kind;
+		ctx->gkind = (elem_kind == PFX_Q1HEX || elem_kind == PFX_Q2HEX) ? PFX_Q1HEX : PFX_P1TET;
+		ctx->n_loc = n_loc;
+		ctx->n_gloc = n_gloc;
+		ctx->n_pts = ctx->h_tab.n_pts;
+		ctx->quad_order = quad_order;
+		ctx->n_el = n_el;
+		ctx->n_nodes = n_nodes;
+		ctx->n_gnodes = n_gnodes;
+		if (pfx_alloc(ctx, &ctx->d_conn, n_el * n_loc) || pfx_alloc(ctx, &ctx->d_gconn, n_el * n_gloc) || pfx_alloc(ctx, &ctx->d_xyz, n_gnodes * 3))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_conn, conn, sizeof(int32_t) * (size_t)(n_el * n_loc), hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_gconn, gconn, sizeof(int32_t) * (size_t)(n_el * n_gloc), hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_xyz, geom_xyz, sizeof(double) * (size_t)(n_gnodes * 3), hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_tab, &ctx->h_tab, sizeof(pfx_tables), hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_material(pfx_ctx *ctx, int model, int dim, double lambda, double mu)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (model < PFX_LAPLACIAN || model > PFX_NEOHOOKEAN)
+			PFX_FAIL(PFX_ERR_ARG, "unknown model");
+		if (dim != 3)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "only dim = 3 is implemented");
+		const int bs = (model == PFX_LAPLACIAN) ? 1 : dim;
+		if (ctx->d_node_ptr && bs != ctx->bs)
+			release_pattern(ctx); // block size changes the layout
+		ctx->model = model;
+		ctx->dim = dim;
+		ctx->bs = bs;
+		ctx->lambda = lambda;
+		ctx->mu = mu;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_build_pattern(pfx_ctx *ctx, int64_t *nnz)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0 || ctx->model < 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_mesh and pfx_set_material must be called first");
+		PFX_HIP(hipSetDevice(ctx->device));
+		release_pattern(ctx);
+		pfx_status rc = pfx_pattern_build(ctx);
+		if (rc)
+			return rc;
+		const int N = ctx->n_loc * ctx->bs;
+		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_kloc, ctx->n_el * N * N) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemsetAsync(ctx->d_values, 0, sizeof(double) * (size_t)ctx->nnz, ctx->stream));
+		PFX_HIP(hipMemsetAsync(ctx->d_fixed, 0, (size_t)ctx->n_dofs(), ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		if (nnz)
+			*nnz = ctx->nnz;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_get_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx)
+	{
+		if (!ctx || !row_ptr || !col_idx)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		return pfx_export_pattern(ctx, row_ptr, col_idx);
+	}
+
+	pfx_status pfx_get_values(pfx_ctx *ctx, double *values)
+	{
+		if (!ctx || !values)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		PFX_HIP(hipMemcpyAsync(values, ctx->d_values, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_assemble_linear(pfx_ctx *ctx)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->model != PFX_LAPLACIAN && ctx->model != PFX_LINEAR_ELASTICITY)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_assemble_linear needs the Laplacian or LinearElasticity model");
+		{
+			pfx_scoped_timer tm(ctx, "local");
+			pfx_status rc = pfx_launch_local_linear(ctx);
+			if (rc)
+				return rc;
+		}
+		{
+			pfx_scoped_timer tm(ctx, "gather");
+			pfx_status rc = pfx_launch_gather_matrix(ctx, true);
+			if (rc)
+				return rc;
+		}
+		ctx->have_mask = true;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_get_linear_csr(pfx_ctx *ctx, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values)
+	{
+		if (!ctx || !nnz)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (!ctx->have_mask)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_assemble_linear must be called first");
+		int64_t n_rows = 0;
+		return pfx_export_compressed(ctx, true, false, &n_rows, nnz, row_ptr, col_idx, values);
+	}
+
+	pfx_status pfx_energy_dev(pfx_ctx *ctx, const double *d_u, double *d_energy)
+	{
+		if (!ctx || !d_u || !d_energy)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		{
+			pfx_scoped_timer tm(ctx, "local_energy");
+			pfx_status rc = pfx_launch_local_nl(ctx, d_u, true, false, false);
+			if (rc)
+				return rc;
+		}
+		return pfx_launch_reduce_energy(ctx, d_energy);
+	}
+
+	pfx_status pfx_gradient_dev(pfx_ctx *ctx, const double *d_u, double *d_g)
+	{
+		if (!ctx || !d_u || !d_g)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		{
+			pfx_scoped_timer tm(ctx, "local_grad");
+			pfx_status rc = pfx_launch_local_nl(ctx, d_u, false, true, false);
+			if (rc)
+				return rc;
+		}
+		pfx_scoped_timer tm(ctx, "gather_vec");
+		return pfx_launch_gather_vector(ctx, d_g);
+	}
+
+	pfx_status pfx_hessian_dev(pfx_ctx *ctx, const double *d_u)
+	{
+		if (!ctx || !d_u)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		{
+			pfx_scoped_timer tm(ctx, "local");
+			pfx_status rc = pfx_launch_local_nl(ctx, d_u, false, false, true);
+			if (rc)
+				return rc;
+		}
+		ctx->have_mask = false;
+		pfx_scoped_timer tm(ctx, "gather");
+		return pfx_launch_gather_matrix(ctx, false);
+	}
+
+	pfx_status pfx_energy(pfx_ctx *ctx, const double *u, double *energy)
+	{
+		if (!ctx || !u || !energy)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return ctx->err.empty() ? PFX_ERR_ARG : PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc = pfx_energy_dev(ctx, ctx->d_u, ctx->d_vec + n);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(energy, ctx->d_vec + n, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+		rc = check_flag(ctx);
+		if (rc)
+		{
+			*energy = NAN;
+			return rc;
+		}
+		return PFX_OK;
+	}
+
+	pfx_status pfx_gradient(pfx_ctx *ctx, const double *u, double *g)
+	{
+		if (!ctx || !u || !g)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc = pfx_gradient_dev(ctx, ctx->d_u, ctx->d_vec);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(g, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+		return check_flag(ctx);
+	}
+
+	pfx_status pfx_hessian(pfx_ctx *ctx, const double *u, int project_to_psd, double *values)
+	{
+		if (!ctx || !u)
+			return PFX_ERR_ARG;
+		if (project_to_psd)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "project_to_psd is not implemented");
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc = pfx_hessian_dev(ctx, ctx->d_u);
+		if (rc)
+			return rc;
+		if (values)
+			PFX_HIP(hipMemcpyAsync(values, ctx->d_values, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+		return check_flag(ctx);
+	}
+
+	pfx_status pfx_set_dirichlet(pfx_ctx *ctx, const int32_t *sorted_dofs, int64_t n)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		const int64_t nd = ctx->n_dofs();
+		if (n < 0 || (n > 0 && !sorted_dofs))
+			PFX_FAIL(PFX_ERR_ARG, "bad Dirichlet list");
+		for (int64_t k = 0; k < n; ++k)
+		{
+			if (sorted_dofs[k] < 0 || sorted_dofs[k] >= nd)
+				PFX_FAIL(PFX_ERR_ARG, "Dirichlet dof out of range");
+			if (k > 0 && sorted_dofs[k] <= sorted_dofs[k - 1])
+				PFX_FAIL(PFX_ERR_ARG, "Dirichlet dofs must be strictly ascending");
+		}
+		PFX_HIP(hipMemsetAsync(ctx->d_fixed, 0, (size_t)nd, ctx->stream));
+		ctx->n_dirichlet = n;
+		if (n > 0)
+		{
+			if (pfx_alloc(ctx, &ctx->d_dirichlet, n))
+				return PFX_ERR_HIP;
+			PFX_HIP(hipMemcpyAsync(ctx->d_dirichlet, sorted_dofs, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+			hipLaunchKernelGGL(k_set_fixed, dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_dirichlet, n, ctx->d_fixed);
+		}
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_get_reduced_csr(pfx_ctx *ctx, int64_t *n_reduced, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values)
+	{
+		if (!ctx || !n_reduced || !nnz)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		return pfx_export_compressed(ctx, ctx->have_mask, true, n_reduced, nnz, row_ptr, col_idx, values);
+	}
+
+	pfx_status pfx_spmv_dev(pfx_ctx *ctx, const double *d_x, double *d_y)
+	{
+		if (!ctx || !d_x || !d_y)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		return pfx_launch_spmv(ctx, d_x, d_y);
+	}
+
+	pfx_status pfx_spmv(pfx_ctx *ctx, const double *x, double *y)
+	{
+		if (!ctx || !x || !y)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		PFX_HIP(hipMemcpyAsync(ctx->d_u, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc = pfx_launch_spmv(ctx, ctx->d_u, ctx->d_vec);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(y, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res)
+	{
+		if (!ctx || !d_b || !d_x || !iters || !rel_res)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (precond != PFX_PRECOND_IDENTITY && precond != PFX_PRECOND_JACOBI)
+			PFX_FAIL(PFX_ERR_ARG, "unknown preconditioner");
+		return pfx_cg_run(ctx, d_b, d_x, precond, max_iter, tol, iters, rel_res);
+	}
+
+	pfx_status pfx_cg(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol, int *iters, double *rel_res)
+	{
+		if (!ctx || !b || !x || !iters || !rel_res)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		PFX_HIP(hipMemcpyAsync(ctx->d_u, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_vec, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc = pfx_cg_dev(ctx, ctx->d_u, ctx->d_vec, precond, max_iter, tol, iters, rel_res);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(x, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol, int *iters, double *rel_res)
+	{
+		if (!ctx || !b || !x || !iters || !rel_res)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		hipStream_t st = ctx->stream;
+		double *d_b = nullptr, *d_g = nullptr;
+		PFX_HIP(hipMalloc((void **)&d_b, sizeof(double) * (size_t)n));
+		PFX_HIP(hipMalloc((void **)&d_g, sizeof(double) * (size_t)n));
+		PFX_HIP(hipMemcpyAsync(d_b, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+		// lift: g holds the prescribed values; A g with the UNMASKED operator moves them to the right-hand side
+		hipLaunchKernelGGL(k_dirichlet_lift, dim3(grid_for(n)), dim3(256), 0, st, d_b, ctx->d_fixed, n, d_g);
+		const int64_t nd_saved = ctx->n_dirichlet;
+		ctx->n_dirichlet = 0;
+		pfx_status rc = pfx_launch_spmv(ctx, d_g, ctx->d_vec);
+		ctx->n_dirichlet = nd_saved;
+		if (!rc)
+		{
+			hipLaunchKernelGGL(k_dirichlet_rhs, dim3(grid_for(n)), dim3(256), 0, st, d_b, ctx->d_vec, ctx->d_fixed, n, ctx->d_u);
+			PFX_HIP(hipMemsetAsync(ctx->d_vec, 0, sizeof(double) * (size_t)n, st));
+			rc = pfx_cg_run(ctx, ctx->d_u, ctx->d_vec, precond, max_iter, tol, iters, rel_res);
+		}
+		if (!rc)
+		{
+			hipLaunchKernelGGL(k_dirichlet_fill, dim3(grid_for(n)), dim3(256), 0, st, d_b, ctx->d_fixed, n, ctx->d_vec);
+			PFX_HIP(hipMemcpyAsync(x, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+		}
+		(void)hipFree(d_b);
+		(void)hipFree(d_g);
+		return rc;
+	}
+
+	pfx_status pfx_get_info(pfx_ctx *ctx, pfx_info *info)
+	{
+		if (!ctx || !info)
+			return PFX_ERR_ARG;
+		info->n_el = ctx->n_el;
+		info->n_nodes = ctx->n_nodes;
+		info->n_dofs = ctx->n_dofs();
+		info->n_blocks = ctx->n_blocks;
+		info->nnz = ctx->nnz;
+		info->n_loc = ctx->n_loc;
+		info->n_pts = ctx->n_pts;
+		info->dim = ctx->dim;
+		info->bytes_device = ctx->bytes_device;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_timing_enable(pfx_ctx *ctx, int on)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		resolve_timers(ctx);
+		ctx->timing = on != 0;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_timing_get(pfx_ctx *ctx, const char *family, double *avg_ms, int64_t *launches)
+	{
+		if (!ctx || !family || !avg_ms || !launches)
+			return PFX_ERR_ARG;
+		resolve_timers(ctx);
+		auto it = ctx->timers.find(family);
+		if (it == ctx->timers.end() || it->second.launches == 0)
+		{
+			*avg_ms = 0;
+			*launches = 0;
+			return PFX_OK;
+		}
+		*avg_ms = it->second.total_ms / (double)it->second.launches;
+		*launches = it->second.launches;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_timing_reset(pfx_ctx *ctx)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		resolve_timers(ctx);
+		ctx->timers.clear();
+		return PFX_OK;
+	}
+
+} // extern "C"

@@ -1,0 +1,342 @@
+// pfx_gather.hip -- local-to-global accumulation without atomics.
+//
+// The reference scatters element blocks into thread-local buffers and merges them afterwards
+// (src/polyfem/assembler/Assembler.cpp:185-189, 486, 602 and the merges at :227-301, :499-501, :627-632;
+// src/polyfem/utils/MatrixUtils.cpp:120-130 for the cached pattern).  On the GPU every global entry is instead
+// OWNED by one lane, which sums the contributions listed for it by the pattern build (ascending element order)
+// and writes the entry once with a coalesced store.  The result is independent of scheduling (bitwise
+// reproducible), needs no zero-fill of the value array and no FP64 atomics.
+//
+// Value layout = scalar CSR of the structural pattern: node g owns bs consecutive rows, row g*bs+m is the
+// contiguous range [bs*bs*node_ptr[g] + m*deg*bs, +deg*bs) with entry (slot s, n) at offset s*bs+n.
+#include "pfx_internal.h"
+
+namespace
+{
+	template <int NLOC, int BS>
+	__global__ __launch_bounds__(256) void k_gather_matrix(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr,
+															const uint32_t *__restrict__ blk_src, const double *__restrict__ kloc, int64_t n_nodes,
+															double *__restrict__ values, uint8_t *__restrict__ mask, int write_mask)
+	{
+		constexpr int N = NLOC * BS;
+		constexpr uint32_t NL2 = NLOC * NLOC;
+		const int lane = threadIdx.x & 63;
+		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+		for (int64_t g = wave; g < n_nodes; g += n_waves)
+		{
+			const int64_t b0 = node_ptr[g];
+			const int deg = (int)(node_ptr[g + 1] - b0);
+			const int rowlen = deg * BS;
+			const int items = rowlen * BS;
+			const int64_t base = b0 * (BS * BS);
+			for (int t = lane; t < items; t += 64)
+			{
+				int m = 0, rem = t;
+				if (BS > 1)
+				{
+					m = (t >= 2 * rowlen) ? 2 : (t >= rowlen ? 1 : 0);
+					rem = t - m * rowlen;
+				}
+				const int s = rem / BS, n = rem - s * BS;
+				const int64_t b = b0 + s;
+				const int64_t c0 = blk_ptr[b], c1 = blk_ptr[b + 1];
+				double sum = 0.0;
+				int any = 0;
+				for (int64_t c = c0; c < c1; ++c)
+				{
+					const uint32_t src = blk_src[c];
+					const uint32_t e = src / NL2;
+					const uint32_t ij = src - e * NL2;
+					const uint32_t i = ij / NLOC, j = ij - i * NLOC;
+					const double v = kloc[(int64_t)e * (N * N) + (i * BS + m) * N + (j * BS + n)];
+					sum += v;
+					any |= (v != 0.0);
+				}
+				values[base + t] = sum;
+				if (write_mask)
+					mask[base + t] = (uint8_t)any;
+			}
+		}
+	}
+
+	template <int NLOC, int BS>
+	__global__ __launch_bounds__(256) void k_gather_vector(const int64_t *__restrict__ ne_ptr, const uint32_t *__restrict__ ne_src,
+															const double *__restrict__ gloc, int64_t n_nodes, double *__restrict__ out)
+	{
+		const int64_t n = n_nodes * BS;
+		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t g = r / BS;
+			const int d = (int)(r - g * BS);
+			double sum = 0.0;
+			for (int64_t c = ne_ptr[g]; c < ne_ptr[g + 1]; ++c)
+			{
+				const double v = gloc[(int64_t)ne_src[c] * BS + d];
+				if (fabs(v) < 1e-30) // Assembler.cpp:476
+					continue;
+				sum += v;
+			}
+			out[r] = sum;
+		}
+	}
+
+	// two-stage, fixed-order sum of the per-element energies
+	__global__ __launch_bounds__(256) void k_reduce_stage1(const double *__restrict__ in, int64_t n, double *__restrict__ partial)
+	{
+		__shared__ double sh[256];
+		double acc = 0.0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			acc += in[k];
+		sh[threadIdx.x] = acc;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1)
+		{
+			if ((int)threadIdx.x < s)
+				sh[threadIdx.x] += sh[threadIdx.x + s];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0)
+			partial[blockIdx.x] = sh[0];
+	}
+
+	__global__ __launch_bounds__(256) void k_reduce_stage2(const double *__restrict__ partial, int n, double *__restrict__ out)
+	{
+		__shared__ double sh[256];
+		double acc = 0.0;
+		for (int k = threadIdx.x; k < n; k += 256)
+			acc += partial[k];
+		sh[threadIdx.x] = acc;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1)
+		{
+			if ((int)threadIdx.x < s)
+				sh[threadIdx.x] += sh[threadIdx.x + s];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0)
+			*out = sh[0];
+	}
+
+	// ---- export of value-dependent / reduced patterns ------------------------------------------------------
+
+	// per scalar row: number of kept entries; keep = mask (if any) && row/col not constrained (if drop_fixed)
+	__global__ void k_count_kept(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes, int bs,
+								 const uint8_t *__restrict__ mask, const uint8_t *__restrict__ fixed, int64_t *__restrict__ cnt)
+	{
+		const int64_t n_rows = n_nodes * bs;
+		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+		{
+			if (fixed && fixed[r])
+				continue; // constrained rows are compacted away: they get no slot in cnt (handled by the caller's map)
+			const int64_t g = r / bs;
+			const int m = (int)(r - g * bs);
+			const int64_t b0 = node_ptr[g], deg = node_ptr[g + 1] - b0;
+			const int64_t start = b0 * bs * bs + (int64_t)m * deg * bs;
+			int64_t c = 0;
+			for (int64_t s = 0; s < deg; ++s)
+				for (int n = 0; n < bs; ++n)
+				{
+					const int64_t col = (int64_t)node_col[b0 + s] * bs + n;
+					if (fixed && fixed[col])
+						continue;
+					if (mask && !mask[start + s * bs + n])
+						continue;
+					++c;
+				}
+			cnt[r] = c;
+		}
+	}
+
+	__global__ void k_write_kept(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes, int bs,
+								 const uint8_t *__restrict__ mask, const uint8_t *__restrict__ fixed, const int64_t *__restrict__ newrow,
+								 const int64_t *__restrict__ off, const double *__restrict__ values,
+								 int64_t *__restrict__ row_ptr, int32_t *__restrict__ col_idx, double *__restrict__ out_values)
+	{
+		const int64_t n_rows = n_nodes * bs;
+		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+		{
+			if (fixed && fixed[r])
+				continue;
+			const int64_t g = r / bs;
+			const int m = (int)(r - g * bs);
+			const int64_t b0 = node_ptr[g], deg = node_ptr[g + 1] - b0;
+			const int64_t start = b0 * bs * bs + (int64_t)m * deg * bs;
+			int64_t w = off[r];
+			row_ptr[newrow ? newrow[r] : r] = w;
+			for (int64_t s = 0; s < deg; ++s)
+				for (int n = 0; n < bs; ++n)
+				{
+					const int64_t col = (int64_t)node_col[b0 + s] * bs + n;
+					if (fixed && fixed[col])
+						continue;
+					if (mask && !mask[start + s * bs + n])
+						continue;
+					col_idx[w] = (int32_t)(newrow ? newrow[col] : col);
+					out_values[w] = values[start + s * bs + n];
+					++w;
+				}
+		}
+	}
+
+	__global__ void k_free_flag(const uint8_t *__restrict__ fixed, int64_t n, int64_t *__restrict__ flag)
+	{
+		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+			flag[r] = fixed[r] ? 0 : 1;
+	}
+
+	inline int grid_for(int64_t n, int block = 256)
+	{
+		int64_t g = (n + block - 1) / block;
+		if (g > 256 * 16)
+			g = 256 * 16;
+		if (g < 1)
+			g = 1;
+		return (int)g;
+	}
+
+	template <int NLOC, int BS>
+	void launch_gm(pfx_ctx *ctx, bool write_mask)
+	{
+		const int64_t waves = ctx->n_nodes;
+		int64_t blocks = (waves + 3) / 4;
+		if (blocks > 256 * 32)
+			blocks = 256 * 32;
+		hipLaunchKernelGGL((k_gather_matrix<NLOC, BS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
+						   ctx->d_blk_src, ctx->d_kloc, ctx->n_nodes, ctx->d_values, ctx->d_mask, write_mask ? 1 : 0);
+	}
+
+	template <int NLOC, int BS>
+	void launch_gv(pfx_ctx *ctx, double *d_g)
+	{
+		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3(grid_for(ctx->n_nodes * BS)), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
+						   ctx->d_gloc, ctx->n_nodes, d_g);
+	}
+} // namespace
+
+#define PFX_DISPATCH_NLOC_BS(FN, ...)                          \
+	switch (ctx->n_loc * 10 + ctx->bs)                         \
+	{                                                          \
+	case 41:                                                   \
+		FN<4, 1>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 43:                                                   \
+		FN<4, 3>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 101:                                                  \
+		FN<10, 1>(__VA_ARGS__);                                \
+		break;                                                 \
+	case 103:                                                  \
+		FN<10, 3>(__VA_ARGS__);                                \
+		break;                                                 \
+	case 81:                                                   \
+		FN<8, 1>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 83:                                                   \
+		FN<8, 3>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 271:                                                  \
+		FN<27, 1>(__VA_ARGS__);                                \
+		break;                                                 \
+	case 273:                                                  \
+		FN<27, 3>(__VA_ARGS__);                                \
+		break;                                                 \
+	default:                                                   \
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "unsupported n_loc/bs"); \
+	}
+
+pfx_status pfx_launch_gather_matrix(pfx_ctx *ctx, bool write_mask)
+{
+	PFX_DISPATCH_NLOC_BS(launch_gm, ctx, write_mask);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g)
+{
+	PFX_DISPATCH_NLOC_BS(launch_gv, ctx, d_g);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy)
+{
+	const int nb = 256;
+	hipLaunchKernelGGL(k_reduce_stage1, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_eloc, ctx->n_el, ctx->d_partials);
+	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, nb, d_energy);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+#include <rocprim/rocprim.hpp>
+
+// Exports the device matrix as a compressed scalar CSR after dropping (a) entries absent from the reference's
+// value-dependent pattern (use_mask; Assembler.cpp:170-173) and/or (b) constrained rows and columns with
+// renumbering (drop_fixed; utils/MatrixUtils.cpp:429-464).  row_ptr == nullptr: only sizes are returned.
+pfx_status pfx_export_compressed(pfx_ctx *ctx, bool use_mask, bool drop_fixed, int64_t *n_rows_out, int64_t *nnz_out,
+								 int64_t *row_ptr, int32_t *col_idx, double *values)
+{
+	const int64_t n_rows = ctx->n_dofs();
+	hipStream_t st = ctx->stream;
+	const uint8_t *mask = use_mask ? ctx->d_mask : nullptr;
+	const uint8_t *fixed = (drop_fixed && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
+	int64_t *cnt = nullptr, *off = nullptr, *newrow = nullptr, *fl = nullptr;
+	void *tmp = nullptr;
+	size_t tb = 0;
+	PFX_HIP(hipMalloc((void **)&cnt, sizeof(int64_t) * (size_t)(n_rows + 1)));
+	PFX_HIP(hipMalloc((void **)&off, sizeof(int64_t) * (size_t)(n_rows + 1)));
+	PFX_HIP(hipMemsetAsync(cnt, 0, sizeof(int64_t) * (size_t)(n_rows + 1), st));
+	hipLaunchKernelGGL(k_count_kept, dim3(grid_for(n_rows)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, mask, fixed, cnt);
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, cnt, off, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipMalloc(&tmp, tb));
+	PFX_HIP(rocprim::exclusive_scan(tmp, tb, cnt, off, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+	int64_t total = 0, n_red = n_rows;
+	PFX_HIP(hipMemcpyAsync(&total, off + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	tmp = nullptr;
+	if (fixed)
+	{
+		PFX_HIP(hipMalloc((void **)&fl, sizeof(int64_t) * (size_t)(n_rows + 1)));
+		PFX_HIP(hipMalloc((void **)&newrow, sizeof(int64_t) * (size_t)(n_rows + 1)));
+		PFX_HIP(hipMemsetAsync(fl, 0, sizeof(int64_t) * (size_t)(n_rows + 1), st));
+		hipLaunchKernelGGL(k_free_flag, dim3(grid_for(n_rows)), dim3(256), 0, st, fixed, n_rows, fl);
+		tb = 0;
+		PFX_HIP(rocprim::exclusive_scan(nullptr, tb, fl, newrow, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(hipMalloc(&tmp, tb));
+		PFX_HIP(rocprim::exclusive_scan(tmp, tb, fl, newrow, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(hipMemcpyAsync(&n_red, newrow + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		(void)hipFree(tmp);
+		tmp = nullptr;
+	}
+	*n_rows_out = n_red;
+	*nnz_out = total;
+	if (row_ptr)
+	{
+		int64_t *d_rp = nullptr;
+		int32_t *d_ci = nullptr;
+		double *d_v = nullptr;
+		PFX_HIP(hipMalloc((void **)&d_rp, sizeof(int64_t) * (size_t)(n_red + 1)));
+		PFX_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * (size_t)(total ? total : 1)));
+		PFX_HIP(hipMalloc((void **)&d_v, sizeof(double) * (size_t)(total ? total : 1)));
+		hipLaunchKernelGGL(k_write_kept, dim3(grid_for(n_rows)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, mask, fixed,
+						   newrow, off, ctx->d_values, d_rp, d_ci, d_v);
+		PFX_HIP(hipMemcpyAsync(row_ptr, d_rp, sizeof(int64_t) * (size_t)n_red, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(col_idx, d_ci, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(values, d_v, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		row_ptr[n_red] = total;
+		(void)hipFree(d_rp);
+		(void)hipFree(d_ci);
+		(void)hipFree(d_v);
+	}
+	(void)hipFree(cnt);
+	(void)hipFree(off);
+	if (fl)
+		(void)hipFree(fl);
+	if (newrow)
+		(void)hipFree(newrow);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}

@@ -1,0 +1,175 @@
+// pfx_internal.h -- context layout and launch helpers shared by the HIP translation units of libpolyfem_amd.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstring>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/polyfem_amd.h"
+
+#define PFX_MAX_LOC 27
+#define PFX_MAX_GLOC 8
+#define PFX_MAX_PTS 27
+
+// Reference-element tables of one element kind, resident in device memory.
+struct pfx_tables
+{
+	int n_loc, n_gloc, n_pts;
+	double w[PFX_MAX_PTS];                        // quadrature weights (already /6 for tets)
+	double grad[PFX_MAX_PTS][PFX_MAX_LOC][3];     // d(basis j)/d(ref coord) at point k
+	double ggrad[PFX_MAX_PTS][PFX_MAX_GLOC][3];   // same for the geometry bases
+};
+
+struct pfx_timer_family
+{
+	double total_ms = 0;
+	int64_t launches = 0;
+};
+
+struct pfx_ctx
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	std::string err;
+
+	// mesh
+	int kind = -1, gkind = -1, n_loc = 0, n_gloc = 0, n_pts = 0, quad_order = -1;
+	int64_t n_el = 0, n_nodes = 0, n_gnodes = 0;
+	int32_t *d_conn = nullptr, *d_gconn = nullptr;
+	double *d_xyz = nullptr;
+	pfx_tables *d_tab = nullptr;
+	pfx_tables h_tab;
+
+	// material
+	int model = -1, dim = 3, bs = 0; // bs = block size (1 or dim)
+	double lambda = 0, mu = 0;
+
+	// pattern: node-block structure; the scalar CSR is implied (row gi*bs+m holds, for every neighbour slot s,
+	// the bs columns node_col[s]*bs+n) and the values array IS that CSR's value array.
+	int64_t n_blocks = 0, nnz = 0;
+	int64_t *d_node_ptr = nullptr; // n_nodes+1
+	int32_t *d_node_col = nullptr; // n_blocks, ascending per node
+	int64_t *d_blk_ptr = nullptr;  // n_blocks+1 -> contribution list
+	uint32_t *d_blk_src = nullptr; // n_el*n_loc^2 : e*n_loc^2 + i*n_loc + j, ascending e inside a block
+	int64_t *d_ne_ptr = nullptr;   // n_nodes+1 -> incident (element, local index) list
+	uint32_t *d_ne_src = nullptr;  // n_el*n_loc : e*n_loc + i, ascending
+	double *d_values = nullptr;    // nnz
+	uint8_t *d_mask = nullptr;     // nnz, 1 = entry exists in the reference's value-dependent pattern
+	bool have_mask = false;
+
+	// scratch for the two-pass (local blocks, then per-row sums) assembly
+	double *d_kloc = nullptr; // n_el * (n_loc*bs)^2
+	double *d_gloc = nullptr; // n_el * n_loc*bs
+	double *d_eloc = nullptr; // n_el
+	int *d_flag = nullptr;    // numeric failure flag
+
+	// Dirichlet
+	int64_t n_dirichlet = 0;
+	uint8_t *d_fixed = nullptr; // n_dofs, 1 = constrained
+	int32_t *d_dirichlet = nullptr;
+
+	// solver work vectors
+	double *d_work = nullptr; // 6 * n_dofs
+	double *d_partials = nullptr;
+	int *d_cgstate = nullptr;
+	double *d_u = nullptr, *d_vec = nullptr; // staging for host-pointer entry points
+
+	int64_t bytes_device = 0;
+
+	bool timing = false;
+	std::map<std::string, pfx_timer_family> timers;
+	struct pending_pair
+	{
+		const char *family;
+		hipEvent_t e0, e1;
+	};
+	std::vector<hipEvent_t> ev_free;
+	std::vector<pending_pair> ev_pending;
+
+	int64_t n_dofs() const { return n_nodes * bs; }
+};
+
+#define PFX_HIP(call)                                                                                        \
+	do                                                                                                       \
+	{                                                                                                        \
+		hipError_t e_ = (call);                                                                              \
+		if (e_ != hipSuccess)                                                                                \
+		{                                                                                                    \
+			ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                   \
+			return PFX_ERR_HIP;                                                                              \
+		}                                                                                                    \
+	} while (0)
+
+#define PFX_FAIL(code, msg)  \
+	do                       \
+	{                        \
+		ctx->err = (msg);    \
+		return (code);       \
+	} while (0)
+
+template <typename T>
+pfx_status pfx_alloc(pfx_ctx *ctx, T **p, int64_t count)
+{
+	if (*p)
+	{
+		(void)hipFree(*p);
+		*p = nullptr;
+	}
+	if (count <= 0)
+		count = 1;
+	PFX_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)count));
+	ctx->bytes_device += (int64_t)sizeof(T) * count;
+	return PFX_OK;
+}
+
+// Times one kernel family with a pair of HIP events recorded on the context's stream; nothing synchronises
+// until pfx_timing_get()/pfx_timing_reset() resolves the pending pairs.
+struct pfx_scoped_timer
+{
+	pfx_ctx *ctx;
+	const char *family;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	pfx_scoped_timer(pfx_ctx *c, const char *f) : ctx(c), family(f)
+	{
+		if (!ctx->timing)
+			return;
+		if (ctx->ev_free.size() < 2)
+		{
+			hipEvent_t a, b;
+			if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+				return;
+			ctx->ev_free.push_back(a);
+			ctx->ev_free.push_back(b);
+		}
+		e0 = ctx->ev_free.back();
+		ctx->ev_free.pop_back();
+		e1 = ctx->ev_free.back();
+		ctx->ev_free.pop_back();
+		(void)hipEventRecord(e0, ctx->stream);
+	}
+	~pfx_scoped_timer()
+	{
+		if (!e0)
+			return;
+		(void)hipEventRecord(e1, ctx->stream);
+		ctx->ev_pending.push_back({family, e0, e1});
+	}
+};
+
+// translation-unit entry points
+void pfx_fill_tables(int kind, int quad_order, pfx_tables *t);
+pfx_status pfx_pattern_build(pfx_ctx *ctx);
+pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                                                   // strict arithmetic
+pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess); // NeoHookean
+pfx_status pfx_launch_gather_matrix(pfx_ctx *ctx, bool write_mask);
+pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
+pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
+pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
+pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res);
+pfx_status pfx_export_compressed(pfx_ctx *ctx, bool use_mask, bool drop_fixed, int64_t *n_rows, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values);
+pfx_status pfx_export_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx);

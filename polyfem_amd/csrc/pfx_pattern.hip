@@ -1,0 +1,233 @@
+// pfx_pattern.hip -- device-side construction of the global sparsity pattern and of the element -> entry maps.
+//
+// Replaces what utils::SpareMatrixCache learns during the reference's first Hessian assembly
+// (src/polyfem/utils/MatrixUtils.cpp:108-116 records every add_value call, :171-241 freezes the CSC arrays and
+// the per-element value-index list `second_cache_`).  Here the same information is produced without assembling
+// anything:
+//   1. every (element e, local row i, local col j) emits the key (node_i, node_j); a stable radix sort of the
+//      keys with the payload e*n_loc^2 + i*n_loc + j groups all contributions of one node pair, in ascending
+//      element order (a fixed summation order, so assembly is deterministic);
+//   2. run heads of the sorted keys are the node blocks: node_ptr / node_col (ascending columns per row, as in
+//      Eigen's compressed storage), and blk_ptr delimits each block's contribution list;
+//   3. the same is done per node for (element, local index) incidences, used by the gradient.
+// The scalar CSR of a block size bs > 1 is implied: row node*bs+m owns, per neighbour slot s, the bs columns
+// node_col[s]*bs+n; it is materialised only when the caller asks for it (pfx_export_pattern).
+#include "pfx_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace
+{
+	__global__ void k_pair_keys(const int32_t *__restrict__ conn, int64_t n_items, int n_loc, int64_t n_nodes,
+								uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+	{
+		const int nl2 = n_loc * n_loc;
+		for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_items; idx += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t e = idx / nl2;
+			const int ij = (int)(idx - e * nl2);
+			const int i = ij / n_loc, j = ij - i * n_loc;
+			const uint64_t gi = (uint64_t)conn[e * n_loc + i], gj = (uint64_t)conn[e * n_loc + j];
+			keys[idx] = gi * (uint64_t)n_nodes + gj;
+			vals[idx] = (uint32_t)idx;
+		}
+	}
+
+	__global__ void k_node_keys(const int32_t *__restrict__ conn, int64_t n_items, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+	{
+		for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_items; idx += (int64_t)gridDim.x * blockDim.x)
+		{
+			keys[idx] = (uint32_t)conn[idx];
+			vals[idx] = (uint32_t)idx;
+		}
+	}
+
+	struct head_flag
+	{
+		const uint64_t *keys;
+		__host__ __device__ int64_t operator()(int64_t k) const { return (k == 0 || keys[k] != keys[k - 1]) ? 1 : 0; }
+	};
+
+	__global__ void k_fill_blocks(const uint64_t *__restrict__ keys, const int64_t *__restrict__ pos, int64_t n_items, int64_t n_nodes,
+								  int64_t *__restrict__ blk_ptr, int32_t *__restrict__ node_col, int64_t *__restrict__ deg)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const uint64_t key = keys[k];
+			if (k == 0 || key != keys[k - 1])
+			{
+				const int64_t b = pos[k];
+				blk_ptr[b] = k;
+				const uint64_t gi = key / (uint64_t)n_nodes;
+				node_col[b] = (int32_t)(key - gi * (uint64_t)n_nodes);
+				atomicAdd((unsigned long long *)&deg[gi], 1ull);
+			}
+		}
+	}
+
+	__global__ void k_count_u32(const uint32_t *__restrict__ keys, int64_t n_items, int64_t *__restrict__ cnt)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * blockDim.x)
+			atomicAdd((unsigned long long *)&cnt[keys[k]], 1ull);
+	}
+
+	__global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
+
+	// scalar CSR export: one thread per scalar row
+	__global__ void k_export_pattern(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes, int bs,
+									 int64_t *__restrict__ row_ptr, int32_t *__restrict__ col_idx)
+	{
+		const int64_t n_rows = n_nodes * bs;
+		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * blockDim.x)
+		{
+			if (r == n_rows)
+			{
+				row_ptr[r] = node_ptr[n_nodes] * bs * bs;
+				continue;
+			}
+			const int64_t g = r / bs;
+			const int m = (int)(r - g * bs);
+			const int64_t b0 = node_ptr[g], deg = node_ptr[g + 1] - b0;
+			const int64_t start = b0 * bs * bs + (int64_t)m * deg * bs;
+			row_ptr[r] = start;
+			for (int64_t s = 0; s < deg; ++s)
+				for (int n = 0; n < bs; ++n)
+					col_idx[start + s * bs + n] = node_col[b0 + s] * bs + n;
+		}
+	}
+
+	int bits_for(uint64_t v)
+	{
+		int b = 1;
+		while (b < 64 && (v >> b))
+			++b;
+		return b;
+	}
+
+	inline int grid_for(int64_t n, int block = 256)
+	{
+		int64_t g = (n + block - 1) / block;
+		if (g > 256 * 16)
+			g = 256 * 16;
+		if (g < 1)
+			g = 1;
+		return (int)g;
+	}
+} // namespace
+
+pfx_status pfx_pattern_build(pfx_ctx *ctx)
+{
+	const int n_loc = ctx->n_loc;
+	const int64_t n_el = ctx->n_el, n_nodes = ctx->n_nodes;
+	const int64_t n_pair = n_el * n_loc * n_loc;
+	const int64_t n_inc = n_el * n_loc;
+	if (n_pair >= ((int64_t)1 << 32))
+		PFX_FAIL(PFX_ERR_SIZE, "n_el * n_loc^2 exceeds the 32-bit contribution index; partition the mesh over more devices");
+	hipStream_t st = ctx->stream;
+
+	// ---- node-pair blocks ----------------------------------------------------------------------------------
+	uint64_t *keys_a = nullptr, *keys_b = nullptr;
+	uint32_t *vals_a = nullptr;
+	int64_t *pos = nullptr, *deg = nullptr;
+	void *tmp = nullptr;
+	size_t tmp_bytes = 0;
+	PFX_HIP(hipMalloc((void **)&keys_a, sizeof(uint64_t) * (size_t)n_pair));
+	PFX_HIP(hipMalloc((void **)&keys_b, sizeof(uint64_t) * (size_t)n_pair));
+	PFX_HIP(hipMalloc((void **)&vals_a, sizeof(uint32_t) * (size_t)n_pair));
+	if (pfx_alloc(ctx, &ctx->d_blk_src, n_pair))
+		return PFX_ERR_HIP;
+	hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, ctx->d_conn, n_pair, n_loc, n_nodes, keys_a, vals_a);
+	const int end_bit = bits_for((uint64_t)n_nodes * (uint64_t)n_nodes);
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
+	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	tmp = nullptr;
+	(void)hipFree(keys_a);
+	(void)hipFree(vals_a);
+
+	// positions of run heads
+	PFX_HIP(hipMalloc((void **)&pos, sizeof(int64_t) * (size_t)(n_pair + 1)));
+	auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), head_flag{keys_b});
+	tmp_bytes = 0;
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pos, (int64_t)0, (size_t)n_pair, rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
+	PFX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pos, (int64_t)0, (size_t)n_pair, rocprim::plus<int64_t>(), st));
+	int64_t last_pos = 0;
+	PFX_HIP(hipMemcpyAsync(&last_pos, pos + (n_pair - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	tmp = nullptr;
+	// the last item is a head iff its key differs from its predecessor; count = pos[last] + flag[last]
+	uint64_t k_last[2] = {0, 0};
+	if (n_pair >= 2)
+		PFX_HIP(hipMemcpy(k_last, keys_b + (n_pair - 2), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	const int64_t last_flag = (n_pair == 1) ? 1 : (k_last[0] != k_last[1] ? 1 : 0);
+	const int64_t n_blocks = last_pos + last_flag;
+	ctx->n_blocks = n_blocks;
+	ctx->nnz = n_blocks * ctx->bs * ctx->bs;
+
+	if (pfx_alloc(ctx, &ctx->d_blk_ptr, n_blocks + 1) || pfx_alloc(ctx, &ctx->d_node_col, n_blocks) || pfx_alloc(ctx, &ctx->d_node_ptr, n_nodes + 1))
+		return PFX_ERR_HIP;
+	PFX_HIP(hipMalloc((void **)&deg, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+	PFX_HIP(hipMemsetAsync(deg, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
+	hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b, pos, n_pair, n_nodes, ctx->d_blk_ptr, ctx->d_node_col, deg);
+	hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, st, ctx->d_blk_ptr + n_blocks, n_pair);
+	tmp_bytes = 0;
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
+	PFX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, deg, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	tmp = nullptr;
+	(void)hipFree(pos);
+	(void)hipFree(keys_b);
+
+	// ---- node -> (element, local index) incidences ---------------------------------------------------------
+	uint32_t *nk_a = nullptr, *nk_b = nullptr, *nv_a = nullptr;
+	PFX_HIP(hipMalloc((void **)&nk_a, sizeof(uint32_t) * (size_t)n_inc));
+	PFX_HIP(hipMalloc((void **)&nk_b, sizeof(uint32_t) * (size_t)n_inc));
+	PFX_HIP(hipMalloc((void **)&nv_a, sizeof(uint32_t) * (size_t)n_inc));
+	if (pfx_alloc(ctx, &ctx->d_ne_src, n_inc) || pfx_alloc(ctx, &ctx->d_ne_ptr, n_nodes + 1))
+		return PFX_ERR_HIP;
+	hipLaunchKernelGGL(k_node_keys, dim3(grid_for(n_inc)), dim3(256), 0, st, ctx->d_conn, n_inc, nk_a, nv_a);
+	const int nb = bits_for((uint64_t)n_nodes);
+	tmp_bytes = 0;
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, nk_a, nk_b, nv_a, ctx->d_ne_src, (size_t)n_inc, 0, nb, st));
+	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, nk_a, nk_b, nv_a, ctx->d_ne_src, (size_t)n_inc, 0, nb, st));
+	PFX_HIP(hipMemsetAsync(deg, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
+	hipLaunchKernelGGL(k_count_u32, dim3(grid_for(n_inc)), dim3(256), 0, st, nk_b, n_inc, deg);
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	tmp = nullptr;
+	tmp_bytes = 0;
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
+	PFX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, deg, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	(void)hipFree(deg);
+	(void)hipFree(nk_a);
+	(void)hipFree(nk_b);
+	(void)hipFree(nv_a);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_export_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx)
+{
+	const int64_t n_rows = ctx->n_dofs();
+	int64_t *d_rp = nullptr;
+	int32_t *d_ci = nullptr;
+	PFX_HIP(hipMalloc((void **)&d_rp, sizeof(int64_t) * (size_t)(n_rows + 1)));
+	PFX_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * (size_t)(ctx->nnz ? ctx->nnz : 1)));
+	hipLaunchKernelGGL(k_export_pattern, dim3(grid_for(n_rows + 1)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, d_rp, d_ci);
+	PFX_HIP(hipMemcpyAsync(row_ptr, d_rp, sizeof(int64_t) * (size_t)(n_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
+	PFX_HIP(hipMemcpyAsync(col_idx, d_ci, sizeof(int32_t) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+	PFX_HIP(hipStreamSynchronize(ctx->stream));
+	(void)hipFree(d_rp);
+	(void)hipFree(d_ci);
+	return PFX_OK;
+}

@@ -1,0 +1,413 @@
+// pfx_solve.hip -- sparse matrix-vector product and the conjugate-gradient solver.
+//
+// Replaces the polysolve::LinearSolver "Eigen::ConjugateGradient" path called from
+// src/polyfem/solver/SparseNewtonDescentSolver.tpp:128-155 and src/polyfem/state/StateSolveLinear.cpp:14-68.
+// polysolve and Eigen are not part of the reference tree; the iteration below restates
+// Eigen 3.4 IterativeLinearSolvers/ConjugateGradient.h (same operation order, same stopping rule
+// ||r||^2 < max(tol^2 ||b||^2, DBL_MIN), same iteration count convention) with its DiagonalPreconditioner.
+//
+// Matrix storage is the assembler's node-block CSR: the value array is a scalar CSR's, but column indices exist
+// only per node block (4 B per bs*bs values), so an SpMV streams ~8.4 B per entry instead of 12.
+// Constrained (Dirichlet) dofs are handled by masking rows instead of rebuilding a reduced matrix
+// (utils::full_to_reduced_matrix, src/polyfem/utils/MatrixUtils.cpp:408-469): all solver vectors are kept zero
+// on constrained dofs, for which the masked operator is the identity; the iterates on the free dofs are those of
+// CG on the reduced system.
+//
+// One CG iteration = 3 launches, no host synchronisation:
+//   k_spmv_dot    tmp = A p, per-block partial sums of p.tmp
+//   k_cg_update   alpha from the partials; x += alpha p; r -= alpha tmp; partials of r.r and r.M^-1 r
+//   k_cg_direction reduces those partials, tests convergence (device flag), p = M^-1 r + beta p
+// Partial sums are reduced in a fixed order by every block, so all blocks see the same scalars and results are
+// bitwise reproducible.
+#include "pfx_internal.h"
+
+#include <cfloat>
+#include <cmath>
+
+#define PFX_NPART 1024 // number of partial sums (= grid size of the reducing kernels)
+
+// device-resident solver state
+struct pfx_cg_state
+{
+	double abs_new[2]; // r.z ping-pong by iteration parity
+	double rr;         // last ||r||^2
+	double threshold;
+	double rhs_norm2;
+	int done;  // 1 once converged
+	int iters; // Eigen's iteration count at exit
+};
+
+namespace
+{
+	__device__ __forceinline__ double wave_sum(double v)
+	{
+		for (int off = 32; off > 0; off >>= 1)
+			v += __shfl_down(v, off, 64);
+		return v;
+	}
+
+	// block-wide sum of one value per thread (256 threads), result valid in thread 0
+	__device__ __forceinline__ double block_sum(double v, double *sh)
+	{
+		v = wave_sum(v);
+		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+		if (lane == 0)
+			sh[w] = v;
+		__syncthreads();
+		double r = 0;
+		if (threadIdx.x == 0)
+			r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+		__syncthreads();
+		return r;
+	}
+
+	// every thread of the block returns the same fixed-order sum of part[0..PFX_NPART)
+	__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, double *sh)
+	{
+		double acc = 0;
+		for (int k = threadIdx.x; k < PFX_NPART; k += 256)
+			acc += part[k];
+		sh[threadIdx.x] = acc;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1)
+		{
+			if ((int)threadIdx.x < s)
+				sh[threadIdx.x] += sh[threadIdx.x + s];
+			__syncthreads();
+		}
+		const double r = sh[0];
+		__syncthreads();
+		return r;
+	}
+
+	// y = A x (rows of constrained dofs: y = x); optionally the per-block partial of x.y
+	template <int BS, bool DOT>
+	__global__ __launch_bounds__(256) void k_spmv(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
+												   const double *__restrict__ values, const uint8_t *__restrict__ fixed, int64_t n_nodes,
+												   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part,
+												   const pfx_cg_state *__restrict__ state)
+	{
+		__shared__ double sh[4];
+		if (DOT && state->done)
+			return;
+		const int lane = threadIdx.x & 63;
+		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+		double dot = 0.0;
+		for (int64_t g = wave; g < n_nodes; g += n_waves)
+		{
+			const int64_t b0 = node_ptr[g];
+			const int deg = (int)(node_ptr[g + 1] - b0);
+			const int rowlen = deg * BS;
+			const double *v = values + b0 * (BS * BS);
+			double acc[BS];
+#pragma unroll
+			for (int m = 0; m < BS; ++m)
+				acc[m] = 0.0;
+			for (int k = lane; k < rowlen; k += 64)
+			{
+				const int s = k / BS, n = k - s * BS;
+				const double xv = x[(int64_t)node_col[b0 + s] * BS + n];
+#pragma unroll
+				for (int m = 0; m < BS; ++m)
+					acc[m] += v[m * rowlen + k] * xv;
+			}
+#pragma unroll
+			for (int m = 0; m < BS; ++m)
+				acc[m] = wave_sum(acc[m]);
+			if (lane == 0)
+			{
+#pragma unroll
+				for (int m = 0; m < BS; ++m)
+				{
+					const int64_t r = g * BS + m;
+					const double xr = x[r];
+					const double yr = (fixed && fixed[r]) ? xr : acc[m];
+					y[r] = yr;
+					if (DOT)
+						dot += xr * yr;
+				}
+			}
+		}
+		if (DOT)
+		{
+			const double b = block_sum(dot, sh);
+			if (threadIdx.x == 0)
+				part[blockIdx.x] = b;
+		}
+	}
+
+	// invdiag = 1/diag (1 where diag == 0 or the dof is constrained)  -- Eigen DiagonalPreconditioner::factorize
+	template <int BS>
+	__global__ void k_invdiag(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, const double *__restrict__ values,
+							  const uint8_t *__restrict__ fixed, int64_t n_nodes, int jacobi, double *__restrict__ invdiag)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t b0 = node_ptr[g];
+			const int deg = (int)(node_ptr[g + 1] - b0);
+			int lo = 0, hi = deg - 1, s = -1;
+			while (lo <= hi)
+			{
+				const int mid = (lo + hi) >> 1;
+				const int32_t c = node_col[b0 + mid];
+				if (c == g)
+				{
+					s = mid;
+					break;
+				}
+				if (c < g)
+					lo = mid + 1;
+				else
+					hi = mid - 1;
+			}
+			for (int m = 0; m < BS; ++m)
+			{
+				double d = 1.0;
+				const int64_t r = g * BS + m;
+				if (jacobi && s >= 0 && !(fixed && fixed[r]))
+				{
+					const double a = values[b0 * (BS * BS) + (int64_t)m * deg * BS + s * BS + m];
+					if (a != 0.0)
+						d = 1.0 / a;
+				}
+				invdiag[r] = d;
+			}
+		}
+	}
+
+	// r = b - tmp (tmp = A x), with b and x forced to zero on constrained dofs; partials: [0] b.b  [1] r.r
+	__global__ __launch_bounds__(256) void k_cg_init1(const double *__restrict__ b, const double *__restrict__ tmp, const uint8_t *__restrict__ fixed,
+													   int64_t n, double *__restrict__ r, double *__restrict__ part)
+	{
+		__shared__ double sh[4];
+		double bb = 0, rr = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const bool fx = fixed && fixed[k];
+			const double bk = fx ? 0.0 : b[k];
+			const double rk = fx ? 0.0 : bk - tmp[k];
+			r[k] = rk;
+			bb += bk * bk;
+			rr += rk * rk;
+		}
+		const double s0 = block_sum(bb, sh);
+		const double s1 = block_sum(rr, sh);
+		if (threadIdx.x == 0)
+		{
+			part[blockIdx.x] = s0;
+			part[PFX_NPART + blockIdx.x] = s1;
+		}
+	}
+
+	// reduces b.b and r.r, sets threshold / early exit; p = M^-1 r; partial of r.p
+	__global__ __launch_bounds__(256) void k_cg_init2(const double *__restrict__ r, const double *__restrict__ invdiag, int64_t n, double tol,
+													   double *__restrict__ p, double *__restrict__ part, pfx_cg_state *__restrict__ state, double *__restrict__ x)
+	{
+		__shared__ double sh[256];
+		const double bb = reduce_partials(part, sh);
+		const double rr = reduce_partials(part + PFX_NPART, sh);
+		double thr = tol * tol * bb;
+		if (thr < DBL_MIN)
+			thr = DBL_MIN;
+		const bool zero_rhs = (bb == 0.0);
+		const bool conv = zero_rhs || (rr < thr);
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+		{
+			state->rhs_norm2 = bb;
+			state->threshold = thr;
+			state->rr = zero_rhs ? 0.0 : rr;
+			state->done = conv ? 1 : 0;
+			state->iters = 0;
+		}
+		double rp = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			if (zero_rhs)
+				x[k] = 0.0; // Eigen: rhsNorm2 == 0 -> x.setZero()
+			const double pk = invdiag[k] * r[k];
+			p[k] = pk;
+			rp += r[k] * pk;
+		}
+		const double s = block_sum(rp, sh);
+		if (threadIdx.x == 0)
+			part[2 * PFX_NPART + blockIdx.x] = s;
+	}
+
+	// abs_new[0] = r.p
+	__global__ __launch_bounds__(256) void k_cg_init3(const double *__restrict__ part, pfx_cg_state *__restrict__ state)
+	{
+		__shared__ double sh[256];
+		const double rp = reduce_partials(part + 2 * PFX_NPART, sh);
+		if (threadIdx.x == 0)
+			state->abs_new[0] = rp;
+	}
+
+	// alpha = abs_new / p.tmp ; x += alpha p ; r -= alpha tmp ; partials of r.r and r.(M^-1 r)
+	__global__ __launch_bounds__(256) void k_cg_update(const double *__restrict__ p, const double *__restrict__ tmp, const double *__restrict__ invdiag,
+														int64_t n, int it, double *__restrict__ x, double *__restrict__ r, double *__restrict__ part,
+														const pfx_cg_state *__restrict__ state)
+	{
+		__shared__ double sh[256];
+		if (state->done)
+			return;
+		const double pAp = reduce_partials(part, sh);
+		const double alpha = state->abs_new[it & 1] / pAp;
+		double rr = 0, rz = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			x[k] += alpha * p[k];
+			const double rk = r[k] - alpha * tmp[k];
+			r[k] = rk;
+			rr += rk * rk;
+			rz += rk * (invdiag[k] * rk);
+		}
+		const double s0 = block_sum(rr, sh);
+		const double s1 = block_sum(rz, sh);
+		if (threadIdx.x == 0)
+		{
+			part[PFX_NPART + blockIdx.x] = s0;
+			part[2 * PFX_NPART + blockIdx.x] = s1;
+		}
+	}
+
+	// convergence test, beta, p = M^-1 r + beta p
+	__global__ __launch_bounds__(256) void k_cg_direction(const double *__restrict__ r, const double *__restrict__ invdiag, int64_t n, int it,
+														   double *__restrict__ p, const double *__restrict__ part, pfx_cg_state *__restrict__ state)
+	{
+		__shared__ double sh[256];
+		if (state->done)
+			return;
+		const double rr = reduce_partials(part + PFX_NPART, sh);
+		const double rz = reduce_partials(part + 2 * PFX_NPART, sh);
+		const bool conv = rr < state->threshold;
+		const double beta = rz / state->abs_new[it & 1];
+		if (!conv)
+			for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+				p[k] = invdiag[k] * r[k] + beta * p[k];
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+		{
+			state->rr = rr;
+			if (conv)
+			{
+				state->done = 1;
+				state->iters = it; // Eigen breaks before i++
+			}
+			else
+			{
+				state->abs_new[(it + 1) & 1] = rz;
+				state->iters = it + 1;
+			}
+		}
+	}
+
+	__global__ void k_mask_copy(const double *__restrict__ in, const uint8_t *__restrict__ fixed, int64_t n, double *__restrict__ out)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			out[k] = (fixed && fixed[k]) ? 0.0 : in[k];
+	}
+
+	inline int grid_for(int64_t n, int block = 256)
+	{
+		int64_t g = (n + block - 1) / block;
+		if (g > 256 * 16)
+			g = 256 * 16;
+		if (g < 1)
+			g = 1;
+		return (int)g;
+	}
+
+	template <bool DOT>
+	pfx_status spmv_launch(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const pfx_cg_state *state)
+	{
+		const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+		int64_t blocks = DOT ? PFX_NPART : (ctx->n_nodes + 3) / 4;
+		if (blocks > 256 * 32)
+			blocks = 256 * 32;
+		if (blocks < 1)
+			blocks = 1;
+		pfx_scoped_timer tm(ctx, "spmv");
+		if (ctx->bs == 1)
+			hipLaunchKernelGGL((k_spmv<1, DOT>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
+							   ctx->n_nodes, d_x, d_y, part, state);
+		else if (ctx->bs == 3)
+			hipLaunchKernelGGL((k_spmv<3, DOT>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
+							   ctx->n_nodes, d_x, d_y, part, state);
+		else
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+		return PFX_OK;
+	}
+} // namespace
+
+pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y)
+{
+	if (spmv_launch<false>(ctx, d_x, d_y, nullptr, nullptr))
+		return PFX_ERR_UNSUPPORTED;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res)
+{
+	const int64_t n = ctx->n_dofs();
+	hipStream_t st = ctx->stream;
+	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	if (!ctx->d_work)
+		if (pfx_alloc(ctx, &ctx->d_work, 5 * n))
+			return PFX_ERR_HIP;
+	if (!ctx->d_cgstate)
+		if (pfx_alloc(ctx, (pfx_cg_state **)&ctx->d_cgstate, 1))
+			return PFX_ERR_HIP;
+	pfx_cg_state *state = (pfx_cg_state *)ctx->d_cgstate;
+	double *r = ctx->d_work, *p = r + n, *tmp = p + n, *invdiag = tmp + n, *xm = invdiag + n;
+	double *part = ctx->d_partials;
+	const int gv = PFX_NPART;
+
+	PFX_HIP(hipMemsetAsync(state, 0, sizeof(pfx_cg_state), st));
+	// initial guess with constrained dofs zeroed (solveWithGuess)
+	hipLaunchKernelGGL(k_mask_copy, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n, xm);
+	PFX_HIP(hipMemcpyAsync(d_x, xm, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+	if (ctx->bs == 1)
+		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_nodes, precond == PFX_PRECOND_JACOBI ? 1 : 0, invdiag);
+	else
+		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_nodes, precond == PFX_PRECOND_JACOBI ? 1 : 0, invdiag);
+	if (spmv_launch<false>(ctx, d_x, tmp, nullptr, nullptr))
+		return PFX_ERR_UNSUPPORTED;
+	hipLaunchKernelGGL(k_cg_init1, dim3(gv), dim3(256), 0, st, d_b, tmp, fixed, n, r, part);
+	hipLaunchKernelGGL(k_cg_init2, dim3(gv), dim3(256), 0, st, r, invdiag, n, tol, p, part, state, d_x);
+	hipLaunchKernelGGL(k_cg_init3, dim3(1), dim3(256), 0, st, part, state);
+
+	pfx_cg_state h;
+	const int check_every = 16;
+	int it = 0;
+	bool finished = false;
+	while (it < max_iter && !finished)
+	{
+		const int stop = (it + check_every < max_iter) ? it + check_every : max_iter;
+		for (; it < stop; ++it)
+		{
+			if (spmv_launch<true>(ctx, p, tmp, part, state))
+				return PFX_ERR_UNSUPPORTED;
+			{
+				pfx_scoped_timer tm(ctx, "cg_update");
+				hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, st, p, tmp, invdiag, n, it, d_x, r, part, state);
+			}
+			{
+				pfx_scoped_timer tm(ctx, "cg_dir");
+				hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, st, r, invdiag, n, it, p, part, state);
+			}
+		}
+		PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		finished = h.done != 0;
+	}
+	if (max_iter <= 0)
+	{
+		PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+	}
+	PFX_HIP(hipGetLastError());
+	*iters = h.iters;
+	*rel_res = (h.rhs_norm2 == 0.0) ? 0.0 : std::sqrt(h.rr / h.rhs_norm2);
+	return PFX_OK;
+}

@@ -1,0 +1,264 @@
+// pfx_tables.cpp -- reference-element data: quadrature rules and shape-function gradients at the quadrature
+// points, evaluated once on the host and uploaded (they are the same for every element of a mesh).
+//
+// Built with -ffp-contract=off: the linear assembler's sparsity pattern depends on exact zeros, so every
+// expression is written in the operation order of the reference's generated code
+//   tets : src/polyfem/autogen/auto_p_bases.cpp:1000-1078 (P1), :1152-1326 (P2)
+//   hexes: src/polyfem/autogen/auto_q_bases.cpp:1115-1260 (Q1), :1420-1871 (Q2, as 1-D factor products)
+// and of the quadrature set-up
+//   src/polyfem/quadrature/TetQuadrature.cpp:31-43, LineQuadrature.cpp:4707-4734, HexQuadrature.cpp:17-45,
+//   order rule src/polyfem/basis/FEBasis3d.cpp:1467,1506.
+#include "pfx_internal.h"
+#include "pf_quad_tables.h"
+
+#include <cstring>
+
+namespace
+{
+	struct rule
+	{
+		int n = 0;
+		double p[PFX_MAX_PTS][3];
+		double w[PFX_MAX_PTS];
+	};
+
+	bool tet_rule(int order, rule &r)
+	{
+		const double *p = nullptr, *w = nullptr;
+		switch (order)
+		{
+		case 1:
+			p = pf_tet_pts_1, w = pf_tet_wts_1, r.n = PF_TET_NPTS_1;
+			break;
+		case 2:
+			p = pf_tet_pts_2, w = pf_tet_wts_2, r.n = PF_TET_NPTS_2;
+			break;
+		case 3:
+			p = pf_tet_pts_3, w = pf_tet_wts_3, r.n = PF_TET_NPTS_3;
+			break;
+		case 4:
+			p = pf_tet_pts_4, w = pf_tet_wts_4, r.n = PF_TET_NPTS_4;
+			break;
+		case 5:
+			p = pf_tet_pts_5, w = pf_tet_wts_5, r.n = PF_TET_NPTS_5;
+			break;
+		default:
+			return false;
+		}
+		for (int k = 0; k < r.n; ++k)
+		{
+			for (int c = 0; c < 3; ++c)
+				r.p[k][c] = p[3 * k + c];
+			r.w[k] = w[k] / 6;
+		}
+		return true;
+	}
+
+	bool line_rule(int n, double *x, double *w)
+	{
+		const double *p = nullptr, *ww = nullptr;
+		switch (n)
+		{
+		case 1:
+			p = pf_line_pts_1, ww = pf_line_wts_1;
+			break;
+		case 2:
+			p = pf_line_pts_2, ww = pf_line_wts_2;
+			break;
+		case 3:
+			p = pf_line_pts_3, ww = pf_line_wts_3;
+			break;
+		default:
+			return false; // 4^3 = 64 points exceed PFX_MAX_PTS
+		}
+		double sum = 0;
+		for (int k = 0; k < n; ++k)
+		{
+			w[k] = ww[k] / 2;
+			x[k] = p[k] / 2 + 1.0 * 0.5;
+		}
+		for (int k = 0; k < n; ++k)
+			sum += w[k];
+		for (int k = 0; k < n; ++k)
+			w[k] /= sum;
+		return true;
+	}
+
+	bool hex_rule(int order, rule &r)
+	{
+		double x[8], w[8];
+		if (!line_rule(order, x, w))
+			return false;
+		const int n = order;
+		r.n = n * n * n;
+		for (int i = 0; i < n; ++i)
+			for (int j = 0; j < n; ++j)
+				for (int k = 0; k < n; ++k)
+				{
+					const int idx = (i * n + j) * n + k;
+					r.p[idx][0] = x[k];
+					r.p[idx][1] = x[j];
+					r.p[idx][2] = x[i];
+					r.w[idx] = w[i] * w[j] * w[k];
+				}
+		return true;
+	}
+
+	void p1_grad(int li, double *g)
+	{
+		static const double t[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+		g[0] = t[li][0], g[1] = t[li][1], g[2] = t[li][2];
+	}
+
+	void p2_grad(int li, const double *pt, double *g)
+	{
+		const double x = pt[0], y = pt[1], z = pt[2];
+		switch (li)
+		{
+		case 0:
+			g[0] = g[1] = g[2] = 4 * x + 4 * y + 4 * z - 3;
+			break;
+		case 1:
+			g[0] = 4 * x - 1, g[1] = 0, g[2] = 0;
+			break;
+		case 2:
+			g[0] = 0, g[1] = 4 * y - 1, g[2] = 0;
+			break;
+		case 3:
+			g[0] = 0, g[1] = 0, g[2] = 4 * z - 1;
+			break;
+		case 4:
+			g[0] = 4 * (-2 * x - y - z + 1), g[1] = -4 * x, g[2] = -4 * x;
+			break;
+		case 5:
+			g[0] = 4 * y, g[1] = 4 * x, g[2] = 0;
+			break;
+		case 6:
+			g[0] = -4 * y, g[1] = 4 * (-x - 2 * y - z + 1), g[2] = -4 * y;
+			break;
+		case 7:
+			g[0] = -4 * z, g[1] = -4 * z, g[2] = 4 * (-x - y - 2 * z + 1);
+			break;
+		case 8:
+			g[0] = 4 * z, g[1] = 0, g[2] = 4 * x;
+			break;
+		case 9:
+			g[0] = 0, g[1] = 4 * z, g[2] = 4 * y;
+			break;
+		}
+	}
+
+	// Q1: corner c has reference position q1c[c]; N_c = prod_axis (s ? t : -(t-1)); printed factor order differs
+	// per corner in the reference, which only reorders exact-sign factors of two-term products.
+	const int q1c[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+
+	void q1_grad(int li, const double *pt, double *g)
+	{
+		// d/d(axis a) of prod_b f_b = sign_a * prod_{b != a} f_b, f_b = t_b (corner at 1) or (t_b - 1) with an
+		// overall sign (-1)^(number of corner coordinates at 0)
+		double f[3];
+		int nzero = 0;
+		for (int b = 0; b < 3; ++b)
+		{
+			f[b] = q1c[li][b] ? pt[b] : (pt[b] - 1);
+			nzero += q1c[li][b] ? 0 : 1;
+		}
+		const double sign = (nzero % 2) ? -1.0 : 1.0;
+		// auto_q_bases.cpp:1115-1260 prints "+-1.0 * a * b": the +-1.0 factor is exact and a two-factor product
+		// is commutative in IEEE arithmetic, so the factor order does not change the result.
+		for (int a = 0; a < 3; ++a)
+		{
+			const int b0 = (a == 0) ? 1 : 0;
+			const int b1 = 3 - a - b0;
+			g[a] = sign * f[b0] * f[b1];
+		}
+	}
+
+	const int q2n[27][3] = {
+		{0, 0, 0}, {2, 0, 0}, {2, 2, 0}, {0, 2, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2},
+		{1, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 1, 0}, {0, 0, 1}, {2, 0, 1}, {2, 2, 1}, {0, 2, 1},
+		{1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {0, 1, 1}, {2, 1, 1}, {1, 0, 1}, {1, 2, 1},
+		{1, 1, 0}, {1, 1, 2}, {1, 1, 1}};
+
+	double q2_l(int a, double t)
+	{
+		switch (a)
+		{
+		case 0:
+			return (t - 1) * (2.0 * t - 1.0);
+		case 2:
+			return t * (2.0 * t - 1.0);
+		default:
+			return -4.0 * t * (t - 1);
+		}
+	}
+	double q2_dl(int a, double t)
+	{
+		switch (a)
+		{
+		case 0:
+			return 4.0 * t - 3.0;
+		case 2:
+			return 4.0 * t - 1.0;
+		default:
+			return -4.0 * (2.0 * t - 1.0);
+		}
+	}
+
+	void q2_grad(int li, const double *pt, double *g)
+	{
+		const int a = q2n[li][0], b = q2n[li][1], c = q2n[li][2];
+		g[0] = q2_dl(a, pt[0]) * q2_l(b, pt[1]) * q2_l(c, pt[2]);
+		g[1] = q2_l(a, pt[0]) * q2_dl(b, pt[1]) * q2_l(c, pt[2]);
+		g[2] = q2_l(a, pt[0]) * q2_l(b, pt[1]) * q2_dl(c, pt[2]);
+	}
+
+	void basis_grad(int kind, int li, const double *pt, double *g)
+	{
+		switch (kind)
+		{
+		case PFX_P1TET:
+			p1_grad(li, g);
+			break;
+		case PFX_P2TET:
+			p2_grad(li, pt, g);
+			break;
+		case PFX_Q1HEX:
+			q1_grad(li, pt, g);
+			break;
+		case PFX_Q2HEX:
+			q2_grad(li, pt, g);
+			break;
+		}
+	}
+} // namespace
+
+void pfx_fill_tables(int kind, int quad_order, pfx_tables *t)
+{
+	std::memset(t, 0, sizeof(*t));
+	static const int nloc[4] = {4, 10, 8, 27};
+	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX);
+	const int gkind = hex ? PFX_Q1HEX : PFX_P1TET;
+	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX) ? 1 : 2;
+	int real_order = (p - 1) * 2 + 1;
+	if (quad_order > real_order)
+		real_order = quad_order;
+	rule r;
+	const bool ok = hex ? hex_rule(real_order, r) : tet_rule(real_order, r);
+	if (!ok)
+	{
+		t->n_pts = 0;
+		return;
+	}
+	t->n_loc = nloc[kind];
+	t->n_gloc = nloc[gkind];
+	t->n_pts = r.n;
+	for (int k = 0; k < r.n; ++k)
+	{
+		t->w[k] = r.w[k];
+		for (int j = 0; j < t->n_loc; ++j)
+			basis_grad(kind, j, r.p[k], t->grad[k][j]);
+		for (int j = 0; j < t->n_gloc; ++j)
+			basis_grad(gkind, j, r.p[k], t->ggrad[k][j]);
+	}
+}

@@ -1,0 +1,431 @@
+"""ctypes binding of libpolyfem_amd.so (the C ABI of include/polyfem_amd.h) plus a host-side mirror of the
+reference's assembler / linear-solver interface for this path.
+
+Names follow the reference:
+  * `Assembler.assemble`                                 <- assembler::Assembler<L>::assemble        (Assembler.hpp:32-39)
+  * `NLAssembler.assemble / assemble_grad / assemble_hessian`
+                                                         <- assembler::NLAssembler<L>::...           (Assembler.hpp:80-113)
+  * `LinearSolver.create / set_parameters / analyze_pattern / factorize / solve / get_info`
+                                                         <- polysolve::LinearSolver                  (call sites
+                                                            solver/SparseNewtonDescentSolver.tpp:128-155)
+There is no CPU fallback: if the HIP library cannot be loaded every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpolyfem_amd.so")
+
+P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN = 0, 1, 2
+PRECOND_IDENTITY, PRECOND_JACOBI = 0, 1
+MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN}
+
+EXPORTED_SYMBOLS = [
+    "pfx_create", "pfx_destroy", "pfx_last_error", "pfx_set_stream", "pfx_synchronize", "pfx_set_mesh",
+    "pfx_set_material", "pfx_build_pattern", "pfx_get_pattern", "pfx_get_values", "pfx_assemble_linear",
+    "pfx_get_linear_csr", "pfx_energy", "pfx_gradient", "pfx_hessian", "pfx_energy_dev", "pfx_gradient_dev",
+    "pfx_hessian_dev", "pfx_set_dirichlet", "pfx_get_reduced_csr", "pfx_spmv", "pfx_spmv_dev", "pfx_cg",
+    "pfx_cg_dev", "pfx_dirichlet_solve", "pfx_get_info", "pfx_timing_enable", "pfx_timing_get", "pfx_timing_reset",
+]
+
+
+class PfxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pfx error {code}: {msg}")
+        self.code = code
+
+
+class Info(C.Structure):
+    _fields_ = [("n_el", C.c_int64), ("n_nodes", C.c_int64), ("n_dofs", C.c_int64), ("n_blocks", C.c_int64),
+                ("nnz", C.c_int64), ("n_loc", C.c_int), ("n_pts", C.c_int), ("dim", C.c_int),
+                ("bytes_device", C.c_int64)]
+
+
+_lib = None
+
+_i64, _i32, _dbl, _vp = C.c_int64, C.c_int, C.c_double, C.c_void_p
+_pi64, _pi32, _pd = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+
+
+def load():
+    """Loads the HIP library; raises if it is missing (no CPU fallback exists on purpose)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C polyfem_amd/csrc` (python -c 'import "
+                           "__graft_entry__ as g; g.build()')")
+    L = C.CDLL(LIB_PATH)
+    sig = {
+        "pfx_create": [C.POINTER(_vp), _i32],
+        "pfx_destroy": [_vp],
+        "pfx_set_stream": [_vp, _vp],
+        "pfx_synchronize": [_vp],
+        "pfx_set_mesh": [_vp, _i32, _i64, _i64, _i64, _pi32, _pi32, _pd, _i32],
+        "pfx_set_material": [_vp, _i32, _i32, _dbl, _dbl],
+        "pfx_build_pattern": [_vp, _pi64],
+        "pfx_get_pattern": [_vp, _pi64, _pi32],
+        "pfx_get_values": [_vp, _pd],
+        "pfx_assemble_linear": [_vp],
+        "pfx_get_linear_csr": [_vp, _pi64, _pi64, _pi32, _pd],
+        "pfx_energy": [_vp, _pd, _pd],
+        "pfx_gradient": [_vp, _pd, _pd],
+        "pfx_hessian": [_vp, _pd, _i32, _pd],
+        "pfx_energy_dev": [_vp, _vp, _vp],
+        "pfx_gradient_dev": [_vp, _vp, _vp],
+        "pfx_hessian_dev": [_vp, _vp],
+        "pfx_set_dirichlet": [_vp, _pi32, _i64],
+        "pfx_get_reduced_csr": [_vp, _pi64, _pi64, _pi64, _pi32, _pd],
+        "pfx_spmv": [_vp, _pd, _pd],
+        "pfx_spmv_dev": [_vp, _vp, _vp],
+        "pfx_cg": [_vp, _pd, _pd, _i32, _i32, _dbl, C.POINTER(C.c_int), _pd],
+        "pfx_cg_dev": [_vp, _vp, _vp, _i32, _i32, _dbl, C.POINTER(C.c_int), _pd],
+        "pfx_dirichlet_solve": [_vp, _pd, _pd, _i32, _i32, _dbl, C.POINTER(C.c_int), _pd],
+        "pfx_get_info": [_vp, C.POINTER(Info)],
+        "pfx_timing_enable": [_vp, _i32],
+        "pfx_timing_get": [_vp, C.c_char_p, _pd, _pi64],
+        "pfx_timing_reset": [_vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = None if name == "pfx_destroy" else C.c_int
+    L.pfx_last_error.argtypes = [_vp]
+    L.pfx_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(_pd)
+
+
+def _i(a):
+    return a.ctypes.data_as(_pi32)
+
+
+def _l(a):
+    return a.ctypes.data_as(_pi64)
+
+
+class Engine:
+    """One device context (one per process / GPU)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        self.h = _vp()
+        rc = self.L.pfx_create(C.byref(self.h), device)
+        if rc != 0:
+            raise PfxError(rc, "pfx_create failed (no usable HIP device?)")
+        self.mesh = None
+        self.model = None
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.pfx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PfxError(rc, self.L.pfx_last_error(self.h).decode())
+
+    # ---- setup -------------------------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        self._ck(self.L.pfx_set_stream(self.h, _vp(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._ck(self.L.pfx_synchronize(self.h))
+
+    def set_mesh(self, mesh):
+        conn = np.ascontiguousarray(mesh.conn, dtype=np.int32)
+        gconn = np.ascontiguousarray(mesh.gconn, dtype=np.int32)
+        xyz = np.ascontiguousarray(mesh.xyz, dtype=np.float64)
+        self._ck(self.L.pfx_set_mesh(self.h, mesh.kind, conn.shape[0], mesh.n_nodes, xyz.shape[0], _i(conn), _i(gconn),
+                                     _d(xyz), mesh.quad_order))
+        self.mesh = mesh
+
+    def set_material(self, model: int, lam: float = 1.0, mu: float = 1.0, dim: int = 3):
+        self._ck(self.L.pfx_set_material(self.h, model, dim, lam, mu))
+        self.model = model
+
+    def build_pattern(self) -> int:
+        nnz = C.c_int64()
+        self._ck(self.L.pfx_build_pattern(self.h, C.byref(nnz)))
+        return nnz.value
+
+    def info(self) -> Info:
+        inf = Info()
+        self._ck(self.L.pfx_get_info(self.h, C.byref(inf)))
+        return inf
+
+    # ---- pattern / values --------------------------------------------------------------------------------
+    def get_pattern(self):
+        inf = self.info()
+        row_ptr = np.zeros(inf.n_dofs + 1, dtype=np.int64)
+        col_idx = np.zeros(max(inf.nnz, 1), dtype=np.int32)
+        self._ck(self.L.pfx_get_pattern(self.h, _l(row_ptr), _i(col_idx)))
+        return row_ptr, col_idx[: inf.nnz]
+
+    def get_values(self):
+        inf = self.info()
+        v = np.zeros(max(inf.nnz, 1))
+        self._ck(self.L.pfx_get_values(self.h, _d(v)))
+        return v[: inf.nnz]
+
+    # ---- assembly ----------------------------------------------------------------------------------------
+    def assemble_linear(self):
+        self._ck(self.L.pfx_assemble_linear(self.h))
+
+    def get_linear_csr(self):
+        nnz = C.c_int64()
+        self._ck(self.L.pfx_get_linear_csr(self.h, C.byref(nnz), None, None, None))
+        n = self.info().n_dofs
+        row_ptr = np.zeros(n + 1, dtype=np.int64)
+        col_idx = np.zeros(max(nnz.value, 1), dtype=np.int32)
+        vals = np.zeros(max(nnz.value, 1))
+        self._ck(self.L.pfx_get_linear_csr(self.h, C.byref(nnz), _l(row_ptr), _i(col_idx), _d(vals)))
+        return row_ptr, col_idx[: nnz.value], vals[: nnz.value]
+
+    def energy(self, u) -> float:
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        e = C.c_double()
+        self._ck(self.L.pfx_energy(self.h, _d(u), C.byref(e)))
+        return e.value
+
+    def gradient(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        g = np.zeros_like(u)
+        self._ck(self.L.pfx_gradient(self.h, _d(u), _d(g)))
+        return g
+
+    def hessian(self, u, project_to_psd: bool = False, fetch: bool = True):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if fetch:
+            v = np.zeros(max(self.info().nnz, 1))
+            self._ck(self.L.pfx_hessian(self.h, _d(u), int(project_to_psd), _d(v)))
+            return v[: self.info().nnz]
+        self._ck(self.L.pfx_hessian(self.h, _d(u), int(project_to_psd), None))
+        return None
+
+    # device-pointer variants (raw integer addresses, e.g. torch.Tensor.data_ptr())
+    def energy_dev(self, d_u: int, d_e: int):
+        self._ck(self.L.pfx_energy_dev(self.h, _vp(d_u), _vp(d_e)))
+
+    def gradient_dev(self, d_u: int, d_g: int):
+        self._ck(self.L.pfx_gradient_dev(self.h, _vp(d_u), _vp(d_g)))
+
+    def hessian_dev(self, d_u: int):
+        self._ck(self.L.pfx_hessian_dev(self.h, _vp(d_u)))
+
+    # ---- Dirichlet ---------------------------------------------------------------------------------------
+    def set_dirichlet(self, sorted_dofs):
+        d = np.ascontiguousarray(sorted_dofs, dtype=np.int32)
+        self._ck(self.L.pfx_set_dirichlet(self.h, _i(d) if d.size else None, d.size))
+
+    def get_reduced_csr(self):
+        nr, nnz = C.c_int64(), C.c_int64()
+        self._ck(self.L.pfx_get_reduced_csr(self.h, C.byref(nr), C.byref(nnz), None, None, None))
+        row_ptr = np.zeros(nr.value + 1, dtype=np.int64)
+        col_idx = np.zeros(max(nnz.value, 1), dtype=np.int32)
+        vals = np.zeros(max(nnz.value, 1))
+        self._ck(self.L.pfx_get_reduced_csr(self.h, C.byref(nr), C.byref(nnz), _l(row_ptr), _i(col_idx), _d(vals)))
+        return row_ptr, col_idx[: nnz.value], vals[: nnz.value]
+
+    # ---- solve -------------------------------------------------------------------------------------------
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        self._ck(self.L.pfx_spmv(self.h, _d(x), _d(y)))
+        return y
+
+    def spmv_dev(self, d_x: int, d_y: int):
+        self._ck(self.L.pfx_spmv_dev(self.h, _vp(d_x), _vp(d_y)))
+
+    def cg(self, b, x0=None, precond: int = PRECOND_JACOBI, max_iter: int = 1000, tol: float = 1e-12):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+        it, err = C.c_int(), C.c_double()
+        self._ck(self.L.pfx_cg(self.h, _d(b), _d(x), precond, max_iter, tol, C.byref(it), C.byref(err)))
+        return x, it.value, err.value
+
+    def cg_dev(self, d_b: int, d_x: int, precond: int = PRECOND_JACOBI, max_iter: int = 1000, tol: float = 1e-12):
+        it, err = C.c_int(), C.c_double()
+        self._ck(self.L.pfx_cg_dev(self.h, _vp(d_b), _vp(d_x), precond, max_iter, tol, C.byref(it), C.byref(err)))
+        return it.value, err.value
+
+    def dirichlet_solve(self, b, precond: int = PRECOND_JACOBI, max_iter: int = 1000, tol: float = 1e-12):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        it, err = C.c_int(), C.c_double()
+        self._ck(self.L.pfx_dirichlet_solve(self.h, _d(b), _d(x), precond, max_iter, tol, C.byref(it), C.byref(err)))
+        return x, it.value, err.value
+
+    # ---- timing ------------------------------------------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        self._ck(self.L.pfx_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._ck(self.L.pfx_timing_reset(self.h))
+
+    def timing_get(self, family: str):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.L.pfx_timing_get(self.h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+# --------------------------------------------------------------------------------------------------------
+# Host-side mirror of the reference interface
+# --------------------------------------------------------------------------------------------------------
+
+
+class StiffnessMatrix:
+    """Eigen::SparseMatrix<double, ColMajor, int> stand-in (utils/Types.hpp:16-20): compressed arrays of a
+    structurally symmetric matrix, so (outer, inner) are both the CSC and the CSR index arrays."""
+
+    def __init__(self, n: int, outer, inner, values):
+        self.n, self.outer, self.inner, self.values = n, outer, inner, values
+
+    def rows(self):
+        return self.n
+
+    def cols(self):
+        return self.n
+
+    def non_zeros(self):
+        return int(self.inner.size)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.values, self.inner, self.outer), shape=(self.n, self.n))
+
+
+class SpareMatrixCache:
+    """utils::SpareMatrixCache (utils/MatrixUtils.hpp:39-100) as seen by a caller of assemble_hessian: it owns
+    the reusable pattern.  Here the pattern lives on the device; the object records that it has been built."""
+
+    def __init__(self):
+        self.engine = None
+        self.outer = self.inner = None
+
+    def non_zeros(self):
+        return 0 if self.inner is None else int(self.inner.size)
+
+
+class _AssemblerBase:
+    def __init__(self, formulation: str, engine: Engine | None = None, device: int = 0):
+        if formulation not in MODEL_BY_NAME:
+            raise ValueError(f"unsupported formulation {formulation}")
+        self.formulation = formulation
+        self.engine = engine or Engine(device)
+        self.lam, self.mu = 1.0, 1.0
+        self._bound = None
+
+    def set_size(self, size: int):
+        if size != 3:
+            raise ValueError("only 3-D problems are implemented")
+
+    def add_multimaterial(self, index: int, params: dict):
+        """LameParameters::add_multimaterial (utils/ElasticityUtils.cpp:519-560) for uniform parameters given
+        as (lambda, mu) or (E, nu)."""
+        if "lambda" in params and "mu" in params:
+            self.lam, self.mu = float(params["lambda"]), float(params["mu"])
+        elif "E" in params and "nu" in params:
+            E, nu = float(params["E"]), float(params["nu"])
+            self.lam = (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu))
+            self.mu = E / (2.0 * (1.0 + nu))
+        self._bound = None
+
+    def _bind(self, mesh):
+        key = (id(mesh), self.lam, self.mu)
+        if self._bound != key:
+            self.engine.set_mesh(mesh)
+            self.engine.set_material(MODEL_BY_NAME[self.formulation], self.lam, self.mu)
+            self.engine.build_pattern()
+            self._bound = key
+
+
+class Assembler(_AssemblerBase):
+    """assembler::Assembler<LocalAssembler> for Laplacian / LinearElasticity."""
+
+    def assemble(self, is_volume: bool, n_basis: int, bases, gbases=None, cache=None, is_mass: bool = False) -> StiffnessMatrix:
+        if not is_volume or is_mass:
+            raise NotImplementedError("3-D stiffness assembly only")
+        mesh = bases
+        if n_basis != mesh.n_nodes:
+            raise ValueError("n_basis does not match the bases")
+        self._bind(mesh)
+        self.engine.assemble_linear()
+        rp, ci, v = self.engine.get_linear_csr()
+        return StiffnessMatrix(int(rp.size - 1), rp, ci, v)
+
+
+class NLAssembler(_AssemblerBase):
+    """assembler::NLAssembler<LocalAssembler> for NeoHookean."""
+
+    def assemble(self, is_volume, bases, gbases, cache, dt, displacement, displacement_prev=None) -> float:
+        self._bind(bases)
+        return self.engine.energy(np.asarray(displacement).reshape(-1))
+
+    def assemble_grad(self, is_volume, n_basis, bases, gbases, cache, dt, displacement, displacement_prev=None):
+        self._bind(bases)
+        return self.engine.gradient(np.asarray(displacement).reshape(-1)).reshape(-1, 1)
+
+    def assemble_hessian(self, is_volume, n_basis, project_to_psd, bases, gbases, cache, dt, displacement,
+                         displacement_prev, mat_cache: SpareMatrixCache) -> StiffnessMatrix:
+        self._bind(bases)
+        if mat_cache.engine is not self.engine or mat_cache.outer is None:
+            mat_cache.engine = self.engine
+            mat_cache.outer, mat_cache.inner = self.engine.get_pattern()
+        v = self.engine.hessian(np.asarray(displacement).reshape(-1), project_to_psd)
+        return StiffnessMatrix(int(mat_cache.outer.size - 1), mat_cache.outer, mat_cache.inner, v)
+
+
+class LinearSolver:
+    """polysolve::LinearSolver for solver "Eigen::ConjugateGradient" working on the matrix that the bound
+    engine holds on the device (no copy of the matrix crosses PCIe)."""
+
+    def __init__(self, engine: Engine, precond: str):
+        self.engine = engine
+        self.precond = PRECOND_JACOBI if precond in ("", "Eigen::DiagonalPreconditioner", "Jacobi") else PRECOND_IDENTITY
+        self.max_iter, self.tolerance = 1000, 1e-12  # input-spec.json:1326-1336
+        self._info = {}
+
+    @staticmethod
+    def create(solver: str, precond: str, engine: Engine) -> "LinearSolver":
+        if solver not in ("Eigen::ConjugateGradient", ""):
+            raise RuntimeError(f"Unrecognized solver type: {solver}")
+        return LinearSolver(engine, precond)
+
+    def name(self) -> str:
+        return "Eigen::ConjugateGradient"
+
+    def set_parameters(self, params: dict):
+        p = params.get(self.name(), params)
+        self.max_iter = int(p.get("max_iter", self.max_iter))
+        self.tolerance = float(p.get("tolerance", self.tolerance))
+
+    def analyze_pattern(self, A=None, precond_num: int = 0):
+        pass  # pattern already resident
+
+    def factorize(self, A=None):
+        pass  # Jacobi diagonal is extracted inside solve
+
+    def solve(self, b, x):
+        sol, it, err = self.engine.cg(b, x, self.precond, self.max_iter, self.tolerance)
+        self._info = {"solver_iter": it, "solver_error": err, "solver_tol": self.tolerance, "solver_maxiter": self.max_iter}
+        x[...] = sol
+        return x
+
+    def get_info(self) -> dict:
+        return dict(self._info)

@@ -1,0 +1,39 @@
+"""CPU test: the C-ABI library loads and exports every symbol declared in include/polyfem_amd.h
+(no compute call is made here: there is no GPU in the CPU test tier)."""
+import ctypes
+import os
+import re
+
+from polyfem_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "polyfem_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfx_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(engine.LIB_PATH), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/polyfem_amd.h but not exported"
+    assert sorted(engine.EXPORTED_SYMBOLS) == names
+
+
+def test_no_cpu_fallback_when_no_device():
+    """Without a GPU the engine must refuse to start, never silently compute elsewhere."""
+    import pytest
+    L = engine.load()
+    h = ctypes.c_void_p()
+    rc = L.pfx_create(ctypes.byref(h), 0)
+    if rc == 0:  # running on a GPU box
+        L.pfx_destroy(h)
+        pytest.skip("a HIP device is present")
+    assert rc < 0 and not h
+    with pytest.raises(engine.PfxError):
+        engine.Engine(0)

@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bars (north_star): sparsity pattern bit-exact; FP64 matrix entries, energies, gradients within 1e-12 relative
+(measured against the largest entry of the compared array); CG relative residual <= 1e-10 and iteration count
+within +-2 of the oracle's Eigen-order CG.
+"""
+import numpy as np
+import pytest
+
+from polyfem_amd import engine as E
+from polyfem_amd import mesh as M
+from tests.helpers import csc_to_scipy, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+def _setup(eng, mesh, model, lam, mu):
+    eng.set_mesh(mesh)
+    eng.set_material(model, lam, mu)
+    return eng.build_pattern()
+
+
+MESHES = {
+    "p1_aligned": lambda: M.cube_tets(4, 1),
+    "p1_jitter": lambda: M.cube_tets(4, 1, jitter=0.2, seed=1),
+    "p2_aligned": lambda: M.cube_tets(3, 2),
+    "p2_jitter_polyfem": lambda: M.cube_tets(3, 2, numbering="polyfem", jitter=0.2, seed=2),
+    "p2_stretched": lambda: M.cube_tets(2, 2, scale=(1.0, 2.0, 0.5)),
+    "q1": lambda: M.cube_hexes(3, 1),
+    "q2": lambda: M.cube_hexes(2, 2),
+    "single_tet_cell": lambda: M.cube_tets(1, 2),
+}
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+@pytest.mark.parametrize("model", ["Laplacian", "LinearElasticity"])
+def test_linear_assembly_pattern_bit_exact_and_values(eng, oracle, name, model):
+    mesh = MESHES[name]()
+    mid = E.MODEL_BY_NAME[model]
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, mid, lam, mu)
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, mid, lam, mu)
+    assert np.array_equal(rp, outer.astype(np.int64)), "row_ptr differs from the oracle"
+    assert np.array_equal(ci, inner), "col_idx differs from the oracle"
+    assert rel_err(v, vals) <= TOL
+    # the value-dependent pattern is a subset of the structural one
+    assert v.size <= eng.info().nnz
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_aligned", "p2_jitter_polyfem", "p2_stretched", "q1", "q2"])
+def test_neohookean_energy_gradient_hessian(eng, oracle, name):
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    nnz = _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    h = 1.0 / round((mesh.n_el / (6 if mesh.kind < 2 else 1)) ** (1 / 3))
+    for amp in (0.0, 1e-2 * h):
+        x = M.seeded_displacement(mesh, 3, amp)
+        e_ref = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        g_ref = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        outer, inner, vals = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        e = eng.energy(x)
+        g = eng.gradient(x)
+        v = eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner), "Hessian pattern not bit-exact"
+        assert nnz == inner.size
+        if amp == 0.0:
+            assert abs(e) <= 1e-9 and abs(e_ref) <= 1e-9
+            assert np.abs(g).max() <= 1e-9 * np.abs(vals).max()
+        else:
+            assert abs(e - e_ref) <= TOL * abs(e_ref)
+            assert rel_err(g, g_ref) <= TOL
+        assert rel_err(v, vals) <= TOL
+
+
+def test_hessian_pattern_reuse_is_deterministic(eng, oracle):
+    """Newton steps reuse the pattern (SpareMatrixCache second pass == first pass) and repeated assemblies of
+    the same state are bitwise identical (no atomics in the accumulation)."""
+    mesh = M.cube_tets(3, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    cache = oracle.Cache(n)
+    for step in range(3):
+        x = M.seeded_displacement(mesh, 3, 2e-3, seed=100 + step)
+        ref = oracle.assemble_hessian_cached(mesh, oracle.NEOHOOKEAN, lam, mu, x, cache)
+        v1 = eng.hessian(x)
+        v2 = eng.hessian(x)
+        assert np.array_equal(v1, v2)
+        assert rel_err(v1, ref[2]) <= TOL
+        g1, g2 = eng.gradient(x), eng.gradient(x)
+        assert np.array_equal(g1, g2)
+
+
+def test_invalid_state_reports_numeric_error(eng, oracle):
+    mesh = M.cube_tets(2, 1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    x = np.zeros(mesh.n_nodes * 3)
+    x[0::3] = -5.0 * mesh.node_xyz[:, 0]  # collapses and inverts every element
+    with pytest.raises(E.PfxError) as ei:
+        eng.energy(x)
+    assert ei.value.code == -4
+
+
+@pytest.mark.parametrize("case", ["laplace_p1", "elastic_p2", "neohookean_p2"])
+def test_reduced_matrix_and_cg(eng, oracle, case):
+    if case == "laplace_p1":
+        mesh, model, bs = M.cube_tets(6, 1), E.LAPLACIAN, 1
+    elif case == "elastic_p2":
+        mesh, model, bs = M.cube_tets(3, 2), E.LINEAR_ELASTICITY, 3
+    else:
+        mesh, model, bs = M.cube_tets(3, 2, jitter=0.1), E.NEOHOOKEAN, 3
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, model, lam, mu)
+    n = mesh.n_nodes * bs
+    if model == E.NEOHOOKEAN:
+        x = M.seeded_displacement(mesh, 3, 1e-3)
+        eng.hessian(x, fetch=False)
+        full = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+    else:
+        eng.assemble_linear()
+        full = oracle.assemble_linear(mesh, model, lam, mu)
+    bd = M.boundary_dofs(mesh, bs, "x0" if bs == 3 else "all")
+    eng.set_dirichlet(bd)
+    # full_to_reduced_matrix parity
+    red = oracle.full_to_reduced_matrix(full, bd)
+    rp, ci, v = eng.get_reduced_csr()
+    assert np.array_equal(rp, red[0].astype(np.int64)) and np.array_equal(ci, red[1])
+    assert rel_err(v, red[2]) <= TOL
+    # CG on the reduced system == masked CG on the device
+    keep = np.setdiff1d(np.arange(n), bd)
+    rng = np.random.default_rng(5)
+    b_full = rng.standard_normal(n)
+    xr, it_ref, err_ref = oracle.cg(red, b_full[keep], jacobi=True, max_iter=1000, tol=1e-12)
+    xg, it, err = eng.cg(b_full, None, E.PRECOND_JACOBI, 1000, 1e-12)
+    assert abs(it - it_ref) <= 2, (it, it_ref)
+    assert not xg[bd].any()
+    A = csc_to_scipy(red, keep.size)
+    res = np.linalg.norm(A @ xg[keep] - b_full[keep]) / np.linalg.norm(b_full[keep])
+    assert res <= 1e-10
+    assert np.linalg.norm(xg[keep] - xr) <= 1e-8 * np.linalg.norm(xr)
+    # identity preconditioner too
+    xr2, it_ref2, _ = oracle.cg(red, b_full[keep], jacobi=False, max_iter=2000, tol=1e-10)
+    xg2, it2, _ = eng.cg(b_full, None, E.PRECOND_IDENTITY, 2000, 1e-10)
+    assert abs(it2 - it_ref2) <= 2
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+
+
+def test_cg_edge_cases(eng, oracle):
+    mesh = M.cube_tets(3, 1)
+    _setup(eng, mesh, E.LAPLACIAN, 1.0, 1.0)
+    eng.assemble_linear()
+    bd = M.boundary_dofs(mesh, 1, "all")
+    eng.set_dirichlet(bd)
+    n = mesh.n_nodes
+    # zero right-hand side -> x = 0, 0 iterations, error 0 (Eigen's early exit)
+    x, it, err = eng.cg(np.zeros(n), np.ones(n))
+    assert it == 0 and err == 0 and not x.any()
+    # max_iter reached
+    b = np.ones(n)
+    x, it, err = eng.cg(b, None, E.PRECOND_JACOBI, 2, 1e-14)
+    K = oracle.full_to_reduced_matrix(oracle.assemble_linear(mesh, oracle.LAPLACIAN, 1.0, 1.0), bd)
+    keep = np.setdiff1d(np.arange(n), bd)
+    xr, it_ref, err_ref = oracle.cg(K, b[keep], max_iter=2, tol=1e-14)
+    assert it == it_ref == 2
+    assert abs(err - err_ref) <= 1e-10 * err_ref
+    assert np.abs(x[keep] - xr).max() <= 1e-12 * np.abs(xr).max()
+    # initial guess already the solution -> 0 iterations
+    xs, _, _ = eng.cg(b, None, E.PRECOND_JACOBI, 1000, 1e-13)
+    x2, it2, _ = eng.cg(b, xs, E.PRECOND_JACOBI, 1000, 1e-10)
+    assert it2 == 0 and np.array_equal(x2, xs)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+
+
+def test_dirichlet_solve_matches_oracle(eng, oracle):
+    mesh = M.cube_tets(5, 1)
+    _setup(eng, mesh, E.LAPLACIAN, 1.0, 1.0)
+    eng.assemble_linear()
+    n = mesh.n_nodes
+    bd = M.boundary_dofs(mesh, 1, "all")
+    eng.set_dirichlet(bd)
+    b = np.full(n, -1.0 / n)
+    b[bd] = mesh.node_xyz[bd, 0] ** 2  # prescribed boundary values
+    K = oracle.assemble_linear(mesh, oracle.LAPLACIAN, 1.0, 1.0)
+    (o2, i2, v2), b2 = oracle.dirichlet_modify(K, b, bd)
+    xr, it_ref, _ = oracle.cg((o2, i2, v2), b2, jacobi=True, tol=1e-12)
+    x, it, err = eng.dirichlet_solve(b)
+    assert abs(it - it_ref) <= 2
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    assert np.array_equal(x[bd], b[bd])
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+
+
+def test_spmv_matches_oracle(eng, oracle):
+    mesh = M.cube_tets(3, 2, jitter=0.1)
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+    eng.assemble_linear()
+    K = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    x = np.random.default_rng(0).standard_normal(mesh.n_nodes * 3)
+    assert rel_err(eng.spmv(x), oracle.spmv(K, x)) <= TOL
+
+
+def test_host_mirror_of_reference_interface(oracle):
+    """Reads like the reference's tests/test_assembler.cpp:12-64 ("hessian_lin"): stiffness from the linear
+    Assembler == what the NL interface returns, through the reference-shaped host classes."""
+    mesh = M.cube_tets(2, 2, jitter=0.1)
+    asm = E.Assembler("LinearElasticity")
+    asm.set_size(3)
+    asm.add_multimaterial(0, {"E": 1e5, "nu": 0.3})
+    K = asm.assemble(True, mesh.n_nodes, mesh, mesh, None)
+    lam, mu = oracle.lame(1e5, 0.3)
+    ref = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert K.rows() == mesh.n_nodes * 3 and K.non_zeros() == ref[1].size
+    assert np.array_equal(K.inner, ref[1]) and rel_err(K.values, ref[2]) <= TOL
+    nl = E.NLAssembler("NeoHookean", engine=asm.engine)
+    nl.add_multimaterial(0, {"E": 2e4, "nu": 0.3})
+    cache = E.SpareMatrixCache()
+    x = M.seeded_displacement(mesh, 3, 1e-3).reshape(-1, 1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    H = nl.assemble_hessian(True, mesh.n_nodes, False, mesh, mesh, None, 0.0, x, x, cache)
+    g = nl.assemble_grad(True, mesh.n_nodes, mesh, mesh, None, 0.0, x, x)
+    e = nl.assemble(True, mesh, mesh, None, 0.0, x, x)
+    href = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x.reshape(-1))
+    assert np.array_equal(H.inner, href[1]) and rel_err(H.values, href[2]) <= TOL
+    assert rel_err(g.reshape(-1), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x.reshape(-1))) <= TOL
+    assert abs(e - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x.reshape(-1))) <= TOL * abs(e)
+    solver = E.LinearSolver.create("Eigen::ConjugateGradient", "Eigen::DiagonalPreconditioner", asm.engine)
+    solver.set_parameters({"Eigen::ConjugateGradient": {"max_iter": 500, "tolerance": 1e-10}})
+    bd = M.boundary_dofs(mesh, 3, "x0")
+    asm.engine.set_dirichlet(bd)
+    dx = np.zeros(mesh.n_nodes * 3)
+    solver.analyze_pattern(H, H.rows())
+    solver.factorize(H)
+    solver.solve(-g.reshape(-1), dx)
+    info = solver.get_info()
+    assert info["solver_error"] < 1e-10 and 0 < info["solver_iter"] <= 500
+    asm.engine.close()

@@ -1,0 +1,259 @@
+"""CPU tests: the oracle against the reference's own self-contained known-answer tests.
+
+  tests/test_bases.cpp:173-343 (hand-written P1/P2 tet closed forms, margin 1e-10), :40-58 (node tables)
+  tests/test_quadrature.cpp:42-76 (weight sums, points in [0,1])
+  tests/test_matrix.cpp:17-31 (determinant), :200-247 (SpareMatrixCache "cache")
+and property checks re-created on synthetic meshes:
+  tests/test_assembler.cpp:12-64       (LinearElasticity stiffness == Hessian of its energy)
+  tests/test_form_derivatives.cpp:84-143, 200-227 (finite-difference gradient / Hessian of NeoHookean)
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from polyfem_amd import mesh as M
+from tests.helpers import csc_to_scipy
+
+
+# ---- independent closed forms, as written in the reference's tests/test_bases.cpp:173-343 -----------------
+def _lin_tet(i, p):
+    x, n, e = p
+    return [1 - x - n - e, x, n, e][i]
+
+
+def _lin_tet_grad(i):
+    return [(-1, -1, -1), (1, 0, 0), (0, 1, 0), (0, 0, 1)][i]
+
+
+def _quad_tet(i, p):
+    x, n, e = p
+    return [(1 - 2 * x - 2 * n - 2 * e) * (1 - x - n - e), (2 * x - 1) * x, (2 * n - 1) * n, (2 * e - 1) * e,
+            4 * x * (1 - x - n - e), 4 * x * n, 4 * (1 - x - n - e) * n, 4 * (1 - x - n - e) * e, 4 * x * e, 4 * n * e][i]
+
+
+def _quad_tet_grad(i, p):
+    x, n, e = p
+    return [(-3 + 4 * x + 4 * n + 4 * e,) * 3, (4 * x - 1, 0, 0), (0, 4 * n - 1, 0), (0, 0, 4 * e - 1),
+            (4 - 8 * x - 4 * n - 4 * e, -4 * x, -4 * x), (4 * n, 4 * x, 0), (-4 * n, -8 * n + 4 - 4 * x - 4 * e, -4 * n),
+            (-4 * e, -4 * e, -8 * e + 4 - 4 * x - 4 * n), (4 * e, 0, 4 * x), (0, 4 * e, 4 * n)][i]
+
+
+def test_p1_p2_tet_bases_match_reference_closed_forms(oracle):
+    pts, _ = oracle.tet_quadrature(5)
+    for p in pts:
+        for i in range(4):
+            assert abs(oracle.basis_value(oracle.P1TET, i, p) - _lin_tet(i, p)) < 1e-10
+            assert np.abs(oracle.basis_grad(oracle.P1TET, i, p) - _lin_tet_grad(i)).max() < 1e-10
+        for i in range(10):
+            assert abs(oracle.basis_value(oracle.P2TET, i, p) - _quad_tet(i, p)) < 1e-10
+            assert np.abs(oracle.basis_grad(oracle.P2TET, i, p) - _quad_tet_grad(i, p)).max() < 1e-10
+
+
+def test_node_tables(oracle):
+    lin = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)], dtype=float)
+    quad = np.array([(0, 0, 0), (2, 0, 0), (0, 2, 0), (0, 0, 2), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1),
+                     (0, 1, 1)], dtype=float) / 2
+    assert np.abs(oracle.basis_nodes(oracle.P1TET) - lin).max() < 1e-10
+    assert np.abs(oracle.basis_nodes(oracle.P2TET) - quad).max() < 1e-10
+    for kind in (oracle.P1TET, oracle.P2TET, oracle.Q1HEX, oracle.Q2HEX):
+        nodes = oracle.basis_nodes(kind)
+        K = np.array([[oracle.basis_value(kind, i, nodes[j]) for j in range(len(nodes))] for i in range(len(nodes))])
+        assert np.abs(K - np.eye(len(nodes))).max() < 1e-12
+
+
+def test_hex_bases_partition_of_unity_and_fd(oracle):
+    rng = np.random.default_rng(3)
+    for kind in (oracle.Q1HEX, oracle.Q2HEX):
+        n = len(oracle.basis_nodes(kind))
+        for _ in range(5):
+            p = rng.uniform(0, 1, 3)
+            assert abs(sum(oracle.basis_value(kind, i, p) for i in range(n)) - 1) < 1e-12
+            assert np.abs(sum(oracle.basis_grad(kind, i, p) for i in range(n))).max() < 1e-11
+            h = 1e-6
+            for i in range(n):
+                g = oracle.basis_grad(kind, i, p)
+                for c in range(3):
+                    d = np.zeros(3)
+                    d[c] = h
+                    fd = (oracle.basis_value(kind, i, p + d) - oracle.basis_value(kind, i, p - d)) / (2 * h)
+                    assert abs(fd - g[c]) < 1e-8
+
+
+def test_quadrature_weights(oracle):
+    for order in range(1, 6):
+        x, w = oracle.line_quadrature(order)
+        assert abs(w.sum() - 1.0) < 1e-12 and x.min() >= 0 and x.max() <= 1
+        p, w = oracle.tet_quadrature(order)
+        assert abs(w.sum() - 1.0 / 6.0) < 1e-12 and p.min() >= 0 and p.max() <= 1
+    # table order is kept by the reference's no-op sort: 3 Gauss points are {0, -0.7746, +0.7746} mapped to [0,1]
+    x, _ = oracle.line_quadrature(3)
+    assert x[0] == 0.5 and x[1] < x[0] < x[2]
+    p, w = oracle.quadrature(oracle.P2TET)
+    assert len(w) == 6
+    p, w = oracle.quadrature(oracle.Q2HEX)
+    assert len(w) == 27 and abs(w.sum() - 1) < 1e-14
+    p, w = oracle.quadrature(oracle.P1TET)
+    assert len(w) == 1 and np.allclose(p, 0.25)
+
+
+def test_determinant(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        m = rng.uniform(-1, 1, (3, 3))
+        assert abs(oracle.determinant3(m) - np.linalg.det(m)) < 1e-12
+
+
+def test_sparse_matrix_cache_kat(oracle):
+    def check(c):
+        outer, inner, vals = c.get_matrix()
+        A = sp.csc_matrix((vals, inner, outer), shape=(10, 10))
+        assert A[0, 0] == 1 and A[0, 1] == 2 and A[9, 4] == 6 and A[9, 9] == 4
+
+    c = oracle.Cache(10)
+    for e, i, j, v in [(0, 0, 0, 1), (0, 0, 1, 2), (0, 9, 4, 3), (0, 9, 4, 3), (0, 9, 9, 4)]:
+        c.add_value(e, i, j, v)
+    check(c)
+    c1 = oracle.Cache(10)
+    c1.add_value(0, 0, 0, 1)
+    c1.add_value(0, 0, 1, 2)
+    c1.prune()
+    c1.add_value(0, 9, 4, 3)
+    c1.add_value(0, 9, 4, 3)
+    c1.add_value(0, 9, 9, 4)
+    check(c1)
+    c2 = c1.clone()
+    c2.add_value(0, 0, 0, 1)
+    c2.add_value(0, 0, 1, 2)
+    c2.prune()
+    c2.add_value(0, 9, 4, 3)
+    c2.add_value(0, 9, 4, 3)
+    c2.add_value(0, 9, 9, 4)
+    check(c2)
+
+
+def test_mesh_generators():
+    for n in (1, 2, 3):
+        m = M.cube_tets(n, 1)
+        assert m.n_el == 6 * n ** 3 and m.n_nodes == (n + 1) ** 3
+        m = M.cube_tets(n, 2)
+        assert m.n_el == 6 * n ** 3 and m.n_nodes == (2 * n + 1) ** 3 and m.conn.shape[1] == 10
+        mp = M.cube_tets(n, 2, numbering="polyfem")
+        assert mp.n_nodes == m.n_nodes and np.array_equal(np.sort(np.unique(mp.conn)), np.arange(m.n_nodes))
+        # vertices first
+        assert mp.conn[:, :4].max() < (n + 1) ** 3 <= mp.conn[:, 4:].min() + 0
+        h = M.cube_hexes(n, 2)
+        assert h.n_el == n ** 3 and h.n_nodes == (2 * n + 1) ** 3 and h.conn.shape[1] == 27
+
+
+def test_volume_and_positive_jacobians(oracle):
+    for mesh in (M.cube_tets(2, 2, jitter=0.2), M.cube_hexes(2, 2), M.cube_tets(3, 1)):
+        vol = 0.0
+        for e in range(mesh.n_el):
+            v = oracle.compute_vals(mesh, e)
+            assert (v["det"] > 0).all()
+            vol += (v["det"] * v["w"]).sum()
+        assert abs(vol - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_linear_elasticity_stiffness_is_energy_hessian(oracle, order):
+    mesh = M.cube_tets(2, order, jitter=0.15)
+    lam, mu = oracle.lame(1e5, 0.3)
+    n = mesh.n_nodes * 3
+    K = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    assert abs(K - K.T).max() < 1e-9 * abs(K).max()
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        x = rng.standard_normal(n)
+        e = oracle.assemble_energy(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x)
+        assert abs(e - 0.5 * x @ (K @ x)) < 1e-10 * abs(e)
+
+
+@pytest.mark.parametrize("kind", ["tet1", "tet2", "hex1"])
+def test_neohookean_fd(oracle, kind):
+    mesh = {"tet1": lambda: M.cube_tets(2, 1, jitter=0.2), "tet2": lambda: M.cube_tets(2, 2, jitter=0.2),
+            "hex1": lambda: M.cube_hexes(2, 1)}[kind]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    x = M.seeded_displacement(mesh, 3, 1e-2 / 2)
+    g = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+    H = csc_to_scipy(oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x), n)
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal(n)
+    h = 1e-6
+    ep = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x + h * d)
+    em = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x - h * d)
+    assert abs((ep - em) / (2 * h) - g @ d) < 1e-6 * abs(g @ d)
+    gp = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x + h * d)
+    gm = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x - h * d)
+    fd = (gp - gm) / (2 * h)
+    assert np.linalg.norm(fd - H @ d) < 1e-6 * np.linalg.norm(fd)
+
+
+def test_hessian_pattern_is_structural_and_cache_reuse(oracle):
+    mesh = M.cube_tets(2, 2)
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    x0 = np.zeros(n)
+    x1 = M.seeded_displacement(mesh, 3, 2e-3)
+    cache = oracle.Cache(n)
+    A0 = oracle.assemble_hessian_cached(mesh, oracle.NEOHOOKEAN, lam, mu, x0, cache)
+    assert cache.mapping_size() == n
+    A1 = oracle.assemble_hessian_cached(mesh, oracle.NEOHOOKEAN, lam, mu, x1, cache)
+    B1 = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x1)
+    assert np.array_equal(A0[0], A1[0]) and np.array_equal(A0[1], A1[1])
+    assert np.array_equal(A1[0], B1[0]) and np.array_equal(A1[1], B1[1])
+    assert np.abs(A1[2] - B1[2]).max() <= 1e-12 * np.abs(B1[2]).max()
+    # structural: every node pair sharing an element gives a full 3x3 block
+    pairs = set()
+    for el in mesh.conn:
+        for a in el:
+            for b in el:
+                pairs.add((int(a), int(b)))
+    assert A0[1].size == 9 * len(pairs)
+
+
+def test_threaded_oracle_equals_serial(oracle):
+    mesh = M.cube_tets(3, 2)
+    lam, mu = oracle.lame(1e5, 0.3)
+    a = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu, 1)
+    b = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu, 4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.abs(a[2] - b[2]).max() <= 1e-13 * np.abs(a[2]).max()
+
+
+def test_cg_against_scipy_and_reduction(oracle):
+    mesh = M.cube_tets(4, 1)
+    n = mesh.n_nodes
+    K = oracle.assemble_linear(mesh, oracle.LAPLACIAN, 1.0, 1.0)
+    bd = M.boundary_dofs(mesh, 1, "all")
+    Kr = oracle.full_to_reduced_matrix(K, bd)
+    nr = n - bd.size
+    A = csc_to_scipy(Kr, nr)
+    keep = np.setdiff1d(np.arange(n), bd)
+    Afull = csc_to_scipy(K, n)
+    assert abs(A - Afull[keep][:, keep]).max() == 0
+    b = np.ones(nr)
+    x, it, err = oracle.cg(Kr, b, tol=1e-12)
+    assert err < 1e-12 and 0 < it < 200
+    assert np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b)
+    import scipy.sparse.linalg as spl
+    xs = spl.spsolve(A.tocsc(), b)
+    assert np.linalg.norm(x - xs) < 1e-9 * np.linalg.norm(xs)
+    # zero right-hand side: Eigen returns x = 0 with 0 iterations
+    x0, it0, err0 = oracle.cg(Kr, np.zeros(nr), x0=np.ones(nr))
+    assert it0 == 0 and err0 == 0 and not x0.any()
+
+
+def test_linear_pattern_drops_exact_zeros(oracle):
+    """On an axis-aligned mesh many local couplings are exactly 0 and the reference never inserts them
+    (Assembler.cpp:170-173): the value-dependent pattern is a strict subset of the structural one."""
+    mesh = M.cube_tets(2, 1)
+    K = oracle.assemble_linear(mesh, oracle.LAPLACIAN, 1.0, 1.0)
+    pairs = set()
+    for el in mesh.conn:
+        for a in el:
+            for b in el:
+                pairs.add((int(a), int(b)))
+    assert K[1].size < len(pairs)
+    assert (K[2] != 0).any()
