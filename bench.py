@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the assembly + CG hot path on MI355X.
+
+Default workload (BASELINE.json configs[1]): linear elasticity, P2 tetrahedra on the linear geometry of a 55^3
+Kuhn-split unit cube (998 250 elements, 4.1 M dofs), E = 1e5, nu = 0.3.  One STEP = stiffness assembly into the
+resident pattern + one Jacobi-CG solve with the reference's defaults (tolerance 1e-12, max_iter 1000; it runs into
+max_iter, exactly as the reference would).  `value` = elements through the whole step per second.  Inputs (mesh,
+pattern, right-hand side) are resident in HBM before the timed region.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel of the step (the CG SpMV): algorithmic bytes / average launch duration (HIP events on
+                the engine's stream) against the 8 TB/s HBM peak
+  assembly      elements/s and the same roofline accounting for the two assembly kernels
+  cpu_baseline  the CPU oracle (reference-algorithm restatement) on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def spmv_bytes(nnz, n_blocks, n_nodes, n_dofs):
+    """Compulsory traffic of one node-block SpMV: values 8 B/nnz, one 4-B column per block, the 8-B node_ptr,
+    x read once and y written once."""
+    return 8.0 * nnz + 4.0 * n_blocks + 8.0 * (n_nodes + 1) + 16.0 * n_dofs
+
+
+def assembly_bytes(n_el, n_loc, n_gloc, n_gnodes, n_nodes, nnz, nonlinear):
+    """Compulsory traffic of one assembly (indices 4 B, values 8 B): conn + gconn + geometry (+ displacement) read
+    once, every matrix entry written once."""
+    b = 4.0 * n_loc * n_el + 4.0 * n_gloc * n_el + 24.0 * n_gnodes + 8.0 * nnz
+    if nonlinear:
+        b += 24.0 * n_nodes
+    return b
+
+
+def cpu_baseline(args, oracle, M):
+    """Oracle on a bounded sample of the same workload, on this host's cores."""
+    n = args.cpu_n
+    mesh = M.cube_tets(n, 2)
+    lam, mu = oracle.lame(1e5, 0.3)
+    cores = min(os.cpu_count() or 1, 16)
+    om = oracle.OMesh(mesh)
+    t0 = time.perf_counter()
+    if args.workload == "neohookean":
+        x = M.seeded_displacement(mesh, 3, 1e-2 / n)
+        K = oracle.assemble_hessian(om, oracle.NEOHOOKEAN, lam, mu, x, cores)
+    else:
+        K = oracle.assemble_linear(om, oracle.LINEAR_ELASTICITY, lam, mu, cores)
+    t_asm = time.perf_counter() - t0
+    bd = M.boundary_dofs(mesh, 3, "x0")
+    Kr = oracle.full_to_reduced_matrix(K, bd)
+    nr = Kr[0].size - 1
+    b = np.random.default_rng(1).standard_normal(nr)
+    iters = args.cpu_cg_iters
+    t0 = time.perf_counter()
+    _, it, _ = oracle.cg(Kr, b, jacobi=True, max_iter=iters, tol=1e-12)
+    t_cg = (time.perf_counter() - t0) * (args.cg_max_iter / max(it, 1))
+    return {
+        "value": mesh.n_el / (t_asm + t_cg), "unit": "elements/s", "cores": cores, "kind": "port",
+        "sample": f"P2 tets {n}^3 grid ({mesh.n_el} elements): assembly with {cores} threads {t_asm:.3f}s + "
+                  f"{it} single-thread CG iterations scaled to {args.cg_max_iter} ({t_cg:.3f}s)",
+        "assembly_elements_per_s": mesh.n_el / t_asm,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
+    ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean"])
+    ap.add_argument("--cg-max-iter", type=int, default=1000)
+    ap.add_argument("--cg-tol", type=float, default=1e-12)
+    ap.add_argument("--cpu-n", type=int, default=14)
+    ap.add_argument("--cpu-cg-iters", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from polyfem_amd import engine as E
+    from polyfem_amd import mesh as M
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    nonlinear = args.workload == "neohookean"
+    mesh = M.cube_tets(args.n, 2)
+    eng = E.Engine(local_rank)
+    eng.set_mesh(mesh)
+    if nonlinear:
+        lam = (2e4 * 0.3) / ((1 + 0.3) * (1 - 0.6))
+        mu = 2e4 / (2 * 1.3)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+    else:
+        lam = (1e5 * 0.3) / ((1 + 0.3) * (1 - 0.6))
+        mu = 1e5 / (2 * 1.3)
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+    t0 = time.perf_counter()
+    nnz = eng.build_pattern()
+    eng.synchronize()
+    t_pattern = time.perf_counter() - t0
+    inf = eng.info()
+    eng.set_dirichlet(M.boundary_dofs(mesh, 3, "x0"))
+
+    n = inf.n_dofs
+    # torch owns the vectors; the engine enqueues on the same (non-default) stream, so no cross-stream syncs
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
+    u = torch.from_numpy(M.seeded_displacement(mesh, 3, 1e-2 / args.n)).to(dev)
+    rhs = torch.from_numpy(np.random.default_rng(1).standard_normal(n)).to(dev)
+    x = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        if nonlinear:
+            eng.hessian_dev(u.data_ptr())
+            eng.gradient_dev(u.data_ptr(), x.data_ptr())
+        else:
+            eng.assemble_linear()
+        x.zero_()
+        return eng.cg_dev(rhs.data_ptr(), x.data_ptr(), E.PRECOND_JACOBI, args.cg_max_iter, args.cg_tol)
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    eng.timing_reset()
+    eng.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    it = err = None
+    for _ in range(args.steps):
+        it, err = step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    spmv_ms, spmv_n = eng.timing_get("spmv")
+    loc_ms, loc_n = eng.timing_get("local")
+    gat_ms, gat_n = eng.timing_get("gather")
+    upd_ms, _ = eng.timing_get("cg_update")
+    dir_ms, _ = eng.timing_get("cg_dir")
+
+    sb = spmv_bytes(inf.nnz, inf.n_blocks, inf.n_nodes, n)
+    ab = assembly_bytes(inf.n_el, inf.n_loc, 4, mesh.xyz.shape[0], inf.n_nodes, inf.nnz, nonlinear)
+    spmv_gbs = sb / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    asm_ms = loc_ms + gat_ms
+    asm_gbs = ab / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "elements/s Hessian assembly + CG SpMV GB/s, P2 elasticity tets, 1-8 GPUs",
+            "value": world * inf.n_el * args.steps / elapsed,
+            "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": ("NeoHookean Hessian+gradient" if nonlinear else "LinearElasticity stiffness")
+                            + f" assembly + Jacobi-CG (tol {args.cg_tol:g}, max_iter {args.cg_max_iter}), P2 tets, "
+                              f"{args.n}^3 Kuhn grid",
+                "elements": inf.n_el, "dofs": n, "nnz": inf.nnz, "cg_iters": it, "cg_rel_residual": err,
+                "parallelism": "replicas" if world > 1 else "single",
+            },
+            "roofline": {"kernel": "k_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "avg_ms": spmv_ms, "launches": spmv_n, "algorithmic_bytes": sb},
+            "assembly": {"elements_per_s": inf.n_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
+                         "gather_ms": gat_ms,
+                         "roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": asm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": ab}},
+            "cg": {"update_ms": upd_ms, "direction_ms": dir_ms, "spmv_ms": spmv_ms,
+                   "ms_per_iter": spmv_ms + upd_ms + dir_ms},
+            "pattern_build_s": t_pattern,
+        }
+        if not args.no_cpu_baseline:
+            from oracle import pf_oracle
+            pf_oracle.build()
+            out["cpu_baseline"] = cpu_baseline(args, pf_oracle, M)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
