@@ -150,7 +150,7 @@ extern "C"
 			return PFX_ERR_HIP;
 		}
 		ctx->own_stream = true;
-		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * 3 * 1024) != hipSuccess)
+		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * 3 * 2048) != hipSuccess)
 		{
 			delete ctx;
 			return PFX_ERR_HIP;
@@ -286,9 +286,9 @@ extern "C"
 		if (rc)
 			return rc;
 		const int N = ctx->n_loc * ctx->bs;
-		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_kloc, ctx->n_el * N * N) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
+		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz + 2) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_kloc, ctx->n_el * N * N) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
 			return PFX_ERR_HIP;
-		PFX_HIP(hipMemsetAsync(ctx->d_values, 0, sizeof(double) * (size_t)ctx->nnz, ctx->stream));
+		PFX_HIP(hipMemsetAsync(ctx->d_values, 0, sizeof(double) * (size_t)(ctx->nnz + 2), ctx->stream));
 		PFX_HIP(hipMemsetAsync(ctx->d_fixed, 0, (size_t)ctx->n_dofs(), ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		if (nnz)

@@ -24,7 +24,7 @@
 #include <cfloat>
 #include <cmath>
 
-#define PFX_NPART 1024 // number of partial sums (= grid size of the reducing kernels)
+#define PFX_NPART 2048 // number of partial sums (= grid size of the reducing kernels)
 
 // device-resident solver state
 struct pfx_cg_state
@@ -80,8 +80,11 @@ namespace
 		return r;
 	}
 
-	// y = A x (rows of constrained dofs: y = x); optionally the per-block partial of x.y
-	template <int BS, bool DOT>
+	// y = A x (rows of constrained dofs: y = x); optionally the per-block partial of x.y.
+	// LPN lanes cooperate on one node (bs rows), so a wave keeps 64/LPN independent row chains in flight; each block
+	// owns a contiguous node range and the block -> range map keeps ranges that are close on the same XCD (blocks b
+	// and b+8 share an L2), so the x entries gathered by neighbouring rows are L2 hits.
+	template <int BS, int LPN, bool DOT>
 	__global__ __launch_bounds__(256) void k_spmv(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
 												   const double *__restrict__ values, const uint8_t *__restrict__ fixed, int64_t n_nodes,
 												   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part,
@@ -90,45 +93,56 @@ namespace
 		__shared__ double sh[4];
 		if (DOT && state->done)
 			return;
-		const int lane = threadIdx.x & 63;
-		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+		constexpr int GPB = 256 / LPN; // node groups per block
+		const int nblk = gridDim.x;
+		// XCD-aware: the 8 XCDs take blocks round-robin; give each XCD one contiguous eighth of the node ranges
+		const int per = (nblk + 7) / 8;
+		const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+		const int64_t npb = (n_nodes + nblk - 1) / nblk;
+		const int64_t g_begin = (int64_t)vb * npb;
+		int64_t g_end = g_begin + npb;
+		if (g_end > n_nodes)
+			g_end = n_nodes;
+		const int sl = threadIdx.x % LPN;
+		const int grp = threadIdx.x / LPN;
 		double dot = 0.0;
-		for (int64_t g = wave; g < n_nodes; g += n_waves)
-		{
-			const int64_t b0 = node_ptr[g];
-			const int deg = (int)(node_ptr[g + 1] - b0);
-			const int rowlen = deg * BS;
-			const double *v = values + b0 * (BS * BS);
-			double acc[BS];
-#pragma unroll
-			for (int m = 0; m < BS; ++m)
-				acc[m] = 0.0;
-			for (int k = lane; k < rowlen; k += 64)
+		if (vb < nblk)
+			for (int64_t g = g_begin + grp; g < g_end; g += GPB)
 			{
-				const int s = k / BS, n = k - s * BS;
-				const double xv = x[(int64_t)node_col[b0 + s] * BS + n];
+				const int64_t b0 = node_ptr[g];
+				const int deg = (int)(node_ptr[g + 1] - b0);
+				const int rowlen = deg * BS;
+				const double *v = values + b0 * (BS * BS);
+				double acc[BS];
 #pragma unroll
 				for (int m = 0; m < BS; ++m)
-					acc[m] += v[m * rowlen + k] * xv;
-			}
-#pragma unroll
-			for (int m = 0; m < BS; ++m)
-				acc[m] = wave_sum(acc[m]);
-			if (lane == 0)
-			{
-#pragma unroll
-				for (int m = 0; m < BS; ++m)
+					acc[m] = 0.0;
+				for (int k = sl; k < rowlen; k += LPN)
 				{
-					const int64_t r = g * BS + m;
+					const int s = k / BS, n = k - s * BS;
+					const double xv = x[(int64_t)node_col[b0 + s] * BS + n];
+#pragma unroll
+					for (int m = 0; m < BS; ++m)
+						acc[m] += v[m * rowlen + k] * xv;
+				}
+#pragma unroll
+				for (int m = 0; m < BS; ++m)
+					for (int off = LPN / 2; off > 0; off >>= 1)
+						acc[m] += __shfl_xor(acc[m], off, LPN);
+				if (sl < BS)
+				{
+					double a = acc[0];
+#pragma unroll
+					for (int m = 1; m < BS; ++m)
+						a = (sl == m) ? acc[m] : a;
+					const int64_t r = g * BS + sl;
 					const double xr = x[r];
-					const double yr = (fixed && fixed[r]) ? xr : acc[m];
+					const double yr = (fixed && fixed[r]) ? xr : a;
 					y[r] = yr;
 					if (DOT)
 						dot += xr * yr;
 				}
 			}
-		}
 		if (DOT)
 		{
 			const double b = block_sum(dot, sh);
@@ -317,22 +331,46 @@ namespace
 		return (int)g;
 	}
 
+	template <int BS, int LPN, bool DOT>
+	void spmv_go(pfx_ctx *ctx, const uint8_t *fixed, const double *d_x, double *d_y, double *part, const pfx_cg_state *state)
+	{
+		hipLaunchKernelGGL((k_spmv<BS, LPN, DOT>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
+						   ctx->n_nodes, d_x, d_y, part, state);
+	}
+
 	template <bool DOT>
 	pfx_status spmv_launch(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const pfx_cg_state *state)
 	{
 		const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-		int64_t blocks = DOT ? PFX_NPART : (ctx->n_nodes + 3) / 4;
-		if (blocks > 256 * 32)
-			blocks = 256 * 32;
-		if (blocks < 1)
-			blocks = 1;
+		static int lpn_env = -1;
+		if (lpn_env < 0)
+		{
+			const char *e = getenv("PFX_SPMV_LPN");
+			lpn_env = e ? atoi(e) : 0;
+		}
 		pfx_scoped_timer tm(ctx, "spmv");
 		if (ctx->bs == 1)
-			hipLaunchKernelGGL((k_spmv<1, DOT>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
-							   ctx->n_nodes, d_x, d_y, part, state);
+		{
+			const int lpn = lpn_env ? lpn_env : 8;
+			if (lpn == 4)
+				spmv_go<1, 4, DOT>(ctx, fixed, d_x, d_y, part, state);
+			else if (lpn == 16)
+				spmv_go<1, 16, DOT>(ctx, fixed, d_x, d_y, part, state);
+			else
+				spmv_go<1, 8, DOT>(ctx, fixed, d_x, d_y, part, state);
+		}
 		else if (ctx->bs == 3)
-			hipLaunchKernelGGL((k_spmv<3, DOT>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
-							   ctx->n_nodes, d_x, d_y, part, state);
+		{
+			const int lpn = lpn_env ? lpn_env : 32;
+			if (lpn == 8)
+				spmv_go<3, 8, DOT>(ctx, fixed, d_x, d_y, part, state);
+			else if (lpn == 32)
+				spmv_go<3, 32, DOT>(ctx, fixed, d_x, d_y, part, state);
+			else if (lpn == 64)
+				spmv_go<3, 64, DOT>(ctx, fixed, d_x, d_y, part, state);
+			else
+				spmv_go<3, 16, DOT>(ctx, fixed, d_x, d_y, part, state);
+		}
 		else
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
 		return PFX_OK;
