@@ -103,8 +103,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    from polyfem_amd import distributed as D
+
     nonlinear = args.workload == "neohookean"
-    mesh = M.cube_tets(args.n, 2)
+    # weak scaling: the global grid is n x n x (n*world) cells; every rank owns the node planes of n cell layers
+    # (plus one layer of its lower neighbour's elements, which it assembles redundantly instead of communicating)
+    part, bounds, n_nodes_global = D.slab_part(args.n, args.n, rank, world, 2)
+    mesh = part.mesh
     eng = E.Engine(local_rank)
     eng.set_mesh(mesh)
     if nonlinear:
@@ -120,17 +125,33 @@ def main():
     eng.synchronize()
     t_pattern = time.perf_counter() - t0
     inf = eng.info()
-    eng.set_dirichlet(M.boundary_dofs(mesh, 3, "x0"))
+    eng.set_owned(part.n_owned, part.elem_owned)
+    fixed_nodes = np.nonzero(np.abs(mesh.node_xyz[:, 0]) < 1e-12)[0]
+    eng.set_dirichlet(np.sort((fixed_nodes[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
 
     n = inf.n_dofs
     # torch owns the vectors; the engine enqueues on the same (non-default) stream, so no cross-stream syncs
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
-    u = torch.from_numpy(M.seeded_displacement(mesh, 3, 1e-2 / args.n)).to(dev)
-    rhs = torch.from_numpy(np.random.default_rng(1).standard_normal(n)).to(dev)
+    l2g = part.local_to_global()
+
+    def global_field(seed, amp):
+        # value of a globally defined pseudo-random field at this rank's nodes (same on every rank for shared nodes)
+        h = (l2g[:, None] * 3 + np.arange(3)[None]).reshape(-1).astype(np.uint64)
+        z = (h + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        z ^= z >> np.uint64(31)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(29)
+        return ((z >> np.uint64(11)).astype(np.float64) / float(1 << 53) - 0.5) * 2.0 * amp
+
+    u = torch.from_numpy(global_field(12345, 1e-2 / args.n)).to(dev)
+    rhs = torch.from_numpy(global_field(1, 1.0)).to(dev)
     x = torch.zeros(n, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
+
+    comm = D.Comm()
+    dcg = D.DistributedCG(D.HipOps(eng), part, 3, comm, dev) if world > 1 else None
 
     def step():
         if nonlinear:
@@ -139,6 +160,8 @@ def main():
         else:
             eng.assemble_linear()
         x.zero_()
+        if dcg is not None:
+            return dcg.solve(rhs, x, E.PRECOND_JACOBI, args.cg_max_iter, args.cg_tol, check_every=50)
         return eng.cg_dev(rhs.data_ptr(), x.data_ptr(), E.PRECOND_JACOBI, args.cg_max_iter, args.cg_tol)
 
     for _ in range(args.warmup):
@@ -176,10 +199,12 @@ def main():
     asm_ms = loc_ms + gat_ms
     asm_gbs = ab / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0
 
+    n_el_global = 6 * args.n * args.n * args.n * world
+    owned_el = int(part.elem_owned.sum())
     if rank == 0:
         out = {
             "metric": "elements/s Hessian assembly + CG SpMV GB/s, P2 elasticity tets, 1-8 GPUs",
-            "value": world * inf.n_el * args.steps / elapsed,
+            "value": n_el_global * args.steps / elapsed,
             "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -189,13 +214,15 @@ def main():
                 "workload": ("NeoHookean Hessian+gradient" if nonlinear else "LinearElasticity stiffness")
                             + f" assembly + Jacobi-CG (tol {args.cg_tol:g}, max_iter {args.cg_max_iter}), P2 tets, "
                               f"{args.n}^3 Kuhn grid",
-                "elements": inf.n_el, "dofs": n, "nnz": inf.nnz, "cg_iters": it, "cg_rel_residual": err,
-                "parallelism": "replicas" if world > 1 else "single",
+                "elements": n_el_global, "elements_per_gpu_owned": owned_el, "elements_per_gpu_assembled": inf.n_el,
+                "dofs_per_gpu": part.n_owned * 3, "nnz_per_gpu": inf.nnz, "cg_iters": it, "cg_rel_residual": err,
+                "parallelism": f"row/element partition over {world} GPUs, RCCL halo exchange + all-reduce"
+                               if world > 1 else "single GPU",
             },
             "roofline": {"kernel": "k_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
                          "avg_ms": spmv_ms, "launches": spmv_n, "algorithmic_bytes": sb},
-            "assembly": {"elements_per_s": inf.n_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
+            "assembly": {"elements_per_s": world * owned_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
                          "gather_ms": gat_ms,
                          "roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": asm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": ab}},

@@ -149,6 +149,37 @@ pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x_inout, int pr
 pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol,
 							   int *iters, double *rel_res);
 
+/* ---- multi-GPU building blocks (no counterpart in the reference, which is single-process) -------------------------
+ *
+ * One process per GPU holds one part of a node partition: its mesh is every element that touches an owned node,
+ * local node numbering is [owned nodes | halo nodes].  Assembly then needs no communication (owned rows are
+ * complete); the solver needs (a) the halo entries of the search direction before every SpMV and (b) sums over the
+ * ranks of three scalars per iteration.  Both are done by the caller with RCCL (torch.distributed) between the step
+ * functions below, which only enqueue kernels on the context's stream.
+ *
+ *   pfx_cgs_prepare   mask x on constrained dofs, build the Jacobi diagonal              -> exchange halo of x
+ *   pfx_cgs_residual  r = b - A x ; scal[0] = b.b, scal[1] = r.r (local sums)            -> all-reduce scal[0..1]
+ *   pfx_cgs_start     threshold, early exit, p = M^-1 r ; scal[2] = r.p                  -> all-reduce scal[2]
+ *   pfx_cgs_start2    stores r.p
+ *   per iteration it: (exchange halo of p)  pfx_cgs_spmv: tmp = A p, scal[0] = p.tmp     -> all-reduce scal[0]
+ *                     pfx_cgs_update: x += a p, r -= a tmp, scal[1] = r.r, scal[2] = r.z -> all-reduce scal[1..2]
+ *                     pfx_cgs_direction: convergence test, p = M^-1 r + beta p
+ *   pfx_cgs_status    synchronises and reports (done, iterations, ||r||^2, ||b||^2)
+ *
+ * d_scal is a device array of >= 4 doubles owned by the caller.  With d_scal == NULL the steps reduce locally and
+ * form exactly the single-GPU pfx_cg_dev.  d_work (4 * n_local_dofs doubles: r, p, tmp, invdiag in this order) is the
+ * caller-owned workspace, so that the caller can address the halo part of p. */
+pfx_status pfx_set_owned(pfx_ctx *ctx, int64_t n_owned_nodes, const uint8_t *elem_owned /* n_el flags or NULL */);
+pfx_status pfx_cgs_set_workspace(pfx_ctx *ctx, double *d_work);
+pfx_status pfx_cgs_prepare(pfx_ctx *ctx, double *d_x, int precond);
+pfx_status pfx_cgs_residual(pfx_ctx *ctx, const double *d_b, const double *d_x, double *d_scal);
+pfx_status pfx_cgs_start(pfx_ctx *ctx, double *d_x, double tol, double *d_scal);
+pfx_status pfx_cgs_start2(pfx_ctx *ctx, const double *d_scal);
+pfx_status pfx_cgs_spmv(pfx_ctx *ctx, double *d_scal);
+pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal);
+pfx_status pfx_cgs_direction(pfx_ctx *ctx, int it, const double *d_scal);
+pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);
+
 /* ---- introspection for benchmarks ----------------------------------------------------------------------------- */
 
 typedef struct
@@ -160,7 +191,8 @@ typedef struct
 pfx_status pfx_get_info(pfx_ctx *ctx, pfx_info *info);
 
 /* Average duration (ms) of the launches of one named kernel family since the last reset, measured with HIP events
- * on the context's stream when timing is enabled.  Families: "local", "gather", "spmv", "cg_update", "cg_dir". */
+ * on the context's stream when timing is enabled.  Families: "local", "gather" (matrix assembly), "local_grad",
+ * "gather_vec", "local_energy", "spmv", "cg_update", "cg_dir". */
 pfx_status pfx_timing_enable(pfx_ctx *ctx, int on);
 pfx_status pfx_timing_get(pfx_ctx *ctx, const char *family, double *avg_ms, int64_t *launches);
 pfx_status pfx_timing_reset(pfx_ctx *ctx);

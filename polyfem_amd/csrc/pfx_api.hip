@@ -172,6 +172,7 @@ extern "C"
 		free_dev(ctx->d_xyz);
 		free_dev(ctx->d_tab);
 		free_dev(ctx->d_flag);
+		free_dev(ctx->d_elem_owned);
 		free_dev(ctx->d_partials);
 		free_dev(ctx->d_cgstate);
 		resolve_timers(ctx);
@@ -244,6 +245,8 @@ extern "C"
 		ctx->quad_order = quad_order;
 		ctx->n_el = n_el;
 		ctx->n_nodes = n_nodes;
+		ctx->n_owned = n_nodes;
+		free_dev(ctx->d_elem_owned);
 		ctx->n_gnodes = n_gnodes;
 		if (pfx_alloc(ctx, &ctx->d_conn, n_el * n_loc) || pfx_alloc(ctx, &ctx->d_gconn, n_el * n_gloc) || pfx_alloc(ctx, &ctx->d_xyz, n_gnodes * 3))
 			return PFX_ERR_HIP;
@@ -578,6 +581,81 @@ extern "C"
 		(void)hipFree(d_b);
 		(void)hipFree(d_g);
 		return rc;
+	}
+
+	pfx_status pfx_set_owned(pfx_ctx *ctx, int64_t n_owned_nodes, const uint8_t *elem_owned)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_mesh must be called first");
+		if (n_owned_nodes < 0 || n_owned_nodes > ctx->n_nodes)
+			PFX_FAIL(PFX_ERR_ARG, "n_owned_nodes out of range");
+		ctx->n_owned = n_owned_nodes;
+		free_dev(ctx->d_elem_owned);
+		if (elem_owned)
+		{
+			if (pfx_alloc(ctx, &ctx->d_elem_owned, ctx->n_el))
+				return PFX_ERR_HIP;
+			PFX_HIP(hipMemcpyAsync(ctx->d_elem_owned, elem_owned, (size_t)ctx->n_el, hipMemcpyHostToDevice, ctx->stream));
+			PFX_HIP(hipStreamSynchronize(ctx->stream));
+		}
+		return PFX_OK;
+	}
+
+	pfx_status pfx_cgs_set_workspace(pfx_ctx *ctx, double *d_work)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		ctx->d_work_ext = d_work;
+		return PFX_OK;
+	}
+
+#define PFX_NEED(cond)         \
+	if (!ctx || !(cond))       \
+		return PFX_ERR_ARG;    \
+	if (need_pattern(ctx))     \
+		return PFX_ERR_ARG;
+
+	pfx_status pfx_cgs_prepare(pfx_ctx *ctx, double *d_x, int precond)
+	{
+		PFX_NEED(d_x);
+		return pfx_cgs_prepare_impl(ctx, d_x, precond);
+	}
+	pfx_status pfx_cgs_residual(pfx_ctx *ctx, const double *d_b, const double *d_x, double *d_scal)
+	{
+		PFX_NEED(d_b && d_x);
+		return pfx_cgs_residual_impl(ctx, d_b, d_x, d_scal);
+	}
+	pfx_status pfx_cgs_start(pfx_ctx *ctx, double *d_x, double tol, double *d_scal)
+	{
+		PFX_NEED(d_x);
+		return pfx_cgs_start_impl(ctx, d_x, tol, d_scal);
+	}
+	pfx_status pfx_cgs_start2(pfx_ctx *ctx, const double *d_scal)
+	{
+		PFX_NEED(true);
+		return pfx_cgs_start2_impl(ctx, d_scal);
+	}
+	pfx_status pfx_cgs_spmv(pfx_ctx *ctx, double *d_scal)
+	{
+		PFX_NEED(true);
+		return pfx_cgs_spmv_impl(ctx, d_scal);
+	}
+	pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal)
+	{
+		PFX_NEED(d_x);
+		return pfx_cgs_update_impl(ctx, it, d_x, d_scal);
+	}
+	pfx_status pfx_cgs_direction(pfx_ctx *ctx, int it, const double *d_scal)
+	{
+		PFX_NEED(true);
+		return pfx_cgs_direction_impl(ctx, it, d_scal);
+	}
+	pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb)
+	{
+		PFX_NEED(done && iters && rr && bb);
+		return pfx_cgs_status_impl(ctx, done, iters, rr, bb);
 	}
 
 	pfx_status pfx_get_info(pfx_ctx *ctx, pfx_info *info)

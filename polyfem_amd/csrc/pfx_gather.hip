@@ -82,12 +82,13 @@ namespace
 	}
 
 	// two-stage, fixed-order sum of the per-element energies
-	__global__ __launch_bounds__(256) void k_reduce_stage1(const double *__restrict__ in, int64_t n, double *__restrict__ partial)
+	__global__ __launch_bounds__(256) void k_reduce_stage1(const double *__restrict__ in, const uint8_t *__restrict__ owned, int64_t n, double *__restrict__ partial)
 	{
 		__shared__ double sh[256];
 		double acc = 0.0;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
-			acc += in[k];
+			if (!owned || owned[k])
+				acc += in[k];
 		sh[threadIdx.x] = acc;
 		__syncthreads();
 		for (int s = 128; s > 0; s >>= 1)
@@ -262,7 +263,7 @@ pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g)
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy)
 {
 	const int nb = 256;
-	hipLaunchKernelGGL(k_reduce_stage1, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_eloc, ctx->n_el, ctx->d_partials);
+	hipLaunchKernelGGL(k_reduce_stage1, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_eloc, ctx->d_elem_owned, ctx->n_el, ctx->d_partials);
 	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, nb, d_energy);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;

@@ -40,6 +40,7 @@ struct pfx_ctx
 	// mesh
 	int kind = -1, gkind = -1, n_loc = 0, n_gloc = 0, n_pts = 0, quad_order = -1;
 	int64_t n_el = 0, n_nodes = 0, n_gnodes = 0;
+	int64_t n_owned = 0; // rows [0, n_owned) belong to this rank (== n_nodes unless the mesh is one part of a partition)
 	int32_t *d_conn = nullptr, *d_gconn = nullptr;
 	double *d_xyz = nullptr;
 	pfx_tables *d_tab = nullptr;
@@ -67,6 +68,7 @@ struct pfx_ctx
 	double *d_gloc = nullptr; // n_el * n_loc*bs
 	double *d_eloc = nullptr; // n_el
 	int *d_flag = nullptr;    // numeric failure flag
+	uint8_t *d_elem_owned = nullptr; // optional: 1 = this rank sums the element's energy (partitioned meshes)
 
 	// Dirichlet
 	int64_t n_dirichlet = 0;
@@ -74,7 +76,8 @@ struct pfx_ctx
 	int32_t *d_dirichlet = nullptr;
 
 	// solver work vectors
-	double *d_work = nullptr; // 6 * n_dofs
+	double *d_work = nullptr;     // 4 * n_dofs: r, p, tmp, invdiag
+	double *d_work_ext = nullptr; // caller-owned workspace of the same layout (multi-GPU driver)
 	double *d_partials = nullptr;
 	int *d_cgstate = nullptr;
 	double *d_u = nullptr, *d_vec = nullptr; // staging for host-pointer entry points
@@ -171,5 +174,13 @@ pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
 pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res);
+pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond);
+pfx_status pfx_cgs_residual_impl(pfx_ctx *ctx, const double *d_b, const double *d_x, double *gscal);
+pfx_status pfx_cgs_start_impl(pfx_ctx *ctx, double *d_x, double tol, double *gscal);
+pfx_status pfx_cgs_start2_impl(pfx_ctx *ctx, const double *gscal);
+pfx_status pfx_cgs_spmv_impl(pfx_ctx *ctx, double *gscal);
+pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal);
+pfx_status pfx_cgs_direction_impl(pfx_ctx *ctx, int it, const double *gscal);
+pfx_status pfx_cgs_status_impl(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);
 pfx_status pfx_export_compressed(pfx_ctx *ctx, bool use_mask, bool drop_fixed, int64_t *n_rows, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values);
 pfx_status pfx_export_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx);

@@ -190,7 +190,29 @@ namespace
 		}
 	}
 
-	// r = b - tmp (tmp = A x), with b and x forced to zero on constrained dofs; partials: [0] b.b  [1] r.r
+	// Scalars of the iteration come either from the per-block partial sums of the producing kernel (single GPU:
+	// every block reduces them in the same fixed order) or, when several GPUs cooperate, from `gscal`, which the
+	// caller has all-reduced over the ranks after k_finish_partials wrote the local sums there.
+	__device__ __forceinline__ double get_scalar(const double *__restrict__ part, const double *__restrict__ gscal, int idx, double *sh)
+	{
+		if (gscal)
+			return gscal[idx];
+		return reduce_partials(part + idx * PFX_NPART, sh);
+	}
+
+	// gscal[idx0 + q] = fixed-order sum of partial array q (one block)
+	__global__ __launch_bounds__(256) void k_finish_partials(const double *__restrict__ part, int first, int count, double *__restrict__ gscal)
+	{
+		__shared__ double sh[256];
+		for (int q = 0; q < count; ++q)
+		{
+			const double v = reduce_partials(part + (first + q) * PFX_NPART, sh);
+			if (threadIdx.x == 0)
+				gscal[first + q] = v;
+		}
+	}
+
+	// r = b - tmp (tmp = A x), with b forced to zero on constrained dofs; partials: [0] b.b  [1] r.r
 	__global__ __launch_bounds__(256) void k_cg_init1(const double *__restrict__ b, const double *__restrict__ tmp, const uint8_t *__restrict__ fixed,
 													   int64_t n, double *__restrict__ r, double *__restrict__ part)
 	{
@@ -214,13 +236,14 @@ namespace
 		}
 	}
 
-	// reduces b.b and r.r, sets threshold / early exit; p = M^-1 r; partial of r.p
+	// threshold / early exit from b.b and r.r; p = M^-1 r; partial [2] of r.p
 	__global__ __launch_bounds__(256) void k_cg_init2(const double *__restrict__ r, const double *__restrict__ invdiag, int64_t n, double tol,
-													   double *__restrict__ p, double *__restrict__ part, pfx_cg_state *__restrict__ state, double *__restrict__ x)
+													   double *__restrict__ p, double *__restrict__ part, const double *__restrict__ gscal,
+													   pfx_cg_state *__restrict__ state, double *__restrict__ x)
 	{
 		__shared__ double sh[256];
-		const double bb = reduce_partials(part, sh);
-		const double rr = reduce_partials(part + PFX_NPART, sh);
+		const double bb = get_scalar(part, gscal, 0, sh);
+		const double rr = get_scalar(part, gscal, 1, sh);
 		double thr = tol * tol * bb;
 		if (thr < DBL_MIN)
 			thr = DBL_MIN;
@@ -249,23 +272,23 @@ namespace
 	}
 
 	// abs_new[0] = r.p
-	__global__ __launch_bounds__(256) void k_cg_init3(const double *__restrict__ part, pfx_cg_state *__restrict__ state)
+	__global__ __launch_bounds__(256) void k_cg_init3(const double *__restrict__ part, const double *__restrict__ gscal, pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
-		const double rp = reduce_partials(part + 2 * PFX_NPART, sh);
+		const double rp = get_scalar(part, gscal, 2, sh);
 		if (threadIdx.x == 0)
 			state->abs_new[0] = rp;
 	}
 
-	// alpha = abs_new / p.tmp ; x += alpha p ; r -= alpha tmp ; partials of r.r and r.(M^-1 r)
+	// alpha = abs_new / p.tmp ; x += alpha p ; r -= alpha tmp ; partials [1], [2] of r.r and r.(M^-1 r)
 	__global__ __launch_bounds__(256) void k_cg_update(const double *__restrict__ p, const double *__restrict__ tmp, const double *__restrict__ invdiag,
 														int64_t n, int it, double *__restrict__ x, double *__restrict__ r, double *__restrict__ part,
-														const pfx_cg_state *__restrict__ state)
+														const double *__restrict__ gscal, const pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
 		if (state->done)
 			return;
-		const double pAp = reduce_partials(part, sh);
+		const double pAp = get_scalar(part, gscal, 0, sh);
 		const double alpha = state->abs_new[it & 1] / pAp;
 		double rr = 0, rz = 0;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
@@ -287,13 +310,14 @@ namespace
 
 	// convergence test, beta, p = M^-1 r + beta p
 	__global__ __launch_bounds__(256) void k_cg_direction(const double *__restrict__ r, const double *__restrict__ invdiag, int64_t n, int it,
-														   double *__restrict__ p, const double *__restrict__ part, pfx_cg_state *__restrict__ state)
+														   double *__restrict__ p, const double *__restrict__ part, const double *__restrict__ gscal,
+														   pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
 		if (state->done)
 			return;
-		const double rr = reduce_partials(part + PFX_NPART, sh);
-		const double rz = reduce_partials(part + 2 * PFX_NPART, sh);
+		const double rr = get_scalar(part, gscal, 1, sh);
+		const double rz = get_scalar(part, gscal, 2, sh);
 		const bool conv = rr < state->threshold;
 		const double beta = rz / state->abs_new[it & 1];
 		if (!conv)
@@ -315,10 +339,11 @@ namespace
 		}
 	}
 
-	__global__ void k_mask_copy(const double *__restrict__ in, const uint8_t *__restrict__ fixed, int64_t n, double *__restrict__ out)
+	__global__ void k_mask_inplace(double *__restrict__ v, const uint8_t *__restrict__ fixed, int64_t n)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
-			out[k] = (fixed && fixed[k]) ? 0.0 : in[k];
+			if (fixed[k])
+				v[k] = 0.0;
 	}
 
 	inline int grid_for(int64_t n, int block = 256)
@@ -335,7 +360,7 @@ namespace
 	void spmv_go(pfx_ctx *ctx, const uint8_t *fixed, const double *d_x, double *d_y, double *part, const pfx_cg_state *state)
 	{
 		hipLaunchKernelGGL((k_spmv<BS, LPN, DOT>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
-						   ctx->n_nodes, d_x, d_y, part, state);
+						   ctx->n_owned, d_x, d_y, part, state);
 	}
 
 	template <bool DOT>
@@ -385,67 +410,169 @@ pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y)
 	return PFX_OK;
 }
 
+namespace
+{
+	struct cg_vecs
+	{
+		double *r, *p, *tmp, *invdiag;
+	};
+
+	pfx_status cg_workspace(pfx_ctx *ctx, cg_vecs *w)
+	{
+		const int64_t n = ctx->n_dofs();
+		double *base = ctx->d_work_ext;
+		if (!base)
+		{
+			if (!ctx->d_work)
+				if (pfx_alloc(ctx, &ctx->d_work, 4 * n))
+					return PFX_ERR_HIP;
+			base = ctx->d_work;
+		}
+		if (!ctx->d_cgstate)
+			if (pfx_alloc(ctx, (pfx_cg_state **)&ctx->d_cgstate, 1))
+				return PFX_ERR_HIP;
+		w->r = base;
+		w->p = base + n;
+		w->tmp = base + 2 * n;
+		w->invdiag = base + 3 * n;
+		return PFX_OK;
+	}
+
+	void finish(pfx_ctx *ctx, int first, int count, double *gscal)
+	{
+		if (gscal)
+			hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, first, count, gscal);
+	}
+} // namespace
+
+// ---- step functions: one CG iteration is spmv -> update -> direction; with several ranks the caller all-reduces
+// ---- gscal between the steps and refreshes the halo entries of p before every spmv --------------------------------
+
+pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	hipStream_t st = ctx->stream;
+	const int64_t n = ctx->n_owned * ctx->bs;
+	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	PFX_HIP(hipMemsetAsync(ctx->d_cgstate, 0, sizeof(pfx_cg_state), st));
+	if (fixed) // initial guess with constrained dofs zeroed (solveWithGuess on the reduced system)
+		hipLaunchKernelGGL(k_mask_inplace, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n);
+	const int jac = precond == PFX_PRECOND_JACOBI ? 1 : 0;
+	if (ctx->bs == 1)
+		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, w.invdiag);
+	else
+		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, w.invdiag);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_residual_impl(pfx_ctx *ctx, const double *d_b, const double *d_x, double *gscal)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	const int64_t n = ctx->n_owned * ctx->bs;
+	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	if (spmv_launch<false>(ctx, d_x, w.tmp, nullptr, nullptr))
+		return PFX_ERR_UNSUPPORTED;
+	hipLaunchKernelGGL(k_cg_init1, dim3(PFX_NPART), dim3(256), 0, ctx->stream, d_b, w.tmp, fixed, n, w.r, ctx->d_partials);
+	finish(ctx, 0, 2, gscal);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_start_impl(pfx_ctx *ctx, double *d_x, double tol, double *gscal)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	const int64_t n = ctx->n_owned * ctx->bs;
+	hipLaunchKernelGGL(k_cg_init2, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.r, w.invdiag, n, tol, w.p, ctx->d_partials, gscal, (pfx_cg_state *)ctx->d_cgstate, d_x);
+	finish(ctx, 2, 1, gscal);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_start2_impl(pfx_ctx *ctx, const double *gscal)
+{
+	hipLaunchKernelGGL(k_cg_init3, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, gscal, (pfx_cg_state *)ctx->d_cgstate);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_spmv_impl(pfx_ctx *ctx, double *gscal)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	if (spmv_launch<true>(ctx, w.p, w.tmp, ctx->d_partials, (pfx_cg_state *)ctx->d_cgstate))
+		return PFX_ERR_UNSUPPORTED;
+	finish(ctx, 0, 1, gscal);
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	const int64_t n = ctx->n_owned * ctx->bs;
+	{
+		pfx_scoped_timer tm(ctx, "cg_update");
+		hipLaunchKernelGGL(k_cg_update, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, w.invdiag, n, it, d_x, w.r, ctx->d_partials, gscal, (pfx_cg_state *)ctx->d_cgstate);
+	}
+	finish(ctx, 1, 2, gscal);
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_direction_impl(pfx_ctx *ctx, int it, const double *gscal)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	const int64_t n = ctx->n_owned * ctx->bs;
+	pfx_scoped_timer tm(ctx, "cg_dir");
+	hipLaunchKernelGGL(k_cg_direction, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.r, w.invdiag, n, it, w.p, ctx->d_partials, gscal, (pfx_cg_state *)ctx->d_cgstate);
+	return PFX_OK;
+}
+
+pfx_status pfx_cgs_status_impl(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb)
+{
+	pfx_cg_state h;
+	if (!ctx->d_cgstate)
+		PFX_FAIL(PFX_ERR_ARG, "no solve in progress");
+	PFX_HIP(hipMemcpyAsync(&h, ctx->d_cgstate, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+	PFX_HIP(hipStreamSynchronize(ctx->stream));
+	*done = h.done;
+	*iters = h.iters;
+	*rr = h.rr;
+	*bb = h.rhs_norm2;
+	return PFX_OK;
+}
+
 pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res)
 {
-	const int64_t n = ctx->n_dofs();
-	hipStream_t st = ctx->stream;
-	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-	if (!ctx->d_work)
-		if (pfx_alloc(ctx, &ctx->d_work, 5 * n))
-			return PFX_ERR_HIP;
-	if (!ctx->d_cgstate)
-		if (pfx_alloc(ctx, (pfx_cg_state **)&ctx->d_cgstate, 1))
-			return PFX_ERR_HIP;
-	pfx_cg_state *state = (pfx_cg_state *)ctx->d_cgstate;
-	double *r = ctx->d_work, *p = r + n, *tmp = p + n, *invdiag = tmp + n, *xm = invdiag + n;
-	double *part = ctx->d_partials;
-	const int gv = PFX_NPART;
-
-	PFX_HIP(hipMemsetAsync(state, 0, sizeof(pfx_cg_state), st));
-	// initial guess with constrained dofs zeroed (solveWithGuess)
-	hipLaunchKernelGGL(k_mask_copy, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n, xm);
-	PFX_HIP(hipMemcpyAsync(d_x, xm, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-	if (ctx->bs == 1)
-		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_nodes, precond == PFX_PRECOND_JACOBI ? 1 : 0, invdiag);
-	else
-		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_nodes, precond == PFX_PRECOND_JACOBI ? 1 : 0, invdiag);
-	if (spmv_launch<false>(ctx, d_x, tmp, nullptr, nullptr))
-		return PFX_ERR_UNSUPPORTED;
-	hipLaunchKernelGGL(k_cg_init1, dim3(gv), dim3(256), 0, st, d_b, tmp, fixed, n, r, part);
-	hipLaunchKernelGGL(k_cg_init2, dim3(gv), dim3(256), 0, st, r, invdiag, n, tol, p, part, state, d_x);
-	hipLaunchKernelGGL(k_cg_init3, dim3(1), dim3(256), 0, st, part, state);
-
-	pfx_cg_state h;
+	pfx_status rc;
+	if ((rc = pfx_cgs_prepare_impl(ctx, d_x, precond)) || (rc = pfx_cgs_residual_impl(ctx, d_b, d_x, nullptr)) || (rc = pfx_cgs_start_impl(ctx, d_x, tol, nullptr)) || (rc = pfx_cgs_start2_impl(ctx, nullptr)))
+		return rc;
 	const int check_every = 16;
-	int it = 0;
-	bool finished = false;
-	while (it < max_iter && !finished)
+	int it = 0, done = 0, its = 0;
+	double rr = 0, bb = 0;
+	while (it < max_iter && !done)
 	{
 		const int stop = (it + check_every < max_iter) ? it + check_every : max_iter;
 		for (; it < stop; ++it)
-		{
-			if (spmv_launch<true>(ctx, p, tmp, part, state))
-				return PFX_ERR_UNSUPPORTED;
-			{
-				pfx_scoped_timer tm(ctx, "cg_update");
-				hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, st, p, tmp, invdiag, n, it, d_x, r, part, state);
-			}
-			{
-				pfx_scoped_timer tm(ctx, "cg_dir");
-				hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, st, r, invdiag, n, it, p, part, state);
-			}
-		}
-		PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipStreamSynchronize(st));
-		finished = h.done != 0;
+			if ((rc = pfx_cgs_spmv_impl(ctx, nullptr)) || (rc = pfx_cgs_update_impl(ctx, it, d_x, nullptr)) || (rc = pfx_cgs_direction_impl(ctx, it, nullptr)))
+				return rc;
+		if ((rc = pfx_cgs_status_impl(ctx, &done, &its, &rr, &bb)))
+			return rc;
 	}
-	if (max_iter <= 0)
-	{
-		PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipStreamSynchronize(st));
-	}
+	if (max_iter <= 0 && (rc = pfx_cgs_status_impl(ctx, &done, &its, &rr, &bb)))
+		return rc;
 	PFX_HIP(hipGetLastError());
-	*iters = h.iters;
-	*rel_res = (h.rhs_norm2 == 0.0) ? 0.0 : std::sqrt(h.rr / h.rhs_norm2);
+	*iters = its;
+	*rel_res = (bb == 0.0) ? 0.0 : std::sqrt(rr / bb);
 	return PFX_OK;
 }

@@ -1,0 +1,291 @@
+"""Multi-GPU layer: node partition, halo maps and the distributed CG driver (one process per GPU).
+
+The reference is single-process (no MPI/NCCL anywhere in its tree); this module is the new work the hot path
+needs to run on the 8 GPUs of one node:
+
+  * nodes (matrix rows) are split into contiguous owner ranges;
+  * every rank takes all elements that touch one of its nodes (its own elements plus one layer of its
+    neighbours'), numbers its nodes [owned | halo] and assembles with the single-GPU kernels -- owned rows are then
+    complete, so ASSEMBLY NEEDS NO COMMUNICATION (energy: each element is summed by the owner of its lowest node,
+    followed by one all-reduce of a double);
+  * the CG solve keeps all vectors distributed by rows; per iteration one halo exchange of the search direction
+    (grouped point-to-point send/recv between neighbouring ranks, i.e. ncclSend/ncclRecv over xGMI under
+    torch.distributed's "nccl" backend = RCCL) and two tiny all-reduces (p.Ap, then r.r and r.z together) -- the
+    classic two-reduction CG, so the iterates are those of the serial Eigen-order iteration.
+
+The per-rank compute is delegated to an `ops` object: `HipOps` (the HIP engine, the product path) or any object
+with the same methods working on CPU tensors (the CPU tests use one built on the oracle to check the partition
+and the communication pattern under the gloo backend).
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from . import mesh as M
+
+
+# ------------------------------------------------------------------------------------------------------------
+# partition
+# ------------------------------------------------------------------------------------------------------------
+
+
+def owner_ranges(n_nodes: int, world: int) -> np.ndarray:
+    """Contiguous, nearly equal node ranges: rank r owns [b[r], b[r+1])."""
+    return np.array([(n_nodes * r) // world for r in range(world + 1)], dtype=np.int64)
+
+
+@dataclasses.dataclass
+class Part:
+    mesh: M.Mesh               # local mesh: conn in local numbering [owned | halo]
+    n_owned: int
+    lo: int                    # owned global ids are lo .. lo+n_owned-1
+    halo_global: np.ndarray    # global ids of the halo nodes, ascending
+    halo_owner: np.ndarray     # owner rank per halo node
+    elem_owned: np.ndarray     # uint8 per local element: its energy is summed on this rank
+    elem_global: np.ndarray    # index of each local element in the candidate list handed to partition()
+
+    @property
+    def n_local(self) -> int:
+        return self.n_owned + int(self.halo_global.size)
+
+    def local_to_global(self) -> np.ndarray:
+        return np.concatenate([np.arange(self.lo, self.lo + self.n_owned, dtype=np.int64), self.halo_global])
+
+
+def partition(kind: int, conn: np.ndarray, gconn: np.ndarray, xyz: np.ndarray, bounds: np.ndarray, rank: int,
+              node_xyz=None, quad_order: int = -1) -> Part:
+    """Local part of rank `rank`.  `conn` (global basis ids) / `gconn` (global geometry ids) may be any superset of
+    the elements that touch the rank's nodes; `xyz` is indexed by global geometry id."""
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    touch = np.nonzero(((conn >= lo) & (conn < hi)).any(axis=1))[0]
+    c = conn[touch].astype(np.int64)
+    used = np.unique(c)
+    owned_mask = (used >= lo) & (used < hi)
+    halo_global = used[~owned_mask]
+    n_owned = hi - lo  # every node of the range is owned, used or not (keeps ranges contiguous)
+    # local id: owned -> g - lo ; halo -> n_owned + rank in halo_global
+    loc = np.where((c >= lo) & (c < hi), c - lo, n_owned + np.searchsorted(halo_global, c))
+    halo_owner = (np.searchsorted(bounds, halo_global, side="right") - 1).astype(np.int32)
+    gused, ginv = np.unique(gconn[touch], return_inverse=True)
+    lmesh = M.Mesh(kind, M.GEOM_KIND[kind], np.ascontiguousarray(loc.astype(np.int32)),
+                   np.ascontiguousarray(ginv.reshape(-1, gconn.shape[1]).astype(np.int32)),
+                   np.ascontiguousarray(xyz[gused]), n_owned + int(halo_global.size), None, quad_order)
+    if node_xyz is not None:
+        l2g = np.concatenate([np.arange(lo, hi, dtype=np.int64), halo_global])
+        lmesh.node_xyz = node_xyz(l2g) if callable(node_xyz) else node_xyz[l2g]
+    cmin = c.min(axis=1)
+    elem_owned = ((cmin >= lo) & (cmin < hi)).astype(np.uint8)
+    return Part(lmesh, n_owned, lo, halo_global, halo_owner, elem_owned, touch)
+
+
+def cube_tets_slab(n: int, nz: int, zc0: int, zc1: int, order: int = 2):
+    """Cells z in [zc0, zc1) of the n x n x nz Kuhn grid on [0,1]^2 x [0, nz/n], P1/P2 bases, GLOBAL lattice
+    numbering (x fastest).  Returns (kind, conn, gconn, xyz_of_all_vertices, n_nodes_global, lattice_dim_xy)."""
+    tets = M._kuhn_tets()
+    kz, ky, kx = np.meshgrid(np.arange(zc0, zc1), np.arange(n), np.arange(n), indexing="ij")
+    cell = np.stack([kx, ky, kz], axis=-1).reshape(-1, 1, 1, 3)
+    corners = (cell + tets[None]).reshape(-1, 4, 3)
+    nv = n + 1
+    gconn = corners[..., 0] + nv * (corners[..., 1] + nv * corners[..., 2])
+    gz, gy, gx = np.meshgrid(np.arange(nz + 1), np.arange(nv), np.arange(nv), indexing="ij")
+    xyz = np.stack([gx, gy, gz], axis=-1).reshape(-1, 3).astype(np.float64) / n
+    if order == 1:
+        return M.P1TET, gconn.astype(np.int64), gconn, xyz, nv * nv * (nz + 1), nv
+    L = 2 * n + 1
+    c2 = 2 * corners
+    loc = [c2[:, k] for k in range(4)]
+    for a, b in M._P2_EDGES:
+        loc.append((c2[:, a] + c2[:, b]) // 2)
+    loc = np.stack(loc, axis=1)
+    conn = loc[..., 0] + L * (loc[..., 1] + L * loc[..., 2])
+    return M.P2TET, conn.astype(np.int64), gconn, xyz, L * L * (2 * nz + 1), L
+
+
+def slab_part(n: int, cells_per_rank: int, rank: int, world: int, order: int = 2) -> tuple[Part, np.ndarray, int]:
+    """Weak-scaling decomposition used by the benchmark: the global grid is n x n x (cells_per_rank*world) cells,
+    rank r owns the lattice planes of its cell layers (the last rank also the top plane)."""
+    nz = cells_per_rank * world
+    step = 2 if order == 2 else 1
+    z0, z1 = rank * cells_per_rank, (rank + 1) * cells_per_rank
+    kind, conn, gconn, xyz, n_nodes, L = cube_tets_slab(n, nz, max(z0 - 1, 0), z1, order)
+    bounds = np.array([step * r * cells_per_rank * L * L for r in range(world)] + [n_nodes], dtype=np.int64)
+    h = (0.5 if order == 2 else 1.0) / n
+
+    def node_xyz(g):
+        return np.stack([g % L, (g // L) % L, g // (L * L)], axis=1) * h
+
+    return partition(kind, conn, gconn, xyz, bounds, rank, node_xyz), bounds, n_nodes
+
+
+# ------------------------------------------------------------------------------------------------------------
+# communication
+# ------------------------------------------------------------------------------------------------------------
+
+
+class Comm:
+    """Thin wrapper over torch.distributed (backend "nccl" = RCCL on the GPUs; "gloo" in the CPU tests).  With
+    world size 1 (or no process group) every call is a no-op."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.stage_cpu = self.on and dist.get_backend() == "gloo"  # gloo moves device tensors through the host
+
+    def all_reduce_sum(self, t):
+        if not self.on:
+            return
+        if self.stage_cpu and t.is_cuda:
+            c = t.cpu()
+            self.dist.all_reduce(c)
+            t.copy_(c)
+        else:
+            self.dist.all_reduce(t)
+
+    def all_gather_object(self, obj):
+        if not self.on:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+class HaloExchange:
+    """Fills the halo part of a node-major vector [owned | halo] from the owners: one grouped batch of
+    point-to-point sends/receives per call.  Receives land directly in the vector (halo nodes are sorted by global
+    id, so each neighbour's nodes are one contiguous slice); sends are packed with an index gather."""
+
+    def __init__(self, part: Part, comm: Comm, device):
+        import torch
+        self.torch, self.comm, self.part = torch, comm, part
+        self.n_owned = part.n_owned
+        want = {}
+        for s in np.unique(part.halo_owner):
+            sel = np.nonzero(part.halo_owner == s)[0]
+            want[int(s)] = (int(sel[0]), int(sel[-1]) + 1, part.halo_global[sel])
+        self.recv = {s: (a, b) for s, (a, b, _) in want.items()}
+        requests = comm.all_gather_object({s: ids for s, (_, _, ids) in want.items()})
+        self.send_idx = {}
+        for s, req in enumerate(requests):
+            if s != comm.rank and comm.rank in req:
+                idx = np.asarray(req[comm.rank], dtype=np.int64) - part.lo
+                assert idx.min() >= 0 and idx.max() < part.n_owned
+                self.send_idx[s] = torch.from_numpy(idx).to(device)
+        self.send_buf = {}
+
+    def neighbours(self):
+        return sorted(set(self.recv) | set(self.send_idx))
+
+    def bytes_per_exchange(self, bs: int) -> int:
+        return 8 * bs * (sum(int(v.numel()) for v in self.send_idx.values()) + sum(b - a for a, b in self.recv.values()))
+
+    def __call__(self, vec_nodes):
+        """vec_nodes: (n_local, bs) tensor view of the vector."""
+        if not self.comm.on:
+            return
+        torch, dist = self.torch, self.comm.dist
+        ops, staged = [], []
+        for s, idx in self.send_idx.items():
+            buf = self.send_buf.get(s)
+            if buf is None or buf.shape[1] != vec_nodes.shape[1]:
+                buf = torch.empty((idx.numel(), vec_nodes.shape[1]), dtype=vec_nodes.dtype, device=vec_nodes.device)
+                self.send_buf[s] = buf
+            torch.index_select(vec_nodes, 0, idx, out=buf)
+            ops.append(dist.P2POp(dist.isend, buf.cpu() if self.comm.stage_cpu and buf.is_cuda else buf, s))
+        for s, (a, b) in self.recv.items():
+            dst = vec_nodes[self.n_owned + a: self.n_owned + b]
+            if self.comm.stage_cpu and dst.is_cuda:
+                tmp = torch.empty(dst.shape, dtype=dst.dtype)
+                staged.append((dst, tmp))
+                ops.append(dist.P2POp(dist.irecv, tmp, s))
+            else:
+                ops.append(dist.P2POp(dist.irecv, dst, s))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for dst, tmp in staged:
+            dst.copy_(tmp)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-rank compute back end (product path: the HIP engine)
+# ------------------------------------------------------------------------------------------------------------
+
+
+class HipOps:
+    """Adapter from tensors to the engine's device-pointer step functions (include/polyfem_amd.h, pfx_cgs_*)."""
+
+    def __init__(self, engine):
+        self.e = engine
+
+    def set_workspace(self, work):
+        self.e.cgs_set_workspace(work.data_ptr())
+
+    def prepare(self, x, precond):
+        self.e.cgs_prepare(x.data_ptr(), precond)
+
+    def residual(self, b, x, scal):
+        self.e.cgs_residual(b.data_ptr(), x.data_ptr(), scal.data_ptr())
+
+    def start(self, x, tol, scal):
+        self.e.cgs_start(x.data_ptr(), tol, scal.data_ptr())
+
+    def start2(self, scal):
+        self.e.cgs_start2(scal.data_ptr())
+
+    def spmv(self, scal):
+        self.e.cgs_spmv(scal.data_ptr())
+
+    def update(self, it, x, scal):
+        self.e.cgs_update(it, x.data_ptr(), scal.data_ptr())
+
+    def direction(self, it, scal):
+        self.e.cgs_direction(it, scal.data_ptr())
+
+    def status(self):
+        return self.e.cgs_status()
+
+
+class DistributedCG:
+    """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition."""
+
+    def __init__(self, ops, part: Part, bs: int, comm: Comm, device):
+        import torch
+        self.torch, self.ops, self.part, self.bs, self.comm = torch, ops, part, bs, comm
+        self.n_local = part.n_local
+        self.n = self.n_local * bs
+        self.halo = HaloExchange(part, comm, device)
+        self.work = torch.zeros(4 * self.n, dtype=torch.float64, device=device)
+        self.scal = torch.zeros(4, dtype=torch.float64, device=device)
+        self.ops.set_workspace(self.work)
+        self.p_nodes = self.work[self.n: 2 * self.n].view(self.n_local, bs)
+
+    def solve(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 25):
+        """b, x: local vectors of n_local*bs doubles (halo entries of b are ignored).  Returns (iters, rel_res)."""
+        ops, scal, ar = self.ops, self.scal, self.comm.all_reduce_sum
+        ops.prepare(x, precond)
+        self.halo(x.view(self.n_local, self.bs))
+        ops.residual(b, x, scal)
+        ar(scal[0:2])
+        ops.start(x, tol, scal)
+        ar(scal[2:3])
+        ops.start2(scal)
+        it, done, iters, rr, bb = 0, False, 0, 0.0, 0.0
+        while it < max_iter and not done:
+            stop = min(it + check_every, max_iter)
+            while it < stop:
+                self.halo(self.p_nodes)
+                ops.spmv(scal)
+                ar(scal[0:1])
+                ops.update(it, x, scal)
+                ar(scal[1:3])
+                ops.direction(it, scal)
+                it += 1
+            done, iters, rr, bb = ops.status()
+        if max_iter <= 0:
+            done, iters, rr, bb = ops.status()
+        return iters, (0.0 if bb == 0.0 else float(np.sqrt(rr / bb)))

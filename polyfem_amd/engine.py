@@ -31,6 +31,8 @@ EXPORTED_SYMBOLS = [
     "pfx_get_linear_csr", "pfx_energy", "pfx_gradient", "pfx_hessian", "pfx_energy_dev", "pfx_gradient_dev",
     "pfx_hessian_dev", "pfx_set_dirichlet", "pfx_get_reduced_csr", "pfx_spmv", "pfx_spmv_dev", "pfx_cg",
     "pfx_cg_dev", "pfx_dirichlet_solve", "pfx_get_info", "pfx_timing_enable", "pfx_timing_get", "pfx_timing_reset",
+    "pfx_set_owned", "pfx_cgs_set_workspace", "pfx_cgs_prepare", "pfx_cgs_residual", "pfx_cgs_start", "pfx_cgs_start2",
+    "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
 ]
 
 
@@ -90,6 +92,16 @@ def load():
         "pfx_timing_enable": [_vp, _i32],
         "pfx_timing_get": [_vp, C.c_char_p, _pd, _pi64],
         "pfx_timing_reset": [_vp],
+        "pfx_set_owned": [_vp, _i64, C.POINTER(C.c_uint8)],
+        "pfx_cgs_set_workspace": [_vp, _vp],
+        "pfx_cgs_prepare": [_vp, _vp, _i32],
+        "pfx_cgs_residual": [_vp, _vp, _vp, _vp],
+        "pfx_cgs_start": [_vp, _vp, _dbl, _vp],
+        "pfx_cgs_start2": [_vp, _vp],
+        "pfx_cgs_spmv": [_vp, _vp],
+        "pfx_cgs_update": [_vp, _i32, _vp, _vp],
+        "pfx_cgs_direction": [_vp, _i32, _vp],
+        "pfx_cgs_status": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pd, _pd],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -270,6 +282,43 @@ class Engine:
         it, err = C.c_int(), C.c_double()
         self._ck(self.L.pfx_dirichlet_solve(self.h, _d(b), _d(x), precond, max_iter, tol, C.byref(it), C.byref(err)))
         return x, it.value, err.value
+
+    # ---- multi-GPU building blocks (device pointers as integers) ---------------------------------------------
+    def set_owned(self, n_owned_nodes: int, elem_owned=None):
+        if elem_owned is None:
+            self._ck(self.L.pfx_set_owned(self.h, n_owned_nodes, None))
+        else:
+            f = np.ascontiguousarray(elem_owned, dtype=np.uint8)
+            self._ck(self.L.pfx_set_owned(self.h, n_owned_nodes, f.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def cgs_set_workspace(self, d_work: int):
+        self._ck(self.L.pfx_cgs_set_workspace(self.h, _vp(d_work) if d_work else None))
+
+    def cgs_prepare(self, d_x: int, precond: int):
+        self._ck(self.L.pfx_cgs_prepare(self.h, _vp(d_x), precond))
+
+    def cgs_residual(self, d_b: int, d_x: int, d_scal: int):
+        self._ck(self.L.pfx_cgs_residual(self.h, _vp(d_b), _vp(d_x), _vp(d_scal) if d_scal else None))
+
+    def cgs_start(self, d_x: int, tol: float, d_scal: int):
+        self._ck(self.L.pfx_cgs_start(self.h, _vp(d_x), tol, _vp(d_scal) if d_scal else None))
+
+    def cgs_start2(self, d_scal: int):
+        self._ck(self.L.pfx_cgs_start2(self.h, _vp(d_scal) if d_scal else None))
+
+    def cgs_spmv(self, d_scal: int):
+        self._ck(self.L.pfx_cgs_spmv(self.h, _vp(d_scal) if d_scal else None))
+
+    def cgs_update(self, it: int, d_x: int, d_scal: int):
+        self._ck(self.L.pfx_cgs_update(self.h, it, _vp(d_x), _vp(d_scal) if d_scal else None))
+
+    def cgs_direction(self, it: int, d_scal: int):
+        self._ck(self.L.pfx_cgs_direction(self.h, it, _vp(d_scal) if d_scal else None))
+
+    def cgs_status(self):
+        done, it, rr, bb = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        self._ck(self.L.pfx_cgs_status(self.h, C.byref(done), C.byref(it), C.byref(rr), C.byref(bb)))
+        return bool(done.value), it.value, rr.value, bb.value
 
     # ---- timing ------------------------------------------------------------------------------------------
     def timing_enable(self, on: bool = True):

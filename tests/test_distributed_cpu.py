@@ -1,0 +1,119 @@
+"""CPU tests of the multi-GPU layer under the gloo backend (world size 2 and 3): node partition, halo maps,
+grouped point-to-point exchange and the two-reduction distributed CG, with the oracle doing each rank's local
+arithmetic.  The distributed result must reproduce the serial Eigen-order CG of the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from polyfem_amd import distributed as D
+from polyfem_amd import mesh as M
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pf_oracle as O
+        from tests.dist_helpers import OracleOps, csc_tuple_to_csr
+        if case == "laplace_p1":
+            mesh, model, bs = M.cube_tets(5, 1), O.LAPLACIAN, 1
+        else:
+            mesh, model, bs = M.cube_tets(3, 2, jitter=0.1), O.LINEAR_ELASTICITY, 3
+        lam, mu = O.lame(1e5, 0.3)
+        bounds = D.owner_ranges(mesh.n_nodes, world)
+        part = D.partition(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds, rank, mesh.node_xyz)
+        l2g = part.local_to_global()
+        nl = part.n_local
+        # --- partition invariants
+        assert part.n_owned == bounds[rank + 1] - bounds[rank]
+        assert np.all(np.diff(part.halo_global) > 0) and np.all(part.halo_owner != rank)
+        counts = [None] * world
+        dist.all_gather_object(counts, int(part.elem_owned.sum()))
+        assert sum(counts) == mesh.n_el, "every element's energy must be owned by exactly one rank"
+        # --- local assembly of the local mesh == owned rows of the global matrix
+        n_glob = mesh.n_nodes * bs
+        Kg = csc_tuple_to_csr(O.assemble_linear(mesh, model, lam, mu), n_glob)
+        Kl = csc_tuple_to_csr(O.assemble_linear(part.mesh, model, lam, mu), nl * bs)
+        dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
+        no = part.n_owned * bs
+        ref_rows = Kg[dof_l2g[:no]][:, dof_l2g]
+        assert abs(Kl[:no] - ref_rows).max() <= 1e-12 * abs(Kg).max()
+        # --- distributed CG == serial CG
+        bd = M.boundary_dofs(mesh, bs, "all" if bs == 1 else "x0")
+        fixed_g = np.zeros(n_glob, dtype=bool)
+        fixed_g[bd] = True
+        b_g = np.random.default_rng(3).standard_normal(n_glob)
+        ops = OracleOps(Kl, no, fixed_g[dof_l2g])
+        comm = D.Comm()
+        cg = D.DistributedCG(ops, part, bs, comm, torch.device("cpu"))
+        b = torch.from_numpy(b_g[dof_l2g].copy())
+        x = torch.zeros(nl * bs, dtype=torch.float64)
+        iters, err = cg.solve(b, x, 1, 1000, 1e-12, check_every=7)
+        xs = [None] * world
+        dist.all_gather_object(xs, (int(part.lo), x.numpy()[:no].copy()))
+        # halo exchange check: after one more exchange the halo of x equals the owners' values
+        cg.halo(x.view(nl, bs))
+        if rank == 0:
+            xg = np.zeros(n_glob)
+            for lo, v in xs:
+                xg[lo * bs: lo * bs + v.size] = v
+            keep = np.setdiff1d(np.arange(n_glob), bd)
+            red = O.full_to_reduced_matrix(O.assemble_linear(mesh, model, lam, mu), bd)
+            xr, it_ref, err_ref = O.cg(red, b_g[keep], jacobi=True, max_iter=1000, tol=1e-12)
+            ret["iters"], ret["it_ref"], ret["err"] = iters, it_ref, err
+            ret["dx"] = float(np.abs(xg[keep] - xr).max() / np.abs(xr).max())
+            ret["fixed_zero"] = bool(not xg[bd].any())
+        allx = [None] * world
+        dist.all_gather_object(allx, None)
+        xg_all = np.zeros(n_glob)
+        for lo, v in xs:
+            xg_all[lo * bs: lo * bs + v.size] = v
+        assert np.array_equal(x.numpy(), xg_all[dof_l2g]), "halo entries must equal the owners' values"
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "laplace_p1"), (2, "elastic_p2"), (3, "elastic_p2")])
+def test_distributed_cg_gloo(world, case):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, case, ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        assert abs(ret["iters"] - ret["it_ref"]) <= 2, (ret["iters"], ret["it_ref"])
+        assert ret["err"] < 1e-11 and ret["dx"] < 1e-8 and ret["fixed_zero"]
+
+
+def test_slab_partition_matches_generic():
+    """The benchmark's direct slab generator gives the same local parts as partitioning the full mesh."""
+    n, cpr, world = 3, 2, 3
+    nz = cpr * world
+    kind, conn, gconn, xyz, n_nodes, L = D.cube_tets_slab(n, nz, 0, nz, 2)
+    step_bounds = None
+    for rank in range(world):
+        part, bounds, nn = D.slab_part(n, cpr, rank, world, 2)
+        assert nn == n_nodes
+        ref = D.partition(kind, conn, gconn, xyz, bounds, rank)
+        assert part.n_owned == ref.n_owned and np.array_equal(part.halo_global, ref.halo_global)
+        assert part.mesh.n_el == ref.mesh.n_el
+        a = np.sort(part.local_to_global()[part.mesh.conn], axis=1)
+        b = np.sort(ref.local_to_global()[ref.mesh.conn], axis=1)
+        assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+        assert part.elem_owned.sum() == ref.elem_owned.sum()
+        step_bounds = bounds
+    assert step_bounds[-1] == n_nodes

@@ -1,0 +1,111 @@
+"""GPU test of the multi-GPU path on ONE card: two ranks share cuda:0 and talk through gloo (device tensors are
+staged through the host by polyfem_amd.distributed.Comm), so the real HIP step kernels, owned-row ranges, halo
+exchange and scalar all-reduces are exercised end to end.  Reference: the single-engine solve of the whole mesh."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        from polyfem_amd import mesh as M
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        n, cpr = 6, 3
+        part, bounds, n_nodes = D.slab_part(n, cpr, rank, world, 2)
+        lam, mu = 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        l2g = part.local_to_global()
+        nl, bs = part.n_local, 3
+        dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
+        rng = np.random.default_rng(7)
+        u_g = rng.standard_normal(n_nodes * bs) * 1e-3
+        b_g = rng.standard_normal(n_nodes * bs)
+        u = torch.from_numpy(u_g[dof_l2g]).to(dev)
+        eng.hessian_dev(u.data_ptr())
+        e_loc = torch.zeros(1, dtype=torch.float64, device=dev)
+        eng.energy_dev(u.data_ptr(), e_loc.data_ptr())
+        g_loc = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        eng.gradient_dev(u.data_ptr(), g_loc.data_ptr())
+        comm = D.Comm()
+        comm.all_reduce_sum(e_loc)
+        fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 0]) < 1e-12)[0]
+        eng.set_dirichlet(np.sort((fixed[:, None] * bs + np.arange(bs)[None]).reshape(-1)).astype(np.int32))
+        cg = D.DistributedCG(D.HipOps(eng), part, bs, comm, dev)
+        b = torch.from_numpy(b_g[dof_l2g]).to(dev)
+        x = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        iters, err = cg.solve(b, x, E.PRECOND_JACOBI, 1000, 1e-12, check_every=10)
+        torch.cuda.synchronize()
+        no = part.n_owned * bs
+        out = [None] * world
+        dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no], g_loc.cpu().numpy()[:no]))
+        if rank == 0:
+            ret["iters"], ret["err"], ret["energy"] = iters, err, float(e_loc.item())
+            xg = np.zeros(n_nodes * bs)
+            gg = np.zeros(n_nodes * bs)
+            for lo, xv, gv in out:
+                xg[lo * bs: lo * bs + xv.size] = xv
+                gg[lo * bs: lo * bs + gv.size] = gv
+            ret["x"], ret["g"] = xg, gg
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_engine():
+    import torch.multiprocessing as mp
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        iters, err, energy, xg, gg = ret["iters"], ret["err"], ret["energy"], ret["x"], ret["g"]
+    # single engine on the whole mesh (world = 1 slab == whole grid, same global numbering)
+    part, bounds, n_nodes = D.slab_part(6, 6, 0, 1, 2)
+    eng = E.Engine(0)
+    eng.set_mesh(part.mesh)
+    eng.set_material(E.NEOHOOKEAN, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+    eng.build_pattern()
+    rng = np.random.default_rng(7)
+    u = rng.standard_normal(n_nodes * 3) * 1e-3
+    b = rng.standard_normal(n_nodes * 3)
+    eng.hessian(u, fetch=False)
+    e_ref = eng.energy(u)
+    g_ref = eng.gradient(u)
+    fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 0]) < 1e-12)[0]
+    eng.set_dirichlet(np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+    x_ref, it_ref, err_ref = eng.cg(b, None, E.PRECOND_JACOBI, 1000, 1e-12)
+    eng.close()
+    assert abs(energy - e_ref) <= 1e-12 * abs(e_ref)
+    assert np.abs(gg - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
+    assert abs(iters - it_ref) <= 2 and err < 1e-11
+    assert np.abs(xg - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
