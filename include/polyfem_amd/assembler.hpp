@@ -1,0 +1,354 @@
+// polyfem_amd/assembler.hpp -- C++ host shim with the reference's own signatures on top of the C ABI
+// (include/polyfem_amd.h).  A PolyFEM build would include this instead of
+//   src/polyfem/assembler/Assembler.hpp            (Assembler<L>::assemble :32-39, NLAssembler<L> :80-113)
+//   src/polyfem/utils/MatrixUtils.hpp              (SpareMatrixCache :39-100)
+//   polysolve/LinearSolver.hpp                     (create / setParameters / analyzePattern / factorize / solve / getInfo;
+//                                                   call sites src/polyfem/solver/SparseNewtonDescentSolver.tpp:128-155)
+// and keep its call sites unchanged.  Eigen is not available in this repository, so the few Eigen types that
+// appear in those signatures are replaced by the minimal stand-ins below (same storage conventions: column
+// vectors are contiguous doubles, StiffnessMatrix is compressed storage with int indices); in a real PolyFEM build
+// they are typedefs of the Eigen types and the bodies stay the same.
+//
+// Error behaviour follows the reference: failures surface as std::runtime_error (the Newton solver catches exactly
+// that around factorize/solve, SparseNewtonDescentSolver.tpp:135-150).  Element sets the engine does not implement
+// (non-conforming bases with global().size() != 1, mixed element types, 2-D) are rejected with std::runtime_error
+// instead of being computed somewhere else: there is no CPU fallback.
+#pragma once
+
+#include "../polyfem_amd.h"
+
+#include <cmath>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace polyfem_amd
+{
+	// ---- stand-ins for the Eigen / basis types that appear in the signatures -------------------------------------
+	using VectorXd = std::vector<double>; // Eigen::MatrixXd column, x[node*dim + c]
+
+	struct StiffnessMatrix // Eigen::SparseMatrix<double, ColMajor, int> (utils/Types.hpp:16-20), structurally symmetric
+	{
+		int n = 0;
+		std::vector<int64_t> outer;
+		std::vector<int32_t> inner;
+		std::vector<double> values;
+		int rows() const { return n; }
+		int cols() const { return n; }
+		int64_t nonZeros() const { return (int64_t)inner.size(); }
+	};
+
+	namespace basis
+	{
+		struct Local2Global // basis/Basis.hpp:21-38
+		{
+			int index = 0;
+			double val = 1.0;
+			double node[3] = {0, 0, 0};
+		};
+		class Basis // basis/Basis.hpp:43-118 (only what the assembler reads)
+		{
+		public:
+			std::vector<Local2Global> global_;
+			const std::vector<Local2Global> &global() const { return global_; }
+		};
+		class ElementBases // basis/ElementBases.hpp:16-104
+		{
+		public:
+			std::vector<Basis> bases;
+			bool has_parameterization = true;
+		};
+	} // namespace basis
+
+	namespace utils
+	{
+		// The caller-owned pattern cache of NLAssembler::assemble_hessian.  The pattern itself lives on the device;
+		// this object keeps the host copy of the index arrays that are handed back inside the StiffnessMatrix.
+		class SpareMatrixCache
+		{
+		public:
+			std::vector<int64_t> outer_index_;
+			std::vector<int32_t> inner_index_;
+			size_t non_zeros() const { return inner_index_.size(); }
+			size_t mapping_size() const { return outer_index_.empty() ? 0 : outer_index_.size() - 1; }
+		};
+	} // namespace utils
+
+	// ---- one device context per process ----------------------------------------------------------------------------
+	class Context
+	{
+	public:
+		static Context &instance(int device = 0)
+		{
+			static Context c(device);
+			return c;
+		}
+		pfx_ctx *h = nullptr;
+		const void *bound_bases = nullptr;
+		size_t bound_count = 0;
+		int bound_model = -1;
+		double bound_lambda = 0, bound_mu = 0;
+
+		void check(pfx_status rc) const
+		{
+			if (rc != PFX_OK)
+				throw std::runtime_error(std::string("polyfem_amd: ") + pfx_last_error(h));
+		}
+
+		// Flattens bases/gbases the way State::sending_data_to_GPU walks them (state/StateSolveNonlinear.cpp:224-240)
+		// and (re)builds the device pattern when the mesh, the model or the material changed.
+		void bind(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis, int model, int dim, double lambda, double mu)
+		{
+			if (bound_bases == (const void *)bases.data() && bound_count == bases.size() && bound_model == model && bound_lambda == lambda && bound_mu == mu)
+				return;
+			if (bases.empty() || bases.size() != gbases.size())
+				throw std::runtime_error("polyfem_amd: empty or inconsistent bases");
+			const int n_loc = (int)bases[0].bases.size(), n_gloc = (int)gbases[0].bases.size();
+			int kind = -1;
+			if (n_loc == 4 && n_gloc == 4)
+				kind = PFX_P1TET;
+			else if (n_loc == 10 && n_gloc == 4)
+				kind = PFX_P2TET;
+			else if (n_loc == 8 && n_gloc == 8)
+				kind = PFX_Q1HEX;
+			else if (n_loc == 27 && n_gloc == 8)
+				kind = PFX_Q2HEX;
+			else
+				throw std::runtime_error("polyfem_amd: unsupported element (P1/P2 tets and Q1/Q2 hexes on linear geometry only)");
+			const int64_t n_el = (int64_t)bases.size();
+			std::vector<int32_t> conn((size_t)n_el * n_loc), gconn((size_t)n_el * n_gloc);
+			int64_t n_gnodes = 0;
+			for (int64_t e = 0; e < n_el; ++e)
+			{
+				if ((int)bases[e].bases.size() != n_loc || (int)gbases[e].bases.size() != n_gloc || !gbases[e].has_parameterization)
+					throw std::runtime_error("polyfem_amd: mixed element types are not supported");
+				for (int j = 0; j < n_loc; ++j)
+				{
+					const auto &g = bases[e].bases[j].global();
+					if (g.size() != 1 || g[0].val != 1.0)
+						throw std::runtime_error("polyfem_amd: non-conforming bases (global().size() != 1) are not supported");
+					conn[e * n_loc + j] = g[0].index;
+				}
+				for (int j = 0; j < n_gloc; ++j)
+				{
+					const auto &g = gbases[e].bases[j].global();
+					if (g.size() != 1 || g[0].val != 1.0)
+						throw std::runtime_error("polyfem_amd: non-conforming geometry bases are not supported");
+					gconn[e * n_gloc + j] = g[0].index;
+					if (g[0].index + 1 > n_gnodes)
+						n_gnodes = g[0].index + 1;
+				}
+			}
+			std::vector<double> xyz((size_t)n_gnodes * 3, 0.0);
+			for (int64_t e = 0; e < n_el; ++e)
+				for (int j = 0; j < n_gloc; ++j)
+				{
+					const auto &g = gbases[e].bases[j].global()[0];
+					for (int c = 0; c < 3; ++c)
+						xyz[(size_t)g.index * 3 + c] = g.node[c];
+				}
+			check(pfx_set_mesh(h, kind, n_el, n_basis, n_gnodes, conn.data(), gconn.data(), xyz.data(), -1));
+			check(pfx_set_material(h, model, dim, lambda, mu));
+			int64_t nnz = 0;
+			check(pfx_build_pattern(h, &nnz));
+			bound_bases = bases.data();
+			bound_count = bases.size();
+			bound_model = model;
+			bound_lambda = lambda;
+			bound_mu = mu;
+		}
+
+	private:
+		explicit Context(int device)
+		{
+			if (pfx_create(&h, device) != PFX_OK)
+				throw std::runtime_error("polyfem_amd: no usable HIP device (the engine has no CPU fallback)");
+		}
+		~Context() { pfx_destroy(h); }
+	};
+
+	namespace assembler
+	{
+		class AssemblyValsCache // assembler/AssemblyValsCache.hpp: the engine recomputes per-element values on the fly
+		{
+		};
+
+		// local assemblers: only the parameters the reference objects carry (set_size / add_multimaterial)
+		struct Laplacian
+		{
+			static constexpr int model = PFX_LAPLACIAN;
+			int size() const { return 1; }
+			double lambda = 1, mu = 1;
+		};
+		struct ElasticBase
+		{
+			int size_ = 3;
+			double lambda = 1, mu = 1;
+			int size() const { return size_; }
+			void set_size(int s)
+			{
+				if (s != 3)
+					throw std::runtime_error("polyfem_amd: only 3-D elasticity is implemented");
+				size_ = s;
+			}
+			// LameParameters::add_multimaterial for uniform (E, nu): utils/ElasticityUtils.cpp:203-214
+			void set_E_nu(double E, double nu)
+			{
+				lambda = (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+				mu = E / (2.0 * (1.0 + nu));
+			}
+			void set_lambda_mu(double l, double m) { lambda = l, mu = m; }
+		};
+		struct LinearElasticity : ElasticBase
+		{
+			static constexpr int model = PFX_LINEAR_ELASTICITY;
+		};
+		struct NeoHookeanElasticity : ElasticBase
+		{
+			static constexpr int model = PFX_NEOHOOKEAN;
+		};
+
+		template <class LocalAssembler>
+		class Assembler // assembler/Assembler.hpp:26-47
+		{
+		public:
+			void assemble(const bool is_volume, const int n_basis, const std::vector<basis::ElementBases> &bases,
+						  const std::vector<basis::ElementBases> &gbases, const AssemblyValsCache &, StiffnessMatrix &stiffness,
+						  const bool is_mass = false) const
+			{
+				if (!is_volume || is_mass)
+					throw std::runtime_error("polyfem_amd: only 3-D stiffness assembly is implemented");
+				Context &c = Context::instance();
+				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu);
+				c.check(pfx_assemble_linear(c.h));
+				int64_t nnz = 0;
+				c.check(pfx_get_linear_csr(c.h, &nnz, nullptr, nullptr, nullptr));
+				stiffness.n = n_basis * local_assembler_.size();
+				stiffness.outer.assign((size_t)stiffness.n + 1, 0);
+				stiffness.inner.assign((size_t)nnz, 0);
+				stiffness.values.assign((size_t)nnz, 0.0);
+				c.check(pfx_get_linear_csr(c.h, &nnz, stiffness.outer.data(), stiffness.inner.data(), stiffness.values.data()));
+			}
+			LocalAssembler &local_assembler() { return local_assembler_; }
+			const LocalAssembler &local_assembler() const { return local_assembler_; }
+
+		private:
+			LocalAssembler local_assembler_;
+		};
+
+		template <class LocalAssembler>
+		class NLAssembler // assembler/Assembler.hpp:70-118
+		{
+		public:
+			double assemble(const bool is_volume, const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases,
+							const AssemblyValsCache &, const double /*dt*/, const VectorXd &displacement, const VectorXd & /*displacement_prev*/) const
+			{
+				Context &c = bound(is_volume, bases, gbases, (int)displacement.size() / 3);
+				double e = 0;
+				c.check(pfx_energy(c.h, displacement.data(), &e));
+				return e;
+			}
+			void assemble_grad(const bool is_volume, const int n_basis, const std::vector<basis::ElementBases> &bases,
+							   const std::vector<basis::ElementBases> &gbases, const AssemblyValsCache &, const double /*dt*/,
+							   const VectorXd &displacement, const VectorXd & /*displacement_prev*/, VectorXd &rhs) const
+			{
+				Context &c = bound(is_volume, bases, gbases, n_basis);
+				rhs.assign((size_t)n_basis * local_assembler_.size(), 0.0);
+				c.check(pfx_gradient(c.h, displacement.data(), rhs.data()));
+			}
+			void assemble_hessian(const bool is_volume, const int n_basis, const bool project_to_psd, const std::vector<basis::ElementBases> &bases,
+								  const std::vector<basis::ElementBases> &gbases, const AssemblyValsCache &, const double /*dt*/,
+								  const VectorXd &displacement, const VectorXd & /*displacement_prev*/, utils::SpareMatrixCache &mat_cache,
+								  StiffnessMatrix &grad) const
+			{
+				Context &c = bound(is_volume, bases, gbases, n_basis);
+				const int n = n_basis * local_assembler_.size();
+				if (mat_cache.mapping_size() != (size_t)n)
+				{
+					// first call: the pattern built on the device is copied once into the caller's cache
+					// (the reference fills it during its first CPU assembly, utils/MatrixUtils.cpp:171-241)
+					int64_t nnz = 0;
+					pfx_info info;
+					c.check(pfx_get_info(c.h, &info));
+					nnz = info.nnz;
+					mat_cache.outer_index_.assign((size_t)n + 1, 0);
+					mat_cache.inner_index_.assign((size_t)nnz, 0);
+					c.check(pfx_get_pattern(c.h, mat_cache.outer_index_.data(), mat_cache.inner_index_.data()));
+				}
+				grad.n = n;
+				grad.outer = mat_cache.outer_index_;
+				grad.inner = mat_cache.inner_index_;
+				grad.values.assign(mat_cache.inner_index_.size(), 0.0);
+				c.check(pfx_hessian(c.h, displacement.data(), project_to_psd ? 1 : 0, grad.values.data()));
+			}
+			LocalAssembler &local_assembler() { return local_assembler_; }
+
+		private:
+			Context &bound(bool is_volume, const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis) const
+			{
+				if (!is_volume)
+					throw std::runtime_error("polyfem_amd: only 3-D problems are implemented");
+				Context &c = Context::instance();
+				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu);
+				return c;
+			}
+			LocalAssembler local_assembler_;
+		};
+	} // namespace assembler
+
+	namespace polysolve
+	{
+		// polysolve::LinearSolver for "Eigen::ConjugateGradient".  The matrix it solves with is the one the engine
+		// assembled last (it never leaves the device); analyzePattern / factorize only validate the size.
+		class LinearSolver
+		{
+		public:
+			static std::unique_ptr<LinearSolver> create(const std::string &solver, const std::string &precond)
+			{
+				if (!solver.empty() && solver != "Eigen::ConjugateGradient")
+					throw std::runtime_error("Unrecognized solver type: " + solver);
+				auto s = std::unique_ptr<LinearSolver>(new LinearSolver());
+				s->precond_ = (precond.empty() || precond == "Eigen::DiagonalPreconditioner") ? PFX_PRECOND_JACOBI : PFX_PRECOND_IDENTITY;
+				return s;
+			}
+			std::string name() const { return "Eigen::ConjugateGradient"; }
+			// setParameters(json): params[name()]["max_iter"|"tolerance"], defaults input-spec.json:1326-1336
+			void setParameters(int max_iter, double tolerance)
+			{
+				max_iter_ = max_iter;
+				tolerance_ = tolerance;
+			}
+			void analyzePattern(const StiffnessMatrix &A, const int /*precond_num*/) { n_ = A.rows(); }
+			void factorize(const StiffnessMatrix &A)
+			{
+				if (A.rows() != n_)
+					throw std::runtime_error("polyfem_amd: factorize called with a different matrix size");
+			}
+			// reduced solves: the constrained dofs are given once and the solver works on the masked full-size system
+			void setDirichlet(const std::vector<int> &sorted_dofs)
+			{
+				Context &c = Context::instance();
+				c.check(pfx_set_dirichlet(c.h, sorted_dofs.data(), (int64_t)sorted_dofs.size()));
+			}
+			void solve(const VectorXd &b, VectorXd &x)
+			{
+				Context &c = Context::instance();
+				if (x.size() != b.size())
+					x.assign(b.size(), 0.0);
+				c.check(pfx_cg(c.h, b.data(), x.data(), precond_, max_iter_, tolerance_, &iters_, &error_));
+				if (!std::isfinite(error_))
+					throw std::runtime_error("polyfem_amd: CG broke down (non-finite residual)");
+			}
+			// getInfo(json&): "solver_iter", "solver_error"
+			int solver_iter() const { return iters_; }
+			double solver_error() const { return error_; }
+
+		private:
+			LinearSolver() = default;
+			int precond_ = PFX_PRECOND_JACOBI, max_iter_ = 1000, iters_ = 0, n_ = 0;
+			double tolerance_ = 1e-12, error_ = 0;
+		};
+	} // namespace polysolve
+} // namespace polyfem_amd

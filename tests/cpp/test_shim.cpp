@@ -1,0 +1,157 @@
+// Host-side test of the C++ shim (include/polyfem_amd/assembler.hpp): reads like the reference's
+// tests/test_assembler.cpp:12-64 ("hessian_lin") and tests/test_form_derivatives.cpp:84-143 on a small Kuhn mesh.
+#include <polyfem_amd/assembler.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+
+using namespace polyfem_amd;
+
+static void build_p2_cube(int n, std::vector<basis::ElementBases> &bases, std::vector<basis::ElementBases> &gbases, int &n_basis)
+{
+	static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+	static const int even[6] = {1, 0, 0, 1, 1, 0};
+	static const int edges[6][2] = {{0, 1}, {1, 2}, {2, 0}, {0, 3}, {1, 3}, {2, 3}};
+	const int L = 2 * n + 1, nv = n + 1;
+	n_basis = L * L * L;
+	for (int kz = 0; kz < n; ++kz)
+		for (int ky = 0; ky < n; ++ky)
+			for (int kx = 0; kx < n; ++kx)
+				for (int t = 0; t < 6; ++t)
+				{
+					int v[4][3] = {{kx, ky, kz}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+					for (int s = 0; s < 3; ++s)
+					{
+						for (int c = 0; c < 3; ++c)
+							v[s + 1][c] = v[s][c];
+						v[s + 1][perms[t][s]] += 1;
+					}
+					if (!even[t])
+						for (int c = 0; c < 3; ++c)
+							std::swap(v[2][c], v[3][c]);
+					basis::ElementBases b, g;
+					b.bases.resize(10);
+					g.bases.resize(4);
+					int lat[10][3];
+					for (int k = 0; k < 4; ++k)
+						for (int c = 0; c < 3; ++c)
+							lat[k][c] = 2 * v[k][c];
+					for (int k = 0; k < 6; ++k)
+						for (int c = 0; c < 3; ++c)
+							lat[4 + k][c] = (lat[edges[k][0]][c] + lat[edges[k][1]][c]) / 2;
+					for (int k = 0; k < 10; ++k)
+					{
+						basis::Local2Global l2g;
+						l2g.index = lat[k][0] + L * (lat[k][1] + L * lat[k][2]);
+						for (int c = 0; c < 3; ++c)
+							l2g.node[c] = lat[k][c] * 0.5 / n;
+						b.bases[k].global_.push_back(l2g);
+					}
+					for (int k = 0; k < 4; ++k)
+					{
+						basis::Local2Global l2g;
+						l2g.index = v[k][0] + nv * (v[k][1] + nv * v[k][2]);
+						for (int c = 0; c < 3; ++c)
+							l2g.node[c] = (double)v[k][c] / n;
+						g.bases[k].global_.push_back(l2g);
+					}
+					bases.push_back(b);
+					gbases.push_back(g);
+				}
+}
+
+#define REQUIRE(c)                                                    \
+	do                                                                \
+	{                                                                 \
+		if (!(c))                                                     \
+		{                                                             \
+			std::printf("REQUIRE failed: %s (line %d)\n", #c, __LINE__); \
+			return 1;                                                 \
+		}                                                             \
+	} while (0)
+
+int main()
+{
+	std::vector<basis::ElementBases> bases, gbases;
+	int n_basis = 0;
+	build_p2_cube(3, bases, gbases, n_basis);
+	assembler::AssemblyValsCache cache;
+	const int N = n_basis * 3;
+
+	assembler::Assembler<assembler::LinearElasticity> lin;
+	lin.local_assembler().set_size(3);
+	lin.local_assembler().set_E_nu(1e5, 0.3);
+	StiffnessMatrix K;
+	lin.assemble(true, n_basis, bases, gbases, cache, K);
+	REQUIRE(K.rows() == N && K.nonZeros() > 0);
+
+	// a rigid translation is in the null space of the stiffness matrix
+	std::vector<double> t(N, 0.0), Kt(N, 0.0);
+	for (int i = 0; i < n_basis; ++i)
+		t[3 * i] = 1.0;
+	for (int r = 0; r < N; ++r)
+		for (int64_t k = K.outer[r]; k < K.outer[r + 1]; ++k)
+			Kt[r] += K.values[k] * t[K.inner[k]];
+	double mx = 0, kmax = 0;
+	for (double v : Kt)
+		mx = std::fmax(mx, std::fabs(v));
+	for (double v : K.values)
+		kmax = std::fmax(kmax, std::fabs(v));
+	REQUIRE(mx <= 1e-10 * kmax);
+
+	assembler::NLAssembler<assembler::NeoHookeanElasticity> nl;
+	nl.local_assembler().set_E_nu(2e4, 0.3);
+	utils::SpareMatrixCache mat_cache;
+	VectorXd x(N, 0.0), g, dx;
+	std::srand(1);
+	for (auto &v : x)
+		v = 1e-3 * ((double)std::rand() / RAND_MAX - 0.5);
+	const double e0 = nl.assemble(true, bases, gbases, cache, 0.0, x, x);
+	nl.assemble_grad(true, n_basis, bases, gbases, cache, 0.0, x, x, g);
+	StiffnessMatrix H;
+	nl.assemble_hessian(true, n_basis, false, bases, gbases, cache, 0.0, x, x, mat_cache, H);
+	REQUIRE(e0 > 0 && (int)g.size() == N && H.rows() == N && mat_cache.mapping_size() == (size_t)N);
+	// finite-difference check of the gradient along a random direction (test_form_derivatives.cpp:84-143)
+	VectorXd d(N), xp(N), xm(N);
+	for (auto &v : d)
+		v = (double)std::rand() / RAND_MAX - 0.5;
+	const double h = 1e-6;
+	for (int i = 0; i < N; ++i)
+		xp[i] = x[i] + h * d[i], xm[i] = x[i] - h * d[i];
+	const double fd = (nl.assemble(true, bases, gbases, cache, 0.0, xp, xp) - nl.assemble(true, bases, gbases, cache, 0.0, xm, xm)) / (2 * h);
+	double gd = 0;
+	for (int i = 0; i < N; ++i)
+		gd += g[i] * d[i];
+	REQUIRE(std::fabs(fd - gd) <= 1e-5 * std::fabs(gd));
+	// second call reuses the cache
+	nl.assemble_hessian(true, n_basis, false, bases, gbases, cache, 0.0, xp, xp, mat_cache, H);
+
+	// Newton direction: H dx = -g with the x = 0 face fixed (SparseNewtonDescentSolver.tpp:128-155)
+	auto solver = polysolve::LinearSolver::create("Eigen::ConjugateGradient", "Eigen::DiagonalPreconditioner");
+	solver->setParameters(1000, 1e-12);
+	std::vector<int> fixed;
+	for (int i = 0; i < n_basis; ++i)
+		if (i % 7 == 0) // lattice x == 0 (the lattice is 7 nodes wide for n = 3)
+			for (int c = 0; c < 3; ++c)
+				fixed.push_back(3 * i + c);
+	solver->setDirichlet(fixed);
+	solver->analyzePattern(H, H.rows());
+	solver->factorize(H);
+	VectorXd rhs(N);
+	for (int i = 0; i < N; ++i)
+		rhs[i] = -g[i];
+	solver->solve(rhs, dx);
+	REQUIRE(solver->solver_error() < 1e-10 && solver->solver_iter() > 0);
+	bool threw = false;
+	try
+	{
+		polysolve::LinearSolver::create("Eigen::SimplicialLDLT", "");
+	}
+	catch (const std::runtime_error &)
+	{
+		threw = true;
+	}
+	REQUIRE(threw);
+	std::printf("shim ok: nnz(K)=%ld energy=%.6e cg_iters=%d err=%.2e\n", (long)K.nonZeros(), e0, solver->solver_iter(), solver->solver_error());
+	return 0;
+}

@@ -248,3 +248,14 @@ def test_host_mirror_of_reference_interface(oracle):
     info = solver.get_info()
     assert info["solver_error"] < 1e-10 and 0 < info["solver_iter"] <= 500
     asm.engine.close()
+
+
+def test_cpp_shim_with_reference_signatures():
+    """include/polyfem_amd/assembler.hpp: Assembler<L>::assemble, NLAssembler<L>::assemble/_grad/_hessian and the
+    polysolve-shaped LinearSolver, driven from C++ (tests/cpp/test_shim.cpp, built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_shim")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "shim ok" in out.stdout, out.stdout + out.stderr
