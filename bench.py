@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
+    ap.add_argument("--grid", dest="n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
     ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean"])
     ap.add_argument("--cg-max-iter", type=int, default=1000)
     ap.add_argument("--cg-tol", type=float, default=1e-12)
