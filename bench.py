@@ -224,7 +224,7 @@ def main():
                 "parallelism": f"row/element partition over {world} GPUs, RCCL halo exchange + all-reduce"
                                if world > 1 else "single GPU",
             },
-            "roofline": {"kernel": "k_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
+            "roofline": {"kernel": "k_sell_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
                          "avg_ms": spmv_ms, "launches": spmv_n, "algorithmic_bytes": sb},
             "assembly": {"elements_per_s": world * owned_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,

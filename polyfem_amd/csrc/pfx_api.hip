@@ -71,6 +71,8 @@ namespace
 		free_dev(ctx->d_work);
 		free_dev(ctx->d_u);
 		free_dev(ctx->d_vec);
+		free_dev(ctx->d_part0);
+		pfx_sell_release(ctx);
 		ctx->n_blocks = ctx->nnz = 0;
 		ctx->n_dirichlet = 0;
 		ctx->have_mask = false;
@@ -340,6 +342,7 @@ extern "C"
 				return rc;
 		}
 		ctx->have_mask = true;
+		ctx->values_gen++;
 		return PFX_OK;
 	}
 
@@ -399,6 +402,7 @@ extern "C"
 				return rc;
 		}
 		ctx->have_mask = false;
+		ctx->values_gen++;
 		pfx_scoped_timer tm(ctx, "gather");
 		return pfx_launch_gather_matrix(ctx, false);
 	}

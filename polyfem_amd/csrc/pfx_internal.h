@@ -78,7 +78,15 @@ struct pfx_ctx
 	// solver work vectors
 	double *d_work = nullptr;     // 4 * n_dofs: r, p, tmp, invdiag
 	double *d_work_ext = nullptr; // caller-owned workspace of the same layout (multi-GPU driver)
-	double *d_partials = nullptr;
+	double *d_partials = nullptr; // 3 x 2048 per-block partial sums of the vector kernels
+	double *d_part0 = nullptr;    // per-block partials of the SpMV (one per SpMV block)
+
+	// solver copy of the matrix (block-SELL-64, pfx_sell.hip)
+	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
+	int64_t *d_sell_base = nullptr;
+	double *d_sell_vals = nullptr;
+	int64_t sell_slices = 0, sell_rows = 0, sell_owned = -1;
+	int64_t values_gen = 0, sell_gen = -1; // assembly counter / counter value the solver copy was made from
 	int *d_cgstate = nullptr;
 	double *d_u = nullptr, *d_vec = nullptr; // staging for host-pointer entry points
 
@@ -173,6 +181,10 @@ pfx_status pfx_launch_gather_matrix(pfx_ctx *ctx, bool write_mask);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
+void pfx_sell_release(pfx_ctx *ctx);
+pfx_status pfx_sell_refresh(pfx_ctx *ctx);
+int pfx_sell_grid(const pfx_ctx *ctx);
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done);
 pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res);
 pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond);
 pfx_status pfx_cgs_residual_impl(pfx_ctx *ctx, const double *d_b, const double *d_x, double *gscal);

@@ -1,0 +1,337 @@
+// pfx_sell.hip -- the solver's matrix format and its matrix-vector product.
+//
+// Plays the role of polysolve's analyzePattern (structure, once per pattern) + factorize (values, once per
+// assembled matrix) for the CG solver (call sites src/polyfem/solver/SparseNewtonDescentSolver.tpp:128-155).
+//
+// Format: block-SELL-64.  Owned nodes are sorted by degree inside windows of SIGMA consecutive nodes and cut into
+// slices of 64; lane l of a slice owns one node = bs matrix rows.  A slice stores, for slot j = 0..len-1 (len = the
+// largest degree in the slice, shorter rows padded with zero blocks pointing at the node itself):
+//     cols  [j][lane]                      int32 column node
+//     values[j][entry][lane]               the bs*bs block entries, lane fastest
+// (for bs = 3 entries 0..7 are stored as 4 lane-interleaved double2 so that they are fetched with 16-byte loads).
+// Every load of the value stream is therefore one fully coalesced 512 B / 1 KiB wave access, a lane accumulates its
+// bs rows in registers (no cross-lane reduction) and the loop over j unrolls freely, which keeps ~36 loads in flight
+// per lane.  Measured on MI355X, 1 M P2 tets: 0.65 ms per product against 0.81 ms for a lanes-per-row CSR kernel on
+// the same data; a pure streaming read of the value array takes 0.50 ms.  Sorting only inside windows keeps the x
+// entries gathered by one slice close together (L2 hits) and the padding below 0.2 %.
+#include "pfx_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace
+{
+	constexpr int SL = 64;
+
+	__global__ void k_sell_keys(const int64_t *__restrict__ node_ptr, int64_t n_owned, int sigma, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_owned; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const uint64_t deg = (uint64_t)(node_ptr[g + 1] - node_ptr[g]);
+			keys[g] = ((uint64_t)(g / sigma) << 24) | (0xFFFFFFull - (deg & 0xFFFFFFull));
+			vals[g] = (uint32_t)g;
+		}
+	}
+
+	__global__ void k_sell_perm(const uint32_t *__restrict__ sorted, int64_t n_owned, int64_t n_pad, const int64_t *__restrict__ node_ptr,
+								int32_t *__restrict__ perm, int64_t *__restrict__ slice_len)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_pad; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int32_t g = k < n_owned ? (int32_t)sorted[k] : -1;
+			perm[k] = g;
+			if ((k & (SL - 1)) == 0)
+				slice_len[k / SL] = g >= 0 ? node_ptr[g + 1] - node_ptr[g] : 0; // first lane has the largest degree
+		}
+	}
+
+	__global__ void k_sell_cols(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, const int32_t *__restrict__ perm,
+								const int64_t *__restrict__ slice_base, int64_t n_slices, int32_t *__restrict__ cols)
+	{
+		const int lane = threadIdx.x & 63;
+		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+		for (int64_t s = wave; s < n_slices; s += n_waves)
+		{
+			const int64_t base = slice_base[s];
+			const int len = (int)(slice_base[s + 1] - base);
+			const int g = perm[s * SL + lane];
+			const int64_t b0 = g >= 0 ? node_ptr[g] : 0;
+			const int deg = g >= 0 ? (int)(node_ptr[g + 1] - b0) : 0;
+			for (int j = 0; j < len; ++j)
+				cols[(base + j) * SL + lane] = j < deg ? node_col[b0 + j] : (g >= 0 ? g : 0);
+		}
+	}
+
+	// entry offset inside one slot of a slice
+	template <int BS>
+	__device__ __forceinline__ int entry_offset(int c, int lane)
+	{
+		if (BS == 3)
+			return c < 8 ? (c >> 1) * 128 + lane * 2 + (c & 1) : 512 + lane;
+		return c * SL + lane;
+	}
+
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_sell_values(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
+														  const int64_t *__restrict__ slice_base, int64_t n_slices, const double *__restrict__ csr,
+														  double *__restrict__ out)
+	{
+		constexpr int B2 = BS * BS;
+		const int lane = threadIdx.x & 63;
+		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+		for (int64_t s = wave; s < n_slices; s += n_waves)
+		{
+			const int64_t base = slice_base[s];
+			const int len = (int)(slice_base[s + 1] - base);
+			const int g = perm[s * SL + lane];
+			const int64_t b0 = g >= 0 ? node_ptr[g] : 0;
+			const int deg = g >= 0 ? (int)(node_ptr[g + 1] - b0) : 0;
+			const double *row0 = csr + b0 * B2;
+			double *o = out + base * (SL * B2);
+			for (int j = 0; j < len; ++j)
+#pragma unroll
+				for (int c = 0; c < B2; ++c)
+				{
+					const int m = c / BS, n = c - m * BS;
+					const double v = j < deg ? row0[(int64_t)m * deg * BS + j * BS + n] : 0.0;
+					o[(int64_t)j * (SL * B2) + entry_offset<BS>(c, lane)] = v;
+				}
+		}
+	}
+
+	__device__ __forceinline__ double wave_sum(double v)
+	{
+		for (int off = 32; off > 0; off >>= 1)
+			v += __shfl_down(v, off, 64);
+		return v;
+	}
+
+	// y = A x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per wave; blocks
+	// b and b+8 run on the same XCD, so each XCD walks one contiguous eighth of the slices (x gathers stay in its L2).
+	template <int BS, bool DOT>
+	__global__ __launch_bounds__(256) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
+														const int32_t *__restrict__ cols, const double *__restrict__ values, int64_t n_slices,
+														const uint8_t *__restrict__ fixed, const double *__restrict__ x, double *__restrict__ y,
+														double *__restrict__ part, const int *__restrict__ done)
+	{
+		__shared__ double sh[4];
+		if (DOT && *done)
+			return;
+		constexpr int B2 = BS * BS;
+		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+		const int nblk = gridDim.x;
+		const int per = (nblk + 7) / 8;
+		const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+		const int64_t s = (int64_t)vb * 4 + w;
+		double dot = 0.0;
+		if (s < n_slices)
+		{
+			const int64_t base = slice_base[s];
+			const int len = (int)(slice_base[s + 1] - base);
+			const double *v = values + base * (SL * B2);
+			const int32_t *c = cols + base * SL + lane;
+			double a0 = 0, a1 = 0, a2 = 0;
+			if (BS == 3)
+			{
+#pragma unroll 4
+				for (int j = 0; j < len; ++j)
+				{
+					const int64_t cc = (int64_t)c[j * SL] * 3;
+					const double x0 = x[cc], x1 = x[cc + 1], x2 = x[cc + 2];
+					const double *vj = v + (int64_t)j * (SL * 9);
+					const double2 p0 = reinterpret_cast<const double2 *>(vj)[lane];
+					const double2 p1 = reinterpret_cast<const double2 *>(vj + 128)[lane];
+					const double2 p2 = reinterpret_cast<const double2 *>(vj + 256)[lane];
+					const double2 p3 = reinterpret_cast<const double2 *>(vj + 384)[lane];
+					const double p4 = vj[512 + lane];
+					a0 += p0.x * x0 + p0.y * x1 + p1.x * x2;
+					a1 += p1.y * x0 + p2.x * x1 + p2.y * x2;
+					a2 += p3.x * x0 + p3.y * x1 + p4 * x2;
+				}
+			}
+			else
+			{
+#pragma unroll 8
+				for (int j = 0; j < len; ++j)
+					a0 += v[(int64_t)j * SL + lane] * x[c[j * SL]];
+			}
+			const int g = perm[s * SL + lane];
+			if (g >= 0)
+			{
+				const double acc[3] = {a0, a1, a2};
+#pragma unroll
+				for (int m = 0; m < BS; ++m)
+				{
+					const int64_t r = (int64_t)g * BS + m;
+					const double xr = x[r];
+					const double yr = (fixed && fixed[r]) ? xr : acc[m];
+					y[r] = yr;
+					if (DOT)
+						dot += xr * yr;
+				}
+			}
+		}
+		if (DOT)
+		{
+			dot = wave_sum(dot);
+			if (lane == 0)
+				sh[w] = dot;
+			__syncthreads();
+			if (threadIdx.x == 0)
+				part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+		}
+	}
+
+	inline int grid_for(int64_t n, int block = 256)
+	{
+		int64_t g = (n + block - 1) / block;
+		if (g > 256 * 16)
+			g = 256 * 16;
+		if (g < 1)
+			g = 1;
+		return (int)g;
+	}
+
+	template <typename T>
+	void free_dev(T *&p)
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+	}
+} // namespace
+
+void pfx_sell_release(pfx_ctx *ctx)
+{
+	free_dev(ctx->d_sell_perm);
+	free_dev(ctx->d_sell_base);
+	free_dev(ctx->d_sell_cols);
+	free_dev(ctx->d_sell_vals);
+	ctx->sell_slices = 0;
+	ctx->sell_owned = -1;
+	ctx->sell_gen = -1;
+}
+
+// structure: once per (pattern, owned range)
+static pfx_status sell_build(pfx_ctx *ctx)
+{
+	pfx_sell_release(ctx);
+	hipStream_t st = ctx->stream;
+	const int64_t n_owned = ctx->n_owned;
+	int sigma = 32768;
+	if (const char *e = getenv("PFX_SELL_SIGMA"))
+		sigma = atoi(e) > 0 ? (atoi(e) + SL - 1) / SL * SL : sigma;
+	const int64_t n_slices = (n_owned + SL - 1) / SL;
+	const int64_t n_pad = n_slices * SL;
+	uint64_t *ka = nullptr, *kb = nullptr;
+	uint32_t *va = nullptr, *vb = nullptr;
+	int64_t *len = nullptr;
+	void *tmp = nullptr;
+	size_t tb = 0;
+	PFX_HIP(hipMalloc((void **)&ka, sizeof(uint64_t) * (size_t)(n_owned + 1)));
+	PFX_HIP(hipMalloc((void **)&kb, sizeof(uint64_t) * (size_t)(n_owned + 1)));
+	PFX_HIP(hipMalloc((void **)&va, sizeof(uint32_t) * (size_t)(n_owned + 1)));
+	PFX_HIP(hipMalloc((void **)&vb, sizeof(uint32_t) * (size_t)(n_owned + 1)));
+	PFX_HIP(hipMalloc((void **)&len, sizeof(int64_t) * (size_t)(n_slices + 1)));
+	PFX_HIP(hipMemsetAsync(len, 0, sizeof(int64_t) * (size_t)(n_slices + 1), st));
+	hipLaunchKernelGGL(k_sell_keys, dim3(grid_for(n_owned)), dim3(256), 0, st, ctx->d_node_ptr, n_owned, sigma, ka, va);
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tb, ka, kb, va, vb, (size_t)n_owned, 0, 64, st));
+	PFX_HIP(hipMalloc(&tmp, tb));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp, tb, ka, kb, va, vb, (size_t)n_owned, 0, 64, st));
+	if (pfx_alloc(ctx, &ctx->d_sell_perm, n_pad) || pfx_alloc(ctx, &ctx->d_sell_base, n_slices + 1))
+		return PFX_ERR_HIP;
+	hipLaunchKernelGGL(k_sell_perm, dim3(grid_for(n_pad)), dim3(256), 0, st, vb, n_owned, n_pad, ctx->d_node_ptr, ctx->d_sell_perm, len);
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	tmp = nullptr;
+	tb = 0;
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, len, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(hipMalloc(&tmp, tb));
+	PFX_HIP(rocprim::exclusive_scan(tmp, tb, len, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
+	int64_t total = 0;
+	PFX_HIP(hipMemcpyAsync(&total, ctx->d_sell_base + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PFX_HIP(hipStreamSynchronize(st));
+	(void)hipFree(tmp);
+	(void)hipFree(ka);
+	(void)hipFree(kb);
+	(void)hipFree(va);
+	(void)hipFree(vb);
+	(void)hipFree(len);
+	ctx->sell_rows = total;
+	ctx->sell_slices = n_slices;
+	const int b2 = ctx->bs * ctx->bs;
+	if (pfx_alloc(ctx, &ctx->d_sell_cols, total * SL) || pfx_alloc(ctx, &ctx->d_sell_vals, total * SL * b2 + 2))
+		return PFX_ERR_HIP;
+	int64_t blocks = (n_slices + 3) / 4;
+	if (blocks > 256 * 32)
+		blocks = 256 * 32;
+	if (blocks < 1)
+		blocks = 1;
+	hipLaunchKernelGGL(k_sell_cols, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_sell_perm, ctx->d_sell_base, n_slices, ctx->d_sell_cols);
+	PFX_HIP(hipGetLastError());
+	ctx->sell_owned = n_owned;
+	ctx->sell_gen = -1;
+	return PFX_OK;
+}
+
+// makes the solver copy of the matrix current (structure and values)
+pfx_status pfx_sell_refresh(pfx_ctx *ctx)
+{
+	if (ctx->sell_owned != ctx->n_owned || !ctx->d_sell_perm)
+	{
+		pfx_status rc = sell_build(ctx);
+		if (rc)
+			return rc;
+	}
+	if (ctx->sell_gen != ctx->values_gen)
+	{
+		pfx_scoped_timer tm(ctx, "sell_convert");
+		int64_t blocks = (ctx->sell_slices + 3) / 4;
+		if (blocks > 256 * 32)
+			blocks = 256 * 32;
+		if (blocks < 1)
+			blocks = 1;
+		if (ctx->bs == 1)
+			hipLaunchKernelGGL((k_sell_values<1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, ctx->d_sell_vals);
+		else if (ctx->bs == 3)
+			hipLaunchKernelGGL((k_sell_values<3>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, ctx->d_sell_vals);
+		else
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+		PFX_HIP(hipGetLastError());
+		ctx->sell_gen = ctx->values_gen;
+	}
+	return PFX_OK;
+}
+
+int pfx_sell_grid(const pfx_ctx *ctx)
+{
+	const int64_t b = (ctx->sell_slices + 3) / 4;
+	return (int)((b + 7) / 8 * 8);
+}
+
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done)
+{
+	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	const int grid = pfx_sell_grid(ctx);
+	pfx_scoped_timer tm(ctx, "spmv");
+#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, ctx->sell_slices, fixed, d_x, d_y, part, done)
+	if (ctx->bs == 1)
+	{
+		if (part)
+			PFX_GO(1, true);
+		else
+			PFX_GO(1, false);
+	}
+	else if (ctx->bs == 3)
+	{
+		if (part)
+			PFX_GO(3, true);
+		else
+			PFX_GO(3, false);
+	}
+	else
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+#undef PFX_GO
+	return PFX_OK;
+}

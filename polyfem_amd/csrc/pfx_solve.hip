@@ -61,11 +61,11 @@ namespace
 		return r;
 	}
 
-	// every thread of the block returns the same fixed-order sum of part[0..PFX_NPART)
-	__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, double *sh)
+	// every thread of the block returns the same fixed-order sum of part[0..count)
+	__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int count, double *sh)
 	{
 		double acc = 0;
-		for (int k = threadIdx.x; k < PFX_NPART; k += 256)
+		for (int k = threadIdx.x; k < count; k += 256)
 			acc += part[k];
 		sh[threadIdx.x] = acc;
 		__syncthreads();
@@ -78,77 +78,6 @@ namespace
 		const double r = sh[0];
 		__syncthreads();
 		return r;
-	}
-
-	// y = A x (rows of constrained dofs: y = x); optionally the per-block partial of x.y.
-	// LPN lanes cooperate on one node (bs rows), so a wave keeps 64/LPN independent row chains in flight; each block
-	// owns a contiguous node range and the block -> range map keeps ranges that are close on the same XCD (blocks b
-	// and b+8 share an L2), so the x entries gathered by neighbouring rows are L2 hits.
-	template <int BS, int LPN, bool DOT>
-	__global__ __launch_bounds__(256) void k_spmv(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
-												   const double *__restrict__ values, const uint8_t *__restrict__ fixed, int64_t n_nodes,
-												   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part,
-												   const pfx_cg_state *__restrict__ state)
-	{
-		__shared__ double sh[4];
-		if (DOT && state->done)
-			return;
-		constexpr int GPB = 256 / LPN; // node groups per block
-		const int nblk = gridDim.x;
-		// XCD-aware: the 8 XCDs take blocks round-robin; give each XCD one contiguous eighth of the node ranges
-		const int per = (nblk + 7) / 8;
-		const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-		const int64_t npb = (n_nodes + nblk - 1) / nblk;
-		const int64_t g_begin = (int64_t)vb * npb;
-		int64_t g_end = g_begin + npb;
-		if (g_end > n_nodes)
-			g_end = n_nodes;
-		const int sl = threadIdx.x % LPN;
-		const int grp = threadIdx.x / LPN;
-		double dot = 0.0;
-		if (vb < nblk)
-			for (int64_t g = g_begin + grp; g < g_end; g += GPB)
-			{
-				const int64_t b0 = node_ptr[g];
-				const int deg = (int)(node_ptr[g + 1] - b0);
-				const int rowlen = deg * BS;
-				const double *v = values + b0 * (BS * BS);
-				double acc[BS];
-#pragma unroll
-				for (int m = 0; m < BS; ++m)
-					acc[m] = 0.0;
-				for (int k = sl; k < rowlen; k += LPN)
-				{
-					const int s = k / BS, n = k - s * BS;
-					const double xv = x[(int64_t)node_col[b0 + s] * BS + n];
-#pragma unroll
-					for (int m = 0; m < BS; ++m)
-						acc[m] += v[m * rowlen + k] * xv;
-				}
-#pragma unroll
-				for (int m = 0; m < BS; ++m)
-					for (int off = LPN / 2; off > 0; off >>= 1)
-						acc[m] += __shfl_xor(acc[m], off, LPN);
-				if (sl < BS)
-				{
-					double a = acc[0];
-#pragma unroll
-					for (int m = 1; m < BS; ++m)
-						a = (sl == m) ? acc[m] : a;
-					const int64_t r = g * BS + sl;
-					const double xr = x[r];
-					const double yr = (fixed && fixed[r]) ? xr : a;
-					y[r] = yr;
-					if (DOT)
-						dot += xr * yr;
-				}
-			}
-		if (DOT)
-		{
-			const double b = block_sum(dot, sh);
-			if (threadIdx.x == 0)
-				part[blockIdx.x] = b;
-		}
 	}
 
 	// invdiag = 1/diag (1 where diag == 0 or the dof is constrained)  -- Eigen DiagonalPreconditioner::factorize
@@ -193,23 +122,20 @@ namespace
 	// Scalars of the iteration come either from the per-block partial sums of the producing kernel (single GPU:
 	// every block reduces them in the same fixed order) or, when several GPUs cooperate, from `gscal`, which the
 	// caller has all-reduced over the ranks after k_finish_partials wrote the local sums there.
-	__device__ __forceinline__ double get_scalar(const double *__restrict__ part, const double *__restrict__ gscal, int idx, double *sh)
+	__device__ __forceinline__ double get_scalar(const double *__restrict__ part, int count, const double *__restrict__ gscal, int idx, double *sh)
 	{
 		if (gscal)
 			return gscal[idx];
-		return reduce_partials(part + idx * PFX_NPART, sh);
+		return reduce_partials(part, count, sh);
 	}
 
 	// gscal[idx0 + q] = fixed-order sum of partial array q (one block)
-	__global__ __launch_bounds__(256) void k_finish_partials(const double *__restrict__ part, int first, int count, double *__restrict__ gscal)
+	__global__ __launch_bounds__(256) void k_finish_partials(const double *__restrict__ part, int count, double *__restrict__ out)
 	{
 		__shared__ double sh[256];
-		for (int q = 0; q < count; ++q)
-		{
-			const double v = reduce_partials(part + (first + q) * PFX_NPART, sh);
-			if (threadIdx.x == 0)
-				gscal[first + q] = v;
-		}
+		const double v = reduce_partials(part, count, sh);
+		if (threadIdx.x == 0)
+			*out = v;
 	}
 
 	// r = b - tmp (tmp = A x), with b forced to zero on constrained dofs; partials: [0] b.b  [1] r.r
@@ -242,8 +168,8 @@ namespace
 													   pfx_cg_state *__restrict__ state, double *__restrict__ x)
 	{
 		__shared__ double sh[256];
-		const double bb = get_scalar(part, gscal, 0, sh);
-		const double rr = get_scalar(part, gscal, 1, sh);
+		const double bb = get_scalar(part, PFX_NPART, gscal, 0, sh);
+		const double rr = get_scalar(part + PFX_NPART, PFX_NPART, gscal, 1, sh);
 		double thr = tol * tol * bb;
 		if (thr < DBL_MIN)
 			thr = DBL_MIN;
@@ -275,7 +201,7 @@ namespace
 	__global__ __launch_bounds__(256) void k_cg_init3(const double *__restrict__ part, const double *__restrict__ gscal, pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
-		const double rp = get_scalar(part, gscal, 2, sh);
+		const double rp = get_scalar(part + 2 * PFX_NPART, PFX_NPART, gscal, 2, sh);
 		if (threadIdx.x == 0)
 			state->abs_new[0] = rp;
 	}
@@ -283,12 +209,13 @@ namespace
 	// alpha = abs_new / p.tmp ; x += alpha p ; r -= alpha tmp ; partials [1], [2] of r.r and r.(M^-1 r)
 	__global__ __launch_bounds__(256) void k_cg_update(const double *__restrict__ p, const double *__restrict__ tmp, const double *__restrict__ invdiag,
 														int64_t n, int it, double *__restrict__ x, double *__restrict__ r, double *__restrict__ part,
-														const double *__restrict__ gscal, const pfx_cg_state *__restrict__ state)
+														const double *__restrict__ part0, int n0, const double *__restrict__ gscal,
+														const pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
 		if (state->done)
 			return;
-		const double pAp = get_scalar(part, gscal, 0, sh);
+		const double pAp = get_scalar(part0, n0, gscal, 0, sh);
 		const double alpha = state->abs_new[it & 1] / pAp;
 		double rr = 0, rz = 0;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
@@ -316,8 +243,8 @@ namespace
 		__shared__ double sh[256];
 		if (state->done)
 			return;
-		const double rr = get_scalar(part, gscal, 1, sh);
-		const double rz = get_scalar(part, gscal, 2, sh);
+		const double rr = get_scalar(part + PFX_NPART, PFX_NPART, gscal, 1, sh);
+		const double rz = get_scalar(part + 2 * PFX_NPART, PFX_NPART, gscal, 2, sh);
 		const bool conv = rr < state->threshold;
 		const double beta = rz / state->abs_new[it & 1];
 		if (!conv)
@@ -356,56 +283,15 @@ namespace
 		return (int)g;
 	}
 
-	template <int BS, int LPN, bool DOT>
-	void spmv_go(pfx_ctx *ctx, const uint8_t *fixed, const double *d_x, double *d_y, double *part, const pfx_cg_state *state)
-	{
-		hipLaunchKernelGGL((k_spmv<BS, LPN, DOT>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed,
-						   ctx->n_owned, d_x, d_y, part, state);
-	}
-
-	template <bool DOT>
-	pfx_status spmv_launch(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const pfx_cg_state *state)
-	{
-		const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-		static int lpn_env = -1;
-		if (lpn_env < 0)
-		{
-			const char *e = getenv("PFX_SPMV_LPN");
-			lpn_env = e ? atoi(e) : 0;
-		}
-		pfx_scoped_timer tm(ctx, "spmv");
-		if (ctx->bs == 1)
-		{
-			const int lpn = lpn_env ? lpn_env : 8;
-			if (lpn == 4)
-				spmv_go<1, 4, DOT>(ctx, fixed, d_x, d_y, part, state);
-			else if (lpn == 16)
-				spmv_go<1, 16, DOT>(ctx, fixed, d_x, d_y, part, state);
-			else
-				spmv_go<1, 8, DOT>(ctx, fixed, d_x, d_y, part, state);
-		}
-		else if (ctx->bs == 3)
-		{
-			const int lpn = lpn_env ? lpn_env : 32;
-			if (lpn == 8)
-				spmv_go<3, 8, DOT>(ctx, fixed, d_x, d_y, part, state);
-			else if (lpn == 32)
-				spmv_go<3, 32, DOT>(ctx, fixed, d_x, d_y, part, state);
-			else if (lpn == 64)
-				spmv_go<3, 64, DOT>(ctx, fixed, d_x, d_y, part, state);
-			else
-				spmv_go<3, 16, DOT>(ctx, fixed, d_x, d_y, part, state);
-		}
-		else
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
-		return PFX_OK;
-	}
 } // namespace
 
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y)
 {
-	if (spmv_launch<false>(ctx, d_x, d_y, nullptr, nullptr))
-		return PFX_ERR_UNSUPPORTED;
+	pfx_status rc = pfx_sell_refresh(ctx);
+	if (rc)
+		return rc;
+	if ((rc = pfx_sell_spmv(ctx, d_x, d_y, nullptr, nullptr)))
+		return rc;
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
@@ -438,10 +324,13 @@ namespace
 		return PFX_OK;
 	}
 
+	// local sums -> gscal[first..first+count) for the caller's all-reduce (multi-GPU only)
 	void finish(pfx_ctx *ctx, int first, int count, double *gscal)
 	{
-		if (gscal)
-			hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, first, count, gscal);
+		if (!gscal)
+			return;
+		for (int q = first; q < first + count; ++q)
+			hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials + q * PFX_NPART, PFX_NPART, gscal + q);
 	}
 } // namespace
 
@@ -456,6 +345,13 @@ pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond)
 	hipStream_t st = ctx->stream;
 	const int64_t n = ctx->n_owned * ctx->bs;
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	{
+		pfx_status rc = pfx_sell_refresh(ctx); // "factorize": the solver's copy of the matrix
+		if (rc)
+			return rc;
+		if (pfx_alloc(ctx, &ctx->d_part0, pfx_sell_grid(ctx)))
+			return PFX_ERR_HIP;
+	}
 	PFX_HIP(hipMemsetAsync(ctx->d_cgstate, 0, sizeof(pfx_cg_state), st));
 	if (fixed) // initial guess with constrained dofs zeroed (solveWithGuess on the reduced system)
 		hipLaunchKernelGGL(k_mask_inplace, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n);
@@ -475,8 +371,11 @@ pfx_status pfx_cgs_residual_impl(pfx_ctx *ctx, const double *d_b, const double *
 		return PFX_ERR_HIP;
 	const int64_t n = ctx->n_owned * ctx->bs;
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-	if (spmv_launch<false>(ctx, d_x, w.tmp, nullptr, nullptr))
-		return PFX_ERR_UNSUPPORTED;
+	{
+		pfx_status rc = pfx_sell_spmv(ctx, d_x, w.tmp, nullptr, nullptr);
+		if (rc)
+			return rc;
+	}
 	hipLaunchKernelGGL(k_cg_init1, dim3(PFX_NPART), dim3(256), 0, ctx->stream, d_b, w.tmp, fixed, n, w.r, ctx->d_partials);
 	finish(ctx, 0, 2, gscal);
 	PFX_HIP(hipGetLastError());
@@ -507,9 +406,11 @@ pfx_status pfx_cgs_spmv_impl(pfx_ctx *ctx, double *gscal)
 	cg_vecs w;
 	if (cg_workspace(ctx, &w))
 		return PFX_ERR_HIP;
-	if (spmv_launch<true>(ctx, w.p, w.tmp, ctx->d_partials, (pfx_cg_state *)ctx->d_cgstate))
-		return PFX_ERR_UNSUPPORTED;
-	finish(ctx, 0, 1, gscal);
+	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done);
+	if (rc)
+		return rc;
+	if (gscal)
+		hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal);
 	return PFX_OK;
 }
 
@@ -521,7 +422,7 @@ pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal)
 	const int64_t n = ctx->n_owned * ctx->bs;
 	{
 		pfx_scoped_timer tm(ctx, "cg_update");
-		hipLaunchKernelGGL(k_cg_update, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, w.invdiag, n, it, d_x, w.r, ctx->d_partials, gscal, (pfx_cg_state *)ctx->d_cgstate);
+		hipLaunchKernelGGL(k_cg_update, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, w.invdiag, n, it, d_x, w.r, ctx->d_partials, ctx->d_part0, pfx_sell_grid(ctx), gscal, (pfx_cg_state *)ctx->d_cgstate);
 	}
 	finish(ctx, 1, 2, gscal);
 	return PFX_OK;

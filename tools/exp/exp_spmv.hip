@@ -129,6 +129,36 @@ __global__ __launch_bounds__(256) void k_sell1(const int64_t* __restrict__ slice
 	if (g >= 0) { y[3 * (int64_t)g] = a0; y[3 * (int64_t)g + 1] = a1; y[3 * (int64_t)g + 2] = a2; }
 }
 
+
+// SELL with 16-byte value loads: per slot, entries (0,1),(2,3),(4,5),(6,7) as double2 per lane, entry 8 single
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_sell2(const int64_t* __restrict__ slice_vbase, const int64_t* __restrict__ slice_cbase, const int32_t* __restrict__ slice_len,
+	const int32_t* __restrict__ perm, const int32_t* __restrict__ cols, const double* __restrict__ values, int64_t n_slices, const double* __restrict__ x, double* __restrict__ y) {
+	const int lane = threadIdx.x & 63;
+	const int nblk = gridDim.x; const int per = (nblk + 7) / 8; const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+	const int64_t s = (int64_t)vb * 4 + (threadIdx.x >> 6);
+	if (vb >= nblk || s >= n_slices) return;
+	const int len = slice_len[s];
+	const double* v = values + slice_vbase[s];
+	const int32_t* c = cols + slice_cbase[s] + lane;
+	double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll UNROLL
+	for (int j = 0; j < len; ++j) {
+		const int64_t cc = (int64_t)c[j * 64] * 3; const double x0 = x[cc], x1 = x[cc + 1], x2 = x[cc + 2];
+		const double* vj = v + (int64_t)j * 9 * 64;
+		const double2 p0 = reinterpret_cast<const double2*>(vj)[lane];
+		const double2 p1 = reinterpret_cast<const double2*>(vj + 128)[lane];
+		const double2 p2 = reinterpret_cast<const double2*>(vj + 256)[lane];
+		const double2 p3 = reinterpret_cast<const double2*>(vj + 384)[lane];
+		const double p4 = vj[512 + lane];
+		a0 += p0.x * x0 + p0.y * x1 + p1.x * x2;
+		a1 += p1.y * x0 + p2.x * x1 + p2.y * x2;
+		a2 += p3.x * x0 + p3.y * x1 + p4 * x2;
+	}
+	const int g = perm[s * 64 + lane];
+	if (g >= 0) { y[3 * (int64_t)g] = a0; y[3 * (int64_t)g + 1] = a1; y[3 * (int64_t)g + 2] = a2; }
+}
+
 // group kernel with the first three k-iterations issued together (rowlen <= 96 needs no further loop)
 __global__ __launch_bounds__(256) void k_group32_u3(const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ node_col, const double* __restrict__ values,
 	int64_t n_nodes, const double* __restrict__ x, double* __restrict__ y) {
@@ -227,6 +257,9 @@ int main(int argc, char** argv) {
 	{ const int GB = (int)((n_slices + 3) / 4); const int GB8 = ((GB + 7) / 8) * 8;
 	  timeit("sell64 slice/wave u4", [&] { k_sell1<4, 0><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell64 slice/wave u8", [&] { k_sell1<8, 0><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell64 b128 slice/wave u2", [&] { k_sell2<2><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell64 b128 slice/wave u4", [&] { k_sell2<4><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell64 b128 slice/wave u8", [&] { k_sell2<8><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell64 slice/wave u4 nox", [&] { k_sell1<4, 2><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes); }
 	timeit("sell64 unroll2 grid x2", [&] { k_sell<2, 0><<<2 * G, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	return 0;
