@@ -204,6 +204,15 @@ def main():
     asm_ms = loc_ms + gat_ms
     asm_gbs = ab / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0
 
+    # HBM bytes per SpMV launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, one rocprofv3 run each) of this
+    # same workload; null when no recording matches the grid or the run is partitioned.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r1_pmc_traffic_grid{args.n}.json")
+    if world == 1 and not nonlinear and os.path.exists(tpath):
+        rec = json.load(open(tpath)).get("k_sell_spmv<3, true>")
+        if rec:
+            traffic, traffic_src = rec["hbm_bytes"], os.path.relpath(tpath, os.path.dirname(os.path.abspath(__file__)))
+
     n_el_global = 6 * args.n * args.n * args.n * world
     owned_el = int(part.elem_owned.sum())
     if rank == 0:
@@ -225,8 +234,8 @@ def main():
                                if world > 1 else "single GPU",
             },
             "roofline": {"kernel": "k_sell_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "avg_ms": spmv_ms, "launches": spmv_n, "algorithmic_bytes": sb},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "avg_ms": spmv_ms, "launches": spmv_n, "algorithmic_bytes": sb},
             "assembly": {"elements_per_s": world * owned_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
                          "gather_ms": gat_ms,
                          "roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -134,17 +134,21 @@ namespace
 			double a0 = 0, a1 = 0, a2 = 0;
 			if (BS == 3)
 			{
-#pragma unroll 4
+				// matrix values and column ids are read once per product: non-temporal loads keep them from evicting
+				// the gathered x entries out of the L2
+				typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll 8
 				for (int j = 0; j < len; ++j)
 				{
-					const int64_t cc = (int64_t)c[j * SL] * 3;
+					const int64_t cc = (int64_t)__builtin_nontemporal_load(c + j * SL) * 3;
 					const double x0 = x[cc], x1 = x[cc + 1], x2 = x[cc + 2];
 					const double *vj = v + (int64_t)j * (SL * 9);
-					const double2 p0 = reinterpret_cast<const double2 *>(vj)[lane];
-					const double2 p1 = reinterpret_cast<const double2 *>(vj + 128)[lane];
-					const double2 p2 = reinterpret_cast<const double2 *>(vj + 256)[lane];
-					const double2 p3 = reinterpret_cast<const double2 *>(vj + 384)[lane];
-					const double p4 = vj[512 + lane];
+					const d2 *vp = reinterpret_cast<const d2 *>(vj) + lane;
+					const d2 p0 = __builtin_nontemporal_load(vp);
+					const d2 p1 = __builtin_nontemporal_load(vp + 64);
+					const d2 p2 = __builtin_nontemporal_load(vp + 128);
+					const d2 p3 = __builtin_nontemporal_load(vp + 192);
+					const double p4 = __builtin_nontemporal_load(vj + 512 + lane);
 					a0 += p0.x * x0 + p0.y * x1 + p1.x * x2;
 					a1 += p1.y * x0 + p2.x * x1 + p2.y * x2;
 					a2 += p3.x * x0 + p3.y * x1 + p4 * x2;
@@ -154,7 +158,7 @@ namespace
 			{
 #pragma unroll 8
 				for (int j = 0; j < len; ++j)
-					a0 += v[(int64_t)j * SL + lane] * x[c[j * SL]];
+					a0 += __builtin_nontemporal_load(v + (int64_t)j * SL + lane) * x[__builtin_nontemporal_load(c + j * SL)];
 			}
 			const int g = perm[s * SL + lane];
 			if (g >= 0)

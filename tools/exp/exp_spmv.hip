@@ -159,6 +159,38 @@ __global__ __launch_bounds__(256) void k_sell2(const int64_t* __restrict__ slice
 	if (g >= 0) { y[3 * (int64_t)g] = a0; y[3 * (int64_t)g + 1] = a1; y[3 * (int64_t)g + 2] = a2; }
 }
 
+// k_sell2 with non-temporal value/column loads (NT) and optionally x padded to 4 doubles per node (PADX)
+template <int UNROLL, bool NT, bool PADX>
+__global__ __launch_bounds__(256) void k_sell3(const int64_t* __restrict__ slice_vbase, const int64_t* __restrict__ slice_cbase, const int32_t* __restrict__ slice_len,
+	const int32_t* __restrict__ perm, const int32_t* __restrict__ cols, const double* __restrict__ values, int64_t n_slices, const double* __restrict__ x, double* __restrict__ y) {
+	const int lane = threadIdx.x & 63;
+	const int nblk = gridDim.x; const int per = (nblk + 7) / 8; const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+	const int64_t s = (int64_t)vb * 4 + (threadIdx.x >> 6);
+	if (vb >= nblk || s >= n_slices) return;
+	const int len = slice_len[s];
+	const double* v = values + slice_vbase[s];
+	const int32_t* c = cols + slice_cbase[s] + lane;
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll UNROLL
+	for (int j = 0; j < len; ++j) {
+		const int32_t ci = NT ? __builtin_nontemporal_load(c + j * 64) : c[j * 64];
+		double x0, x1, x2;
+		if (PADX) { const d2* xp = reinterpret_cast<const d2*>(x + (int64_t)ci * 4); const d2 q = xp[0]; x0 = q.x; x1 = q.y; x2 = x[(int64_t)ci * 4 + 2]; }
+		else { const int64_t cc = (int64_t)ci * 3; x0 = x[cc]; x1 = x[cc + 1]; x2 = x[cc + 2]; }
+		const double* vj = v + (int64_t)j * 9 * 64;
+		const d2* vp = reinterpret_cast<const d2*>(vj) + lane;
+		d2 p0, p1, p2, p3; double p4;
+		if (NT) { p0 = __builtin_nontemporal_load(vp); p1 = __builtin_nontemporal_load(vp + 64); p2 = __builtin_nontemporal_load(vp + 128); p3 = __builtin_nontemporal_load(vp + 192); p4 = __builtin_nontemporal_load(vj + 512 + lane); }
+		else { p0 = vp[0]; p1 = vp[64]; p2 = vp[128]; p3 = vp[192]; p4 = vj[512 + lane]; }
+		a0 += p0.x * x0 + p0.y * x1 + p1.x * x2;
+		a1 += p1.y * x0 + p2.x * x1 + p2.y * x2;
+		a2 += p3.x * x0 + p3.y * x1 + p4 * x2;
+	}
+	const int g = perm[s * 64 + lane];
+	if (g >= 0) { y[3 * (int64_t)g] = a0; y[3 * (int64_t)g + 1] = a1; y[3 * (int64_t)g + 2] = a2; }
+}
+
 // group kernel with the first three k-iterations issued together (rowlen <= 96 needs no further loop)
 __global__ __launch_bounds__(256) void k_group32_u3(const int64_t* __restrict__ node_ptr, const int32_t* __restrict__ node_col, const double* __restrict__ values,
 	int64_t n_nodes, const double* __restrict__ x, double* __restrict__ y) {
@@ -260,6 +292,12 @@ int main(int argc, char** argv) {
 	  timeit("sell64 b128 slice/wave u2", [&] { k_sell2<2><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell64 b128 slice/wave u4", [&] { k_sell2<4><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell64 b128 slice/wave u8", [&] { k_sell2<8><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell3 u4 nt", [&] { k_sell3<4, true, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell3 u8 nt", [&] { k_sell3<8, true, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  { double* d_x4; CK(hipMalloc(&d_x4, 8 * 4 * (n_nodes + 1))); CK(hipMemset(d_x4, 0, 8 * 4 * (n_nodes + 1)));
+	  timeit("sell3 u4 padx", [&] { k_sell3<4, false, true><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x4, d_y); }, bytes);
+	  timeit("sell3 u4 nt padx", [&] { k_sell3<4, true, true><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x4, d_y); }, bytes); }
+	  timeit("sell3 u4 plain (=sell2)", [&] { k_sell3<4, false, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell64 slice/wave u4 nox", [&] { k_sell1<4, 2><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes); }
 	timeit("sell64 unroll2 grid x2", [&] { k_sell<2, 0><<<2 * G, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	return 0;
