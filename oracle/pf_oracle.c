@@ -601,7 +601,7 @@ void pfo_local_linear_elasticity(const pfo_vals *v, int i, int j, const double *
 
 /* F = local_disp^T * grad(p) * jac_it(p) + I ; local_disp is n_loc x 3 (row i = displacement of basis i).
  * NeoHookeanElasticity.cpp:402 / :491 (dense products).  F row-major. */
-static void def_grad_at(const pfo_vals *v, int p, const double *local_disp, double *F)
+static void def_grad_at_id(const pfo_vals *v, int p, const double *local_disp, double *F, double id)
 {
 	double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; /* local_disp^T * grad : A(d,c) = sum_i u_i[d] grad_i[c] */
 	for (int d = 0; d < 3; ++d)
@@ -619,8 +619,13 @@ static void def_grad_at(const pfo_vals *v, int p, const double *local_disp, doub
 			double s = 0;
 			for (int a = 0; a < 3; ++a)
 				s += M(A, d, a) * M(jt, a, c);
-			M(F, d, c) = s + (d == c ? 1.0 : 0.0);
+			M(F, d, c) = (id != 0.0) ? s + (d == c ? id : 0.0) : s;
 		}
+}
+
+static void def_grad_at(const pfo_vals *v, int p, const double *local_disp, double *F)
+{
+	def_grad_at_id(v, p, local_disp, F, 1.0);
 }
 
 /* NeoHookeanElasticity.cpp:250-331 : sum_p da_p [ mu/2 (tr(F^T F) - 3 - 2 ln J) + lambda/2 ln^2 J ] */
@@ -648,9 +653,7 @@ double pfo_local_linear_elasticity_energy(const pfo_vals *v, const double *da, c
 	for (int p = 0; p < v->n_pts; ++p)
 	{
 		double F[9];
-		def_grad_at(v, p, local_disp, F);
-		for (int d = 0; d < 3; ++d)
-			M(F, d, d) -= 1.0; /* grad u */
+		def_grad_at_id(v, p, local_disp, F, 0.0); /* grad u (LinearElasticity.cpp:139-157) */
 		double s = 0, tr = 0;
 		for (int a = 0; a < 3; ++a)
 		{
@@ -664,6 +667,69 @@ double pfo_local_linear_elasticity_energy(const pfo_vals *v, const double *da, c
 		energy += (mu * s + lambda / 2 * tr * tr) * da[p];
 	}
 	return energy;
+}
+
+/* physical gradient of basis i at point p: grad(p) * jac_it(p) */
+static void phys_grad(const pfo_vals *v, int i, int p, double *G)
+{
+	const double *jt = v->jac_it[p];
+	for (int c = 0; c < 3; ++c)
+	{
+		double s = 0;
+		for (int a = 0; a < 3; ++a)
+			s += v->grad[i][p][a] * M(jt, a, c);
+		G[c] = s;
+	}
+}
+
+/* LinearElasticity.cpp:61-77 : gradient of compute_energy_aux w.r.t. the local displacements.  The reference obtains
+ * it by forward autodiff (DScalar1); the derivative written out is  d/du_{i,d} = sum_p da_p (sigma G_i)[d],
+ * sigma = 2 mu eps + lambda tr(eps) I.  G is n_loc*3, entry i*3+d. */
+void pfo_local_linear_elasticity_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G)
+{
+	for (int k = 0; k < 3 * v->n_loc; ++k)
+		G[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double D[9], sg[9];
+		def_grad_at_id(v, p, local_disp, D, 0.0);
+		const double tr = M(D, 0, 0) + M(D, 1, 1) + M(D, 2, 2);
+		for (int a = 0; a < 3; ++a)
+			for (int b = 0; b < 3; ++b)
+				M(sg, a, b) = 2 * mu * ((M(D, a, b) + M(D, b, a)) / 2) + (a == b ? lambda * tr : 0.0);
+		for (int i = 0; i < v->n_loc; ++i)
+		{
+			double Gi[3];
+			phys_grad(v, i, p, Gi);
+			for (int d = 0; d < 3; ++d)
+				G[3 * i + d] += (M(sg, d, 0) * Gi[0] + M(sg, d, 1) * Gi[1] + M(sg, d, 2) * Gi[2]) * da[p];
+		}
+	}
+}
+
+/* LinearElasticity.cpp:79-94 : Hessian of compute_energy_aux (DScalar2 autodiff in the reference), written out:
+ * d2/du_{i,a} du_{j,b} = sum_p da_p [ mu (G_i.G_j) delta_ab + mu G_i[b] G_j[a] + lambda G_i[a] G_j[b] ].
+ * H is (n_loc*3)^2 row-major, row i*3+a, column j*3+b. */
+void pfo_local_linear_elasticity_hessian(const pfo_vals *v, const double *da, double lambda, double mu, double *H)
+{
+	const int N = 3 * v->n_loc;
+	for (int k = 0; k < N * N; ++k)
+		H[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+		for (int i = 0; i < v->n_loc; ++i)
+		{
+			double Gi[3];
+			phys_grad(v, i, p, Gi);
+			for (int j = 0; j < v->n_loc; ++j)
+			{
+				double Gj[3];
+				phys_grad(v, j, p, Gj);
+				const double dot = Gi[0] * Gj[0] + Gi[1] * Gj[1] + Gi[2] * Gj[2];
+				for (int a = 0; a < 3; ++a)
+					for (int b = 0; b < 3; ++b)
+						H[(3 * i + a) * N + 3 * j + b] += (mu * Gi[b] * Gj[a] + lambda * Gi[a] * Gj[b] + (a == b ? mu * dot : 0.0)) * da[p];
+			}
+		}
 }
 
 static void cross3(const double *x, const double *y, double *z)
@@ -1008,7 +1074,10 @@ static void *job_run(void *arg)
 			else if (jb->mode == 2)
 			{
 				/* Assembler.cpp:465-492 */
-				pfo_local_neohookean_grad(v, da, ld, mat->lambda, mat->mu, G);
+				if (mat->model == PFO_NEOHOOKEAN)
+					pfo_local_neohookean_grad(v, da, ld, mat->lambda, mat->mu, G);
+				else
+					pfo_local_linear_elasticity_grad(v, da, ld, mat->lambda, mat->mu, G);
 				for (int j = 0; j < n_loc; ++j)
 					for (int m = 0; m < size; ++m)
 					{
@@ -1021,7 +1090,10 @@ static void *job_run(void *arg)
 			else
 			{
 				/* Assembler.cpp:550-616 : every entry, order (i, j, n, m) */
-				pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+				if (mat->model == PFO_NEOHOOKEAN)
+					pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+				else
+					pfo_local_linear_elasticity_hessian(v, da, mat->lambda, mat->mu, H);
 				const int N = n_loc * size;
 				for (int i = 0; i < n_loc; ++i)
 					for (int j = 0; j < n_loc; ++j)
@@ -1132,7 +1204,7 @@ double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const 
 /* assembler/Assembler.cpp:427-504 */
 int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, double *rhs)
 {
-	if (mat->model != PFO_NEOHOOKEAN)
+	if (mat->model != PFO_NEOHOOKEAN && mat->model != PFO_LINEAR_ELASTICITY)
 		return -1;
 	const int64_t N = mesh->n_nodes * block_size(mat);
 	int nt = n_threads;
@@ -1153,7 +1225,7 @@ int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const d
 /* assembler/Assembler.cpp:506-636, first (pattern-building) pass: triplets of every local entry */
 int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
 {
-	if (mat->model != PFO_NEOHOOKEAN)
+	if (mat->model != PFO_NEOHOOKEAN && mat->model != PFO_LINEAR_ELASTICITY)
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 3, &nt, 0);
@@ -1515,7 +1587,10 @@ int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, c
 		for (int k = 0; k < quad.n_pts; ++k)
 			da[k] = v->det[k] * quad.w[k];
 		gather_local_disp(mesh, e, n_loc, x, ld);
-		pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+		if (mat->model == PFO_NEOHOOKEAN)
+			pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+		else
+			pfo_local_linear_elasticity_hessian(v, da, mat->lambda, mat->mu, H);
 		const int32_t *idx = mesh->conn + e * n_loc;
 		for (int i = 0; i < n_loc; ++i)
 			for (int j = 0; j < n_loc; ++j)

@@ -102,6 +102,8 @@ double pfo_local_neohookean_energy(const pfo_vals *v, const double *da, const do
 void pfo_local_neohookean_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G);
 void pfo_local_neohookean_hessian(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H);
 double pfo_local_linear_elasticity_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu);
+void pfo_local_linear_elasticity_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G);
+void pfo_local_linear_elasticity_hessian(const pfo_vals *v, const double *da, double lambda, double mu, double *H);
 
 /* global assemblers; n_threads > 1 uses thread-local storages merged like the reference does */
 int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_threads, pfo_csc *out);

@@ -63,7 +63,8 @@ namespace
 		free_dev(ctx->d_ne_src);
 		free_dev(ctx->d_values);
 		free_dev(ctx->d_mask);
-		free_dev(ctx->d_kloc);
+		free_dev(ctx->d_estate);
+		ctx->estate_kind = PFX_ESTATE_NONE;
 		free_dev(ctx->d_gloc);
 		free_dev(ctx->d_eloc);
 		free_dev(ctx->d_fixed);
@@ -291,7 +292,7 @@ extern "C"
 		if (rc)
 			return rc;
 		const int N = ctx->n_loc * ctx->bs;
-		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz + 2) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_kloc, ctx->n_el * N * N) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
+		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz + 2) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_estate, ctx->n_el * (int64_t)(22 * ctx->n_pts)) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
 			return PFX_ERR_HIP;
 		PFX_HIP(hipMemsetAsync(ctx->d_values, 0, sizeof(double) * (size_t)(ctx->nnz + 2), ctx->stream));
 		PFX_HIP(hipMemsetAsync(ctx->d_fixed, 0, (size_t)ctx->n_dofs(), ctx->stream));
@@ -337,7 +338,7 @@ extern "C"
 		}
 		{
 			pfx_scoped_timer tm(ctx, "gather");
-			pfx_status rc = pfx_launch_gather_matrix(ctx, true);
+			pfx_status rc = pfx_launch_rows_linear(ctx, true);
 			if (rc)
 				return rc;
 		}
@@ -404,7 +405,7 @@ extern "C"
 		ctx->have_mask = false;
 		ctx->values_gen++;
 		pfx_scoped_timer tm(ctx, "gather");
-		return pfx_launch_gather_matrix(ctx, false);
+		return pfx_launch_rows_nl(ctx);
 	}
 
 	pfx_status pfx_energy(pfx_ctx *ctx, const double *u, double *energy)

@@ -1,65 +1,14 @@
-// pfx_gather.hip -- local-to-global accumulation without atomics.
+// pfx_gather.hip -- local-to-global accumulation of vectors and scalars without atomics, and the export of
+// compressed (value-dependent / reduced) patterns.
 //
-// The reference scatters element blocks into thread-local buffers and merges them afterwards
-// (src/polyfem/assembler/Assembler.cpp:185-189, 486, 602 and the merges at :227-301, :499-501, :627-632;
-// src/polyfem/utils/MatrixUtils.cpp:120-130 for the cached pattern).  On the GPU every global entry is instead
-// OWNED by one lane, which sums the contributions listed for it by the pattern build (ascending element order)
-// and writes the entry once with a coalesced store.  The result is independent of scheduling (bitwise
-// reproducible), needs no zero-fill of the value array and no FP64 atomics.
-//
-// Value layout = scalar CSR of the structural pattern: node g owns bs consecutive rows, row g*bs+m is the
-// contiguous range [bs*bs*node_ptr[g] + m*deg*bs, +deg*bs) with entry (slot s, n) at offset s*bs+n.
+// The reference gives every thread a full-length vector and merges them afterwards
+// (src/polyfem/assembler/Assembler.cpp:442-501); here every global entry is OWNED by one lane, which sums the
+// contributions listed for it by the pattern build (ascending element order) and writes the entry once.  The matrix
+// counterpart is pfx_rowasm.h.
 #include "pfx_internal.h"
 
 namespace
 {
-	template <int NLOC, int BS>
-	__global__ __launch_bounds__(256) void k_gather_matrix(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr,
-															const uint32_t *__restrict__ blk_src, const double *__restrict__ kloc, int64_t n_nodes,
-															double *__restrict__ values, uint8_t *__restrict__ mask, int write_mask)
-	{
-		constexpr int N = NLOC * BS;
-		constexpr uint32_t NL2 = NLOC * NLOC;
-		const int lane = threadIdx.x & 63;
-		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-		for (int64_t g = wave; g < n_nodes; g += n_waves)
-		{
-			const int64_t b0 = node_ptr[g];
-			const int deg = (int)(node_ptr[g + 1] - b0);
-			const int rowlen = deg * BS;
-			const int items = rowlen * BS;
-			const int64_t base = b0 * (BS * BS);
-			for (int t = lane; t < items; t += 64)
-			{
-				int m = 0, rem = t;
-				if (BS > 1)
-				{
-					m = (t >= 2 * rowlen) ? 2 : (t >= rowlen ? 1 : 0);
-					rem = t - m * rowlen;
-				}
-				const int s = rem / BS, n = rem - s * BS;
-				const int64_t b = b0 + s;
-				const int64_t c0 = blk_ptr[b], c1 = blk_ptr[b + 1];
-				double sum = 0.0;
-				int any = 0;
-				for (int64_t c = c0; c < c1; ++c)
-				{
-					const uint32_t src = blk_src[c];
-					const uint32_t e = src / NL2;
-					const uint32_t ij = src - e * NL2;
-					const uint32_t i = ij / NLOC, j = ij - i * NLOC;
-					const double v = kloc[(int64_t)e * (N * N) + (i * BS + m) * N + (j * BS + n)];
-					sum += v;
-					any |= (v != 0.0);
-				}
-				values[base + t] = sum;
-				if (write_mask)
-					mask[base + t] = (uint8_t)any;
-			}
-		}
-	}
-
 	template <int NLOC, int BS>
 	__global__ __launch_bounds__(256) void k_gather_vector(const int64_t *__restrict__ ne_ptr, const uint32_t *__restrict__ ne_src,
 															const double *__restrict__ gloc, int64_t n_nodes, double *__restrict__ out)
@@ -197,17 +146,6 @@ namespace
 	}
 
 	template <int NLOC, int BS>
-	void launch_gm(pfx_ctx *ctx, bool write_mask)
-	{
-		const int64_t waves = ctx->n_nodes;
-		int64_t blocks = (waves + 3) / 4;
-		if (blocks > 256 * 32)
-			blocks = 256 * 32;
-		hipLaunchKernelGGL((k_gather_matrix<NLOC, BS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
-						   ctx->d_blk_src, ctx->d_kloc, ctx->n_nodes, ctx->d_values, ctx->d_mask, write_mask ? 1 : 0);
-	}
-
-	template <int NLOC, int BS>
 	void launch_gv(pfx_ctx *ctx, double *d_g)
 	{
 		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3(grid_for(ctx->n_nodes * BS)), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
@@ -245,13 +183,6 @@ namespace
 	default:                                                   \
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "unsupported n_loc/bs"); \
 	}
-
-pfx_status pfx_launch_gather_matrix(pfx_ctx *ctx, bool write_mask)
-{
-	PFX_DISPATCH_NLOC_BS(launch_gm, ctx, write_mask);
-	PFX_HIP(hipGetLastError());
-	return PFX_OK;
-}
 
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g)
 {

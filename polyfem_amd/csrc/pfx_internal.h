@@ -24,6 +24,13 @@ struct pfx_tables
 	double ggrad[PFX_MAX_PTS][PFX_MAX_GLOC][3];   // same for the geometry bases
 };
 
+enum
+{
+	PFX_ESTATE_NONE = 0,
+	PFX_ESTATE_LINEAR = 1, // J^{-T}, det per point (pfx_local_linear.hip)
+	PFX_ESTATE_NL = 2      // J^{-T}, F, coefficients per point (pfx_local_nl.hip)
+};
+
 struct pfx_timer_family
 {
 	double total_ms = 0;
@@ -64,7 +71,8 @@ struct pfx_ctx
 	bool have_mask = false;
 
 	// scratch for the two-pass (local blocks, then per-row sums) assembly
-	double *d_kloc = nullptr; // n_el * (n_loc*bs)^2
+	double *d_estate = nullptr; // per-element state the row assembly computes its blocks from (n_el * 22 * n_pts doubles)
+	int estate_kind = 0;        // which element kernel wrote it last (PFX_ESTATE_*)
 	double *d_gloc = nullptr; // n_el * n_loc*bs
 	double *d_eloc = nullptr; // n_el
 	int *d_flag = nullptr;    // numeric failure flag
@@ -177,7 +185,8 @@ void pfx_fill_tables(int kind, int quad_order, pfx_tables *t);
 pfx_status pfx_pattern_build(pfx_ctx *ctx);
 pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                                                   // strict arithmetic
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess); // NeoHookean
-pfx_status pfx_launch_gather_matrix(pfx_ctx *ctx, bool write_mask);
+pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask); // strict arithmetic
+pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);

@@ -9,24 +9,18 @@
 // zeros; every expression below is therefore evaluated in the reference's operation order, one IEEE operation
 // per source operation, and the 3x3 determinant / inverse follow Eigen 3.4's fixed-size routines.
 //
-// Work decomposition: TPE lanes cooperate on one element.
-//   phase 1  lanes < n_pts            : Jacobian of the geometric map at a quadrature point -> det, J^{-T}
-//   phase 2  lanes over (point,basis) : physical gradients grad * J^{-T}  -> LDS
-//   phase 3  lanes over pairs j <= i  : local block by the quadrature loop -> LDS tile (mirrored for j < i)
-//   phase 4  all lanes                : coalesced copy of the (n_loc*bs)^2 tile to the element's slot in HBM
+// Two kernels:
+//   k_element_geometry  one lane per (element, quadrature point): Jacobian of the geometric map -> J^{-T} and det,
+//                       10 doubles per point (per element when the geometric map is affine, i.e. 4-node tets, where
+//                       every point yields bitwise the same Jacobian);
+//   k_assemble_rows     (pfx_rowasm.h) with the functor below: one lane per contribution computes the block of the
+//                       pair (i, j), j <= i, by the quadrature loop: physical gradients grad * J^{-T} of the two
+//                       bases, then Laplacian::assemble / LinearElasticity::assemble.
 #include "pfx_internal.h"
+#include "pfx_rowasm.h"
 
 namespace
 {
-	template <int NLOC, int NGLOC, int NPTS, int BS>
-	struct lin_smem
-	{
-		double xs[NGLOC * 3];
-		double jt[NPTS * 9];
-		double da[NPTS];
-		double gt[NPTS * NLOC * 3];
-	};
-
 	__device__ __forceinline__ double det3_fixed(const double *m)
 	{
 		const double h0 = m[0] * (m[4] * m[8] - m[5] * m[7]);
@@ -59,174 +53,187 @@ namespace
 		jt[8] = cof3(m, 2, 2) * invdet;
 	}
 
-	template <int NLOC, int NGLOC, int NPTS, int BS, int TPE, bool STAGE>
-	__global__ __launch_bounds__(256) void k_local_linear(const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
-														   const pfx_tables *__restrict__ tab, int64_t n_el, int model, double lambda, double mu,
-														   double *__restrict__ kloc)
+	// geo[(e*SP + k)*10 ..] = J^{-T} (9, row-major) and det J at point k; SP = 1 for affine maps, n_pts otherwise
+	template <int NGLOC, int SP>
+	__global__ __launch_bounds__(256) void k_element_geometry(const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
+															   const pfx_tables *__restrict__ tab, int64_t n_el, double *__restrict__ geo)
 	{
-		constexpr int EPB = 256 / TPE; // elements per block
-		constexpr int N = NLOC * BS;
-		constexpr int NPAIR = NLOC * (NLOC + 1) / 2;
-		__shared__ lin_smem<NLOC, NGLOC, NPTS, BS> sm[EPB];
-		__shared__ double tile[STAGE ? EPB * N * N : 1];
-
-		const int grp = threadIdx.x / TPE, lane = threadIdx.x % TPE;
-		const int64_t e = (int64_t)blockIdx.x * EPB + grp;
-		const bool active = e < n_el;
-		lin_smem<NLOC, NGLOC, NPTS, BS> &s = sm[grp];
-
-		if (active)
-			for (int t = lane; t < NGLOC * 3; t += TPE)
-				s.xs[t] = xyz[3 * (int64_t)gconn[e * NGLOC + t / 3] + t % 3];
-		__syncthreads();
-
-		if (active)
-			for (int k = lane; k < NPTS; k += TPE)
-			{
-				double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-				for (int j = 0; j < NGLOC; ++j)
-					for (int r = 0; r < 3; ++r)
-						for (int c = 0; c < 3; ++c)
-							tmp[3 * r + c] += tab->ggrad[k][j][r] * s.xs[3 * j + c] * 1.0;
-				s.da[k] = det3_fixed(tmp) * tab->w[k];
-				inv3_transposed(tmp, &s.jt[9 * k]);
-			}
-		__syncthreads();
-
-		if (active)
-			for (int t = lane; t < NPTS * NLOC; t += TPE)
-			{
-				const int k = t / NLOC, i = t % NLOC;
-				const double g0 = tab->grad[k][i][0], g1 = tab->grad[k][i][1], g2 = tab->grad[k][i][2];
-				const double *jt = &s.jt[9 * k];
+		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (t >= n_el * SP)
+			return;
+		const int64_t e = t / SP;
+		const int k = (int)(t - e * SP);
+		double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (int j = 0; j < NGLOC; ++j)
+		{
+			const double *x = xyz + 3 * (int64_t)gconn[e * NGLOC + j];
+			for (int r = 0; r < 3; ++r)
 				for (int c = 0; c < 3; ++c)
-					s.gt[3 * t + c] = (g0 * jt[c] + g1 * jt[3 + c]) + g2 * jt[6 + c];
-			}
-		__syncthreads();
+					tmp[3 * r + c] += tab->ggrad[k][j][r] * x[c] * 1.0;
+		}
+		double out[10];
+		inv3_transposed(tmp, out);
+		out[9] = det3_fixed(tmp);
+		for (int q = 0; q < 10; ++q)
+			geo[t * 10 + q] = out[q];
+	}
 
-		double *dst = STAGE ? &tile[grp * N * N] : (kloc + e * (int64_t)(N * N));
-		if (active)
-			for (int q = lane; q < NPAIR; q += TPE)
-			{
-				int i = 0;
-				while ((i + 1) * (i + 2) / 2 <= q)
-					++i;
-				const int j = q - i * (i + 1) / 2;
-				if (BS == 1)
+	// block of the pair (i, j), j <= i : out[m*BS+n] = (row component m of basis i, column component n of basis j),
+	// values with |v| < 1e-30 replaced by an exact zero (they are absent from the reference's matrix)
+	template <int NLOC, int NPTS, int BS, int SP>
+	struct linear_block
+	{
+		const double *geo;
+		const pfx_tables *tab;
+		double lambda, mu;
+		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + NPTS; // grad[k][i][3], then w[k]
+
+		__device__ __forceinline__ void load_tables(double *lds, int lane) const
+		{
+			for (int t = lane; t < NPTS * NLOC * 3; t += 64)
+				lds[t] = tab->grad[t / (NLOC * 3)][(t / 3) % NLOC][t % 3];
+			for (int t = lane; t < NPTS; t += 64)
+				lds[NPTS * NLOC * 3 + t] = tab->w[t];
+		}
+
+		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[BS * BS]) const
+		{
+			typedef double d2 __attribute__((ext_vector_type(2)));
+			const d2 *ge = reinterpret_cast<const d2 *>(geo + (int64_t)e * (SP * 10));
+			double jt[10];
+			if (SP == 1)
+				for (int q = 0; q < 5; ++q)
 				{
-					double res = 0;
-					for (int k = 0; k < NPTS; ++k)
-					{
-						const double *gi = &s.gt[3 * (k * NLOC + i)], *gj = &s.gt[3 * (k * NLOC + j)];
-						const double dot = (gi[0] * gj[0] + gi[1] * gj[1]) + gi[2] * gj[2];
-						res += dot * s.da[k];
-					}
-					if (fabs(res) < 1e-30)
-						res = 0.0;
-					dst[i * N + j] = res;
-					if (j < i)
-						dst[j * N + i] = res;
+					const d2 v = ge[q];
+					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 				}
+			double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (int k = 0; k < NPTS; ++k)
+			{
+				if (SP != 1)
+					for (int q = 0; q < 5; ++q)
+					{
+						const d2 v = ge[k * 5 + q];
+						jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
+					}
+				const double dak = jt[9] * lds[NPTS * NLOC * 3 + k]; // det * weight
+				const double *ri = lds + (k * NLOC + i) * 3, *rj = lds + (k * NLOC + j) * 3;
+				double gi[3], gj[3];
+				for (int c = 0; c < 3; ++c)
+				{
+					gi[c] = (ri[0] * jt[c] + ri[1] * jt[3 + c]) + ri[2] * jt[6 + c];
+					gj[c] = (rj[0] * jt[c] + rj[1] * jt[3 + c]) + rj[2] * jt[6 + c];
+				}
+				const double dot = (gi[0] * gj[0] + gi[1] * gj[1]) + gi[2] * gj[2];
+				if (BS == 1)
+					res[0] += dot * dak;
 				else
 				{
-					double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-					for (int k = 0; k < NPTS; ++k)
-					{
-						const double *gi = &s.gt[3 * (k * NLOC + i)], *gj = &s.gt[3 * (k * NLOC + j)];
-						double outer[9];
-						for (int col = 0; col < 3; ++col)
-							for (int row = 0; row < 3; ++row)
-								outer[col * 3 + row] = gi[row] * gj[col];
-						const double dot = (gi[0] * gj[0] + gi[1] * gj[1]) + gi[2] * gj[2];
-						const double dak = s.da[k];
-						for (int ii = 0; ii < 3; ++ii)
-							for (int jj = 0; jj < 3; ++jj)
-							{
-								double rk = outer[ii * 3 + jj] * mu + outer[jj * 3 + ii] * lambda;
-								if (ii == jj)
-									rk += mu * dot;
-								res[jj * 3 + ii] += rk * dak;
-							}
-					}
-					// entry (row comp m, col comp n) of block (i,j) is res[n*3+m]  (Assembler.cpp:169,177,182)
-					for (int m = 0; m < 3; ++m)
-						for (int n = 0; n < 3; ++n)
+					double outer[9];
+					for (int col = 0; col < 3; ++col)
+						for (int row = 0; row < 3; ++row)
+							outer[col * 3 + row] = gi[row] * gj[col];
+					for (int ii = 0; ii < 3; ++ii)
+						for (int jj = 0; jj < 3; ++jj)
 						{
-							double v = res[n * 3 + m];
-							if (fabs(v) < 1e-30)
-								v = 0.0;
-							dst[(i * 3 + m) * N + (j * 3 + n)] = v;
-							if (j < i)
-								dst[(j * 3 + n) * N + (i * 3 + m)] = v;
+							double rk = outer[ii * 3 + jj] * mu + outer[jj * 3 + ii] * lambda;
+							if (ii == jj)
+								rk += mu * dot;
+							res[jj * 3 + ii] += rk * dak;
 						}
 				}
 			}
-		if (STAGE)
-		{
-			__syncthreads();
-			if (active)
-			{
-				double *out = kloc + e * (int64_t)(N * N);
-				for (int t = lane; t < N * N; t += TPE)
-					out[t] = tile[grp * N * N + t];
-			}
+			if (BS == 1)
+				out[0] = fabs(res[0]) < 1e-30 ? 0.0 : res[0];
+			else
+				// entry (row comp m, col comp n) of block (i,j) is res[n*3+m]  (Assembler.cpp:169,177,182)
+				for (int m = 0; m < BS; ++m)
+					for (int n = 0; n < BS; ++n)
+					{
+						const double v = res[n * 3 + m];
+						out[m * BS + n] = fabs(v) < 1e-30 ? 0.0 : v;
+					}
 		}
+	};
+
+	template <int NGLOC, int NPTS>
+	void launch_geometry(pfx_ctx *ctx)
+	{
+		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		const int64_t n = ctx->n_el * SP;
+		hipLaunchKernelGGL((k_element_geometry<NGLOC, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz,
+						   ctx->d_tab, ctx->n_el, ctx->d_estate);
 	}
 
-	template <int NLOC, int NGLOC, int NPTS, int BS, int TPE, bool STAGE>
-	void launch(pfx_ctx *ctx)
+	template <int NLOC, int NGLOC, int NPTS>
+	void launch_rows(pfx_ctx *ctx, bool write_mask)
 	{
-		constexpr int EPB = 256 / TPE;
-		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
-		hipLaunchKernelGGL((k_local_linear<NLOC, NGLOC, NPTS, BS, TPE, STAGE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-						   ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, ctx->model, ctx->lambda, ctx->mu, ctx->d_kloc);
+		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		if (ctx->bs == 1)
+			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu}, write_mask);
+		else
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu}, write_mask);
+	}
+
+	bool supported(const pfx_ctx *ctx)
+	{
+		switch (ctx->kind)
+		{
+		case PFX_P1TET:
+		case PFX_Q1HEX:
+			return ctx->n_pts == 1;
+		case PFX_P2TET:
+			return ctx->n_pts == 6;
+		case PFX_Q2HEX:
+			return ctx->n_pts == 27;
+		}
+		return false;
 	}
 } // namespace
 
+// per-element geometry for the linear assemblers
 pfx_status pfx_launch_local_linear(pfx_ctx *ctx)
 {
-	const int np = ctx->n_pts;
-	const int bs = ctx->bs;
-	bool ok = true;
+	if (!supported(ctx))
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "linear assembly: unsupported element kind / quadrature order combination");
 	switch (ctx->kind)
 	{
 	case PFX_P1TET:
-		if (np != 1)
-			ok = false;
-		else if (bs == 1)
-			launch<4, 4, 1, 1, 16, true>(ctx);
-		else
-			launch<4, 4, 1, 3, 16, true>(ctx);
+		launch_geometry<4, 1>(ctx);
 		break;
 	case PFX_P2TET:
-		if (np != 6)
-			ok = false;
-		else if (bs == 1)
-			launch<10, 4, 6, 1, 64, true>(ctx);
-		else
-			launch<10, 4, 6, 3, 64, true>(ctx);
+		launch_geometry<4, 6>(ctx);
 		break;
 	case PFX_Q1HEX:
-		if (np != 1)
-			ok = false;
-		else if (bs == 1)
-			launch<8, 8, 1, 1, 64, true>(ctx);
-		else
-			launch<8, 8, 1, 3, 64, true>(ctx);
-		break;
-	case PFX_Q2HEX:
-		if (np != 27)
-			ok = false;
-		else if (bs == 1)
-			launch<27, 8, 27, 1, 256, true>(ctx);
-		else
-			launch<27, 8, 27, 3, 256, false>(ctx);
+		launch_geometry<8, 1>(ctx);
 		break;
 	default:
-		ok = false;
+		launch_geometry<8, 27>(ctx);
 	}
-	if (!ok)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "linear assembly: unsupported element kind / quadrature order combination");
+	ctx->estate_kind = PFX_ESTATE_LINEAR;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// global matrix from the state left by pfx_launch_local_linear
+pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask)
+{
+	if (!supported(ctx) || ctx->estate_kind != PFX_ESTATE_LINEAR)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "linear assembly: element state missing or unsupported element kind");
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		launch_rows<4, 4, 1>(ctx, write_mask);
+		break;
+	case PFX_P2TET:
+		launch_rows<10, 4, 6>(ctx, write_mask);
+		break;
+	case PFX_Q1HEX:
+		launch_rows<8, 8, 1>(ctx, write_mask);
+		break;
+	default:
+		launch_rows<27, 8, 27>(ctx, write_mask);
+	}
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

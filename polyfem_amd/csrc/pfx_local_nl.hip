@@ -1,4 +1,5 @@
-// pfx_local_nl.hip -- per-element NeoHookean energy, gradient and Hessian blocks.
+// pfx_local_nl.hip -- per-element energy, gradient and Hessian blocks of the nonlinear-assembler interface
+// (NeoHookean, and LinearElasticity used through that interface).
 //
 // Reference: NLAssembler<NeoHookeanElasticity>::assemble / assemble_grad / assemble_hessian element loops
 // (src/polyfem/assembler/Assembler.cpp:638-678, 427-504, 506-636) and the local kernels
@@ -14,13 +15,22 @@
 // The last line is the reference's B^T (mu I + c1 g g^T + c2 d2J/dF2) B (:542-563) with the sparsity of B
 // (three non-zeros per column) and the hat() structure of d2J/dF2 (:527-532) multiplied out; H_ji = H_ij^T.
 //
-// Work decomposition (TPE lanes per element, all intermediate data in LDS):
+// LinearElasticity through the same interface (LinearElasticity.cpp:56-169; the reference differentiates
+// compute_energy_aux with autodiff, here the derivatives are written out): with D = sum_i u_i (x) G_i,
+// eps = (D + D^T)/2, sigma = 2 mu eps + lambda tr(eps) I:
+//   energy += da [ mu eps:eps + lambda/2 tr(eps)^2 ]      grad_i += da sigma G_i
+//   H_ij   += da [ mu (G_i . G_j) I + mu G_j G_i^T + lambda G_i G_j^T ]
+//
+// Element kernel (TPE lanes per element, all intermediate data in LDS):
 //   1 geometry nodes, connectivity, displacements -> LDS      4 F per point (9 lanes per point)
 //   2 J^{-T}, det per quadrature point                       5 per-point scalars, cofactors, energy
 //   3 G for every (point, basis)                              6 w for every (point, basis)
-//   7 gradient rows (one lane per basis) / Hessian blocks (one lane per pair j <= i, mirrored), staged in an LDS
-//     tile and written to the element's slot in HBM with coalesced stores.
+//   7 gradient rows (one lane per basis); for the Hessian the per-point state (J^{-T}, F, mu da, c1 da, c2 da) is
+//     written out instead of any local matrix.
+// The Hessian blocks are then computed straight into the global matrix by k_assemble_rows (pfx_rowasm.h) with the
+// functor nl_block: one lane per contribution (element, i, j) evaluates H_ij from that state.
 #include "pfx_internal.h"
+#include "pfx_rowasm.h"
 
 namespace
 {
@@ -53,19 +63,30 @@ namespace
 		*det = d;
 	}
 
-	template <int NLOC, int NGLOC, int NPTS, int TPE, bool STAGE>
-	__global__ __launch_bounds__(256) void k_local_neohookean(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
+	// doubles of Hessian state per element: affine geometric map (4-node tets): J^{-T} once, then per point F and the
+	// three coefficients (12 doubles); otherwise per point J^{-T}, F and the coefficients
+	template <int NGLOC, int NPTS>
+	struct nl_state
+	{
+		// J^{-T} takes 10 doubles (one of padding) so that every group starts on a 16-byte boundary
+		static constexpr bool affine = (NGLOC == 4);
+		static constexpr int stride = affine ? 10 + 12 * NPTS : 22 * NPTS;
+		__host__ __device__ static constexpr int jt_at(int k) { return affine ? 0 : 22 * k; }
+		__host__ __device__ static constexpr int f_at(int k) { return affine ? 10 + 12 * k : 22 * k + 10; }
+	};
+
+	template <int NLOC, int NGLOC, int NPTS, int TPE, bool NEO>
+	__global__ __launch_bounds__(256) void k_local_nl(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
 																   const double *__restrict__ xyz, const double *__restrict__ u,
 																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda, double mu,
 																   int want_e, int want_g, int want_h,
-																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ kloc,
+																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
 																   int *__restrict__ flag)
 	{
 		constexpr int EPB = 256 / TPE;
 		constexpr int N = NLOC * 3;
-		constexpr int NPAIR = NLOC * (NLOC + 1) / 2;
+		typedef nl_state<NGLOC, NPTS> ST;
 		__shared__ nl_smem<NLOC, NGLOC, NPTS> sm[EPB];
-		__shared__ double tile[STAGE ? EPB * N * N : 1];
 
 		const int grp = threadIdx.x / TPE, lane = threadIdx.x % TPE;
 		const int64_t e = (int64_t)blockIdx.x * EPB + grp;
@@ -112,7 +133,7 @@ namespace
 			for (int t = lane; t < NPTS * 9; t += TPE)
 			{
 				const int k = t / 9, d = (t % 9) / 3, c = t % 3;
-				double acc = (d == c) ? 1.0 : 0.0;
+				double acc = (NEO && d == c) ? 1.0 : 0.0;
 				for (int i = 0; i < NLOC; ++i)
 					acc += s.ul[3 * i + d] * s.G[3 * (k * NLOC + i) + c];
 				s.F[t] = acc; // F(d,c) row-major
@@ -124,22 +145,44 @@ namespace
 			{
 				const double *F = &s.F[9 * k];
 				double *dJ = &s.dJ[9 * k];
-				// cofactor matrix: dJ(r,c) = d det / d F(r,c)
-				dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
-				dJ[3] = F[2] * F[7] - F[1] * F[8], dJ[4] = F[0] * F[8] - F[2] * F[6], dJ[5] = F[1] * F[6] - F[0] * F[7];
-				dJ[6] = F[1] * F[5] - F[2] * F[4], dJ[7] = F[2] * F[3] - F[0] * F[5], dJ[8] = F[0] * F[4] - F[1] * F[3];
-				const double J = F[0] * dJ[0] + F[1] * dJ[1] + F[2] * dJ[2];
-				if (!(J > 0.0))
-					s.bad = 1;
-				const double lj = log(J);
 				const double da = s.da[k];
-				double tr = 0;
-				for (int q = 0; q < 9; ++q)
-					tr += F[q] * F[q];
-				s.coef[4 * k + 0] = mu * da;
-				s.coef[4 * k + 1] = (mu + lambda * (1.0 - lj)) / (J * J) * da;
-				s.coef[4 * k + 2] = (lambda * lj - mu) / J * da;
-				s.coef[4 * k + 3] = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+				if (NEO)
+				{
+					// cofactor matrix: dJ(r,c) = d det / d F(r,c)
+					dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
+					dJ[3] = F[2] * F[7] - F[1] * F[8], dJ[4] = F[0] * F[8] - F[2] * F[6], dJ[5] = F[1] * F[6] - F[0] * F[7];
+					dJ[6] = F[1] * F[5] - F[2] * F[4], dJ[7] = F[2] * F[3] - F[0] * F[5], dJ[8] = F[0] * F[4] - F[1] * F[3];
+					const double J = F[0] * dJ[0] + F[1] * dJ[1] + F[2] * dJ[2];
+					if (!(J > 0.0))
+						s.bad = 1;
+					const double lj = log(J);
+					double tr = 0;
+					for (int q = 0; q < 9; ++q)
+						tr += F[q] * F[q];
+					s.coef[4 * k + 0] = mu * da;
+					s.coef[4 * k + 1] = (mu + lambda * (1.0 - lj)) / (J * J) * da;
+					s.coef[4 * k + 2] = (lambda * lj - mu) / J * da;
+					s.coef[4 * k + 3] = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+				}
+				else
+				{
+					// F holds the displacement gradient D; dJ receives the stress sigma
+					double eps[9], ee = 0;
+					for (int r = 0; r < 3; ++r)
+						for (int c = 0; c < 3; ++c)
+						{
+							eps[3 * r + c] = (F[3 * r + c] + F[3 * c + r]) / 2;
+							ee += eps[3 * r + c] * eps[3 * r + c];
+						}
+					const double tr = eps[0] + eps[4] + eps[8];
+					for (int q = 0; q < 9; ++q)
+						dJ[q] = 2 * mu * eps[q];
+					dJ[0] += lambda * tr, dJ[4] += lambda * tr, dJ[8] += lambda * tr;
+					s.coef[4 * k + 0] = mu * da;
+					s.coef[4 * k + 1] = lambda * da;
+					s.coef[4 * k + 2] = da;
+					s.coef[4 * k + 3] = (mu * ee + lambda / 2 * tr * tr) * da;
+				}
 			}
 		__syncthreads();
 
@@ -153,7 +196,7 @@ namespace
 		if (active && lane == 0 && s.bad)
 			atomicOr(flag, 1);
 
-		if (active && (want_g || want_h))
+		if (NEO && active && want_g)
 			for (int t = lane; t < NPTS * NLOC; t += TPE)
 			{
 				const int k = t / NLOC;
@@ -173,83 +216,156 @@ namespace
 					const double *F = &s.F[9 * k];
 					const double *Gi = &s.G[3 * (k * NLOC + i)], *Wi = &s.W[3 * (k * NLOC + i)];
 					const double a = s.coef[4 * k + 0], c2 = s.coef[4 * k + 2];
-					for (int d = 0; d < 3; ++d)
-						g[d] += a * (F[3 * d] * Gi[0] + F[3 * d + 1] * Gi[1] + F[3 * d + 2] * Gi[2]) + c2 * Wi[d];
+					if (NEO)
+						for (int d = 0; d < 3; ++d)
+							g[d] += a * (F[3 * d] * Gi[0] + F[3 * d + 1] * Gi[1] + F[3 * d + 2] * Gi[2]) + c2 * Wi[d];
+					else
+					{
+						const double *sg = &s.dJ[9 * k];
+						for (int d = 0; d < 3; ++d)
+							g[d] += c2 * (sg[3 * d] * Gi[0] + sg[3 * d + 1] * Gi[1] + sg[3 * d + 2] * Gi[2]);
+					}
 				}
 				for (int d = 0; d < 3; ++d)
 					gloc[e * N + 3 * i + d] = g[d];
 			}
 
-		if (want_h)
+		if (active && want_h)
 		{
-			double *dst = STAGE ? &tile[grp * N * N] : (kloc + e * (int64_t)(N * N));
-			if (active)
-				for (int q = lane; q < NPAIR; q += TPE)
-				{
-					int i = 0;
-					while ((i + 1) * (i + 2) / 2 <= q)
-						++i;
-					const int j = q - i * (i + 1) / 2;
-					double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-					for (int k = 0; k < NPTS; ++k)
-					{
-						const double *F = &s.F[9 * k];
-						const double *Gi = &s.G[3 * (k * NLOC + i)], *Gj = &s.G[3 * (k * NLOC + j)];
-						const double *Wi = &s.W[3 * (k * NLOC + i)], *Wj = &s.W[3 * (k * NLOC + j)];
-						const double a = s.coef[4 * k + 0], c1 = s.coef[4 * k + 1], c2 = s.coef[4 * k + 2];
-						const double dot = a * (Gi[0] * Gj[0] + Gi[1] * Gj[1] + Gi[2] * Gj[2]);
-						const double cx = Gi[1] * Gj[2] - Gi[2] * Gj[1], cy = Gi[2] * Gj[0] - Gi[0] * Gj[2], cz = Gi[0] * Gj[1] - Gi[1] * Gj[0];
-						// t = c2 * F (Gi x Gj);  block -= hat(t)
-						const double t0 = c2 * (F[0] * cx + F[1] * cy + F[2] * cz);
-						const double t1 = c2 * (F[3] * cx + F[4] * cy + F[5] * cz);
-						const double t2 = c2 * (F[6] * cx + F[7] * cy + F[8] * cz);
-						const double w0 = c1 * Wi[0], w1 = c1 * Wi[1], w2 = c1 * Wi[2];
-						b[0] += dot + w0 * Wj[0];
-						b[1] += w0 * Wj[1] + t2;
-						b[2] += w0 * Wj[2] - t1;
-						b[3] += w1 * Wj[0] - t2;
-						b[4] += dot + w1 * Wj[1];
-						b[5] += w1 * Wj[2] + t0;
-						b[6] += w2 * Wj[0] + t1;
-						b[7] += w2 * Wj[1] - t0;
-						b[8] += dot + w2 * Wj[2];
-					}
-					for (int m = 0; m < 3; ++m)
-						for (int n = 0; n < 3; ++n)
-						{
-							dst[(i * 3 + m) * N + (j * 3 + n)] = b[3 * m + n];
-							if (j < i)
-								dst[(j * 3 + n) * N + (i * 3 + m)] = b[3 * m + n];
-						}
-				}
-			if (STAGE)
+			double *st = estate + e * (int64_t)ST::stride;
+			for (int t = lane; t < NPTS * 22; t += TPE)
 			{
-				__syncthreads();
-				if (active)
+				const int k = t / 22, q = t - 22 * k;
+				if (q < 10)
 				{
-					double *out = kloc + e * (int64_t)(N * N);
-					for (int t = lane; t < N * N; t += TPE)
-						out[t] = tile[grp * N * N + t];
+					if (!ST::affine || k == 0)
+						st[ST::jt_at(k) + q] = q < 9 ? s.jt[9 * k + q] : 0.0;
 				}
+				else if (q < 19)
+					st[ST::f_at(k) + q - 10] = s.F[9 * k + q - 10];
+				else
+					st[ST::f_at(k) + q - 10] = s.coef[4 * k + q - 19];
 			}
 		}
 	}
 
-	template <int NLOC, int NGLOC, int NPTS, int TPE, bool STAGE>
+	// H_ij for the pair (i, j), j <= i : out[m*3+n] = d2 E / d u_{i,m} d u_{j,n}
+	template <int NLOC, int NGLOC, int NPTS, bool NEO>
+	struct nl_block
+	{
+		const double *estate;
+		const pfx_tables *tab;
+		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3; // grad[k][i][3]
+
+		__device__ __forceinline__ void load_tables(double *lds, int lane) const
+		{
+			for (int t = lane; t < NPTS * NLOC * 3; t += 64)
+				lds[t] = tab->grad[t / (NLOC * 3)][(t / 3) % NLOC][t % 3];
+		}
+
+		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[9]) const
+		{
+			typedef nl_state<NGLOC, NPTS> ST;
+			typedef double d2 __attribute__((ext_vector_type(2)));
+			const d2 *st = reinterpret_cast<const d2 *>(estate + (int64_t)e * ST::stride);
+			double jt[10], F[12];
+			if (ST::affine)
+				for (int q = 0; q < 5; ++q)
+				{
+					const d2 v = st[q];
+					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
+				}
+			double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (int k = 0; k < NPTS; ++k)
+			{
+				if (!ST::affine)
+					for (int q = 0; q < 5; ++q)
+					{
+						const d2 v = st[ST::jt_at(k) / 2 + q];
+						jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
+					}
+				for (int q = 0; q < 6; ++q)
+				{
+					const d2 v = st[ST::f_at(k) / 2 + q];
+					F[2 * q] = v.x, F[2 * q + 1] = v.y;
+				}
+				const double a = F[9], c1 = F[10], c2 = F[11];
+				const double *ri = lds + (k * NLOC + i) * 3, *rj = lds + (k * NLOC + j) * 3;
+				double Gi[3], Gj[3];
+				for (int c = 0; c < 3; ++c)
+				{
+					Gi[c] = ri[0] * jt[c] + ri[1] * jt[3 + c] + ri[2] * jt[6 + c];
+					Gj[c] = rj[0] * jt[c] + rj[1] * jt[3 + c] + rj[2] * jt[6 + c];
+				}
+				const double dot = a * (Gi[0] * Gj[0] + Gi[1] * Gj[1] + Gi[2] * Gj[2]);
+				if (!NEO)
+				{
+					// a = mu da, c1 = lambda da
+					for (int m = 0; m < 3; ++m)
+						for (int n = 0; n < 3; ++n)
+							b[3 * m + n] += a * Gi[n] * Gj[m] + c1 * Gi[m] * Gj[n] + (m == n ? dot : 0.0);
+					continue;
+				}
+				const double f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
+				// cofactor matrix of F, row-major
+				const double d0 = f4 * f8 - f5 * f7, d1 = f5 * f6 - f3 * f8, d2 = f3 * f7 - f4 * f6;
+				const double d3 = f2 * f7 - f1 * f8, d4 = f0 * f8 - f2 * f6, d5 = f1 * f6 - f0 * f7;
+				const double d6 = f1 * f5 - f2 * f4, d7 = f2 * f3 - f0 * f5, d8 = f0 * f4 - f1 * f3;
+				const double wi0 = c1 * (d0 * Gi[0] + d1 * Gi[1] + d2 * Gi[2]);
+				const double wi1 = c1 * (d3 * Gi[0] + d4 * Gi[1] + d5 * Gi[2]);
+				const double wi2 = c1 * (d6 * Gi[0] + d7 * Gi[1] + d8 * Gi[2]);
+				const double wj0 = d0 * Gj[0] + d1 * Gj[1] + d2 * Gj[2];
+				const double wj1 = d3 * Gj[0] + d4 * Gj[1] + d5 * Gj[2];
+				const double wj2 = d6 * Gj[0] + d7 * Gj[1] + d8 * Gj[2];
+				const double cx = Gi[1] * Gj[2] - Gi[2] * Gj[1], cy = Gi[2] * Gj[0] - Gi[0] * Gj[2], cz = Gi[0] * Gj[1] - Gi[1] * Gj[0];
+				// t = c2 * F (Gi x Gj);  block -= hat(t)
+				const double t0 = c2 * (f0 * cx + f1 * cy + f2 * cz);
+				const double t1 = c2 * (f3 * cx + f4 * cy + f5 * cz);
+				const double t2 = c2 * (f6 * cx + f7 * cy + f8 * cz);
+				b[0] += dot + wi0 * wj0;
+				b[1] += wi0 * wj1 + t2;
+				b[2] += wi0 * wj2 - t1;
+				b[3] += wi1 * wj0 - t2;
+				b[4] += dot + wi1 * wj1;
+				b[5] += wi1 * wj2 + t0;
+				b[6] += wi2 * wj0 + t1;
+				b[7] += wi2 * wj1 - t0;
+				b[8] += dot + wi2 * wj2;
+			}
+			for (int q = 0; q < 9; ++q)
+				out[q] = b[q];
+		}
+	};
+
+	template <int NLOC, int NGLOC, int NPTS, int TPE>
 	void launch(pfx_ctx *ctx, const double *d_u, bool en, bool gr, bool he)
 	{
 		constexpr int EPB = 256 / TPE;
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
-		hipLaunchKernelGGL((k_local_neohookean<NLOC, NGLOC, NPTS, TPE, STAGE>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-						   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu,
-						   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_kloc, ctx->d_flag);
+		if (ctx->model == PFX_NEOHOOKEAN)
+			hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu,
+							   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag);
+		else
+			hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu,
+							   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag);
+	}
+
+	template <int NLOC, int NGLOC, int NPTS>
+	void launch_rows(pfx_ctx *ctx)
+	{
+		if (ctx->model == PFX_NEOHOOKEAN)
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, true>{ctx->d_estate, ctx->d_tab}, false);
+		else
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, false>{ctx->d_estate, ctx->d_tab}, false);
 	}
 } // namespace
 
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess)
 {
-	if (ctx->model != PFX_NEOHOOKEAN)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "nonlinear assembly is implemented for the NeoHookean model");
+	if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the nonlinear-assembler interface is implemented for NeoHookean and LinearElasticity");
 	const int np = ctx->n_pts;
 	bool ok = true;
 	switch (ctx->kind)
@@ -258,31 +374,59 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 		if (np != 1)
 			ok = false;
 		else
-			launch<4, 4, 1, 16, true>(ctx, d_u, energy, grad, hess);
+			launch<4, 4, 1, 16>(ctx, d_u, energy, grad, hess);
 		break;
 	case PFX_P2TET:
 		if (np != 6)
 			ok = false;
 		else
-			launch<10, 4, 6, 64, true>(ctx, d_u, energy, grad, hess);
+			launch<10, 4, 6, 64>(ctx, d_u, energy, grad, hess);
 		break;
 	case PFX_Q1HEX:
 		if (np != 1)
 			ok = false;
 		else
-			launch<8, 8, 1, 64, true>(ctx, d_u, energy, grad, hess);
+			launch<8, 8, 1, 64>(ctx, d_u, energy, grad, hess);
 		break;
 	case PFX_Q2HEX:
 		if (np != 27)
 			ok = false;
 		else
-			launch<27, 8, 27, 256, false>(ctx, d_u, energy, grad, hess);
+			launch<27, 8, 27, 256>(ctx, d_u, energy, grad, hess);
 		break;
 	default:
 		ok = false;
 	}
 	if (!ok)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "nonlinear assembly: unsupported element kind / quadrature order combination");
+	if (hess)
+		ctx->estate_kind = PFX_ESTATE_NL;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// global Hessian from the state left by pfx_launch_local_nl(..., hess = true)
+pfx_status pfx_launch_rows_nl(pfx_ctx *ctx)
+{
+	if (ctx->estate_kind != PFX_ESTATE_NL)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: element state missing");
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		launch_rows<4, 4, 1>(ctx);
+		break;
+	case PFX_P2TET:
+		launch_rows<10, 4, 6>(ctx);
+		break;
+	case PFX_Q1HEX:
+		launch_rows<8, 8, 1>(ctx);
+		break;
+	case PFX_Q2HEX:
+		launch_rows<27, 8, 27>(ctx);
+		break;
+	default:
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: unsupported element kind");
+	}
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

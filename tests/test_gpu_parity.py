@@ -84,6 +84,32 @@ def test_neohookean_energy_gradient_hessian(eng, oracle, name):
         assert rel_err(v, vals) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
+def test_linear_elasticity_through_nonlinear_interface(eng, oracle, name):
+    """LinearElasticity::compute_energy / assemble_grad / assemble_hessian (LinearElasticity.cpp:56-169) against the
+    oracle, and the reference's own property (tests/test_assembler.cpp:12-64): Hessian == stiffness for any x."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(1e5, 0.3)
+    nnz = _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+    n = mesh.n_nodes * 3
+    eng.assemble_linear()
+    k = eng.get_values()
+    rng = np.random.default_rng(5)
+    for rand in (0, 1):
+        x = rng.standard_normal(n) if rand else np.zeros(n)
+        e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+        outer, inner, vals = oracle.assemble_hessian(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x)
+        rp, ci = eng.get_pattern()
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and nnz == inner.size
+        assert rel_err(v, vals) <= TOL
+        assert rel_err(v, k) <= TOL
+        if rand:
+            assert abs(e - oracle.assemble_energy(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x)) <= TOL * abs(e)
+            assert rel_err(g, oracle.assemble_gradient(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x)) <= TOL
+        else:
+            assert e == 0.0 and not g.any()
+
+
 def test_hessian_pattern_reuse_is_deterministic(eng, oracle):
     """Newton steps reuse the pattern (SpareMatrixCache second pass == first pass) and repeated assemblies of
     the same state are bitwise identical (no atomics in the accumulation)."""

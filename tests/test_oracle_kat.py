@@ -169,6 +169,27 @@ def test_linear_elasticity_stiffness_is_energy_hessian(oracle, order):
         assert abs(e - 0.5 * x @ (K @ x)) < 1e-10 * abs(e)
 
 
+@pytest.mark.parametrize("order", [1, 2])
+def test_linear_elasticity_nonlinear_interface_matches_stiffness(oracle, order):
+    """Reference tests/test_assembler.cpp:12-64 ("hessian_lin"): the Hessian of the LinearElasticity energy assembled
+    through the nonlinear interface equals the stiffness matrix for any displacement, also when the pattern cache is
+    reused; its gradient is K x."""
+    mesh = M.cube_tets(2, order, jitter=0.15)
+    lam, mu = oracle.lame(1e5, 0.3)
+    n = mesh.n_nodes * 3
+    K = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    cache = oracle.Cache(n)
+    rng = np.random.default_rng(3)
+    for rand in range(4):
+        x = rng.standard_normal(n) if rand else np.zeros(n)
+        H = csc_to_scipy(oracle.assemble_hessian_cached(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x, cache), n)
+        assert abs(H - K).max() <= 1e-12 * abs(K).max()
+        g = oracle.assemble_gradient(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x)
+        assert np.abs(g - K @ x).max() <= 1e-11 * max(np.abs(K @ x).max(), 1.0)
+    H2 = csc_to_scipy(oracle.assemble_hessian(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x), n)
+    assert abs(H2 - K).max() <= 1e-12 * abs(K).max()
+
+
 @pytest.mark.parametrize("kind", ["tet1", "tet2", "hex1"])
 def test_neohookean_fd(oracle, kind):
     mesh = {"tet1": lambda: M.cube_tets(2, 1, jitter=0.2), "tet2": lambda: M.cube_tets(2, 2, jitter=0.2),
