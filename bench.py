@@ -197,6 +197,7 @@ def main():
     gat_ms, gat_n = eng.timing_get("gather")
     upd_ms, _ = eng.timing_get("cg_update")
     dir_ms, _ = eng.timing_get("cg_dir")
+    conv_ms, _ = eng.timing_get("sell_convert")
 
     sb = spmv_bytes(inf.nnz, inf.n_blocks, inf.n_nodes, n)
     ab = assembly_bytes(inf.n_el, inf.n_loc, 4, mesh.xyz.shape[0], inf.n_nodes, inf.nnz, nonlinear)
@@ -237,7 +238,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "avg_ms": spmv_ms, "launches": spmv_n, "algorithmic_bytes": sb},
             "assembly": {"elements_per_s": world * owned_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
-                         "gather_ms": gat_ms,
+                         "gather_ms": gat_ms, "solver_copy_ms": conv_ms,
                          "roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": asm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": ab}},
             "cg": {"update_ms": upd_ms, "direction_ms": dir_ms, "spmv_ms": spmv_ms,

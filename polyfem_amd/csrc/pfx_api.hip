@@ -59,6 +59,7 @@ namespace
 		free_dev(ctx->d_node_col);
 		free_dev(ctx->d_blk_ptr);
 		free_dev(ctx->d_blk_src);
+		free_dev(ctx->d_blk_slot);
 		free_dev(ctx->d_ne_ptr);
 		free_dev(ctx->d_ne_src);
 		free_dev(ctx->d_values);
@@ -317,9 +318,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_pattern(ctx))
 			return PFX_ERR_ARG;
-		PFX_HIP(hipMemcpyAsync(values, ctx->d_values, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
-		PFX_HIP(hipStreamSynchronize(ctx->stream));
-		return PFX_OK;
+		return pfx_values_to_csr(ctx, values);
 	}
 
 	pfx_status pfx_assemble_linear(pfx_ctx *ctx)
@@ -457,8 +456,8 @@ extern "C"
 		pfx_status rc = pfx_hessian_dev(ctx, ctx->d_u);
 		if (rc)
 			return rc;
-		if (values)
-			PFX_HIP(hipMemcpyAsync(values, ctx->d_values, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+		if (values && (rc = pfx_values_to_csr(ctx, values)))
+			return rc;
 		return check_flag(ctx);
 	}
 

@@ -82,7 +82,6 @@ namespace
 			const int64_t g = r / bs;
 			const int m = (int)(r - g * bs);
 			const int64_t b0 = node_ptr[g], deg = node_ptr[g + 1] - b0;
-			const int64_t start = b0 * bs * bs + (int64_t)m * deg * bs;
 			int64_t c = 0;
 			for (int64_t s = 0; s < deg; ++s)
 				for (int n = 0; n < bs; ++n)
@@ -90,7 +89,7 @@ namespace
 					const int64_t col = (int64_t)node_col[b0 + s] * bs + n;
 					if (fixed && fixed[col])
 						continue;
-					if (mask && !mask[start + s * bs + n])
+					if (mask && !mask[(b0 + s) * bs * bs + m * bs + n])
 						continue;
 					++c;
 				}
@@ -111,7 +110,6 @@ namespace
 			const int64_t g = r / bs;
 			const int m = (int)(r - g * bs);
 			const int64_t b0 = node_ptr[g], deg = node_ptr[g + 1] - b0;
-			const int64_t start = b0 * bs * bs + (int64_t)m * deg * bs;
 			int64_t w = off[r];
 			row_ptr[newrow ? newrow[r] : r] = w;
 			for (int64_t s = 0; s < deg; ++s)
@@ -120,12 +118,35 @@ namespace
 					const int64_t col = (int64_t)node_col[b0 + s] * bs + n;
 					if (fixed && fixed[col])
 						continue;
-					if (mask && !mask[start + s * bs + n])
+					const int64_t at = (b0 + s) * bs * bs + m * bs + n;
+					if (mask && !mask[at])
 						continue;
 					col_idx[w] = (int32_t)(newrow ? newrow[col] : col);
-					out_values[w] = values[start + s * bs + n];
+					out_values[w] = values[at];
 					++w;
 				}
+		}
+	}
+
+	// node-block storage -> scalar CSR order of the structural pattern (row g*bs+m = the bs*deg values of its slots)
+	__global__ void k_values_to_csr(const int64_t *__restrict__ node_ptr, int64_t n_nodes, int bs, const double *__restrict__ blocks,
+									double *__restrict__ csr)
+	{
+		const int lane = threadIdx.x & 63;
+		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+		const int b2 = bs * bs;
+		for (int64_t g = wave; g < n_nodes; g += n_waves)
+		{
+			const int64_t b0 = node_ptr[g];
+			const int deg = (int)(node_ptr[g + 1] - b0);
+			const int rowlen = deg * bs;
+			for (int t = lane; t < rowlen * bs; t += 64)
+			{
+				const int m = t / rowlen, r = t - m * rowlen;
+				const int s = r / bs, n = r - s * bs;
+				csr[b0 * b2 + t] = blocks[(b0 + s) * b2 + m * bs + n];
+			}
 		}
 	}
 
@@ -196,6 +217,20 @@ pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy)
 	const int nb = 256;
 	hipLaunchKernelGGL(k_reduce_stage1, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_eloc, ctx->d_elem_owned, ctx->n_el, ctx->d_partials);
 	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, nb, d_energy);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// copies the matrix values to the host in the order of the scalar CSR returned by pfx_export_pattern
+pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values)
+{
+	double *d_csr = nullptr;
+	PFX_HIP(hipMalloc((void **)&d_csr, sizeof(double) * (size_t)(ctx->nnz ? ctx->nnz : 1)));
+	hipLaunchKernelGGL(k_values_to_csr, dim3(grid_for(ctx->n_nodes * 64)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->n_nodes, ctx->bs,
+					   ctx->d_values, d_csr);
+	PFX_HIP(hipMemcpyAsync(host_values, d_csr, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+	PFX_HIP(hipStreamSynchronize(ctx->stream));
+	(void)hipFree(d_csr);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -24,6 +24,8 @@ struct pfx_tables
 	double ggrad[PFX_MAX_PTS][PFX_MAX_GLOC][3];   // same for the geometry bases
 };
 
+#define PFX_ROWS_PER_GROUP 16
+
 enum
 {
 	PFX_ESTATE_NONE = 0,
@@ -63,11 +65,17 @@ struct pfx_ctx
 	int64_t *d_node_ptr = nullptr; // n_nodes+1
 	int32_t *d_node_col = nullptr; // n_blocks, ascending per node
 	int64_t *d_blk_ptr = nullptr;  // n_blocks+1 -> contribution list
-	uint32_t *d_blk_src = nullptr; // n_el*n_loc^2 : e*n_loc^2 + i*n_loc + j, ascending e inside a block
+	// contribution lists (n_el*n_loc^2 entries).  Position c of the block-ordered list belongs to the block b with
+	// blk_ptr[b] <= c < blk_ptr[b+1] (ascending element inside a block).  The assembly kernel walks that list in windows
+	// of 64 per group of PFX_ROWS_PER_GROUP node rows; inside each window the contributions are stored reordered by
+	// element (lanes that read the same element state sit next to each other): d_blk_src[c] = e*n_loc^2 + i*n_loc + j of
+	// the contribution computed by lane c - window start, d_blk_slot[c] = its position in the window in block order.
+	uint32_t *d_blk_src = nullptr;
+	uint8_t *d_blk_slot = nullptr;
 	int64_t *d_ne_ptr = nullptr;   // n_nodes+1 -> incident (element, local index) list
 	uint32_t *d_ne_src = nullptr;  // n_el*n_loc : e*n_loc + i, ascending
-	double *d_values = nullptr;    // nnz
-	uint8_t *d_mask = nullptr;     // nnz, 1 = entry exists in the reference's value-dependent pattern
+	double *d_values = nullptr;    // nnz, node-block storage: entry (m, n) of block b at b*bs*bs + m*bs + n
+	uint8_t *d_mask = nullptr;     // nnz (same layout), 1 = entry exists in the reference's value-dependent pattern
 	bool have_mask = false;
 
 	// scratch for the two-pass (local blocks, then per-row sums) assembly
@@ -187,6 +195,7 @@ pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                               
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess); // NeoHookean
 pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask); // strict arithmetic
 pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
+pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);

@@ -65,6 +65,33 @@ namespace
 		}
 	}
 
+	// key that orders the contributions by (assembly window, element): see pfx_ctx::d_blk_src
+	__global__ void k_window_keys(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ src, const int64_t *__restrict__ node_ptr,
+								  const int64_t *__restrict__ blk_ptr, int64_t n_items, int64_t n_nodes, uint32_t nl2,
+								  uint64_t *__restrict__ wkeys, uint64_t *__restrict__ wvals)
+	{
+		for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_items; c += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t gi = (int64_t)(keys[c] / (uint64_t)n_nodes);
+			const int64_t g0 = (gi / PFX_ROWS_PER_GROUP) * PFX_ROWS_PER_GROUP;
+			const int64_t wbeg = blk_ptr[node_ptr[g0]];
+			const int64_t wstart = wbeg + ((c - wbeg) / 64) * 64;
+			const uint32_t s = src[c];
+			wkeys[c] = ((uint64_t)wstart << 28) | (uint64_t)(s / nl2);
+			wvals[c] = ((uint64_t)s << 8) | (uint64_t)(c - wstart);
+		}
+	}
+
+	__global__ void k_split_window_vals(const uint64_t *__restrict__ wvals, int64_t n_items, uint32_t *__restrict__ src, uint8_t *__restrict__ slot)
+	{
+		for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_items; c += (int64_t)gridDim.x * blockDim.x)
+		{
+			const uint64_t v = wvals[c];
+			src[c] = (uint32_t)(v >> 8);
+			slot[c] = (uint8_t)(v & 0xff);
+		}
+	}
+
 	__global__ void k_count_u32(const uint32_t *__restrict__ keys, int64_t n_items, int64_t *__restrict__ cnt)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * blockDim.x)
@@ -123,6 +150,8 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	const int64_t n_inc = n_el * n_loc;
 	if (n_pair >= ((int64_t)1 << 32))
 		PFX_FAIL(PFX_ERR_SIZE, "n_el * n_loc^2 exceeds the 32-bit contribution index; partition the mesh over more devices");
+	if (n_el >= ((int64_t)1 << 28))
+		PFX_FAIL(PFX_ERR_SIZE, "more than 2^28 elements on one device; partition the mesh over more devices");
 	hipStream_t st = ctx->stream;
 
 	// ---- node-pair blocks ----------------------------------------------------------------------------------
@@ -182,6 +211,32 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	(void)hipFree(tmp);
 	tmp = nullptr;
 	(void)hipFree(pos);
+
+	// ---- compute order of the contributions inside each assembly window -----------------------------------------
+	{
+		uint64_t *wk_a = nullptr, *wk_b = nullptr, *wv_a = nullptr, *wv_b = nullptr;
+		PFX_HIP(hipMalloc((void **)&wk_a, sizeof(uint64_t) * (size_t)n_pair));
+		PFX_HIP(hipMalloc((void **)&wk_b, sizeof(uint64_t) * (size_t)n_pair));
+		PFX_HIP(hipMalloc((void **)&wv_a, sizeof(uint64_t) * (size_t)n_pair));
+		PFX_HIP(hipMalloc((void **)&wv_b, sizeof(uint64_t) * (size_t)n_pair));
+		if (pfx_alloc(ctx, &ctx->d_blk_slot, n_pair))
+			return PFX_ERR_HIP;
+		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b, ctx->d_blk_src, ctx->d_node_ptr, ctx->d_blk_ptr, n_pair,
+						   n_nodes, (uint32_t)(n_loc * n_loc), wk_a, wv_a);
+		const int wbits = 28 + bits_for((uint64_t)n_pair);
+		tmp_bytes = 0;
+		PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, wk_a, wk_b, wv_a, wv_b, (size_t)n_pair, 0, wbits, st));
+		PFX_HIP(hipMalloc(&tmp, tmp_bytes));
+		PFX_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, wk_a, wk_b, wv_a, wv_b, (size_t)n_pair, 0, wbits, st));
+		hipLaunchKernelGGL(k_split_window_vals, dim3(grid_for(n_pair)), dim3(256), 0, st, wv_b, n_pair, ctx->d_blk_src, ctx->d_blk_slot);
+		PFX_HIP(hipStreamSynchronize(st));
+		(void)hipFree(tmp);
+		tmp = nullptr;
+		(void)hipFree(wk_a);
+		(void)hipFree(wk_b);
+		(void)hipFree(wv_a);
+		(void)hipFree(wv_b);
+	}
 	(void)hipFree(keys_b);
 
 	// ---- node -> (element, local index) incidences ---------------------------------------------------------

@@ -71,32 +71,47 @@ namespace
 		return c * SL + lane;
 	}
 
+	// node-block values -> slice layout.  One wave per slice; for every slot j the 64 blocks (one per row of the slice,
+	// bs*bs contiguous doubles each) are read with the lanes running over consecutive doubles, transposed through LDS
+	// and written as the slot's contiguous run of the slice.
 	template <int BS>
 	__global__ __launch_bounds__(256) void k_sell_values(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
-														  const int64_t *__restrict__ slice_base, int64_t n_slices, const double *__restrict__ csr,
+														  const int64_t *__restrict__ slice_base, int64_t n_slices, const double *__restrict__ blocks,
 														  double *__restrict__ out)
 	{
 		constexpr int B2 = BS * BS;
-		const int lane = threadIdx.x & 63;
-		const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-		const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-		for (int64_t s = wave; s < n_slices; s += n_waves)
+		__shared__ double tile[4][SL * B2];
+		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+		const int64_t s = (int64_t)blockIdx.x * 4 + w;
+		const bool active = s < n_slices;
+		const int64_t base = active ? slice_base[s] : 0;
+		const int len = active ? (int)(slice_base[s + 1] - base) : 0;
+		const int g_mine = active ? perm[s * SL + lane] : -1;
+		const int64_t b0_mine = g_mine >= 0 ? node_ptr[g_mine] : 0;
+		const int deg_mine = g_mine >= 0 ? (int)(node_ptr[g_mine + 1] - b0_mine) : 0;
+		double *o = out + base * (SL * B2);
+		for (int j = 0; j < len; ++j)
 		{
-			const int64_t base = slice_base[s];
-			const int len = (int)(slice_base[s + 1] - base);
-			const int g = perm[s * SL + lane];
-			const int64_t b0 = g >= 0 ? node_ptr[g] : 0;
-			const int deg = g >= 0 ? (int)(node_ptr[g + 1] - b0) : 0;
-			const double *row0 = csr + b0 * B2;
-			double *o = out + base * (SL * B2);
-			for (int j = 0; j < len; ++j)
 #pragma unroll
-				for (int c = 0; c < B2; ++c)
-				{
-					const int m = c / BS, n = c - m * BS;
-					const double v = j < deg ? row0[(int64_t)m * deg * BS + j * BS + n] : 0.0;
-					o[(int64_t)j * (SL * B2) + entry_offset<BS>(c, lane)] = v;
-				}
+			for (int it = 0; it < B2; ++it)
+			{
+				const int t = it * 64 + lane;
+				const int l = t / B2, c = t - l * B2;
+				const int64_t b0 = __shfl(b0_mine, l);
+				const int deg = __shfl(deg_mine, l);
+				const double v = j < deg ? __builtin_nontemporal_load(blocks + (b0 + j) * B2 + c) : 0.0;
+				tile[w][entry_offset<BS>(c, l)] = v;
+			}
+			// one wave reads back what it wrote itself: LDS operations of a wave complete in order
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+			for (int it = 0; it < B2; ++it)
+				o[(int64_t)j * (SL * B2) + it * 64 + lane] = tile[w][it * 64 + lane];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
 	}
 
@@ -291,9 +306,7 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 	if (ctx->sell_gen != ctx->values_gen)
 	{
 		pfx_scoped_timer tm(ctx, "sell_convert");
-		int64_t blocks = (ctx->sell_slices + 3) / 4;
-		if (blocks > 256 * 32)
-			blocks = 256 * 32;
+		int64_t blocks = (ctx->sell_slices + 3) / 4; // one wave per slice
 		if (blocks < 1)
 			blocks = 1;
 		if (ctx->bs == 1)

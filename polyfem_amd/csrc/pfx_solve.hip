@@ -110,7 +110,7 @@ namespace
 				const int64_t r = g * BS + m;
 				if (jacobi && s >= 0 && !(fixed && fixed[r]))
 				{
-					const double a = values[b0 * (BS * BS) + (int64_t)m * deg * BS + s * BS + m];
+					const double a = values[(b0 + s) * (BS * BS) + m * BS + m];
 					if (a != 0.0)
 						d = 1.0 / a;
 				}

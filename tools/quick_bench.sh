@@ -8,6 +8,6 @@ for w in linear_elasticity neohookean; do
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/bench_$w.log").read().strip().splitlines()[-1])
-a=d["assembly"]; print("$w", "local_ms %.3f rows_ms %.3f" % (a["local_ms"], a["gather_ms"]), "spmv_ms %.4f" % d["roofline"]["avg_ms"], "ms_per_step %.2f" % d["ms_per_step"])
+a=d["assembly"]; print("$w", "local_ms %.3f rows_ms %.3f convert_ms %.3f" % (a["local_ms"], a["gather_ms"], a["solver_copy_ms"]), "spmv_ms %.4f" % d["roofline"]["avg_ms"], "ms_per_step %.2f" % d["ms_per_step"])
 PY
 done
