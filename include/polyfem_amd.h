@@ -149,6 +149,59 @@ pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x_inout, int pr
 pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol,
 							   int *iters, double *rel_res);
 
+/* ---- Newton solve with the iterate resident on the device ------------------------------------------------------
+ *
+ * cppoptlib::NonlinearSolver::minimize (solver/NonlinearSolver.tpp:33-275) driving
+ * SparseNewtonDescentSolver::compute_update_direction / check_direction (solver/SparseNewtonDescentSolver.tpp:63-193)
+ * and BacktrackingLineSearch::line_search (solver/line_search/BacktrackingLineSearch.hpp:29-255,
+ * LineSearch.tpp:90-145) on the objective of NLProblem (solver/NLProblem.cpp:79-99) with an ElasticForm and a
+ * BodyForm:  E(x) - rhs.x, the dofs of pfx_set_dirichlet held at their incoming values in x.  x, the gradient and the
+ * direction never leave the device; per iteration only a handful of scalars are read back.  Parameter names and
+ * defaults follow input-spec.json:1587-1647 (solver/nonlinear/...).  The reference's descent strategy 1 ("projected
+ * Newton") is run WITHOUT the per-element projection to PSD: only its regularisation weights are applied. */
+typedef struct
+{
+	double f_delta;             /* 1e-10 */
+	double grad_norm;           /* 1e-8  */
+	double first_grad_norm_tol; /* 1e-10 */
+	double use_grad_norm_tol;   /* line_search/use_grad_norm_tol, 1e-4 */
+	int max_iterations;         /* 1000  */
+	int use_grad_norm;          /* 1     */
+	int relative_gradient;      /* 0     */
+	int line_search;            /* 1 = "backtracking", 0 = none (full steps) */
+	int cg_precond;             /* PFX_PRECOND_JACOBI */
+	int cg_max_iter;            /* 1000  */
+	double cg_tol;              /* 1e-12 */
+} pfx_newton_params;
+
+enum
+{
+	PFX_NEWTON_CONTINUE = 0,
+	PFX_NEWTON_ITERATION_LIMIT = 1, /* the reference throws "Reached iteration limit" */
+	PFX_NEWTON_F_DELTA = 2,
+	PFX_NEWTON_GRAD_NORM = 3,
+	PFX_NEWTON_NOT_STARTED = 4, /* "Not even starting, grad is small enough" */
+	PFX_NEWTON_FAILED = 5       /* nan energy / gradient or a failed line search on gradient descent (the reference throws) */
+};
+
+typedef struct
+{
+	int status;
+	int iterations;
+	int line_search_iterations; /* objective evaluations spent inside the line searches */
+	int descent_strategy;       /* 0 Newton, 1 regularised Newton, 2 gradient descent: strategy of the last accepted step */
+	int64_t cg_iterations;
+	double energy, grad_norm;   /* objective and gradient norm at the start of the last iteration */
+} pfx_newton_info;
+
+void pfx_newton_default_params(pfx_newton_params *params);
+/* rhs (may be NULL) and x are FULL size host vectors; x is the starting point on input, the minimiser on output.
+ * Returns PFX_ERR_NUMERIC (and info->status = PFX_NEWTON_FAILED / ITERATION_LIMIT) where the reference throws. */
+pfx_status pfx_newton_solve(pfx_ctx *ctx, const double *rhs, double *x_inout, const pfx_newton_params *params,
+							pfx_newton_info *info);
+pfx_status pfx_newton_solve_dev(pfx_ctx *ctx, const double *d_rhs, double *d_x_inout, const pfx_newton_params *params,
+								pfx_newton_info *info);
+
 /* ---- multi-GPU building blocks (no counterpart in the reference, which is single-process) -------------------------
  *
  * One process per GPU holds one part of a node partition: its mesh is every element that touches an owned node,

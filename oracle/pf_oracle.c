@@ -1774,3 +1774,320 @@ int pfo_dirichlet_modify(pfo_csc *A, double *b, const int32_t *boundary_nodes, i
 	free(is_b), free(g), free(Ag);
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Newton solver                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+
+void pfo_newton_default_params(pfo_newton_params *p)
+{
+	/* input-spec.json:1587-1647 */
+	p->f_delta = 1e-10;
+	p->grad_norm = 1e-8;
+	p->first_grad_norm_tol = 1e-10;
+	p->use_grad_norm_tol = 1e-4;
+	p->max_iterations = 1000;
+	p->use_grad_norm = 1;
+	p->relative_gradient = 0;
+	p->line_search = 1;
+	p->cg_precond_jacobi = 1;
+	p->cg_max_iter = 1000;
+	p->cg_tol = 1e-12;
+}
+
+typedef struct
+{
+	const pfo_mesh *mesh;
+	const pfo_material *mat;
+	const double *rhs;
+	const int32_t *bnd;
+	int64_t n_bnd;
+	int64_t n;       /* full size */
+	uint8_t *fixed;  /* n */
+	int n_threads;
+} nl_problem;
+
+/* NLProblem::value (solver/NLProblem.cpp:79-83): elastic energy + body form -x.rhs on the full vector */
+static double nlp_value(const nl_problem *p, const double *x)
+{
+	double e = pfo_assemble_energy(p->mesh, p->mat, x, p->n_threads);
+	if (p->rhs)
+		e -= dot(x, p->rhs, p->n);
+	return e;
+}
+
+/* NLProblem::gradient (:85-90): full gradient, constrained entries removed (kept here as zeros) */
+static void nlp_gradient(const nl_problem *p, const double *x, double *g)
+{
+	pfo_assemble_gradient(p->mesh, p->mat, x, p->n_threads, g);
+	for (int64_t k = 0; k < p->n; ++k)
+	{
+		if (p->rhs)
+			g[k] -= p->rhs[k];
+		if (p->fixed[k])
+			g[k] = 0;
+	}
+}
+
+/* cppoptlib checkConvergence (meta.h, un-vendored): iteration limit, then f delta, then gradient norm */
+static int check_convergence(const pfo_newton_params *stop, int iterations, double f_delta, double grad_norm, double grad_tol)
+{
+	if (stop->max_iterations > 0 && iterations > stop->max_iterations)
+		return PFO_NEWTON_ITERATION_LIMIT;
+	if (stop->f_delta > 0 && f_delta < stop->f_delta) /* false for nan */
+		return PFO_NEWTON_F_DELTA;
+	if (grad_tol > 0 && grad_norm < grad_tol)
+		return PFO_NEWTON_GRAD_NORM;
+	return PFO_NEWTON_CONTINUE;
+}
+
+/* BacktrackingLineSearch::line_search (line_search/BacktrackingLineSearch.hpp:29-147) without contact:
+ * nan-free step (LineSearch.tpp:90-145), then the descent step (:157-255).  Returns nan on failure. */
+static double backtracking(const nl_problem *p, const double *x, const double *dx, const pfo_newton_params *par, double *xn, double *g, int *evals)
+{
+	const int64_t n = p->n;
+	const double min_step_size = 0;
+	const int max_step_size_iter = 100;
+	int cur_iter = 0;
+	const double old_energy_in = nlp_value(p, x);
+	++*evals;
+	if (isnan(old_energy_in))
+		return NAN;
+	double step = 1;
+	for (int64_t k = 0; k < n; ++k)
+		xn[k] = x[k] + step * dx[k];
+	while (step > min_step_size && cur_iter < max_step_size_iter)
+	{
+		const double energy = nlp_value(p, xn);
+		++*evals;
+		/* ElasticForm::is_step_valid (forms/ElasticForm.cpp:129-144): the gradient has no nan; for the materials here
+		 * that is the case exactly when the energy is finite */
+		if (!isfinite(energy))
+		{
+			step *= 0.5;
+			for (int64_t k = 0; k < n; ++k)
+				xn[k] = x[k] + step * dx[k];
+		}
+		else
+			break;
+		cur_iter++;
+	}
+	if (cur_iter >= max_step_size_iter || step <= min_step_size)
+		return NAN;
+	nlp_gradient(p, x, g);
+	const double gn = sqrt(dot(g, g, n));
+	const int use_grad_norm = gn < par->use_grad_norm_tol;
+	const double old_energy = use_grad_norm ? dot(g, g, n) : old_energy_in;
+	double cur_energy = NAN;
+	while (step > min_step_size && cur_iter < max_step_size_iter)
+	{
+		for (int64_t k = 0; k < n; ++k)
+			xn[k] = x[k] + step * dx[k];
+		if (use_grad_norm)
+		{
+			nlp_gradient(p, xn, g);
+			cur_energy = dot(g, g, n);
+		}
+		else
+			cur_energy = nlp_value(p, xn);
+		++*evals;
+		if (!isfinite(cur_energy) || cur_energy > old_energy)
+			step /= 2.0;
+		else
+			break;
+		cur_iter++;
+	}
+	if (cur_iter >= max_step_size_iter || step <= min_step_size)
+		return NAN;
+	return step;
+}
+
+int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double *rhs, const int32_t *boundary_nodes, int64_t n_boundary,
+					 double *x, const pfo_newton_params *par, int n_threads, pfo_newton_info *info)
+{
+	const int64_t n = mesh->n_nodes * block_size(mat);
+	nl_problem P = {mesh, mat, rhs, boundary_nodes, n_boundary, n, NULL, n_threads < 1 ? 1 : n_threads};
+	P.fixed = (uint8_t *)calloc((size_t)n, 1);
+	for (int64_t k = 0; k < n_boundary; ++k)
+		P.fixed[boundary_nodes[k]] = 1;
+	const int64_t nr = n - n_boundary;
+	double *grad = (double *)calloc((size_t)n, sizeof(double));
+	double *dx = (double *)calloc((size_t)n, sizeof(double));
+	double *xn = (double *)calloc((size_t)n, sizeof(double));
+	double *gw = (double *)calloc((size_t)n, sizeof(double));
+	double *br = (double *)calloc((size_t)(nr ? nr : 1), sizeof(double));
+	double *xr = (double *)calloc((size_t)(nr ? nr : 1), sizeof(double));
+	double *yr = (double *)calloc((size_t)(nr ? nr : 1), sizeof(double));
+	memset(info, 0, sizeof(*info));
+	int rc = 0;
+
+	/* NonlinearSolver::minimize (solver/NonlinearSolver.tpp:33-275) */
+	double old_energy = NAN;
+	nlp_gradient(&P, x, grad);
+	const double first_grad_norm = sqrt(dot(grad, grad, n));
+	int status = PFO_NEWTON_CONTINUE, iterations = 0, strategy = 0;
+	double reg_weight = 0; /* SparseNewtonDescentSolver.hpp:39-42,62 */
+	const double reg_min = 1e-8, reg_max = 1e8, reg_inc = 10, reg_dec = 2;
+	double grad_norm = first_grad_norm, energy = NAN;
+	if (isnan(first_grad_norm))
+	{
+		status = PFO_NEWTON_FAILED;
+		goto done;
+	}
+	if (check_convergence(par, 0, NAN, first_grad_norm / (par->relative_gradient ? first_grad_norm : 1), par->first_grad_norm_tol) != PFO_NEWTON_CONTINUE)
+	{
+		energy = nlp_value(&P, x);
+		status = PFO_NEWTON_NOT_STARTED;
+		goto done;
+	}
+	do
+	{
+		energy = nlp_value(&P, x);
+		if (!isfinite(energy))
+		{
+			status = PFO_NEWTON_FAILED;
+			break;
+		}
+		nlp_gradient(&P, x, grad);
+		grad_norm = sqrt(dot(grad, grad, n));
+		if (isnan(grad_norm))
+		{
+			status = PFO_NEWTON_FAILED;
+			break;
+		}
+		/* SparseNewtonDescentSolver::compute_update_direction (SparseNewtonDescentSolver.tpp:63-100).
+		 * Strategy 1 is the reference's "projected Newton": the per-element projection to PSD is not restated, only
+		 * the regularisation weight schedule (:40-47, :119-122). */
+		int have_direction = 0;
+		while (!have_direction)
+		{
+			if (strategy == 2)
+			{
+				for (int64_t k = 0; k < n; ++k)
+					dx[k] = -grad[k];
+				have_direction = 1;
+				break;
+			}
+			pfo_csc H, Hr;
+			if (pfo_assemble_hessian(mesh, mat, x, P.n_threads, &H))
+			{
+				rc = -1;
+				goto cleanup;
+			}
+			pfo_full_to_reduced_matrix(&H, boundary_nodes, n_boundary, &Hr);
+			pfo_csc_free(&H);
+			if (reg_weight > 0)
+				for (int32_t c = 0; c < Hr.n; ++c)
+					for (int32_t q = Hr.outer[c]; q < Hr.outer[c + 1]; ++q)
+						if (Hr.inner[q] == c)
+							Hr.values[q] += reg_weight;
+			int64_t w = 0;
+			for (int64_t k = 0; k < n; ++k)
+				if (!P.fixed[k])
+				{
+					br[w] = -grad[k];
+					xr[w] = dx[k]; /* the previous direction is the initial guess (solveWithGuess) */
+					++w;
+				}
+			int its = 0;
+			double err = 0;
+			pfo_cg(&Hr, br, xr, par->cg_precond_jacobi, par->cg_max_iter, par->cg_tol, &its, &err);
+			info->cg_iterations += its;
+			/* check_direction (:160-193) */
+			pfo_spmv(&Hr, xr, yr);
+			double res2 = 0, gd = 0;
+			for (int64_t k = 0; k < nr; ++k)
+			{
+				const double r = yr[k] - br[k];
+				res2 += r * r;
+				gd += -br[k] * xr[k];
+			}
+			pfo_csc_free(&Hr);
+			const double residual = sqrt(res2);
+			const double lim = 1e-8 * grad_norm > 1e-5 ? 1e-8 * grad_norm : 1e-5;
+			if (isnan(residual) || residual > lim || gd >= 0)
+			{
+				/* increase_descent_strategy (:40-47) */
+				if (strategy == 0 || reg_weight > reg_max)
+					strategy++;
+				else
+					reg_weight = reg_inc * reg_weight > reg_min ? reg_inc * reg_weight : reg_min;
+				continue;
+			}
+			w = 0;
+			for (int64_t k = 0; k < n; ++k)
+				dx[k] = P.fixed[k] ? 0.0 : xr[w++];
+			reg_weight /= reg_dec;
+			if (reg_weight < reg_min)
+				reg_weight = 0;
+			have_direction = 1;
+		}
+		const double dg = dot(dx, grad, n);
+		if (grad_norm != 0 && dg >= 0)
+		{
+			if (strategy == 0 || reg_weight > reg_max)
+				strategy++;
+			else
+				reg_weight = reg_inc * reg_weight > reg_min ? reg_inc * reg_weight : reg_min;
+			if (strategy > 2)
+			{
+				status = PFO_NEWTON_FAILED;
+				break;
+			}
+			status = PFO_NEWTON_CONTINUE;
+			continue;
+		}
+		double cur_grad_norm;
+		if (!par->use_grad_norm)
+		{
+			cur_grad_norm = 0;
+			for (int64_t k = 0; k < n; ++k)
+				if (fabs(dx[k]) > cur_grad_norm)
+					cur_grad_norm = fabs(dx[k]);
+		}
+		else
+			cur_grad_norm = grad_norm / (par->relative_gradient ? first_grad_norm : 1);
+		status = check_convergence(par, iterations, fabs(old_energy - energy), cur_grad_norm, par->grad_norm);
+		old_energy = energy;
+		double rate = 1;
+		if (par->line_search)
+		{
+			rate = backtracking(&P, x, dx, par, xn, gw, &info->line_search_iterations);
+			if (isnan(rate))
+			{
+				/* NonlinearSolver::line_search (:278-303) */
+				if (strategy < 2)
+				{
+					if (strategy == 0 || reg_weight > reg_max)
+						strategy++;
+					else
+						reg_weight = reg_inc * reg_weight > reg_min ? reg_inc * reg_weight : reg_min;
+					status = PFO_NEWTON_CONTINUE;
+					continue;
+				}
+				status = PFO_NEWTON_FAILED;
+				break;
+			}
+		}
+		for (int64_t k = 0; k < n; ++k)
+			x[k] += rate * dx[k];
+		info->descent_strategy = strategy;
+		strategy = 0;
+		++iterations;
+	} while (status == PFO_NEWTON_CONTINUE);
+done:
+	info->status = status;
+	info->iterations = iterations;
+	info->energy = energy;
+	info->grad_norm = grad_norm;
+cleanup:
+	free(P.fixed);
+	free(grad);
+	free(dx);
+	free(xn);
+	free(gw);
+	free(br);
+	free(xr);
+	free(yr);
+	return rc;
+}

@@ -136,6 +136,48 @@ int pfo_cg(const pfo_csc *A, const double *b, double *x, int precond_jacobi, int
 /* polysolve::dirichlet_solve system modification (parity unpinned): A,b modified in place */
 int pfo_dirichlet_modify(pfo_csc *A, double *b, const int32_t *boundary_nodes, int64_t n_boundary);
 
+/* Newton solve of  min_x E(x) - rhs.x  with the dofs in boundary_nodes held at their values in x
+ * (cppoptlib::NonlinearSolver::minimize + SparseNewtonDescentSolver + BacktrackingLineSearch on NLProblem).
+ * cppoptlib's checkConvergence and polysolve's CG are un-vendored: parity unpinned. */
+typedef struct
+{
+	double f_delta;             /* solver/nonlinear/f_delta, default 1e-10              */
+	double grad_norm;           /* solver/nonlinear/grad_norm, default 1e-8             */
+	double first_grad_norm_tol; /* default 1e-10                                         */
+	double use_grad_norm_tol;   /* line_search/use_grad_norm_tol, default 1e-4          */
+	int max_iterations;         /* default 1000                                          */
+	int use_grad_norm;          /* default 1                                             */
+	int relative_gradient;      /* default 0                                             */
+	int line_search;            /* 1 = "backtracking" (default), 0 = none (rate 1)       */
+	int cg_precond_jacobi;      /* linear solver: CG, Jacobi or identity preconditioner */
+	int cg_max_iter;            /* default 1000                                          */
+	double cg_tol;              /* default 1e-12                                         */
+} pfo_newton_params;
+
+enum
+{
+	PFO_NEWTON_CONTINUE = 0,
+	PFO_NEWTON_ITERATION_LIMIT = 1,
+	PFO_NEWTON_F_DELTA = 2,
+	PFO_NEWTON_GRAD_NORM = 3,
+	PFO_NEWTON_NOT_STARTED = 4, /* first gradient below first_grad_norm_tol */
+	PFO_NEWTON_FAILED = 5       /* nan energy / gradient, or line search failed on gradient descent */
+};
+
+typedef struct
+{
+	int status;
+	int iterations;
+	int line_search_iterations; /* energy / gradient evaluations spent in the line searches */
+	int descent_strategy;       /* strategy of the last accepted step */
+	int64_t cg_iterations;
+	double energy, grad_norm;
+} pfo_newton_info;
+
+void pfo_newton_default_params(pfo_newton_params *p);
+int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double *rhs, const int32_t *boundary_nodes, int64_t n_boundary,
+					 double *x, const pfo_newton_params *params, int n_threads, pfo_newton_info *info);
+
 #ifdef __cplusplus
 }
 #endif

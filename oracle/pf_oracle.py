@@ -298,3 +298,38 @@ def dirichlet_modify(csc, b, boundary_nodes):
     bn = np.ascontiguousarray(boundary_nodes, dtype=np.int32)
     lib().pfo_dirichlet_modify(C.byref(m), _dp(b), _ip(bn), C.c_int64(bn.size))
     return keep, b
+
+
+class NewtonParams(C.Structure):
+    _fields_ = [("f_delta", C.c_double), ("grad_norm", C.c_double), ("first_grad_norm_tol", C.c_double),
+                ("use_grad_norm_tol", C.c_double), ("max_iterations", C.c_int), ("use_grad_norm", C.c_int),
+                ("relative_gradient", C.c_int), ("line_search", C.c_int), ("cg_precond_jacobi", C.c_int),
+                ("cg_max_iter", C.c_int), ("cg_tol", C.c_double)]
+
+
+class NewtonInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("line_search_iterations", C.c_int),
+                ("descent_strategy", C.c_int), ("cg_iterations", C.c_int64), ("energy", C.c_double),
+                ("grad_norm", C.c_double)]
+
+
+NEWTON_STATUS = ["continue", "iteration_limit", "f_delta", "grad_norm", "not_started", "failed"]
+
+
+def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int = 1, **params):
+    """cppoptlib NonlinearSolver::minimize with SparseNewtonDescentSolver + BacktrackingLineSearch, restated.
+    Returns (x, info dict).  `params` override the reference's defaults (f_delta, grad_norm, max_iterations, ...)."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat = Material(model, 3, lam, mu)
+    p = NewtonParams()
+    lib().pfo_newton_default_params(C.byref(p))
+    for k, v in params.items():
+        setattr(p, k, v)
+    x = np.array(x0, dtype=np.float64, copy=True)
+    bn = np.ascontiguousarray(boundary_nodes, dtype=np.int32)
+    r = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64)
+    info = NewtonInfo()
+    rc = lib().pfo_newton_solve(C.byref(om.s), C.byref(mat), _dp(r) if r is not None else None, _ip(bn), C.c_int64(bn.size),
+                                _dp(x), C.byref(p), int(n_threads), C.byref(info))
+    assert rc == 0
+    return x, {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}

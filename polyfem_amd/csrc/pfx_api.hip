@@ -74,6 +74,9 @@ namespace
 		free_dev(ctx->d_u);
 		free_dev(ctx->d_vec);
 		free_dev(ctx->d_part0);
+		ctx->part0_count = 0;
+		free_dev(ctx->d_newton);
+		ctx->newton_count = 0;
 		pfx_sell_release(ctx);
 		ctx->n_blocks = ctx->nnz = 0;
 		ctx->n_dirichlet = 0;
@@ -522,6 +525,56 @@ extern "C"
 		PFX_HIP(hipMemcpyAsync(y, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
+	}
+
+	void pfx_newton_default_params(pfx_newton_params *p)
+	{
+		if (!p)
+			return;
+		p->f_delta = 1e-10;
+		p->grad_norm = 1e-8;
+		p->first_grad_norm_tol = 1e-10;
+		p->use_grad_norm_tol = 1e-4;
+		p->max_iterations = 1000;
+		p->use_grad_norm = 1;
+		p->relative_gradient = 0;
+		p->line_search = 1;
+		p->cg_precond = PFX_PRECOND_JACOBI;
+		p->cg_max_iter = 1000;
+		p->cg_tol = 1e-12;
+	}
+
+	pfx_status pfx_newton_solve_dev(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info)
+	{
+		if (!ctx || !d_x || !params || !info)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_newton_solve needs an elastic model");
+		if (ctx->n_owned != ctx->n_nodes)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_newton_solve runs on an unpartitioned mesh");
+		PFX_HIP(hipSetDevice(ctx->device));
+		return pfx_newton_run(ctx, d_rhs, d_x, params, info);
+	}
+
+	pfx_status pfx_newton_solve(pfx_ctx *ctx, const double *rhs, double *x, const pfx_newton_params *params, pfx_newton_info *info)
+	{
+		if (!ctx || !x || !params || !info)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		double *d = nullptr;
+		PFX_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(2 * n)));
+		PFX_HIP(hipMemcpyAsync(d, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		if (rhs)
+			PFX_HIP(hipMemcpyAsync(d + n, rhs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		const pfx_status rc = pfx_newton_solve_dev(ctx, rhs ? d + n : nullptr, d, params, info);
+		(void)hipMemcpyAsync(x, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipFree(d);
+		return rc;
 	}
 
 	pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res)

@@ -94,8 +94,12 @@ struct pfx_ctx
 	// solver work vectors
 	double *d_work = nullptr;     // 4 * n_dofs: r, p, tmp, invdiag
 	double *d_work_ext = nullptr; // caller-owned workspace of the same layout (multi-GPU driver)
+	double diag_shift = 0.0;      // the solver works with A + diag_shift * I on the free dofs (Newton regularisation)
 	double *d_partials = nullptr; // 3 x 2048 per-block partial sums of the vector kernels
 	double *d_part0 = nullptr;    // per-block partials of the SpMV (one per SpMV block)
+	int64_t part0_count = 0;
+	double *d_newton = nullptr;   // workspace of the Newton driver (pfx_newton.hip)
+	int64_t newton_count = 0;
 
 	// solver copy of the matrix (block-SELL-64, pfx_sell.hip)
 	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
@@ -196,6 +200,7 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask); // strict arithmetic
 pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
+pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);

@@ -1,0 +1,452 @@
+// pfx_newton.hip -- Newton's method with line search, iterate resident on the device.
+//
+// Reference: cppoptlib::NonlinearSolver::minimize (src/polyfem/solver/NonlinearSolver.tpp:33-275),
+// SparseNewtonDescentSolver (src/polyfem/solver/SparseNewtonDescentSolver.tpp:40-47 increase_descent_strategy,
+// :63-100 compute_update_direction, :105-123 assemble_hessian, :128-155 solve_linear_system, :160-193
+// check_direction; constants SparseNewtonDescentSolver.hpp:39-42), BacktrackingLineSearch
+// (src/polyfem/solver/line_search/BacktrackingLineSearch.hpp:29-147, :157-255; LineSearch.tpp:90-145) and the
+// objective NLProblem (src/polyfem/solver/NLProblem.cpp:79-99) = ElasticForm + BodyForm (value -x.rhs).
+// cppoptlib's checkConvergence (meta.h) is not part of the reference tree; it is restated from the published
+// library: iteration limit, then f delta, then gradient norm.
+//
+// The reference keeps x, grad and delta_x in host Eigen vectors and crosses to the GPU for every energy evaluation
+// (its USE_NONLINEAR_GPU path copies x and delta_x per line-search step, BacktrackingLineSearch.cu).  Here the three
+// vectors live on the device for the whole solve; the host only sees the scalars that steer the iteration.
+#include "pfx_internal.h"
+
+#include <cmath>
+
+namespace
+{
+	constexpr int NB = 512; // blocks of the reduction kernels
+
+	// g = gradient of the objective restricted to the free dofs: (g - rhs), 0 on constrained dofs
+	__global__ __launch_bounds__(256) void k_objective_gradient(double *__restrict__ g, const double *__restrict__ rhs,
+																const uint8_t *__restrict__ fixed, int64_t n)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			double v = g[k];
+			if (rhs)
+				v -= rhs[k];
+			if (fixed && fixed[k])
+				v = 0.0;
+			g[k] = v;
+		}
+	}
+
+	// out = x + a * d (out may be x)
+	__global__ __launch_bounds__(256) void k_step(const double *x, const double *__restrict__ d, double a, int64_t n, double *out)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			out[k] = x[k] + a * d[k];
+	}
+
+	// out = -in
+	__global__ __launch_bounds__(256) void k_negate(const double *__restrict__ in, int64_t n, double *__restrict__ out)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			out[k] = -in[k];
+	}
+
+	// partial[blockIdx] = sum a.b ; partial[NB + blockIdx] = sum (a+c).(a+c) ; partial[2NB + blockIdx] = max |a|
+	// (c may be null).  Fixed order inside a block and over the blocks: results are reproducible.
+	__global__ __launch_bounds__(256) void k_reduce3(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c,
+													 int64_t n, double *__restrict__ partial)
+	{
+		__shared__ double sh[3][256];
+		double s0 = 0, s1 = 0, s2 = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double av = a[k];
+			s0 += av * b[k];
+			const double t = c ? av + c[k] : av;
+			s1 += t * t;
+			const double m = fabs(av);
+			s2 = m > s2 ? m : s2;
+		}
+		sh[0][threadIdx.x] = s0, sh[1][threadIdx.x] = s1, sh[2][threadIdx.x] = s2;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1)
+		{
+			if ((int)threadIdx.x < s)
+			{
+				sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+				sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+				const double o = sh[2][threadIdx.x + s];
+				if (o > sh[2][threadIdx.x])
+					sh[2][threadIdx.x] = o;
+			}
+			__syncthreads();
+		}
+		if (threadIdx.x == 0)
+		{
+			partial[blockIdx.x] = sh[0][0];
+			partial[NB + blockIdx.x] = sh[1][0];
+			partial[2 * NB + blockIdx.x] = sh[2][0];
+		}
+	}
+
+	__global__ __launch_bounds__(256) void k_reduce3_finish(const double *__restrict__ partial, double *__restrict__ out)
+	{
+		__shared__ double sh[3][256];
+		double s0 = 0, s1 = 0, s2 = 0;
+		for (int k = threadIdx.x; k < NB; k += 256)
+		{
+			s0 += partial[k];
+			s1 += partial[NB + k];
+			const double m = partial[2 * NB + k];
+			s2 = m > s2 ? m : s2;
+		}
+		sh[0][threadIdx.x] = s0, sh[1][threadIdx.x] = s1, sh[2][threadIdx.x] = s2;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1)
+		{
+			if ((int)threadIdx.x < s)
+			{
+				sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+				sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+				const double o = sh[2][threadIdx.x + s];
+				if (o > sh[2][threadIdx.x])
+					sh[2][threadIdx.x] = o;
+			}
+			__syncthreads();
+		}
+		if (threadIdx.x == 0)
+			out[0] = sh[0][0], out[1] = sh[1][0], out[2] = sh[2][0];
+	}
+
+	struct newton
+	{
+		pfx_ctx *ctx;
+		const pfx_newton_params *par;
+		pfx_newton_info *info;
+		int64_t n;
+		const double *rhs; // device, may be null
+		const uint8_t *fixed;
+		double *g, *dx, *xn, *w, *gls; // n each
+		double *partial, *scal;        // 3*NB, 4
+
+		// a.b, |a + c|^2 (c may be null), max|a|
+		pfx_status reduce(const double *a, const double *b, const double *c, double out[3])
+		{
+			hipStream_t st = ctx->stream;
+			hipLaunchKernelGGL(k_reduce3, dim3(NB), dim3(256), 0, st, a, b, c, n, partial);
+			hipLaunchKernelGGL(k_reduce3_finish, dim3(1), dim3(256), 0, st, partial, scal);
+			PFX_HIP(hipMemcpyAsync(out, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+			return PFX_OK;
+		}
+
+		// NLProblem::value: elastic energy - rhs.x ; nan when an element is inverted (the reference's log of a
+		// non-positive determinant)
+		pfx_status value(const double *x, double *val)
+		{
+			hipStream_t st = ctx->stream;
+			pfx_status rc = pfx_energy_dev(ctx, x, scal + 3);
+			if (rc)
+				return rc;
+			double e = 0;
+			int flag = 0;
+			PFX_HIP(hipMemcpyAsync(&e, scal + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+			if (flag)
+			{
+				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+				e = std::nan("");
+			}
+			if (rhs && std::isfinite(e))
+			{
+				double r[3];
+				if ((rc = reduce(x, rhs, nullptr, r)))
+					return rc;
+				e -= r[0];
+			}
+			*val = e;
+			return PFX_OK;
+		}
+
+		// NLProblem::gradient into `out`; *norm2 = its squared norm (nan for an inverted element)
+		pfx_status gradient(const double *x, double *out, double *norm2)
+		{
+			hipStream_t st = ctx->stream;
+			pfx_status rc = pfx_gradient_dev(ctx, x, out);
+			if (rc)
+				return rc;
+			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, out, rhs, fixed, n);
+			double r[3];
+			if ((rc = reduce(out, out, nullptr, r)))
+				return rc;
+			int flag = 0;
+			PFX_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+			if (flag)
+			{
+				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+				r[0] = std::nan("");
+			}
+			*norm2 = r[0];
+			return PFX_OK;
+		}
+
+		pfx_status step(const double *x, double a, double *out)
+		{
+			hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, ctx->stream, x, dx, a, n, out);
+			PFX_HIP(hipGetLastError());
+			return PFX_OK;
+		}
+
+		// BacktrackingLineSearch::line_search without contact; *rate = nan on failure
+		pfx_status line_search(const double *x, double *rate)
+		{
+			const double min_step_size = 0;
+			const int max_step_size_iter = 100;
+			int cur_iter = 0;
+			pfx_status rc;
+			double old_energy_in = 0;
+			*rate = std::nan("");
+			if ((rc = value(x, &old_energy_in)))
+				return rc;
+			info->line_search_iterations++;
+			if (std::isnan(old_energy_in))
+				return PFX_OK;
+			double step_size = 1;
+			// finite-energy step (LineSearch.tpp:90-145); ElasticForm::is_step_valid (gradient free of nan) holds
+			// exactly when the energy is finite for the materials implemented here
+			if ((rc = step(x, step_size, xn)))
+				return rc;
+			while (step_size > min_step_size && cur_iter < max_step_size_iter)
+			{
+				double energy = 0;
+				if ((rc = value(xn, &energy)))
+					return rc;
+				info->line_search_iterations++;
+				if (!std::isfinite(energy))
+				{
+					step_size *= 0.5;
+					if ((rc = step(x, step_size, xn)))
+						return rc;
+				}
+				else
+					break;
+				cur_iter++;
+			}
+			if (cur_iter >= max_step_size_iter || step_size <= min_step_size)
+				return PFX_OK;
+			// descent step (BacktrackingLineSearch.hpp:157-255)
+			double gn2 = 0;
+			if ((rc = gradient(x, gls, &gn2)))
+				return rc;
+			const bool use_grad_norm = std::sqrt(gn2) < par->use_grad_norm_tol;
+			const double old_energy = use_grad_norm ? gn2 : old_energy_in;
+			double cur_energy = std::nan("");
+			while (step_size > min_step_size && cur_iter < max_step_size_iter)
+			{
+				if ((rc = step(x, step_size, xn)))
+					return rc;
+				if (use_grad_norm)
+					rc = gradient(xn, gls, &cur_energy);
+				else
+					rc = value(xn, &cur_energy);
+				if (rc)
+					return rc;
+				info->line_search_iterations++;
+				if (!std::isfinite(cur_energy) || cur_energy > old_energy)
+					step_size /= 2.0;
+				else
+					break;
+				cur_iter++;
+			}
+			if (cur_iter >= max_step_size_iter || step_size <= min_step_size)
+				return PFX_OK;
+			*rate = step_size;
+			return PFX_OK;
+		}
+	};
+
+	int check_convergence(const pfx_newton_params *stop, int iterations, double f_delta, double grad_norm, double grad_tol)
+	{
+		if (stop->max_iterations > 0 && iterations > stop->max_iterations)
+			return PFX_NEWTON_ITERATION_LIMIT;
+		if (stop->f_delta > 0 && f_delta < stop->f_delta) // false for nan
+			return PFX_NEWTON_F_DELTA;
+		if (grad_tol > 0 && grad_norm < grad_tol)
+			return PFX_NEWTON_GRAD_NORM;
+		return PFX_NEWTON_CONTINUE;
+	}
+} // namespace
+
+pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
+{
+	const int64_t n = ctx->n_dofs();
+	if (ctx->newton_count < 5 * n + 3 * NB + 8)
+	{
+		if (pfx_alloc(ctx, &ctx->d_newton, 5 * n + 3 * NB + 8))
+			return PFX_ERR_HIP;
+		ctx->newton_count = 5 * n + 3 * NB + 8;
+	}
+	newton S;
+	S.ctx = ctx, S.par = par, S.info = info, S.n = n, S.rhs = d_rhs;
+	S.fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	S.g = ctx->d_newton, S.dx = S.g + n, S.xn = S.dx + n, S.w = S.xn + n, S.gls = S.w + n;
+	S.partial = S.gls + n, S.scal = S.partial + 3 * NB;
+	hipStream_t st = ctx->stream;
+	*info = pfx_newton_info{};
+	PFX_HIP(hipMemsetAsync(S.dx, 0, sizeof(double) * (size_t)n, st));
+	PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+	const double saved_shift = ctx->diag_shift;
+
+	pfx_status rc;
+	double old_energy = std::nan(""), energy = std::nan(""), gn2 = 0;
+	if ((rc = S.gradient(d_x, S.g, &gn2)))
+		return rc;
+	const double first_grad_norm = std::sqrt(gn2);
+	double grad_norm = first_grad_norm;
+	int status = PFX_NEWTON_CONTINUE, iterations = 0, strategy = 0;
+	double reg_weight = 0;
+	const double reg_min = 1e-8, reg_max = 1e8, reg_inc = 10, reg_dec = 2;
+	auto increase_descent_strategy = [&]() {
+		if (strategy == 0 || reg_weight > reg_max)
+			strategy++;
+		else
+			reg_weight = reg_inc * reg_weight > reg_min ? reg_inc * reg_weight : reg_min;
+	};
+	auto finish = [&](pfx_status code, const char *msg) {
+		ctx->diag_shift = saved_shift;
+		info->status = status;
+		info->iterations = iterations;
+		info->energy = energy;
+		info->grad_norm = grad_norm;
+		if (code != PFX_OK)
+			ctx->err = msg;
+		return code;
+	};
+
+	if (std::isnan(first_grad_norm))
+	{
+		status = PFX_NEWTON_FAILED;
+		return finish(PFX_ERR_NUMERIC, "Gradient is nan; stopping");
+	}
+	if (check_convergence(par, 0, std::nan(""), first_grad_norm / (par->relative_gradient ? first_grad_norm : 1), par->first_grad_norm_tol) != PFX_NEWTON_CONTINUE)
+	{
+		if ((rc = S.value(d_x, &energy)))
+			return finish(rc, ctx->err.c_str());
+		status = PFX_NEWTON_NOT_STARTED;
+		return finish(PFX_OK, "");
+	}
+
+	do
+	{
+		if ((rc = S.value(d_x, &energy)))
+			return finish(rc, ctx->err.c_str());
+		if (!std::isfinite(energy))
+		{
+			status = PFX_NEWTON_FAILED;
+			return finish(PFX_ERR_NUMERIC, "f(x) is nan or inf; stopping");
+		}
+		if ((rc = S.gradient(d_x, S.g, &gn2)))
+			return finish(rc, ctx->err.c_str());
+		grad_norm = std::sqrt(gn2);
+		if (std::isnan(grad_norm))
+		{
+			status = PFX_NEWTON_FAILED;
+			return finish(PFX_ERR_NUMERIC, "Gradient is nan; stopping");
+		}
+
+		// ---- compute_update_direction ----
+		double dg = 0, dx_max = 0;
+		bool have_direction = false;
+		while (!have_direction)
+		{
+			if (strategy > 2)
+			{
+				status = PFX_NEWTON_FAILED;
+				return finish(PFX_ERR_NUMERIC, "no descent direction found");
+			}
+			if (strategy == 2)
+			{
+				hipLaunchKernelGGL(k_negate, dim3(NB), dim3(256), 0, st, S.g, n, S.dx);
+				double r[3];
+				if ((rc = S.reduce(S.dx, S.g, nullptr, r)))
+					return finish(rc, ctx->err.c_str());
+				dg = r[0], dx_max = r[2];
+				have_direction = true;
+				break;
+			}
+			if ((rc = pfx_hessian_dev(ctx, d_x)))
+				return finish(rc, ctx->err.c_str());
+			ctx->diag_shift = reg_weight;
+			hipLaunchKernelGGL(k_negate, dim3(NB), dim3(256), 0, st, S.g, n, S.w);
+			int its = 0;
+			double err = 0;
+			// the previous direction is the initial guess (the iterative solver is called with solveWithGuess)
+			if ((rc = pfx_cg_dev(ctx, S.w, S.dx, par->cg_precond, par->cg_max_iter, par->cg_tol, &its, &err)))
+				return finish(rc, ctx->err.c_str());
+			info->cg_iterations += its;
+			// check_direction: || H dx + g || and g.dx
+			if ((rc = pfx_spmv_dev(ctx, S.dx, S.w)))
+				return finish(rc, ctx->err.c_str());
+			double r[3], r2[3];
+			if ((rc = S.reduce(S.w, S.w, S.g, r)) || (rc = S.reduce(S.dx, S.g, nullptr, r2)))
+				return finish(rc, ctx->err.c_str());
+			ctx->diag_shift = saved_shift;
+			const double residual = std::sqrt(r[1]);
+			const double lim = 1e-8 * grad_norm > 1e-5 ? 1e-8 * grad_norm : 1e-5;
+			dg = r2[0], dx_max = r2[2];
+			if (std::isnan(residual) || residual > lim || dg >= 0)
+			{
+				increase_descent_strategy();
+				continue;
+			}
+			reg_weight /= reg_dec;
+			if (reg_weight < reg_min)
+				reg_weight = 0;
+			have_direction = true;
+		}
+
+		if (grad_norm != 0 && dg >= 0)
+		{
+			increase_descent_strategy();
+			status = PFX_NEWTON_CONTINUE;
+			continue;
+		}
+		if (std::isnan(dx_max))
+		{
+			increase_descent_strategy();
+			status = PFX_NEWTON_CONTINUE;
+			continue;
+		}
+		const double cur_grad_norm = par->use_grad_norm ? grad_norm / (par->relative_gradient ? first_grad_norm : 1) : dx_max;
+		status = check_convergence(par, iterations, std::fabs(old_energy - energy), cur_grad_norm, par->grad_norm);
+		old_energy = energy;
+
+		double rate = 1;
+		if (par->line_search)
+		{
+			if ((rc = S.line_search(d_x, &rate)))
+				return finish(rc, ctx->err.c_str());
+			if (std::isnan(rate))
+			{
+				if (strategy < 2)
+				{
+					increase_descent_strategy();
+					status = PFX_NEWTON_CONTINUE;
+					continue;
+				}
+				status = PFX_NEWTON_FAILED;
+				return finish(PFX_ERR_NUMERIC, "Line search failed on gradient descent");
+			}
+		}
+		hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, st, d_x, S.dx, rate, n, d_x);
+		info->descent_strategy = strategy;
+		strategy = 0;
+		++iterations;
+	} while (status == PFX_NEWTON_CONTINUE);
+
+	PFX_HIP(hipStreamSynchronize(st));
+	PFX_HIP(hipGetLastError());
+	if (status == PFX_NEWTON_ITERATION_LIMIT)
+		return finish(PFX_ERR_NUMERIC, "Reached iteration limit");
+	return finish(PFX_OK, "");
+}

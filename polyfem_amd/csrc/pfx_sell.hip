@@ -122,13 +122,13 @@ namespace
 		return v;
 	}
 
-	// y = A x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per wave; blocks
+	// y = (A + shift I) x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per wave; blocks
 	// b and b+8 run on the same XCD, so each XCD walks one contiguous eighth of the slices (x gathers stay in its L2).
 	template <int BS, bool DOT>
 	__global__ __launch_bounds__(256) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
 														const int32_t *__restrict__ cols, const double *__restrict__ values, int64_t n_slices,
-														const uint8_t *__restrict__ fixed, const double *__restrict__ x, double *__restrict__ y,
-														double *__restrict__ part, const int *__restrict__ done)
+														const uint8_t *__restrict__ fixed, double shift, const double *__restrict__ x,
+														double *__restrict__ y, double *__restrict__ part, const int *__restrict__ done)
 	{
 		__shared__ double sh[4];
 		if (DOT && *done)
@@ -184,7 +184,7 @@ namespace
 				{
 					const int64_t r = (int64_t)g * BS + m;
 					const double xr = x[r];
-					const double yr = (fixed && fixed[r]) ? xr : acc[m];
+					const double yr = (fixed && fixed[r]) ? xr : acc[m] + shift * xr;
 					y[r] = yr;
 					if (DOT)
 						dot += xr * yr;
@@ -332,7 +332,7 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	const int grid = pfx_sell_grid(ctx);
 	pfx_scoped_timer tm(ctx, "spmv");
-#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, ctx->sell_slices, fixed, d_x, d_y, part, done)
+#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, ctx->sell_slices, fixed, ctx->diag_shift, d_x, d_y, part, done)
 	if (ctx->bs == 1)
 	{
 		if (part)

@@ -83,7 +83,7 @@ namespace
 	// invdiag = 1/diag (1 where diag == 0 or the dof is constrained)  -- Eigen DiagonalPreconditioner::factorize
 	template <int BS>
 	__global__ void k_invdiag(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, const double *__restrict__ values,
-							  const uint8_t *__restrict__ fixed, int64_t n_nodes, int jacobi, double *__restrict__ invdiag)
+							  const uint8_t *__restrict__ fixed, int64_t n_nodes, int jacobi, double shift, double *__restrict__ invdiag)
 	{
 		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
 		{
@@ -110,7 +110,7 @@ namespace
 				const int64_t r = g * BS + m;
 				if (jacobi && s >= 0 && !(fixed && fixed[r]))
 				{
-					const double a = values[(b0 + s) * (BS * BS) + m * BS + m];
+					const double a = values[(b0 + s) * (BS * BS) + m * BS + m] + shift;
 					if (a != 0.0)
 						d = 1.0 / a;
 				}
@@ -349,17 +349,21 @@ pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond)
 		pfx_status rc = pfx_sell_refresh(ctx); // "factorize": the solver's copy of the matrix
 		if (rc)
 			return rc;
-		if (pfx_alloc(ctx, &ctx->d_part0, pfx_sell_grid(ctx)))
-			return PFX_ERR_HIP;
+		if (ctx->part0_count < pfx_sell_grid(ctx))
+		{
+			if (pfx_alloc(ctx, &ctx->d_part0, pfx_sell_grid(ctx)))
+				return PFX_ERR_HIP;
+			ctx->part0_count = pfx_sell_grid(ctx);
+		}
 	}
 	PFX_HIP(hipMemsetAsync(ctx->d_cgstate, 0, sizeof(pfx_cg_state), st));
 	if (fixed) // initial guess with constrained dofs zeroed (solveWithGuess on the reduced system)
 		hipLaunchKernelGGL(k_mask_inplace, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n);
 	const int jac = precond == PFX_PRECOND_JACOBI ? 1 : 0;
 	if (ctx->bs == 1)
-		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, w.invdiag);
+		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, ctx->diag_shift, w.invdiag);
 	else
-		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, w.invdiag);
+		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, ctx->diag_shift, w.invdiag);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

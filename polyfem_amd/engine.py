@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "pfx_cg_dev", "pfx_dirichlet_solve", "pfx_get_info", "pfx_timing_enable", "pfx_timing_get", "pfx_timing_reset",
     "pfx_set_owned", "pfx_cgs_set_workspace", "pfx_cgs_prepare", "pfx_cgs_residual", "pfx_cgs_start", "pfx_cgs_start2",
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
+    "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev",
 ]
 
 
@@ -40,6 +41,23 @@ class PfxError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"pfx error {code}: {msg}")
         self.code = code
+
+
+class NewtonParams(C.Structure):
+    """pfx_newton_params: solver/nonlinear/... of the reference's input-spec.json."""
+    _fields_ = [("f_delta", C.c_double), ("grad_norm", C.c_double), ("first_grad_norm_tol", C.c_double),
+                ("use_grad_norm_tol", C.c_double), ("max_iterations", C.c_int), ("use_grad_norm", C.c_int),
+                ("relative_gradient", C.c_int), ("line_search", C.c_int), ("cg_precond", C.c_int),
+                ("cg_max_iter", C.c_int), ("cg_tol", C.c_double)]
+
+
+class NewtonInfo(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("line_search_iterations", C.c_int),
+                ("descent_strategy", C.c_int), ("cg_iterations", C.c_int64), ("energy", C.c_double),
+                ("grad_norm", C.c_double)]
+
+
+NEWTON_STATUS = ["continue", "iteration_limit", "f_delta", "grad_norm", "not_started", "failed"]
 
 
 class Info(C.Structure):
@@ -102,11 +120,15 @@ def load():
         "pfx_cgs_update": [_vp, _i32, _vp, _vp],
         "pfx_cgs_direction": [_vp, _i32, _vp],
         "pfx_cgs_status": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pd, _pd],
+        "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
+        "pfx_newton_solve_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = None if name == "pfx_destroy" else C.c_int
+    L.pfx_newton_default_params.argtypes = [C.POINTER(NewtonParams)]
+    L.pfx_newton_default_params.restype = None
     L.pfx_last_error.argtypes = [_vp]
     L.pfx_last_error.restype = C.c_char_p
     _lib = L
@@ -275,6 +297,19 @@ class Engine:
         it, err = C.c_int(), C.c_double()
         self._ck(self.L.pfx_cg_dev(self.h, _vp(d_b), _vp(d_x), precond, max_iter, tol, C.byref(it), C.byref(err)))
         return it.value, err.value
+
+    def newton_solve(self, x0, rhs=None, **params):
+        """Minimises E(x) - rhs.x over the free dofs (see pfx_newton_solve).  Returns (x, info dict); raises PfxError
+        where the reference's solver throws (the iterate reached is lost, as there)."""
+        p = NewtonParams()
+        self.L.pfx_newton_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        x = np.array(x0, dtype=np.float64, copy=True)
+        r = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64)
+        info = NewtonInfo()
+        self._ck(self.L.pfx_newton_solve(self.h, _d(r) if r is not None else None, _d(x), C.byref(p), C.byref(info)))
+        return x, {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
 
     def dirichlet_solve(self, b, precond: int = PRECOND_JACOBI, max_iter: int = 1000, tol: float = 1e-12):
         b = np.ascontiguousarray(b, dtype=np.float64)

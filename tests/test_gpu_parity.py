@@ -239,6 +239,84 @@ def test_spmv_matches_oracle(eng, oracle):
     assert rel_err(eng.spmv(x), oracle.spmv(K, x)) <= TOL
 
 
+@pytest.mark.parametrize("case", ["neohookean_p2", "neohookean_p1_large_load", "linear_elasticity_p2"])
+def test_newton_solve_matches_oracle(eng, oracle, case):
+    """NonlinearSolver::minimize + SparseNewtonDescentSolver + BacktrackingLineSearch on the device against the
+    oracle's restatement: same number of Newton iterations and line-search evaluations, same minimiser."""
+    if case == "neohookean_p2":
+        mesh, model, load = M.cube_tets(3, 2, jitter=0.1), E.NEOHOOKEAN, -50.0
+    elif case == "neohookean_p1_large_load":
+        mesh, model, load = M.cube_tets(4, 1, jitter=0.1), E.NEOHOOKEAN, -2500.0
+    else:
+        mesh, model, load = M.cube_tets(2, 2), E.LINEAR_ELASTICITY, -50.0
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, model, lam, mu)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    eng.set_dirichlet(bnd)
+    rhs = np.zeros(n)
+    rhs[2::3] = load / mesh.n_nodes
+    x0 = np.zeros(n)
+    x_ref, info_ref = oracle.newton_solve(mesh, model, lam, mu, rhs, bnd, x0, n_threads=4)
+    x, info = eng.newton_solve(x0, rhs)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert info["status"] == info_ref["status"] and info["status"] in (2, 3)
+    assert info["iterations"] == info_ref["iterations"] >= 2
+    assert info["line_search_iterations"] == info_ref["line_search_iterations"]
+    assert info["descent_strategy"] == info_ref["descent_strategy"] == 0
+    # +-2 per linear solve; the last solve of a converged run has a right-hand side at round-off level, where the
+    # count is decided by the last bits of the gradient: allow 3 % of the total as well
+    assert abs(info["cg_iterations"] - info_ref["cg_iterations"]) <= max(2 * info["iterations"], 0.03 * info_ref["cg_iterations"])
+    assert np.abs(x - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
+    assert abs(info["energy"] - info_ref["energy"]) <= 1e-9 * abs(info_ref["energy"])
+    assert not x[bnd].any()
+    # stationarity of the minimiser, checked with the oracle's gradient
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    g = oracle.assemble_gradient(mesh, model, lam, mu, x) - rhs
+    assert np.linalg.norm(g[free]) <= 1e-7 * np.linalg.norm(rhs)
+
+
+def test_newton_with_backtracking_matches_oracle(eng, oracle):
+    """A load large enough that full Newton steps invert elements / increase the energy: the line search has to halve
+    steps (more than 3 objective evaluations per iteration)."""
+    mesh = M.cube_tets(3, 1, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    eng.set_dirichlet(bnd)
+    rhs = np.zeros(n)
+    rhs[0::3] = -2e4 / mesh.n_nodes
+    x_ref, info_ref = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, np.zeros(n), n_threads=4)
+    x, info = eng.newton_solve(np.zeros(n), rhs)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert info_ref["line_search_iterations"] > 3 * info_ref["iterations"]
+    assert info["iterations"] == info_ref["iterations"] and info["status"] == info_ref["status"]
+    assert info["line_search_iterations"] == info_ref["line_search_iterations"]
+    assert np.abs(x - x_ref).max() <= 1e-7 * np.abs(x_ref).max()
+
+
+def test_newton_not_started_and_iteration_limit(eng, oracle):
+    mesh = M.cube_tets(2, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    eng.set_dirichlet(bnd)
+    x, info = eng.newton_solve(np.zeros(n), None)  # rest state, no load: gradient is zero
+    assert info["status"] == 4 and info["iterations"] == 0 and not x.any()
+    rhs = np.zeros(n)
+    rhs[2::3] = -200.0 / mesh.n_nodes
+    x_ref, info_ref = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, np.zeros(n), max_iterations=1, f_delta=0.0,
+                                          grad_norm=1e-14)
+    assert info_ref["status"] == 1
+    with pytest.raises(E.PfxError) as ei:  # the reference throws "Reached iteration limit"
+        eng.newton_solve(np.zeros(n), rhs, max_iterations=1, f_delta=0.0, grad_norm=1e-14)
+    assert ei.value.code == -4 and "iteration limit" in str(ei.value)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+
+
 def test_host_mirror_of_reference_interface(oracle):
     """Reads like the reference's tests/test_assembler.cpp:12-64 ("hessian_lin"): stiffness from the linear
     Assembler == what the NL interface returns, through the reference-shaped host classes."""

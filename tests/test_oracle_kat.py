@@ -278,3 +278,42 @@ def test_linear_pattern_drops_exact_zeros(oracle):
                 pairs.add((int(a), int(b)))
     assert K[1].size < len(pairs)
     assert (K[2] != 0).any()
+
+
+def test_newton_restatement(oracle):
+    """The restated NonlinearSolver/SparseNewtonDescentSolver/BacktrackingLineSearch: for LinearElasticity the minimiser
+    solves the reduced linear system (checked with a direct solve), for NeoHookean it is a stationary point, and a
+    large load makes the line search backtrack."""
+    import scipy.sparse.linalg as spla
+    mesh = M.cube_tets(2, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    rhs = np.zeros(n)
+    rhs[2::3] = -50.0 / mesh.n_nodes
+    x, info = oracle.newton_solve(mesh, oracle.LINEAR_ELASTICITY, lam, mu, rhs, bnd, np.zeros(n))
+    assert info["status"] in (2, 3) and 1 <= info["iterations"] <= 3 and not x[bnd].any()
+    K = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n).tocsr()
+    xd = spla.spsolve(K[free][:, free].tocsc(), rhs[free])
+    assert np.abs(x[free] - xd).max() <= 1e-8 * np.abs(xd).max()
+
+    x, info = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, np.zeros(n))
+    g = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x) - rhs
+    assert info["status"] in (2, 3) and np.linalg.norm(g[free]) <= 1e-7 * np.linalg.norm(rhs)
+    assert info["line_search_iterations"] == 3 * info["iterations"]  # full steps: f(x), f(x+dx) twice
+
+    mesh = M.cube_tets(3, 1, jitter=0.1)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    rhs = np.zeros(n)
+    rhs[0::3] = -2e4 / mesh.n_nodes
+    x, info = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, np.zeros(n))
+    assert info["status"] in (2, 3) and info["line_search_iterations"] > 3 * info["iterations"]
+    e0 = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x) - rhs @ x
+    assert abs(e0 - info["energy"]) <= 1e-6 * abs(e0) and e0 < 0
+
+    # nothing to do at the rest state without load
+    x, info = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, None, bnd, np.zeros(n))
+    assert info["status"] == 4 and info["iterations"] == 0
