@@ -85,6 +85,11 @@ pfx_status pfx_set_mesh(pfx_ctx *ctx, int elem_kind, int64_t n_el, int64_t n_nod
 /* Uniform Lame parameters (LameParameters::lambda_mu with constant expressions, utils/ElasticityUtils.cpp:490-517).
  * dim = 3.  The block size of the system is 1 for the Laplacian and dim otherwise. */
 pfx_status pfx_set_material(pfx_ctx *ctx, int model, int dim, double lambda, double mu);
+/* One (lambda, mu) per element: LameParameters holding one entry per element id, which is how the reference stores
+ * multi-material bodies (add_multimaterial, utils/ElasticityUtils.cpp:490-517, 521-560; AssemblerUtils.cpp:604-672).
+ * Call after pfx_set_mesh; a later pfx_set_mesh or pfx_set_material drops the arrays. */
+pfx_status pfx_set_material_per_element(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu,
+										int64_t n_el);
 
 /* ---- sparsity pattern (utils::SpareMatrixCache, utils/MatrixUtils.cpp:108-264) --------------------------------- */
 

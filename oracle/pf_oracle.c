@@ -994,6 +994,10 @@ static int trips_to_csc(int32_t n, const trip *t, int64_t nt, pfo_csc *out)
 /* global assemblers                                                                                */
 /* ------------------------------------------------------------------------------------------------ */
 
+/* LameParameters::lambda_mu (utils/ElasticityUtils.cpp:490-517): one value, or one per element id */
+static double mat_lambda(const pfo_material *mat, int64_t e) { return mat->lambda_e ? mat->lambda_e[e] : mat->lambda; }
+static double mat_mu(const pfo_material *mat, int64_t e) { return mat->mu_e ? mat->mu_e[e] : mat->mu; }
+
 static int block_size(const pfo_material *mat) { return mat->model == PFO_LAPLACIAN ? 1 : mat->dim; }
 
 typedef struct
@@ -1047,7 +1051,7 @@ static void *job_run(void *arg)
 					if (mat->model == PFO_LAPLACIAN)
 						pfo_local_laplacian(v, i, j, da, sv);
 					else
-						pfo_local_linear_elasticity(v, i, j, da, mat->lambda, mat->mu, sv);
+						pfo_local_linear_elasticity(v, i, j, da, mat_lambda(mat, e), mat_mu(mat, e), sv);
 					for (int n = 0; n < size; ++n)
 						for (int m = 0; m < size; ++m)
 						{
@@ -1068,16 +1072,16 @@ static void *job_run(void *arg)
 			if (jb->mode == 1)
 			{
 				/* Assembler.cpp:657-668 */
-				const double val = mat->model == PFO_NEOHOOKEAN ? pfo_local_neohookean_energy(v, da, ld, mat->lambda, mat->mu) : pfo_local_linear_elasticity_energy(v, da, ld, mat->lambda, mat->mu);
+				const double val = mat->model == PFO_NEOHOOKEAN ? pfo_local_neohookean_energy(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e)) : pfo_local_linear_elasticity_energy(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
 				jb->scalar += val;
 			}
 			else if (jb->mode == 2)
 			{
 				/* Assembler.cpp:465-492 */
 				if (mat->model == PFO_NEOHOOKEAN)
-					pfo_local_neohookean_grad(v, da, ld, mat->lambda, mat->mu, G);
+					pfo_local_neohookean_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
 				else
-					pfo_local_linear_elasticity_grad(v, da, ld, mat->lambda, mat->mu, G);
+					pfo_local_linear_elasticity_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
 				for (int j = 0; j < n_loc; ++j)
 					for (int m = 0; m < size; ++m)
 					{
@@ -1091,9 +1095,9 @@ static void *job_run(void *arg)
 			{
 				/* Assembler.cpp:550-616 : every entry, order (i, j, n, m) */
 				if (mat->model == PFO_NEOHOOKEAN)
-					pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+					pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
 				else
-					pfo_local_linear_elasticity_hessian(v, da, mat->lambda, mat->mu, H);
+					pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
 				const int N = n_loc * size;
 				for (int i = 0; i < n_loc; ++i)
 					for (int j = 0; j < n_loc; ++j)
@@ -1588,9 +1592,9 @@ int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, c
 			da[k] = v->det[k] * quad.w[k];
 		gather_local_disp(mesh, e, n_loc, x, ld);
 		if (mat->model == PFO_NEOHOOKEAN)
-			pfo_local_neohookean_hessian(v, da, ld, mat->lambda, mat->mu, H);
+			pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
 		else
-			pfo_local_linear_elasticity_hessian(v, da, mat->lambda, mat->mu, H);
+			pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
 		const int32_t *idx = mesh->conn + e * n_loc;
 		for (int i = 0; i < n_loc; ++i)
 			for (int j = 0; j < n_loc; ++j)

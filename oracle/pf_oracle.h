@@ -63,6 +63,8 @@ typedef struct
 	int model;
 	int dim;          /* problem dimension (3) ; block size is 1 for the Laplacian, dim otherwise */
 	double lambda, mu; /* uniform Lame parameters */
+	const double *lambda_e, *mu_e; /* optional per-element values (LameParameters with one entry per element,
+	                                  utils/ElasticityUtils.cpp:490-517); NULL = uniform */
 } pfo_material;
 
 /* compressed column storage with int32 indices = Eigen::SparseMatrix<double, ColMajor, int> */

@@ -41,7 +41,17 @@ class MeshS(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("model", C.c_int), ("dim", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double)]
+    _fields_ = [("model", C.c_int), ("dim", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double),
+                ("lambda_e", C.POINTER(C.c_double)), ("mu_e", C.POINTER(C.c_double))]
+
+
+def make_material(model: int, lam, mu):
+    """Uniform Lame parameters (scalars) or one value per element (arrays).  Returns (Material, keep-alive)."""
+    if np.ndim(lam) == 0:
+        return Material(model, 3, float(lam), float(mu), None, None), None
+    la = np.ascontiguousarray(lam, dtype=np.float64)
+    ma = np.ascontiguousarray(mu, dtype=np.float64)
+    return Material(model, 3, float(la[0]), float(ma[0]), _dp(la), _dp(ma)), (la, ma)
 
 
 class Csc(C.Structure):
@@ -190,7 +200,7 @@ def compute_vals(mesh, e: int, quad_order: int = -1):
 
 def assemble_linear(mesh, model: int, lam: float, mu: float, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat = Material(model, 3, lam, mu)
+    mat, _keep_mat = make_material(model, lam, mu)
     out = Csc()
     rc = lib().pfo_assemble_linear(C.byref(om.s), C.byref(mat), n_threads, C.byref(out))
     assert rc == 0
@@ -199,14 +209,14 @@ def assemble_linear(mesh, model: int, lam: float, mu: float, n_threads: int = 1)
 
 def assemble_energy(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1) -> float:
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat = Material(model, 3, lam, mu)
+    mat, _keep_mat = make_material(model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     return lib().pfo_assemble_energy(C.byref(om.s), C.byref(mat), _dp(x), n_threads)
 
 
 def assemble_gradient(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat = Material(model, 3, lam, mu)
+    mat, _keep_mat = make_material(model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     rhs = np.zeros(om.n_nodes * 3)
     rc = lib().pfo_assemble_gradient(C.byref(om.s), C.byref(mat), _dp(x), n_threads, _dp(rhs))
@@ -216,7 +226,7 @@ def assemble_gradient(mesh, model: int, lam: float, mu: float, x, n_threads: int
 
 def assemble_hessian(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat = Material(model, 3, lam, mu)
+    mat, _keep_mat = make_material(model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = Csc()
     rc = lib().pfo_assemble_hessian(C.byref(om.s), C.byref(mat), _dp(x), n_threads, C.byref(out))
@@ -257,7 +267,7 @@ class Cache:
 
 def assemble_hessian_cached(mesh, model, lam, mu, x, cache: Cache):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat = Material(model, 3, lam, mu)
+    mat, _keep_mat = make_material(model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = Csc()
     rc = lib().pfo_assemble_hessian_cached(C.byref(om.s), C.byref(mat), _dp(x), cache.p, C.byref(out))
@@ -320,7 +330,7 @@ def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int =
     """cppoptlib NonlinearSolver::minimize with SparseNewtonDescentSolver + BacktrackingLineSearch, restated.
     Returns (x, info dict).  `params` override the reference's defaults (f_delta, grad_norm, max_iterations, ...)."""
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat = Material(model, 3, lam, mu)
+    mat, _keep_mat = make_material(model, lam, mu)
     p = NewtonParams()
     lib().pfo_newton_default_params(C.byref(p))
     for k, v in params.items():

@@ -180,6 +180,8 @@ extern "C"
 		free_dev(ctx->d_tab);
 		free_dev(ctx->d_flag);
 		free_dev(ctx->d_elem_owned);
+		free_dev(ctx->d_lambda_e);
+		free_dev(ctx->d_mu_e);
 		free_dev(ctx->d_partials);
 		free_dev(ctx->d_cgstate);
 		resolve_timers(ctx);
@@ -254,6 +256,8 @@ extern "C"
 		ctx->n_nodes = n_nodes;
 		ctx->n_owned = n_nodes;
 		free_dev(ctx->d_elem_owned);
+		free_dev(ctx->d_lambda_e);
+		free_dev(ctx->d_mu_e);
 		ctx->n_gnodes = n_gnodes;
 		if (pfx_alloc(ctx, &ctx->d_conn, n_el * n_loc) || pfx_alloc(ctx, &ctx->d_gconn, n_el * n_gloc) || pfx_alloc(ctx, &ctx->d_xyz, n_gnodes * 3))
 			return PFX_ERR_HIP;
@@ -281,6 +285,26 @@ extern "C"
 		ctx->bs = bs;
 		ctx->lambda = lambda;
 		ctx->mu = mu;
+		free_dev(ctx->d_lambda_e);
+		free_dev(ctx->d_mu_e);
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_material_per_element(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu, int64_t n_el)
+	{
+		if (!ctx || !lambda || !mu)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0 || n_el != ctx->n_el)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_material_per_element: call pfx_set_mesh first and pass one value per element");
+		pfx_status rc = pfx_set_material(ctx, model, dim, n_el > 0 ? lambda[0] : 0.0, n_el > 0 ? mu[0] : 0.0);
+		if (rc)
+			return rc;
+		PFX_HIP(hipSetDevice(ctx->device));
+		if (pfx_alloc(ctx, &ctx->d_lambda_e, n_el) || pfx_alloc(ctx, &ctx->d_mu_e, n_el))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_lambda_e, lambda, sizeof(double) * (size_t)n_el, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_mu_e, mu, sizeof(double) * (size_t)n_el, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
 	}
 

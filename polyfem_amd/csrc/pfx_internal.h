@@ -79,6 +79,7 @@ struct pfx_ctx
 	bool have_mask = false;
 
 	// scratch for the two-pass (local blocks, then per-row sums) assembly
+	double *d_lambda_e = nullptr, *d_mu_e = nullptr; // per-element Lame parameters (null: uniform ctx->lambda, ctx->mu)
 	double *d_estate = nullptr; // per-element state the row assembly computes its blocks from (n_el * 22 * n_pts doubles)
 	int estate_kind = 0;        // which element kernel wrote it last (PFX_ESTATE_*)
 	double *d_gloc = nullptr; // n_el * n_loc*bs

@@ -85,7 +85,8 @@ namespace
 	{
 		const double *geo;
 		const pfx_tables *tab;
-		double lambda, mu;
+		double lambda, mu;                // uniform Lame parameters, or
+		const double *lambda_e, *mu_e;    // one value per element (LameParameters::lambda_mu, utils/ElasticityUtils.cpp:490-517)
 		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + NPTS; // grad[k][i][3], then w[k]
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
@@ -107,6 +108,7 @@ namespace
 					const d2 v = ge[q];
 					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 				}
+			const double lambda = lambda_e ? lambda_e[e] : this->lambda, mu = mu_e ? mu_e[e] : this->mu;
 			double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 			for (int k = 0; k < NPTS; ++k)
 			{
@@ -170,9 +172,9 @@ namespace
 	{
 		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
 		if (ctx->bs == 1)
-			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu}, write_mask);
+			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu}, write_mask);
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 	}
 
 	bool supported(const pfx_ctx *ctx)

@@ -78,7 +78,8 @@ namespace
 	template <int NLOC, int NGLOC, int NPTS, int TPE, bool NEO>
 	__global__ __launch_bounds__(256) void k_local_nl(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
 																   const double *__restrict__ xyz, const double *__restrict__ u,
-																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda, double mu,
+																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u, double mu_u,
+																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
 																   int want_e, int want_g, int want_h,
 																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
 																   int *__restrict__ flag)
@@ -92,6 +93,8 @@ namespace
 		const int64_t e = (int64_t)blockIdx.x * EPB + grp;
 		const bool active = e < n_el;
 		nl_smem<NLOC, NGLOC, NPTS> &s = sm[grp];
+		// LameParameters::lambda_mu (utils/ElasticityUtils.cpp:490-517): one value, or one per element
+		const double lambda = (lambda_e && active) ? lambda_e[e] : lambda_u, mu = (mu_e && active) ? mu_e[e] : mu_u;
 
 		if (active)
 		{
@@ -344,11 +347,11 @@ namespace
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
 		if (ctx->model == PFX_NEOHOOKEAN)
 			hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu,
+							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e,
 							   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag);
 		else
 			hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu,
+							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e,
 							   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag);
 	}
 

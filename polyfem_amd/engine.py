@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "pfx_cg_dev", "pfx_dirichlet_solve", "pfx_get_info", "pfx_timing_enable", "pfx_timing_get", "pfx_timing_reset",
     "pfx_set_owned", "pfx_cgs_set_workspace", "pfx_cgs_prepare", "pfx_cgs_residual", "pfx_cgs_start", "pfx_cgs_start2",
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
-    "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev",
+    "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
 ]
 
 
@@ -88,6 +88,7 @@ def load():
         "pfx_synchronize": [_vp],
         "pfx_set_mesh": [_vp, _i32, _i64, _i64, _i64, _pi32, _pi32, _pd, _i32],
         "pfx_set_material": [_vp, _i32, _i32, _dbl, _dbl],
+        "pfx_set_material_per_element": [_vp, _i32, _i32, _pd, _pd, _i64],
         "pfx_build_pattern": [_vp, _pi64],
         "pfx_get_pattern": [_vp, _pi64, _pi32],
         "pfx_get_values": [_vp, _pd],
@@ -189,8 +190,15 @@ class Engine:
                                      _d(xyz), mesh.quad_order))
         self.mesh = mesh
 
-    def set_material(self, model: int, lam: float = 1.0, mu: float = 1.0, dim: int = 3):
-        self._ck(self.L.pfx_set_material(self.h, model, dim, lam, mu))
+    def set_material(self, model: int, lam=1.0, mu=1.0, dim: int = 3):
+        """Scalars: uniform Lame parameters; arrays: one value per element (multi-material bodies)."""
+        if np.ndim(lam) == 0:
+            self._ck(self.L.pfx_set_material(self.h, model, dim, float(lam), float(mu)))
+        else:
+            la = np.ascontiguousarray(lam, dtype=np.float64)
+            ma = np.ascontiguousarray(mu, dtype=np.float64)
+            assert la.shape == ma.shape and la.ndim == 1
+            self._ck(self.L.pfx_set_material_per_element(self.h, model, dim, _d(la), _d(ma), la.size))
         self.model = model
 
     def build_pattern(self) -> int:

@@ -110,6 +110,36 @@ def test_linear_elasticity_through_nonlinear_interface(eng, oracle, name):
             assert e == 0.0 and not g.any()
 
 
+@pytest.mark.parametrize("name", ["p2_jitter_polyfem", "q1"])
+def test_per_element_materials(eng, oracle, name):
+    """LameParameters with one entry per element (multi-material bodies, utils/ElasticityUtils.cpp:490-517)."""
+    mesh = MESHES[name]()
+    rng = np.random.default_rng(11)
+    E_el = 1e4 * (1.0 + 4.0 * rng.random(mesh.n_el))
+    nu_el = 0.2 + 0.2 * rng.random(mesh.n_el)
+    lam = E_el * nu_el / ((1 + nu_el) * (1 - 2 * nu_el))
+    mu = E_el / (2 * (1 + nu_el))
+    n = mesh.n_nodes * 3
+    eng.set_mesh(mesh)
+    eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+    eng.build_pattern()
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner)
+    assert rel_err(v, vals) <= TOL
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    h = 1.0 / round((mesh.n_el / (6 if mesh.kind < 2 else 1)) ** (1 / 3))
+    x = M.seeded_displacement(mesh, 3, 1e-2 * h)
+    e, g, hv = eng.energy(x), eng.gradient(x), eng.hessian(x)
+    assert abs(e - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= TOL * abs(e)
+    assert rel_err(g, oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= TOL
+    assert rel_err(hv, oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]) <= TOL
+    # a uniform material set afterwards replaces the arrays
+    eng.set_material(E.NEOHOOKEAN, float(lam[0]), float(mu[0]))
+    assert abs(eng.energy(x) - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, float(lam[0]), float(mu[0]), x)) <= TOL * abs(e)
+
+
 def test_hessian_pattern_reuse_is_deterministic(eng, oracle):
     """Newton steps reuse the pattern (SpareMatrixCache second pass == first pass) and repeated assemblies of
     the same state are bitwise identical (no atomics in the accumulation)."""

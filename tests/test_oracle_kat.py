@@ -317,3 +317,24 @@ def test_newton_restatement(oracle):
     # nothing to do at the rest state without load
     x, info = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, None, bnd, np.zeros(n))
     assert info["status"] == 4 and info["iterations"] == 0
+
+
+def test_per_element_materials_oracle(oracle):
+    """One (lambda, mu) per element: the stiffness is the sum of the single-material stiffnesses of the two halves, and
+    constant arrays reproduce the uniform material bitwise."""
+    mesh = M.cube_tets(2, 2, jitter=0.1)
+    n = mesh.n_nodes * 3
+    l1, m1 = oracle.lame(1e5, 0.3)
+    l2, m2 = oracle.lame(3e4, 0.4)
+    half = np.arange(mesh.n_el) < mesh.n_el // 2
+    lam, mu = np.where(half, l1, l2), np.where(half, m1, m2)
+    K = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    Ka = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, np.where(half, l1, 0.0), np.where(half, m1, 0.0)), n)
+    Kb = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, np.where(half, 0.0, l2), np.where(half, 0.0, m2)), n)
+    assert abs(K - (Ka + Kb)).max() <= 1e-12 * abs(K).max()
+    x = np.random.default_rng(2).standard_normal(n)
+    e = oracle.assemble_energy(mesh, oracle.LINEAR_ELASTICITY, lam, mu, x)
+    assert abs(e - 0.5 * x @ (K @ x)) <= 1e-10 * abs(e)
+    u = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, l1, m1)
+    c = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, np.full(mesh.n_el, l1), np.full(mesh.n_el, m1))
+    assert all(np.array_equal(a, b) for a, b in zip(u, c))
