@@ -250,7 +250,9 @@ pfx_status pfx_get_info(pfx_ctx *ctx, pfx_info *info);
 
 /* Average duration (ms) of the launches of one named kernel family since the last reset, measured with HIP events
  * on the context's stream when timing is enabled.  Families: "local", "gather" (matrix assembly), "local_grad",
- * "gather_vec", "local_energy", "spmv", "cg_update", "cg_dir". */
+ * "gather_vec", "local_energy", "spmv", "cg_update", "cg_dir", "sell_convert".  on = 1 times every launch; on = k > 1
+ * times every k-th launch of each family (two event records per timed launch cost about 3 us of stream time each,
+ * which is visible in a loop of sub-millisecond kernels). */
 pfx_status pfx_timing_enable(pfx_ctx *ctx, int on);
 pfx_status pfx_timing_get(pfx_ctx *ctx, const char *family, double *avg_ms, int64_t *launches);
 pfx_status pfx_timing_reset(pfx_ctx *ctx);

@@ -157,7 +157,7 @@ extern "C"
 			return PFX_ERR_HIP;
 		}
 		ctx->own_stream = true;
-		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * 3 * 2048) != hipSuccess)
+		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess)
 		{
 			delete ctx;
 			return PFX_ERR_HIP;
@@ -761,6 +761,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		resolve_timers(ctx);
 		ctx->timing = on != 0;
+		ctx->timing_stride = on > 1 ? on : 1;
 		return PFX_OK;
 	}
 
@@ -787,6 +788,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		resolve_timers(ctx);
 		ctx->timers.clear();
+		ctx->timing_seen.clear();
 		return PFX_OK;
 	}
 

@@ -96,7 +96,7 @@ struct pfx_ctx
 	double *d_work = nullptr;     // 4 * n_dofs: r, p, tmp, invdiag
 	double *d_work_ext = nullptr; // caller-owned workspace of the same layout (multi-GPU driver)
 	double diag_shift = 0.0;      // the solver works with A + diag_shift * I on the free dofs (Newton regularisation)
-	double *d_partials = nullptr; // 3 x 2048 per-block partial sums of the vector kernels
+	double *d_partials = nullptr; // 3 x 2048 per-block partial sums of the vector kernels, then 8 scalars (first: p.Ap of the current iteration)
 	double *d_part0 = nullptr;    // per-block partials of the SpMV (one per SpMV block)
 	int64_t part0_count = 0;
 	double *d_newton = nullptr;   // workspace of the Newton driver (pfx_newton.hip)
@@ -114,6 +114,8 @@ struct pfx_ctx
 	int64_t bytes_device = 0;
 
 	bool timing = false;
+	int timing_stride = 1;                             // every timing_stride-th launch of a family is timed
+	std::map<std::string, int64_t> timing_seen;        // launches of each family since the last reset
 	std::map<std::string, pfx_timer_family> timers;
 	struct pending_pair
 	{
@@ -169,6 +171,8 @@ struct pfx_scoped_timer
 	pfx_scoped_timer(pfx_ctx *c, const char *f) : ctx(c), family(f)
 	{
 		if (!ctx->timing)
+			return;
+		if (ctx->timing_stride > 1 && (ctx->timing_seen[f]++ % ctx->timing_stride) != 0)
 			return;
 		if (ctx->ev_free.size() < 2)
 		{

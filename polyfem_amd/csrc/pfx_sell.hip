@@ -122,23 +122,22 @@ namespace
 		return v;
 	}
 
-	// y = (A + shift I) x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per wave; blocks
-	// b and b+8 run on the same XCD, so each XCD walks one contiguous eighth of the slices (x gathers stay in its L2).
+	// y = (A + shift I) x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per single-wave block (measured
+	// faster than four waves per block); blocks b and b+8 run on the same XCD, so each XCD walks one contiguous eighth of the slices (x gathers stay in its L2).
 	template <int BS, bool DOT>
-	__global__ __launch_bounds__(256) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
+	__global__ __launch_bounds__(64) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
 														const int32_t *__restrict__ cols, const double *__restrict__ values, int64_t n_slices,
 														const uint8_t *__restrict__ fixed, double shift, const double *__restrict__ x,
 														double *__restrict__ y, double *__restrict__ part, const int *__restrict__ done)
 	{
-		__shared__ double sh[4];
 		if (DOT && *done)
 			return;
 		constexpr int B2 = BS * BS;
-		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+		const int lane = threadIdx.x;
 		const int nblk = gridDim.x;
 		const int per = (nblk + 7) / 8;
 		const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-		const int64_t s = (int64_t)vb * 4 + w;
+		const int64_t s = vb;
 		double dot = 0.0;
 		if (s < n_slices)
 		{
@@ -152,7 +151,7 @@ namespace
 				// matrix values and column ids are read once per product: non-temporal loads keep them from evicting
 				// the gathered x entries out of the L2
 				typedef double d2 __attribute__((ext_vector_type(2)));
-#pragma unroll 8
+#pragma unroll 12
 				for (int j = 0; j < len; ++j)
 				{
 					const int64_t cc = (int64_t)__builtin_nontemporal_load(c + j * SL) * 3;
@@ -195,10 +194,7 @@ namespace
 		{
 			dot = wave_sum(dot);
 			if (lane == 0)
-				sh[w] = dot;
-			__syncthreads();
-			if (threadIdx.x == 0)
-				part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+				part[blockIdx.x] = dot;
 		}
 	}
 
@@ -323,8 +319,7 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 
 int pfx_sell_grid(const pfx_ctx *ctx)
 {
-	const int64_t b = (ctx->sell_slices + 3) / 4;
-	return (int)((b + 7) / 8 * 8);
+	return (int)((ctx->sell_slices + 7) / 8 * 8); // one slice (one wave) per block
 }
 
 pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done)
@@ -332,7 +327,7 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	const int grid = pfx_sell_grid(ctx);
 	pfx_scoped_timer tm(ctx, "spmv");
-#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, ctx->sell_slices, fixed, ctx->diag_shift, d_x, d_y, part, done)
+#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, ctx->sell_slices, fixed, ctx->diag_shift, d_x, d_y, part, done)
 	if (ctx->bs == 1)
 	{
 		if (part)

@@ -209,13 +209,12 @@ namespace
 	// alpha = abs_new / p.tmp ; x += alpha p ; r -= alpha tmp ; partials [1], [2] of r.r and r.(M^-1 r)
 	__global__ __launch_bounds__(256) void k_cg_update(const double *__restrict__ p, const double *__restrict__ tmp, const double *__restrict__ invdiag,
 														int64_t n, int it, double *__restrict__ x, double *__restrict__ r, double *__restrict__ part,
-														const double *__restrict__ part0, int n0, const double *__restrict__ gscal,
-														const pfx_cg_state *__restrict__ state)
+														const double *__restrict__ pap, const pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
 		if (state->done)
 			return;
-		const double pAp = get_scalar(part0, n0, gscal, 0, sh);
+		const double pAp = *pap; // p.Ap, summed over the SpMV blocks (and over the ranks) before this kernel
 		const double alpha = state->abs_new[it & 1] / pAp;
 		double rr = 0, rz = 0;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
@@ -413,8 +412,8 @@ pfx_status pfx_cgs_spmv_impl(pfx_ctx *ctx, double *gscal)
 	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done);
 	if (rc)
 		return rc;
-	if (gscal)
-		hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal);
+	// one partial per slice: summed once here rather than by every block of the update kernel
+	hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal ? gscal : ctx->d_partials + 3 * PFX_NPART);
 	return PFX_OK;
 }
 
@@ -426,7 +425,7 @@ pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal)
 	const int64_t n = ctx->n_owned * ctx->bs;
 	{
 		pfx_scoped_timer tm(ctx, "cg_update");
-		hipLaunchKernelGGL(k_cg_update, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, w.invdiag, n, it, d_x, w.r, ctx->d_partials, ctx->d_part0, pfx_sell_grid(ctx), gscal, (pfx_cg_state *)ctx->d_cgstate);
+		hipLaunchKernelGGL(k_cg_update, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, w.invdiag, n, it, d_x, w.r, ctx->d_partials, gscal ? gscal : ctx->d_partials + 3 * PFX_NPART, (pfx_cg_state *)ctx->d_cgstate);
 	}
 	finish(ctx, 1, 2, gscal);
 	return PFX_OK;
@@ -462,7 +461,8 @@ pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond,
 	pfx_status rc;
 	if ((rc = pfx_cgs_prepare_impl(ctx, d_x, precond)) || (rc = pfx_cgs_residual_impl(ctx, d_b, d_x, nullptr)) || (rc = pfx_cgs_start_impl(ctx, d_x, tol, nullptr)) || (rc = pfx_cgs_start2_impl(ctx, nullptr)))
 		return rc;
-	const int check_every = 16;
+	// the kernels return at once after convergence (device flag), so a late check costs a few empty launches only
+	const int check_every = 64;
 	int it = 0, done = 0, its = 0;
 	double rr = 0, bb = 0;
 	while (it < max_iter && !done)

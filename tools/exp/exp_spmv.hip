@@ -160,12 +160,12 @@ __global__ __launch_bounds__(256) void k_sell2(const int64_t* __restrict__ slice
 }
 
 // k_sell2 with non-temporal value/column loads (NT) and optionally x padded to 4 doubles per node (PADX)
-template <int UNROLL, bool NT, bool PADX>
-__global__ __launch_bounds__(256) void k_sell3(const int64_t* __restrict__ slice_vbase, const int64_t* __restrict__ slice_cbase, const int32_t* __restrict__ slice_len,
+template <int UNROLL, bool NT, bool PADX, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_sell3(const int64_t* __restrict__ slice_vbase, const int64_t* __restrict__ slice_cbase, const int32_t* __restrict__ slice_len,
 	const int32_t* __restrict__ perm, const int32_t* __restrict__ cols, const double* __restrict__ values, int64_t n_slices, const double* __restrict__ x, double* __restrict__ y) {
 	const int lane = threadIdx.x & 63;
 	const int nblk = gridDim.x; const int per = (nblk + 7) / 8; const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-	const int64_t s = (int64_t)vb * 4 + (threadIdx.x >> 6);
+	const int64_t s = (int64_t)vb * WPB + (threadIdx.x >> 6);
 	if (vb >= nblk || s >= n_slices) return;
 	const int len = slice_len[s];
 	const double* v = values + slice_vbase[s];
@@ -293,6 +293,14 @@ int main(int argc, char** argv) {
 	  timeit("sell64 b128 slice/wave u4", [&] { k_sell2<4><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell64 b128 slice/wave u8", [&] { k_sell2<8><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  timeit("sell3 u4 nt", [&] { k_sell3<4, true, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell3 u12 nt", [&] { k_sell3<12, true, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  timeit("sell3 u16 nt", [&] { k_sell3<16, true, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
+	  { const int G2 = (int)((n_slices + 1) / 2); const int G28 = ((G2 + 7) / 8) * 8;
+	    timeit("sell3 u8 nt wpb2", [&] { k_sell3<8, true, false, 2><<<G28, 128>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes); }
+	  { const int G1 = (int)n_slices; const int G18 = ((G1 + 7) / 8) * 8;
+	    timeit("sell3 u8 nt wpb1", [&] { k_sell3<8, true, false, 1><<<G18, 64>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes); }
+	  { const int G8 = (int)((n_slices + 7) / 8); const int G88 = ((G8 + 7) / 8) * 8;
+	    timeit("sell3 u8 nt wpb8", [&] { k_sell3<8, true, false, 8><<<G88, 512>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes); }
 	  timeit("sell3 u8 nt", [&] { k_sell3<8, true, false><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x, d_y); }, bytes);
 	  { double* d_x4; CK(hipMalloc(&d_x4, 8 * 4 * (n_nodes + 1))); CK(hipMemset(d_x4, 0, 8 * 4 * (n_nodes + 1)));
 	  timeit("sell3 u4 padx", [&] { k_sell3<4, false, true><<<GB8, 256>>>(d_svb, d_scb, d_slen, d_perm, d_scol, d_sv, n_slices, d_x4, d_y); }, bytes);
