@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-include-regex "k_sell_spmv|k_cg_|k_gather_matrix|k_local_" --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --cg-max-iter 24 > $out/pmc_$c.log 2>&1
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-include-regex "k_sell_spmv|k_cg_|k_assemble_rows|k_local_|k_element_geometry|k_sell_values|k_finish" --output-format csv -d $out/pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --cg-max-iter 24 > $out/pmc_$c.log 2>&1
 done
 python3 tools/pmc_summary.py $out > $out/pmc_summary.txt
 find $out -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
