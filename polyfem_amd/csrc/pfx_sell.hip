@@ -11,7 +11,7 @@
 // (for bs = 3 entries 0..7 are stored as 4 lane-interleaved double2 so that they are fetched with 16-byte loads).
 // Every load of the value stream is therefore one fully coalesced 512 B / 1 KiB wave access, a lane accumulates its
 // bs rows in registers (no cross-lane reduction) and the loop over j unrolls freely, which keeps ~36 loads in flight
-// per lane.  Measured on MI355X, 1 M P2 tets: 0.65 ms per product against 0.81 ms for a lanes-per-row CSR kernel on
+// per lane.  Measured on MI355X, 1 M P2 tets: 0.62 ms per product against 0.81 ms for a lanes-per-row CSR kernel on
 // the same data; a pure streaming read of the value array takes 0.50 ms.  Sorting only inside windows keeps the x
 // entries gathered by one slice close together (L2 hits) and the padding below 0.2 %.
 #include "pfx_internal.h"
