@@ -248,7 +248,7 @@ def main():
                    "ms_per_iter": spmv_ms + upd_ms + dir_ms},
             "pattern_build_s": t_pattern,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU column is reported with the single-GPU line only
             from oracle import pf_oracle
             pf_oracle.build()
             out["cpu_baseline"] = cpu_baseline(args, pf_oracle, M)
