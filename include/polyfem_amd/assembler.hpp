@@ -2,6 +2,7 @@
 // (include/polyfem_amd.h).  A PolyFEM build would include this instead of
 //   src/polyfem/assembler/Assembler.hpp            (Assembler<L>::assemble :32-39, NLAssembler<L> :80-113)
 //   src/polyfem/utils/MatrixUtils.hpp              (SpareMatrixCache :39-100)
+//   src/polyfem/solver/SparseNewtonDescentSolver.hpp + NLProblem.hpp (minimize on the reduced unknowns)
 //   polysolve/LinearSolver.hpp                     (create / setParameters / analyzePattern / factorize / solve / getInfo;
 //                                                   call sites src/polyfem/solver/SparseNewtonDescentSolver.tpp:128-155)
 // and keep its call sites unchanged.  Eigen is not available in this repository, so the few Eigen types that
@@ -88,8 +89,9 @@ namespace polyfem_amd
 		pfx_ctx *h = nullptr;
 		const void *bound_bases = nullptr;
 		size_t bound_count = 0;
-		int bound_model = -1;
+		int bound_model = -1, bound_bs = 0;
 		double bound_lambda = 0, bound_mu = 0;
+		const double *bound_lambda_e = nullptr;
 
 		void check(pfx_status rc) const
 		{
@@ -98,11 +100,44 @@ namespace polyfem_amd
 		}
 
 		// Flattens bases/gbases the way State::sending_data_to_GPU walks them (state/StateSolveNonlinear.cpp:224-240)
-		// and (re)builds the device pattern when the mesh, the model or the material changed.
-		void bind(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis, int model, int dim, double lambda, double mu)
+		// when the mesh changed, passes the material when it changed and (re)builds the device pattern when needed.
+		// lambda_e / mu_e: one value per element (multi-material bodies) or null.
+		void bind(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis, int model, int dim, double lambda, double mu,
+				  const std::vector<double> *lambda_e = nullptr, const std::vector<double> *mu_e = nullptr)
 		{
-			if (bound_bases == (const void *)bases.data() && bound_count == bases.size() && bound_model == model && bound_lambda == lambda && bound_mu == mu)
+			const bool per_element = lambda_e && !lambda_e->empty();
+			const bool same_mesh = bound_bases == (const void *)bases.data() && bound_count == bases.size();
+			const bool same_material = same_mesh && bound_model == model && bound_lambda == lambda && bound_mu == mu && bound_lambda_e == (per_element ? lambda_e->data() : nullptr);
+			if (same_material)
 				return;
+			if (!same_mesh)
+				set_mesh(bases, gbases, n_basis);
+			if (per_element)
+			{
+				if (!mu_e || lambda_e->size() != bases.size() || mu_e->size() != bases.size())
+					throw std::runtime_error("polyfem_amd: per-element materials need one (lambda, mu) per element");
+				check(pfx_set_material_per_element(h, model, dim, lambda_e->data(), mu_e->data(), (int64_t)bases.size()));
+			}
+			else
+				check(pfx_set_material(h, model, dim, lambda, mu));
+			const int bs = model == PFX_LAPLACIAN ? 1 : dim;
+			if (!same_mesh || bs != bound_bs)
+			{
+				int64_t nnz = 0;
+				check(pfx_build_pattern(h, &nnz)); // once per mesh and block size; reused by every assembly afterwards
+			}
+			bound_bases = bases.data();
+			bound_count = bases.size();
+			bound_model = model;
+			bound_bs = bs;
+			bound_lambda = lambda;
+			bound_mu = mu;
+			bound_lambda_e = per_element ? lambda_e->data() : nullptr;
+		}
+
+	private:
+		void set_mesh(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis)
+		{
 			if (bases.empty() || bases.size() != gbases.size())
 				throw std::runtime_error("polyfem_amd: empty or inconsistent bases");
 			const int n_loc = (int)bases[0].bases.size(), n_gloc = (int)gbases[0].bases.size();
@@ -150,17 +185,9 @@ namespace polyfem_amd
 						xyz[(size_t)g.index * 3 + c] = g.node[c];
 				}
 			check(pfx_set_mesh(h, kind, n_el, n_basis, n_gnodes, conn.data(), gconn.data(), xyz.data(), -1));
-			check(pfx_set_material(h, model, dim, lambda, mu));
-			int64_t nnz = 0;
-			check(pfx_build_pattern(h, &nnz));
-			bound_bases = bases.data();
-			bound_count = bases.size();
-			bound_model = model;
-			bound_lambda = lambda;
-			bound_mu = mu;
+			bound_bs = 0;
 		}
 
-	private:
 		explicit Context(int device)
 		{
 			if (pfx_create(&h, device) != PFX_OK)
@@ -181,6 +208,7 @@ namespace polyfem_amd
 			static constexpr int model = PFX_LAPLACIAN;
 			int size() const { return 1; }
 			double lambda = 1, mu = 1;
+			std::vector<double> lambda_e, mu_e; // unused
 		};
 		struct ElasticBase
 		{
@@ -200,6 +228,10 @@ namespace polyfem_amd
 				mu = E / (2.0 * (1.0 + nu));
 			}
 			void set_lambda_mu(double l, double m) { lambda = l, mu = m; }
+			// LameParameters with one entry per element id, what add_multimaterial builds for multi-body meshes
+			// (utils/ElasticityUtils.cpp:490-560)
+			std::vector<double> lambda_e, mu_e;
+			void set_lambda_mu_per_element(const std::vector<double> &l, const std::vector<double> &m) { lambda_e = l, mu_e = m; }
 		};
 		struct LinearElasticity : ElasticBase
 		{
@@ -221,7 +253,7 @@ namespace polyfem_amd
 				if (!is_volume || is_mass)
 					throw std::runtime_error("polyfem_amd: only 3-D stiffness assembly is implemented");
 				Context &c = Context::instance();
-				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu);
+				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
 				c.check(pfx_assemble_linear(c.h));
 				int64_t nnz = 0;
 				c.check(pfx_get_linear_csr(c.h, &nnz, nullptr, nullptr, nullptr));
@@ -291,7 +323,7 @@ namespace polyfem_amd
 				if (!is_volume)
 					throw std::runtime_error("polyfem_amd: only 3-D problems are implemented");
 				Context &c = Context::instance();
-				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu);
+				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
 				return c;
 			}
 			LocalAssembler local_assembler_;
@@ -351,4 +383,84 @@ namespace polyfem_amd
 			double tolerance_ = 1e-12, error_ = 0;
 		};
 	} // namespace polysolve
+
+	namespace solver
+	{
+		// solver::NLProblem (solver/NLProblem.hpp, NLProblem.cpp:79-211) for one ElasticForm plus one BodyForm: the
+		// unknowns the nonlinear solver sees are the free dofs, boundary_nodes (sorted) keep the values of
+		// `boundary_values` (full size).
+		template <class LocalAssembler>
+		class NLProblem
+		{
+		public:
+			NLProblem(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis,
+					  const LocalAssembler &local_assembler, const std::vector<int> &boundary_nodes, const VectorXd &rhs, const VectorXd &boundary_values)
+				: bases_(bases), gbases_(gbases), n_basis_(n_basis), local_assembler_(local_assembler), boundary_nodes_(boundary_nodes), rhs_(rhs), boundary_values_(boundary_values)
+			{
+				is_fixed_.assign((size_t)full_size(), 0);
+				for (int b : boundary_nodes_)
+					is_fixed_[(size_t)b] = 1;
+			}
+			int full_size() const { return n_basis_ * 3; }
+			int reduced_size() const { return full_size() - (int)boundary_nodes_.size(); }
+			VectorXd full_to_reduced(const VectorXd &full) const
+			{
+				VectorXd r;
+				r.reserve((size_t)reduced_size());
+				for (int k = 0; k < full_size(); ++k)
+					if (!is_fixed_[(size_t)k])
+						r.push_back(full[(size_t)k]);
+				return r;
+			}
+			VectorXd reduced_to_full(const VectorXd &reduced) const
+			{
+				VectorXd f((size_t)full_size());
+				size_t w = 0;
+				for (int k = 0; k < full_size(); ++k)
+					f[(size_t)k] = is_fixed_[(size_t)k] ? (boundary_values_.empty() ? 0.0 : boundary_values_[(size_t)k]) : reduced[w++];
+				return f;
+			}
+			void bind() const
+			{
+				Context &c = Context::instance();
+				c.bind(bases_, gbases_, n_basis_, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
+				c.check(pfx_set_dirichlet(c.h, boundary_nodes_.data(), (int64_t)boundary_nodes_.size()));
+			}
+			const VectorXd &rhs() const { return rhs_; }
+
+		private:
+			const std::vector<basis::ElementBases> &bases_, &gbases_;
+			int n_basis_;
+			LocalAssembler local_assembler_;
+			std::vector<int> boundary_nodes_;
+			VectorXd rhs_, boundary_values_;
+			std::vector<char> is_fixed_;
+		};
+	} // namespace solver
 } // namespace polyfem_amd
+
+namespace cppoptlib
+{
+	// cppoptlib::SparseNewtonDescentSolver<ProblemType> (solver/SparseNewtonDescentSolver.hpp, NonlinearSolver.tpp:33-275):
+	// the whole minimisation runs on the device; solver_params carry solver/nonlinear/* of the input spec.
+	template <class ProblemType>
+	class SparseNewtonDescentSolver
+	{
+	public:
+		pfx_newton_params solver_params;
+		pfx_newton_info solver_info{};
+		SparseNewtonDescentSolver() { pfx_newton_default_params(&solver_params); }
+		std::string name() const { return "Newton"; }
+		// x: the reduced unknowns, starting point on input, minimiser on output.  Throws std::runtime_error where the
+		// reference does ("Reached iteration limit", "f(x) is nan or inf; stopping", "Line search failed on gradient
+		// descent", ...).
+		void minimize(ProblemType &objFunc, polyfem_amd::VectorXd &x)
+		{
+			polyfem_amd::Context &c = polyfem_amd::Context::instance();
+			objFunc.bind();
+			polyfem_amd::VectorXd full = objFunc.reduced_to_full(x);
+			c.check(pfx_newton_solve(c.h, objFunc.rhs().empty() ? nullptr : objFunc.rhs().data(), full.data(), &solver_params, &solver_info));
+			x = objFunc.full_to_reduced(full);
+		}
+	};
+} // namespace cppoptlib

@@ -152,6 +152,74 @@ int main()
 		threw = true;
 	}
 	REQUIRE(threw);
+
+	// "hessian_lin" (tests/test_assembler.cpp:12-64): LinearElasticity through the nonlinear interface reproduces the
+	// stiffness matrix for any displacement
+	{
+		assembler::NLAssembler<assembler::LinearElasticity> nll;
+		nll.local_assembler().set_E_nu(1e5, 0.3);
+		utils::SpareMatrixCache c2;
+		StiffnessMatrix HL;
+		nll.assemble_hessian(true, n_basis, false, bases, gbases, cache, 0.0, x, x, c2, HL);
+		// compare through the action on a vector: the linear assembler's pattern drops exact zeros
+		std::vector<double> y1(N, 0.0), y2(N, 0.0);
+		for (int r = 0; r < N; ++r)
+		{
+			for (int64_t k = K.outer[r]; k < K.outer[r + 1]; ++k)
+				y1[r] += K.values[k] * d[K.inner[k]];
+			for (int64_t k = HL.outer[r]; k < HL.outer[r + 1]; ++k)
+				y2[r] += HL.values[k] * d[HL.inner[k]];
+		}
+		double dm = 0, ym = 0;
+		for (int r = 0; r < N; ++r)
+			dm = std::fmax(dm, std::fabs(y1[r] - y2[r])), ym = std::fmax(ym, std::fabs(y1[r]));
+		REQUIRE(dm <= 1e-11 * ym);
+	}
+
+	// the whole nonlinear solve (SparseNewtonDescentSolver::minimize on NLProblem): clamp x = 0, pull down, two materials
+	{
+		assembler::NeoHookeanElasticity mat;
+		std::vector<double> le(bases.size()), me(bases.size());
+		for (size_t e = 0; e < bases.size(); ++e)
+		{
+			const double E = e < bases.size() / 2 ? 2e4 : 6e4, nu = 0.3;
+			le[e] = (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+			me[e] = E / (2.0 * (1.0 + nu));
+		}
+		mat.set_lambda_mu_per_element(le, me);
+		VectorXd load(N, 0.0), bc(N, 0.0);
+		for (int i = 0; i < n_basis; ++i)
+			load[3 * i + 2] = -50.0 / n_basis;
+		solver::NLProblem<assembler::NeoHookeanElasticity> problem(bases, gbases, n_basis, mat, fixed, load, bc);
+		cppoptlib::SparseNewtonDescentSolver<solver::NLProblem<assembler::NeoHookeanElasticity>> newton;
+		VectorXd xr((size_t)problem.reduced_size(), 0.0);
+		newton.minimize(problem, xr);
+		REQUIRE(newton.solver_info.iterations >= 2 && newton.solver_info.iterations < 20);
+		REQUIRE(newton.solver_info.status == PFX_NEWTON_F_DELTA || newton.solver_info.status == PFX_NEWTON_GRAD_NORM);
+		// stationarity: the elastic gradient balances the load on the free dofs
+		assembler::NLAssembler<assembler::NeoHookeanElasticity> nl2;
+		nl2.local_assembler() = mat;
+		VectorXd xf = problem.reduced_to_full(xr), gf;
+		nl2.assemble_grad(true, n_basis, bases, gbases, cache, 0.0, xf, xf, gf);
+		VectorXd res = problem.full_to_reduced(gf), lr = problem.full_to_reduced(load);
+		double rn = 0, ln = 0;
+		for (size_t k = 0; k < res.size(); ++k)
+			rn += (res[k] - lr[k]) * (res[k] - lr[k]), ln += lr[k] * lr[k];
+		REQUIRE(std::sqrt(rn) <= 1e-7 * std::sqrt(ln));
+		bool limit = false;
+		try
+		{
+			newton.solver_params.max_iterations = 1, newton.solver_params.f_delta = 0, newton.solver_params.grad_norm = 1e-14;
+			VectorXd x2((size_t)problem.reduced_size(), 0.0);
+			newton.minimize(problem, x2);
+		}
+		catch (const std::runtime_error &err)
+		{
+			limit = std::string(err.what()).find("iteration limit") != std::string::npos;
+		}
+		REQUIRE(limit);
+		std::printf("newton ok: %d iterations, %ld cg iterations\n", newton.solver_info.iterations, (long)newton.solver_info.cg_iterations);
+	}
 	std::printf("shim ok: nnz(K)=%ld energy=%.6e cg_iters=%d err=%.2e\n", (long)K.nonZeros(), e0, solver->solver_iter(), solver->solver_error());
 	return 0;
 }
