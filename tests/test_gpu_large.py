@@ -94,3 +94,75 @@ def test_config3_neohookean_properties(big):
     v1 = eng.hessian(u)
     v2 = eng.hessian(u)
     assert np.array_equal(v1, v2)
+
+
+def test_config1_laplacian_p1_full_size_parity(oracle):
+    """Config 1 (Laplacian, P1, 26^3 Kuhn grid = 105 456 tets) is small enough for the oracle: pattern bit-exact,
+    values, and the Dirichlet CG solve (x = 0 face, rhs = 1) against the oracle's CG on the reduced matrix."""
+    mesh = M.cube_tets(26, 1)
+    assert mesh.n_el == 105456 and mesh.n_nodes == 19683
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        eng.set_material(E.LAPLACIAN)
+        eng.build_pattern()
+        eng.assemble_linear()
+        rp, ci, v = eng.get_linear_csr()
+        outer, inner, vals = oracle.assemble_linear(mesh, oracle.LAPLACIAN, 1.0, 1.0, n_threads=8)
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner)
+        assert np.abs(v - vals).max() <= 1e-12 * np.abs(vals).max()
+        bnd = M.boundary_dofs(mesh, 1, "x0")
+        eng.set_dirichlet(bnd)
+        n = mesh.n_nodes
+        b = np.ones(n)
+        x, it, err = eng.cg(b, None, E.PRECOND_JACOBI, 1000, 1e-12)
+        red = oracle.full_to_reduced_matrix((outer, inner, vals), bnd)
+        free = np.ones(n, dtype=bool)
+        free[bnd] = False
+        xr, it_ref, err_ref = oracle.cg(red, b[free], jacobi=True, max_iter=1000, tol=1e-12)
+        assert abs(it - it_ref) <= 2 and err <= 1e-10 and err_ref <= 1e-10
+        assert np.abs(x[free] - xr).max() <= 1e-9 * np.abs(xr).max() and not x[bnd].any()
+    finally:
+        eng.close()
+
+
+def test_config4_q2_hex_full_size_properties():
+    """Config 4 (LinearElasticity, Q2 hexes, structured 100^3 grid: 1 M elements, 24.4 M dofs, 4.6e9 non-zeros) through
+    size-independent properties of the operator; the matrix itself (37 GB) stays on the device."""
+    n_side = 100
+    mesh = M.cube_hexes(n_side, 2)
+    assert mesh.n_el == n_side ** 3 and mesh.n_nodes == (2 * n_side + 1) ** 3
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        lam, mu = 1e5 * 0.3 / (1.3 * 0.4), 1e5 / 2.6
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        nnz = eng.build_pattern()
+        # node couplings of a tensor grid: vertex / edge / face / cell nodes see 5 / 3 nodes per direction, clipped at the boundary
+        per_dir = np.where(np.arange(2 * n_side + 1) % 2 == 0, 5, 3).astype(np.int64)
+        per_dir[0] = per_dir[-1] = 3
+        assert nnz == 9 * int(per_dir.sum()) ** 3
+        eng.assemble_linear()
+        n = mesh.n_nodes * 3
+        rng = np.random.default_rng(4)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        Ax, Ay = eng.spmv(x), eng.spmv(y)
+        scale = np.abs(Ax).max()
+        assert abs(y @ Ax - x @ Ay) <= 1e-11 * abs(y @ Ax)
+        assert np.abs(eng.spmv(2.0 * x - 3.0 * y) - (2.0 * Ax - 3.0 * Ay)).max() <= 1e-11 * scale
+        for c in range(3):
+            t = np.zeros(n)
+            t[c::3] = 1.0
+            assert np.abs(eng.spmv(t)).max() <= 1e-10 * scale
+        rot = np.zeros(n)
+        rot[0::3], rot[1::3] = -mesh.node_xyz[:, 1], mesh.node_xyz[:, 0]
+        assert np.abs(eng.spmv(rot)).max() <= 1e-9 * scale
+        # x^T K x = 2 * energy, with the energy from the element kernel of the nonlinear interface
+        assert abs(x @ Ax - 2.0 * eng.energy(x)) <= 1e-10 * abs(x @ Ax)
+        # a uniform stretch u = (a X, 0, 0): energy = (lambda/2 + mu) a^2 * volume
+        a = 1e-3
+        u = np.zeros(n)
+        u[0::3] = a * mesh.node_xyz[:, 0]
+        assert abs(eng.energy(u) - (lam / 2 + mu) * a * a) <= 1e-10 * (lam / 2 + mu) * a * a
+    finally:
+        eng.close()
