@@ -154,6 +154,21 @@ pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x_inout, int pr
 pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol,
 							   int *iters, double *rel_res);
 
+/* ---- mass matrix and body-force right-hand side -------------------------------------------------------------------
+ *
+ * pfx_assemble_mass = Assembler<Mass>::assemble(..., is_mass = true) (assembler/Assembler.cpp:100-317, mass quadrature
+ * :135-139 of order max(-1, 2p+1), basis/FEBasis3d.cpp:1468,1507; local kernel assembler/Mass.cpp:5-20): rho phi_i phi_j
+ * on the diagonal of every block, into the resident pattern.  Afterwards the matrix of the context IS the mass matrix
+ * (pfx_get_linear_csr returns the reference's value-dependent pattern, pfx_spmv / pfx_cg work with it) until the next
+ * assembly.  density_e: one density per element (Density with one entry per body id, utils/ElasticityUtils.cpp:561-570)
+ * or NULL for the uniform `density`.
+ * pfx_assemble_rhs = RhsAssembler::assemble (assembler/RhsAssembler.cpp:55-98) for a constant force density
+ * `force` (one component per dof of a node): rhs[node*d + c] = sum_e sum_q force_c rho det w phi_i(q), stiffness
+ * quadrature rule. */
+pfx_status pfx_assemble_mass(pfx_ctx *ctx, double density, const double *density_e);
+pfx_status pfx_assemble_rhs(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *rhs);
+pfx_status pfx_assemble_rhs_dev(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *d_rhs);
+
 /* ---- Newton solve with the iterate resident on the device ------------------------------------------------------
  *
  * cppoptlib::NonlinearSolver::minimize (solver/NonlinearSolver.tpp:33-275) driving

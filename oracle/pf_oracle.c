@@ -176,6 +176,15 @@ int pfo_element_quadrature(int kind, int quad_order, pfo_quad *q)
 	return is_hex(kind) ? pfo_hex_quadrature(real_order, q) : pfo_tet_quadrature(real_order, q);
 }
 
+/* basis/FEBasis3d.cpp:1468 (hex), :1507 (tet): real_mass_order = max(mass_quadrature_order, 2p+1), with the default
+ * mass_quadrature_order = -1 */
+int pfo_mass_quadrature(int kind, pfo_quad *q)
+{
+	const int p = pfo_order_of(kind);
+	const int real_mass_order = p * 2 + 1;
+	return is_hex(kind) ? pfo_hex_quadrature(real_mass_order, q) : pfo_tet_quadrature(real_mass_order, q);
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* shape functions                                                                                  */
 /* ------------------------------------------------------------------------------------------------ */
@@ -2094,4 +2103,131 @@ cleanup:
 	free(xr);
 	free(yr);
 	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* mass matrix and body-force right-hand side                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct
+{
+	const pfo_mesh *mesh;
+	int size;
+	double density;
+	const double *density_e;
+	int64_t e0, e1;
+	tripvec tv;
+} mass_job;
+
+static void *mass_job_run(void *arg)
+{
+	mass_job *jb = (mass_job *)arg;
+	const pfo_mesh *mesh = jb->mesh;
+	const int n_loc = pfo_n_loc(mesh->kind), size = jb->size;
+	pfo_quad quad;
+	pfo_mass_quadrature(mesh->kind, &quad);
+	pfo_vals *v = (pfo_vals *)malloc(sizeof(pfo_vals));
+	double da[PFO_MAX_PTS];
+	for (int64_t e = jb->e0; e < jb->e1; ++e)
+	{
+		/* Assembler.cpp:135-139: vals.compute at the mass quadrature points */
+		pfo_compute_vals(mesh, e, &quad, v);
+		for (int k = 0; k < quad.n_pts; ++k)
+			da[k] = v->det[k] * quad.w[k];
+		const double rho = jb->density_e ? jb->density_e[e] : jb->density;
+		const int32_t *idx = mesh->conn + e * n_loc;
+		for (int i = 0; i < n_loc; ++i)
+			for (int j = 0; j <= i; ++j)
+			{
+				/* Mass.cpp:5-20 */
+				double tmp = 0;
+				for (int q = 0; q < quad.n_pts; ++q)
+					tmp += rho * v->val[i][q] * v->val[j][q] * da[q];
+				for (int n = 0; n < size; ++n)
+					for (int m = 0; m < size; ++m)
+					{
+						const double local_value = (n == m) ? tmp : 0.0;
+						if (fabs(local_value) < 1e-30)
+							continue;
+						const int32_t gi = idx[i] * size + m, gj = idx[j] * size + n;
+						tv_push(&jb->tv, gi, gj, local_value * 1.0 * 1.0);
+						if (j < i)
+							tv_push(&jb->tv, gj, gi, local_value * 1.0 * 1.0);
+					}
+			}
+	}
+	free(v);
+	return NULL;
+}
+
+int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const double *density_e, int n_threads, pfo_csc *out)
+{
+	int nt = n_threads < 1 ? 1 : n_threads;
+	if (nt > mesh->n_el)
+		nt = mesh->n_el > 0 ? (int)mesh->n_el : 1;
+	mass_job *jobs = (mass_job *)calloc(nt, sizeof(mass_job));
+	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nt);
+	const int64_t chunk = (mesh->n_el + nt - 1) / nt;
+	for (int t = 0; t < nt; ++t)
+	{
+		jobs[t].mesh = mesh, jobs[t].size = size, jobs[t].density = density, jobs[t].density_e = density_e;
+		jobs[t].e0 = t * chunk < mesh->n_el ? t * chunk : mesh->n_el;
+		jobs[t].e1 = (t + 1) * chunk < mesh->n_el ? (t + 1) * chunk : mesh->n_el;
+	}
+	if (nt == 1)
+		mass_job_run(&jobs[0]);
+	else
+	{
+		for (int t = 0; t < nt; ++t)
+			pthread_create(&th[t], NULL, mass_job_run, &jobs[t]);
+		for (int t = 0; t < nt; ++t)
+			pthread_join(th[t], NULL);
+	}
+	int64_t total = 0;
+	for (int t = 0; t < nt; ++t)
+		total += jobs[t].tv.n;
+	trip *all = (trip *)malloc(sizeof(trip) * (size_t)(total ? total : 1));
+	int64_t off = 0;
+	for (int t = 0; t < nt; ++t)
+	{
+		if (jobs[t].tv.n)
+			memcpy(all + off, jobs[t].tv.t, sizeof(trip) * (size_t)jobs[t].tv.n);
+		off += jobs[t].tv.n;
+		free(jobs[t].tv.t);
+	}
+	const int rc = trips_to_csc((int32_t)(mesh->n_nodes * size), all, total, out);
+	free(all);
+	free(jobs);
+	free(th);
+	return rc;
+}
+
+int pfo_assemble_rhs(const pfo_mesh *mesh, int size, const double *f, double density, const double *density_e, double *rhs)
+{
+	const int n_loc = pfo_n_loc(mesh->kind);
+	pfo_quad quad;
+	if (pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad))
+		return -1;
+	pfo_vals *v = (pfo_vals *)malloc(sizeof(pfo_vals));
+	double rhs_fun[PFO_MAX_PTS][3];
+	for (int64_t k = 0; k < mesh->n_nodes * size; ++k)
+		rhs[k] = 0;
+	for (int64_t e = 0; e < mesh->n_el; ++e)
+	{
+		pfo_compute_vals(mesh, e, &quad, v);
+		const double rho = density_e ? density_e[e] : density;
+		for (int d = 0; d < size; ++d)
+			for (int q = 0; q < quad.n_pts; ++q)
+				rhs_fun[q][d] = f[d] * (v->det[q] * quad.w[q] * rho);
+		for (int i = 0; i < n_loc; ++i)
+			for (int d = 0; d < size; ++d)
+			{
+				double rhs_value = 0; /* (rhs_fun.col(d).array() * v.val.array()).sum() */
+				for (int q = 0; q < quad.n_pts; ++q)
+					rhs_value += rhs_fun[q][d] * v->val[i][q];
+				rhs[(int64_t)mesh->conn[e * n_loc + i] * size + d] += rhs_value * 1.0;
+			}
+	}
+	free(v);
+	return 0;
 }

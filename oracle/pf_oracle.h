@@ -23,7 +23,7 @@ enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3 };
 /* local assemblers */
 enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2 };
 
-#define PFO_MAX_PTS 64
+#define PFO_MAX_PTS 125
 #define PFO_MAX_LOC 27
 
 typedef struct
@@ -112,6 +112,15 @@ int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_thr
 double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads);
 int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, double *rhs);
 int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out);
+
+/* Mass matrix (assembler/Mass.cpp:5-20 through Assembler<Mass>::assemble with is_mass = true, Assembler.cpp:135-139):
+ * mass quadrature of order max(mass_quadrature_order = -1, 2p+1) (basis/FEBasis3d.cpp:1468,1507), rho * phi_i * phi_j on
+ * the diagonal of the size x size block, same 1e-30 drop rule.  density_e: optional per-element density. */
+int pfo_mass_quadrature(int kind, pfo_quad *q);
+int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const double *density_e, int n_threads, pfo_csc *out);
+/* Body-force right-hand side (assembler/RhsAssembler.cpp:55-98) for a constant force density f (size components):
+ * rhs[idx*size+d] += sum_q f_d rho det w phi_i(q), stiffness quadrature, serial element loop. */
+int pfo_assemble_rhs(const pfo_mesh *mesh, int size, const double *f, double density, const double *density_e, double *rhs);
 
 /* SpareMatrixCache restatement */
 typedef struct pfo_cache pfo_cache;

@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(_HERE, "libpf_oracle.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
 LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN = 0, 1, 2
-MAX_PTS, MAX_LOC = 64, 27
+MAX_PTS, MAX_LOC = 125, 27
 
 
 class Quad(C.Structure):
@@ -343,3 +343,34 @@ def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int =
                                 _dp(x), C.byref(p), int(n_threads), C.byref(info))
     assert rc == 0
     return x, {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
+
+
+def assemble_mass(mesh, size: int, density=1.0, n_threads: int = 1):
+    """Assembler<Mass>::assemble(is_mass=true).  density: scalar or one value per element."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    rho_e = None if np.ndim(density) == 0 else np.ascontiguousarray(density, dtype=np.float64)
+    out = Csc()
+    rc = lib().pfo_assemble_mass(C.byref(om.s), int(size), C.c_double(float(density) if rho_e is None else float(rho_e[0])),
+                                 _dp(rho_e) if rho_e is not None else None, int(n_threads), C.byref(out))
+    assert rc == 0
+    return _csc_to_numpy(out)
+
+
+def assemble_rhs(mesh, size: int, force, density=1.0):
+    """RhsAssembler::assemble for a constant body force."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    rho_e = None if np.ndim(density) == 0 else np.ascontiguousarray(density, dtype=np.float64)
+    f = np.ascontiguousarray(force, dtype=np.float64)
+    assert f.size == size
+    rhs = np.zeros(om.s.n_nodes * size)
+    rc = lib().pfo_assemble_rhs(C.byref(om.s), int(size), _dp(f), C.c_double(float(density) if rho_e is None else float(rho_e[0])),
+                                _dp(rho_e) if rho_e is not None else None, _dp(rhs))
+    assert rc == 0
+    return rhs
+
+
+def mass_quadrature(kind: int):
+    q = Quad()
+    assert lib().pfo_mass_quadrature(kind, C.byref(q)) == 0
+    n = q.n_pts
+    return np.ctypeslib.as_array(q.pts).reshape(MAX_PTS, 3)[:n].copy(), np.ctypeslib.as_array(q.w)[:n].copy()

@@ -65,6 +65,7 @@ namespace
 		free_dev(ctx->d_values);
 		free_dev(ctx->d_mask);
 		free_dev(ctx->d_estate);
+		ctx->estate_count = 0;
 		ctx->estate_kind = PFX_ESTATE_NONE;
 		free_dev(ctx->d_gloc);
 		free_dev(ctx->d_eloc);
@@ -97,6 +98,31 @@ namespace
 			return PFX_ERR_HIP;
 		if (!ctx->d_vec && pfx_alloc(ctx, &ctx->d_vec, n + 1))
 			return PFX_ERR_HIP;
+		return PFX_OK;
+	}
+
+	// per-element state buffer of at least `count` doubles
+	pfx_status ensure_estate(pfx_ctx *ctx, int64_t count)
+	{
+		if (ctx->d_estate && ctx->estate_count >= count)
+			return PFX_OK;
+		if (pfx_alloc(ctx, &ctx->d_estate, count))
+			return PFX_ERR_HIP;
+		ctx->estate_count = count;
+		ctx->estate_kind = PFX_ESTATE_NONE;
+		return PFX_OK;
+	}
+
+	// host array of n_el densities -> device (null: uniform)
+	pfx_status upload_density(pfx_ctx *ctx, const double *density_e, const double **d_out)
+	{
+		*d_out = nullptr;
+		if (!density_e)
+			return PFX_OK;
+		if (pfx_alloc(ctx, &ctx->d_density_e, ctx->n_el))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_density_e, density_e, sizeof(double) * (size_t)ctx->n_el, hipMemcpyHostToDevice, ctx->stream));
+		*d_out = ctx->d_density_e;
 		return PFX_OK;
 	}
 
@@ -157,7 +183,7 @@ extern "C"
 			return PFX_ERR_HIP;
 		}
 		ctx->own_stream = true;
-		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess)
+		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_tab_mass, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess)
 		{
 			delete ctx;
 			return PFX_ERR_HIP;
@@ -178,6 +204,8 @@ extern "C"
 		free_dev(ctx->d_gconn);
 		free_dev(ctx->d_xyz);
 		free_dev(ctx->d_tab);
+		free_dev(ctx->d_tab_mass);
+		free_dev(ctx->d_density_e);
 		free_dev(ctx->d_flag);
 		free_dev(ctx->d_elem_owned);
 		free_dev(ctx->d_lambda_e);
@@ -235,6 +263,7 @@ extern "C"
 			PFX_FAIL(PFX_ERR_SIZE, "n_nodes*dim must fit the reference's 32-bit column index");
 		PFX_HIP(hipSetDevice(ctx->device));
 		pfx_fill_tables(elem_kind, quad_order, &ctx->h_tab);
+		pfx_fill_tables_mass(elem_kind, &ctx->h_tab_mass);
 		if (ctx->h_tab.n_pts == 0)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "quadrature order not available for this element kind");
 		const int n_loc = ctx->h_tab.n_loc, n_gloc = ctx->h_tab.n_gloc;
@@ -265,6 +294,7 @@ extern "C"
 		PFX_HIP(hipMemcpyAsync(ctx->d_gconn, gconn, sizeof(int32_t) * (size_t)(n_el * n_gloc), hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipMemcpyAsync(ctx->d_xyz, geom_xyz, sizeof(double) * (size_t)(n_gnodes * 3), hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipMemcpyAsync(ctx->d_tab, &ctx->h_tab, sizeof(pfx_tables), hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_tab_mass, &ctx->h_tab_mass, sizeof(pfx_tables), hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
 	}
@@ -320,7 +350,10 @@ extern "C"
 		if (rc)
 			return rc;
 		const int N = ctx->n_loc * ctx->bs;
-		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz + 2) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_estate, ctx->n_el * (int64_t)(22 * ctx->n_pts)) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
+		if (pfx_alloc(ctx, &ctx->d_values, ctx->nnz + 2) || pfx_alloc(ctx, &ctx->d_mask, ctx->nnz) || pfx_alloc(ctx, &ctx->d_gloc, ctx->n_el * N) || pfx_alloc(ctx, &ctx->d_eloc, ctx->n_el) || pfx_alloc(ctx, &ctx->d_fixed, ctx->n_dofs()))
+			return PFX_ERR_HIP;
+		ctx->estate_count = 0;
+		if (ensure_estate(ctx, ctx->n_el * (int64_t)(22 * ctx->n_pts)))
 			return PFX_ERR_HIP;
 		PFX_HIP(hipMemsetAsync(ctx->d_values, 0, sizeof(double) * (size_t)(ctx->nnz + 2), ctx->stream));
 		PFX_HIP(hipMemsetAsync(ctx->d_fixed, 0, (size_t)ctx->n_dofs(), ctx->stream));
@@ -370,6 +403,60 @@ extern "C"
 		}
 		ctx->have_mask = true;
 		ctx->values_gen++;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_assemble_mass(pfx_ctx *ctx, double density, const double *density_e)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const bool hex = ctx->kind == PFX_Q1HEX || ctx->kind == PFX_Q2HEX;
+		if (ensure_estate(ctx, ctx->n_el * (int64_t)(hex ? 10 * ctx->h_tab_mass.n_pts : 10)))
+			return PFX_ERR_HIP;
+		const double *d_rho = nullptr;
+		pfx_status rc = upload_density(ctx, density_e, &d_rho);
+		if (rc)
+			return rc;
+		{
+			pfx_scoped_timer tm(ctx, "mass");
+			if ((rc = pfx_launch_mass(ctx, density, d_rho)))
+				return rc;
+		}
+		ctx->have_mask = true;
+		ctx->values_gen++;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_assemble_rhs_dev(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *d_rhs)
+	{
+		if (!ctx || !force || !d_rhs)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const double *d_rho = nullptr;
+		pfx_status rc = upload_density(ctx, density_e, &d_rho);
+		if (rc)
+			return rc;
+		if ((rc = pfx_launch_local_rhs(ctx, force, density, d_rho)))
+			return rc;
+		return pfx_launch_gather_vector(ctx, d_rhs, false);
+	}
+
+	pfx_status pfx_assemble_rhs(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *rhs)
+	{
+		if (!ctx || !force || !rhs)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		pfx_status rc = pfx_assemble_rhs_dev(ctx, force, density, density_e, ctx->d_vec);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(rhs, ctx->d_vec, sizeof(double) * (size_t)ctx->n_dofs(), hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
 	}
 

@@ -11,7 +11,7 @@ namespace
 {
 	template <int NLOC, int BS>
 	__global__ __launch_bounds__(256) void k_gather_vector(const int64_t *__restrict__ ne_ptr, const uint32_t *__restrict__ ne_src,
-															const double *__restrict__ gloc, int64_t n_nodes, double *__restrict__ out)
+															const double *__restrict__ gloc, int64_t n_nodes, int drop_tiny, double *__restrict__ out)
 	{
 		const int64_t n = n_nodes * BS;
 		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
@@ -22,7 +22,7 @@ namespace
 			for (int64_t c = ne_ptr[g]; c < ne_ptr[g + 1]; ++c)
 			{
 				const double v = gloc[(int64_t)ne_src[c] * BS + d];
-				if (fabs(v) < 1e-30) // Assembler.cpp:476
+				if (drop_tiny && fabs(v) < 1e-30) // Assembler.cpp:476
 					continue;
 				sum += v;
 			}
@@ -167,10 +167,10 @@ namespace
 	}
 
 	template <int NLOC, int BS>
-	void launch_gv(pfx_ctx *ctx, double *d_g)
+	void launch_gv(pfx_ctx *ctx, double *d_g, bool drop_tiny)
 	{
 		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3(grid_for(ctx->n_nodes * BS)), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
-						   ctx->d_gloc, ctx->n_nodes, d_g);
+						   ctx->d_gloc, ctx->n_nodes, drop_tiny ? 1 : 0, d_g);
 	}
 } // namespace
 
@@ -205,9 +205,9 @@ namespace
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "unsupported n_loc/bs"); \
 	}
 
-pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g)
+pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny)
 {
-	PFX_DISPATCH_NLOC_BS(launch_gv, ctx, d_g);
+	PFX_DISPATCH_NLOC_BS(launch_gv, ctx, d_g, drop_tiny);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

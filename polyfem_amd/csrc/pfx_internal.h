@@ -13,7 +13,7 @@
 
 #define PFX_MAX_LOC 27
 #define PFX_MAX_GLOC 8
-#define PFX_MAX_PTS 27
+#define PFX_MAX_PTS 125 // 5^3: mass quadrature of Q2 hexes
 
 // Reference-element tables of one element kind, resident in device memory.
 struct pfx_tables
@@ -22,6 +22,7 @@ struct pfx_tables
 	double w[PFX_MAX_PTS];                        // quadrature weights (already /6 for tets)
 	double grad[PFX_MAX_PTS][PFX_MAX_LOC][3];     // d(basis j)/d(ref coord) at point k
 	double ggrad[PFX_MAX_PTS][PFX_MAX_GLOC][3];   // same for the geometry bases
+	double val[PFX_MAX_PTS][PFX_MAX_LOC];         // basis j at point k
 };
 
 #define PFX_ROWS_PER_GROUP 16
@@ -54,6 +55,9 @@ struct pfx_ctx
 	double *d_xyz = nullptr;
 	pfx_tables *d_tab = nullptr;
 	pfx_tables h_tab;
+	pfx_tables *d_tab_mass = nullptr; // same for the mass quadrature rule (order 2p+1)
+	pfx_tables h_tab_mass;
+	double *d_density_e = nullptr;    // per-element density of the last mass / rhs assembly
 
 	// material
 	int model = -1, dim = 3, bs = 0; // bs = block size (1 or dim)
@@ -81,6 +85,7 @@ struct pfx_ctx
 	// scratch for the two-pass (local blocks, then per-row sums) assembly
 	double *d_lambda_e = nullptr, *d_mu_e = nullptr; // per-element Lame parameters (null: uniform ctx->lambda, ctx->mu)
 	double *d_estate = nullptr; // per-element state the row assembly computes its blocks from (n_el * 22 * n_pts doubles)
+	int64_t estate_count = 0;   // doubles allocated in d_estate
 	int estate_kind = 0;        // which element kernel wrote it last (PFX_ESTATE_*)
 	double *d_gloc = nullptr; // n_el * n_loc*bs
 	double *d_eloc = nullptr; // n_el
@@ -199,6 +204,7 @@ struct pfx_scoped_timer
 
 // translation-unit entry points
 void pfx_fill_tables(int kind, int quad_order, pfx_tables *t);
+void pfx_fill_tables_mass(int kind, pfx_tables *t);
 pfx_status pfx_pattern_build(pfx_ctx *ctx);
 pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                                                   // strict arithmetic
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess); // NeoHookean
@@ -206,7 +212,9 @@ pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask); // strict arit
 pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info);
-pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g);
+pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = true);
+pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e);                       // strict arithmetic
+pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, double density, const double *d_density_e); // strict arithmetic
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
 void pfx_sell_release(pfx_ctx *ctx);

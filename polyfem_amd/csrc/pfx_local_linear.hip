@@ -158,13 +158,106 @@ namespace
 		}
 	};
 
+	// Mass::assemble (assembler/Mass.cpp:5-20) for the pair (i, j): rho * phi_i * phi_j integrated with the mass
+	// quadrature, on the diagonal of the bs x bs block; |v| < 1e-30 replaced by an exact zero as for the stiffness
+	template <int NLOC, int NPTS, int BS, int SP>
+	struct mass_block
+	{
+		const double *geo;
+		const pfx_tables *tab; // tables of the mass quadrature rule
+		double density;
+		const double *density_e;
+		static constexpr int LDS_DOUBLES = NPTS * NLOC + NPTS; // val[k][i], then w[k]
+
+		__device__ __forceinline__ void load_tables(double *lds, int lane) const
+		{
+			for (int t = lane; t < NPTS * NLOC; t += 64)
+				lds[t] = tab->val[t / NLOC][t % NLOC];
+			for (int t = lane; t < NPTS; t += 64)
+				lds[NPTS * NLOC + t] = tab->w[t];
+		}
+
+		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[BS * BS]) const
+		{
+			const double *ge = geo + (int64_t)e * (SP * 10);
+			const double rho = density_e ? density_e[e] : density;
+			double det = ge[9];
+			double tmp = 0;
+			for (int k = 0; k < NPTS; ++k)
+			{
+				if (SP != 1)
+					det = ge[k * 10 + 9];
+				const double dak = det * lds[NPTS * NLOC + k];
+				tmp += rho * lds[k * NLOC + i] * lds[k * NLOC + j] * dak;
+			}
+			if (fabs(tmp) < 1e-30)
+				tmp = 0.0;
+			for (int m = 0; m < BS; ++m)
+				for (int n = 0; n < BS; ++n)
+					out[m * BS + n] = (m == n) ? tmp : 0.0;
+		}
+	};
+
+	// RhsAssembler::assemble (assembler/RhsAssembler.cpp:55-98) for a constant force density: one lane per
+	// (element, local basis); gloc[e][i][d] = sum_q (f_d * (det w rho)) * phi_i(q)
+	template <int NLOC, int NPTS, int BS, int SP>
+	__global__ __launch_bounds__(256) void k_local_rhs(const double *__restrict__ geo, const pfx_tables *__restrict__ tab, int64_t n_el,
+													   double f0, double f1, double f2, double density, const double *__restrict__ density_e,
+													   double *__restrict__ gloc)
+	{
+		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (t >= n_el * NLOC)
+			return;
+		const int64_t e = t / NLOC;
+		const int i = (int)(t - e * NLOC);
+		const double *ge = geo + e * (SP * 10);
+		const double rho = density_e ? density_e[e] : density;
+		const double f[3] = {f0, f1, f2};
+		double acc[3] = {0, 0, 0};
+		for (int q = 0; q < NPTS; ++q)
+		{
+			const double det = ge[(SP == 1 ? 0 : q) * 10 + 9];
+			const double s = det * tab->w[q] * rho;
+			const double v = tab->val[q][i];
+			for (int d = 0; d < BS; ++d)
+				acc[d] += (f[d] * s) * v;
+		}
+		for (int d = 0; d < BS; ++d)
+			gloc[t * BS + d] = acc[d];
+	}
+
 	template <int NGLOC, int NPTS>
-	void launch_geometry(pfx_ctx *ctx)
+	void launch_geometry(pfx_ctx *ctx, const pfx_tables *d_tab)
 	{
 		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
 		const int64_t n = ctx->n_el * SP;
 		hipLaunchKernelGGL((k_element_geometry<NGLOC, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz,
-						   ctx->d_tab, ctx->n_el, ctx->d_estate);
+						   d_tab, ctx->n_el, ctx->d_estate);
+	}
+
+	template <int NLOC, int NGLOC, int NPTS>
+	void launch_mass_rows(pfx_ctx *ctx, double density, const double *d_density_e)
+	{
+		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab_mass);
+		if (ctx->bs == 1)
+			pfx_launch_assemble_rows<NLOC, 1>(ctx, mass_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e}, true);
+		else
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, mass_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e}, true);
+	}
+
+	template <int NLOC, int NGLOC, int NPTS>
+	void launch_rhs(pfx_ctx *ctx, const double *f, double density, const double *d_density_e)
+	{
+		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab);
+		const int64_t n = ctx->n_el * NLOC;
+		if (ctx->bs == 1)
+			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 1, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
+							   ctx->n_el, f[0], 0.0, 0.0, density, d_density_e, ctx->d_gloc);
+		else
+			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 3, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
+							   ctx->n_el, f[0], f[1], f[2], density, d_density_e, ctx->d_gloc);
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
@@ -201,16 +294,16 @@ pfx_status pfx_launch_local_linear(pfx_ctx *ctx)
 	switch (ctx->kind)
 	{
 	case PFX_P1TET:
-		launch_geometry<4, 1>(ctx);
+		launch_geometry<4, 1>(ctx, ctx->d_tab);
 		break;
 	case PFX_P2TET:
-		launch_geometry<4, 6>(ctx);
+		launch_geometry<4, 6>(ctx, ctx->d_tab);
 		break;
 	case PFX_Q1HEX:
-		launch_geometry<8, 1>(ctx);
+		launch_geometry<8, 1>(ctx, ctx->d_tab);
 		break;
 	default:
-		launch_geometry<8, 27>(ctx);
+		launch_geometry<8, 27>(ctx, ctx->d_tab);
 	}
 	ctx->estate_kind = PFX_ESTATE_LINEAR;
 	PFX_HIP(hipGetLastError());
@@ -236,6 +329,56 @@ pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask)
 	default:
 		launch_rows<27, 8, 27>(ctx, write_mask);
 	}
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// mass matrix into the value array (Assembler<Mass>::assemble with is_mass = true, Assembler.cpp:135-139): geometry at
+// the points of the mass quadrature rule, then the row assembly with mass_block
+pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e)
+{
+	static const int expect[4] = {6, 14, 27, 125}; // mass rules: tet order 3 / 5, hex order 3 / 5
+	if (ctx->kind < 0 || ctx->kind > 3 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "mass assembly: unsupported element kind");
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		launch_mass_rows<4, 4, 6>(ctx, density, d_density_e);
+		break;
+	case PFX_P2TET:
+		launch_mass_rows<10, 4, 14>(ctx, density, d_density_e);
+		break;
+	case PFX_Q1HEX:
+		launch_mass_rows<8, 8, 27>(ctx, density, d_density_e);
+		break;
+	default:
+		launch_mass_rows<27, 8, 125>(ctx, density, d_density_e);
+	}
+	ctx->estate_kind = PFX_ESTATE_NONE;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// per-element body-force vectors into ctx->d_gloc (stiffness quadrature rule)
+pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, double density, const double *d_density_e)
+{
+	if (!supported(ctx))
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "rhs assembly: unsupported element kind / quadrature order combination");
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		launch_rhs<4, 4, 1>(ctx, force, density, d_density_e);
+		break;
+	case PFX_P2TET:
+		launch_rhs<10, 4, 6>(ctx, force, density, d_density_e);
+		break;
+	case PFX_Q1HEX:
+		launch_rhs<8, 8, 1>(ctx, force, density, d_density_e);
+		break;
+	default:
+		launch_rhs<27, 8, 27>(ctx, force, density, d_density_e);
+	}
+	ctx->estate_kind = PFX_ESTATE_NONE;
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -68,8 +68,14 @@ namespace
 		case 3:
 			p = pf_line_pts_3, ww = pf_line_wts_3;
 			break;
+		case 4:
+			p = pf_line_pts_4, ww = pf_line_wts_4;
+			break;
+		case 5:
+			p = pf_line_pts_5, ww = pf_line_wts_5;
+			break;
 		default:
-			return false; // 4^3 = 64 points exceed PFX_MAX_PTS
+			return false;
 		}
 		double sum = 0;
 		for (int k = 0; k < n; ++k)
@@ -231,18 +237,85 @@ namespace
 			break;
 		}
 	}
+	// values: auto_p_bases.cpp:967-999 (P1), :1089-1151 (P2); auto_q_bases.cpp:1067-1110 (Q1, printed factor order),
+	// :1277-1418 (Q2, as 1-D factor products)
+	double basis_value(int kind, int li, const double *pt)
+	{
+		const double x = pt[0], y = pt[1], z = pt[2];
+		switch (kind)
+		{
+		case PFX_P1TET:
+			return li == 0 ? -x - y - z + 1 : pt[li - 1];
+		case PFX_P2TET:
+			switch (li)
+			{
+			case 0:
+				return (x + y + z - 1) * (2 * x + 2 * y + 2 * z - 1);
+			case 1:
+				return x * (2 * x - 1);
+			case 2:
+				return y * (2 * y - 1);
+			case 3:
+				return z * (2 * z - 1);
+			case 4:
+				return -4 * x * (x + y + z - 1);
+			case 5:
+				return 4 * x * y;
+			case 6:
+				return -4 * y * (x + y + z - 1);
+			case 7:
+				return -4 * z * (x + y + z - 1);
+			case 8:
+				return 4 * x * z;
+			default:
+				return 4 * y * z;
+			}
+		case PFX_Q1HEX:
+		{
+			// coefficient and the order in which the generated code multiplies the three axis factors
+			static const double coef[8] = {-1, 1, -1, 1, 1, -1, 1, -1};
+			static const int order[8][3] = {{0, 1, 2}, {0, 1, 2}, {0, 1, 2}, {1, 0, 2}, {2, 0, 1}, {0, 2, 1}, {0, 1, 2}, {1, 2, 0}};
+			double r = 0;
+			for (int k = 0; k < 3; ++k)
+			{
+				const int a = order[li][k];
+				const double f = q1c[li][a] ? pt[a] : (pt[a] - 1);
+				r = k == 0 ? coef[li] * f : r * f;
+			}
+			return r;
+		}
+		default:
+			return q2_l(q2n[li][0], x) * q2_l(q2n[li][1], y) * q2_l(q2n[li][2], z);
+		}
+	}
+
+	void fill(int kind, int real_order, pfx_tables *t);
 } // namespace
 
 void pfx_fill_tables(int kind, int quad_order, pfx_tables *t)
+{
+	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX) ? 1 : 2;
+	int real_order = (p - 1) * 2 + 1;
+	if (quad_order > real_order)
+		real_order = quad_order;
+	fill(kind, real_order, t);
+}
+
+// mass quadrature: order max(mass_quadrature_order = -1, 2p+1)  (basis/FEBasis3d.cpp:1468, 1507)
+void pfx_fill_tables_mass(int kind, pfx_tables *t)
+{
+	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX) ? 1 : 2;
+	fill(kind, 2 * p + 1, t);
+}
+
+namespace
+{
+void fill(int kind, int real_order, pfx_tables *t)
 {
 	std::memset(t, 0, sizeof(*t));
 	static const int nloc[4] = {4, 10, 8, 27};
 	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX);
 	const int gkind = hex ? PFX_Q1HEX : PFX_P1TET;
-	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX) ? 1 : 2;
-	int real_order = (p - 1) * 2 + 1;
-	if (quad_order > real_order)
-		real_order = quad_order;
 	rule r;
 	const bool ok = hex ? hex_rule(real_order, r) : tet_rule(real_order, r);
 	if (!ok)
@@ -257,8 +330,12 @@ void pfx_fill_tables(int kind, int quad_order, pfx_tables *t)
 	{
 		t->w[k] = r.w[k];
 		for (int j = 0; j < t->n_loc; ++j)
+		{
 			basis_grad(kind, j, r.p[k], t->grad[k][j]);
+			t->val[k][j] = basis_value(kind, j, r.p[k]);
+		}
 		for (int j = 0; j < t->n_gloc; ++j)
 			basis_grad(gkind, j, r.p[k], t->ggrad[k][j]);
 	}
 }
+} // namespace

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "pfx_set_owned", "pfx_cgs_set_workspace", "pfx_cgs_prepare", "pfx_cgs_residual", "pfx_cgs_start", "pfx_cgs_start2",
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
+    "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev",
 ]
 
 
@@ -121,6 +122,9 @@ def load():
         "pfx_cgs_update": [_vp, _i32, _vp, _vp],
         "pfx_cgs_direction": [_vp, _i32, _vp],
         "pfx_cgs_status": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pd, _pd],
+        "pfx_assemble_mass": [_vp, _dbl, _pd],
+        "pfx_assemble_rhs": [_vp, _pd, _dbl, _pd, _pd],
+        "pfx_assemble_rhs_dev": [_vp, _pd, _dbl, _pd, _vp],
         "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_newton_solve_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
     }
@@ -305,6 +309,26 @@ class Engine:
         it, err = C.c_int(), C.c_double()
         self._ck(self.L.pfx_cg_dev(self.h, _vp(d_b), _vp(d_x), precond, max_iter, tol, C.byref(it), C.byref(err)))
         return it.value, err.value
+
+    def assemble_mass(self, density=1.0):
+        """Assembler<Mass>::assemble(is_mass=True) into the resident pattern; density: scalar or one value per element."""
+        if np.ndim(density) == 0:
+            self._ck(self.L.pfx_assemble_mass(self.h, float(density), None))
+        else:
+            rho = np.ascontiguousarray(density, dtype=np.float64)
+            self._ck(self.L.pfx_assemble_mass(self.h, float(rho[0]), _d(rho)))
+
+    def assemble_rhs(self, force, density=1.0):
+        """RhsAssembler::assemble for a constant body force (one component per dof of a node)."""
+        f = np.zeros(3)
+        f[:np.size(force)] = np.asarray(force, dtype=np.float64).reshape(-1)
+        out = np.zeros(self.info().n_dofs)
+        if np.ndim(density) == 0:
+            self._ck(self.L.pfx_assemble_rhs(self.h, _d(f), float(density), None, _d(out)))
+        else:
+            rho = np.ascontiguousarray(density, dtype=np.float64)
+            self._ck(self.L.pfx_assemble_rhs(self.h, _d(f), float(rho[0]), _d(rho), _d(out)))
+        return out
 
     def newton_solve(self, x0, rhs=None, **params):
         """Minimises E(x) - rhs.x over the free dofs (see pfx_newton_solve).  Returns (x, info dict); raises PfxError

@@ -140,6 +140,33 @@ def test_per_element_materials(eng, oracle, name):
     assert abs(eng.energy(x) - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, float(lam[0]), float(mu[0]), x)) <= TOL * abs(e)
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "p2_aligned", "q1", "q2"])
+@pytest.mark.parametrize("size", [1, 3])
+def test_mass_matrix_and_body_force(eng, oracle, name, size):
+    """Assembler<Mass>::assemble(is_mass=true) (mass quadrature of order 2p+1, value-dependent pattern) and
+    RhsAssembler::assemble for a constant force, uniform and per-element density."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, E.LAPLACIAN if size == 1 else E.LINEAR_ELASTICITY, lam, mu)
+    rho_e = 1.0 + np.random.default_rng(9).random(mesh.n_el)
+    force = np.array([0.3, -0.2, -9.8])[:size]
+    for rho in (2.5, rho_e):
+        eng.assemble_mass(rho)
+        rp, ci, v = eng.get_linear_csr()
+        outer, inner, vals = oracle.assemble_mass(mesh, size, rho)
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner), "mass pattern differs from the oracle"
+        assert rel_err(v, vals) <= TOL
+        r = eng.assemble_rhs(force, rho)
+        assert rel_err(r, oracle.assemble_rhs(mesh, size, force, rho)) <= TOL
+    # the resident matrix is the mass matrix now: total mass through the operator
+    ones = np.ones(mesh.n_nodes * size)
+    assert abs(ones @ eng.spmv(ones) - size * oracle.assemble_rhs(mesh, 1, [1.0], rho_e).sum()) <= 1e-11 * size * rho_e.sum()
+    # a stiffness assembly afterwards is unaffected
+    eng.assemble_linear()
+    k_ref = oracle.assemble_linear(mesh, oracle.LAPLACIAN if size == 1 else oracle.LINEAR_ELASTICITY, lam, mu)
+    assert rel_err(eng.get_linear_csr()[2], k_ref[2]) <= TOL
+
+
 def test_hessian_pattern_reuse_is_deterministic(eng, oracle):
     """Newton steps reuse the pattern (SpareMatrixCache second pass == first pass) and repeated assemblies of
     the same state are bitwise identical (no atomics in the accumulation)."""

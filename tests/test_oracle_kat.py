@@ -338,3 +338,34 @@ def test_per_element_materials_oracle(oracle):
     u = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, l1, m1)
     c = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, np.full(mesh.n_el, l1), np.full(mesh.n_el, m1))
     assert all(np.array_equal(a, b) for a, b in zip(u, c))
+
+
+@pytest.mark.parametrize("kind", ["tet1", "tet2", "hex1", "hex2"])
+def test_mass_matrix_and_rhs_oracle(oracle, kind):
+    """Mass matrix (mass quadrature of order 2p+1) and body-force rhs: total mass = rho * volume, M is symmetric and
+    positive, M 1 = rhs for a unit force (both integrate rho phi_i exactly on these meshes), block structure of the
+    vector-valued mass matrix, quadrature sizes."""
+    mesh = {"tet1": lambda: M.cube_tets(2, 1, jitter=0.15), "tet2": lambda: M.cube_tets(2, 2, jitter=0.15),
+            "hex1": lambda: M.cube_hexes(2, 1), "hex2": lambda: M.cube_hexes(2, 2)}[kind]()
+    n = mesh.n_nodes
+    pts, w = oracle.mass_quadrature(mesh.kind)
+    assert len(w) == {"tet1": 6, "tet2": 14, "hex1": 27, "hex2": 125}[kind]
+    assert abs(w.sum() - (1.0 if kind.startswith("hex") else 1.0 / 6.0)) < 1e-14
+    rho = 2.5
+    Mm = csc_to_scipy(oracle.assemble_mass(mesh, 1, rho), n)
+    assert abs(Mm.sum() - rho) < 1e-12 and abs(Mm - Mm.T).max() == 0.0
+    x = np.random.default_rng(0).standard_normal(n)
+    assert x @ (Mm @ x) > 0
+    r = oracle.assemble_rhs(mesh, 1, [1.0], rho)
+    assert np.abs(Mm @ np.ones(n) - r).max() < 1e-13
+    M3 = csc_to_scipy(oracle.assemble_mass(mesh, 3, rho, n_threads=3), 3 * n).tocsr()
+    assert M3.nnz == 3 * Mm.nnz  # only the diagonal of every 3x3 block is stored
+    for c in range(3):
+        assert abs(M3[c::3][:, c::3] - Mm).max() < 1e-15
+    r3 = oracle.assemble_rhs(mesh, 3, [0.0, 0.0, -9.8], rho).reshape(-1, 3)
+    assert not r3[:, :2].any() and abs(r3[:, 2].sum() + 9.8 * rho) < 1e-12
+    rho_e = 1.0 + np.arange(mesh.n_el) / mesh.n_el
+    Me = csc_to_scipy(oracle.assemble_mass(mesh, 1, rho_e), n)
+    vol_e = 1.0 / mesh.n_el if kind.startswith("hex") else None
+    if vol_e is not None:
+        assert abs(Me.sum() - rho_e.sum() * vol_e) < 1e-12
