@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
-    ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean"])
+    ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean", "newton"],
+                    help="newton: one step = a full NeoHookean Newton solve (gravity-like load, clamped x = 0 face), single GPU")
     ap.add_argument("--cg-max-iter", type=int, default=1000)
     ap.add_argument("--cg-tol", type=float, default=1e-12)
     ap.add_argument("--cpu-n", type=int, default=14)
@@ -110,7 +111,9 @@ def main():
 
     from polyfem_amd import distributed as D
 
-    nonlinear = args.workload == "neohookean"
+    nonlinear = args.workload in ("neohookean", "newton")
+    if args.workload == "newton" and world > 1:
+        raise SystemExit("the newton workload is single-GPU")
     # weak scaling: the global grid is n x n x (n*world) cells; every rank owns the node planes of n cell layers
     # (plus one layer of its lower neighbour's elements, which it assembles redundantly instead of communicating)
     part, bounds, n_nodes_global = D.slab_part(args.n, args.n, rank, world, 2)
@@ -158,7 +161,15 @@ def main():
     comm = D.Comm()
     dcg = D.DistributedCG(D.HipOps(eng), part, 3, comm, dev) if world > 1 else None
 
+    newton_info = {}
+    load = torch.zeros(n, dtype=torch.float64, device=dev)
+    load[2::3] = -50.0 / inf.n_nodes
+
     def step():
+        if args.workload == "newton":
+            x.zero_()
+            newton_info.update(eng.newton_solve_dev(x.data_ptr(), load.data_ptr(), cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol))
+            return newton_info["cg_iterations"], newton_info["grad_norm"]
         if nonlinear:
             eng.hessian_dev(u.data_ptr())
             eng.gradient_dev(u.data_ptr(), x.data_ptr())
@@ -248,7 +259,11 @@ def main():
                    "ms_per_iter": spmv_ms + upd_ms + dir_ms},
             "pattern_build_s": t_pattern,
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU column is reported with the single-GPU line only
+        if args.workload == "newton":
+            out["config"]["workload"] = (f"NeoHookean Newton solve (backtracking line search, Jacobi-CG tol {args.cg_tol:g} max_iter "
+                                         f"{args.cg_max_iter} per step), P2 tets, {args.n}^3 Kuhn grid")
+            out["newton"] = dict(newton_info)
+        if not args.no_cpu_baseline and world == 1 and args.workload != "newton":  # the CPU column is reported with the single-GPU line only
             from oracle import pf_oracle
             pf_oracle.build()
             out["cpu_baseline"] = cpu_baseline(args, pf_oracle, M)

@@ -343,6 +343,16 @@ class Engine:
         self._ck(self.L.pfx_newton_solve(self.h, _d(r) if r is not None else None, _d(x), C.byref(p), C.byref(info)))
         return x, {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
 
+    def newton_solve_dev(self, d_x: int, d_rhs: int = 0, **params):
+        """Same with device pointers (x in/out, rhs may be 0); returns the info dict."""
+        p = NewtonParams()
+        self.L.pfx_newton_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        info = NewtonInfo()
+        self._ck(self.L.pfx_newton_solve_dev(self.h, _vp(d_rhs) if d_rhs else None, _vp(d_x), C.byref(p), C.byref(info)))
+        return {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
+
     def dirichlet_solve(self, b, precond: int = PRECOND_JACOBI, max_iter: int = 1000, tol: float = 1e-12):
         b = np.ascontiguousarray(b, dtype=np.float64)
         x = np.zeros_like(b)
