@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the assembly + CG hot path on MI355X.
 
-Default workload (BASELINE.json configs[1]): linear elasticity, P2 tetrahedra on the linear geometry of a 55^3
+Default workload: linear elasticity, P2 tetrahedra on the linear geometry of a 55^3
 Kuhn-split unit cube (998 250 elements, 4.1 M dofs), E = 1e5, nu = 0.3.  One STEP = stiffness assembly into the
 resident pattern + one Jacobi-CG solve with the reference's defaults (tolerance 1e-12, max_iter 1000; it runs into
 max_iter, exactly as the reference would).  `value` = elements through the whole step per second.  Inputs (mesh,

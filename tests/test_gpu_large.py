@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the oracle cannot run these sizes in
+"""GPU tests at the full benchmark sizes (1 M P2 tets, 1 M Q2 hexes, 105 k P1 tets), through size-independent properties (the oracle cannot run these sizes in
 seconds): symmetry, null space, energy/stiffness consistency, linearity of the operator, NeoHookean at rest ==
 linear elasticity, CG residual, run-to-run bitwise determinism."""
 import numpy as np
