@@ -6,6 +6,7 @@
  */
 #include "pf_oracle.h"
 #include "pf_quad_tables.h"
+#include "pf_q2_tables.h"
 
 #include <float.h>
 #include <math.h>
@@ -256,6 +257,18 @@ static double qeval(const qexpr *e, const double *pt)
 	return r;
 }
 
+/* same for the generated Q2 tables */
+static double qeval2(const pf_qexpr *e, const double *pt)
+{
+	double r = e->coef;
+	for (int k = 0; k < 8 && e->f[k] != 0xff; ++k)
+	{
+		const double v = qfac(e->f[k] & 15, pt[e->f[k] >> 4]);
+		r = (k == 0) ? (e->coef * v) : (r * v);
+	}
+	return r;
+}
+
 /* autogen/auto_q_bases.cpp:1067-1110 (values), :1115-1260 (gradients) */
 static const qexpr q1_val[8] = {
 	{-1.0, {X(F_XM1), Y(F_XM1), Z(F_XM1), E_}},
@@ -278,12 +291,10 @@ static const qexpr q1_grad[8][3] = {
 	{{-1.0, {Y(F_X), Z(F_X), E_}}, {-1.0, {Z(F_X), X(F_XM1), E_}}, {-1.0, {Y(F_X), X(F_XM1), E_}}},
 };
 
-/* Q2: tensor products of the 1-D quadratic Lagrange factors on nodes {0, 1/2, 1}; local node order from
- * the node table auto_q_bases.cpp:1873-1903.  Values and gradients (auto_q_bases.cpp:1277-1871) are the
- * same polynomials; here the three 1-D factors are formed first and multiplied x*y*z, whereas the
- * reference's generated expressions multiply their factors in the printer's order, so results can differ
- * in the last bit (value parity ~1 ulp; the exact-zero pattern of a Q2 stiffness matrix is therefore
- * pinned only against this restatement). */
+/* Q2: local node order from the node table auto_q_bases.cpp:1873-1903.  Values and gradients
+ * (auto_q_bases.cpp:1277-1871) are evaluated from pf_q2_tables.h, which records the factor order of every generated
+ * expression; q2_l / q2_dl below (the 1-D quadratic Lagrange factors) are kept as an independent cross-check of those
+ * tables (tests compare the two to a few ulp). */
 static const signed char q2_node[27][3] = {
 	/* lattice position of each local node in units of 1/2 (auto_q_bases.cpp:1873-1903) */
 	{0, 0, 0}, {2, 0, 0}, {2, 2, 0}, {0, 2, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2},
@@ -340,6 +351,16 @@ void pfo_basis_nodes(int kind, double *nodes)
 				nodes[3 * i + c] = q2_node[i][c] / 2.0;
 		break;
 	}
+}
+
+/* Q2 basis and gradient as tensor products of the 1-D factors: cross-check of the generated tables */
+void pfo_q2_tensor_basis(int li, const double *pt, double *val, double *g)
+{
+	const int a = q2_node[li][0], b = q2_node[li][1], c = q2_node[li][2];
+	*val = q2_l(a, pt[0]) * q2_l(b, pt[1]) * q2_l(c, pt[2]);
+	g[0] = q2_dl(a, pt[0]) * q2_l(b, pt[1]) * q2_l(c, pt[2]);
+	g[1] = q2_l(a, pt[0]) * q2_dl(b, pt[1]) * q2_l(c, pt[2]);
+	g[2] = q2_l(a, pt[0]) * q2_l(b, pt[1]) * q2_dl(c, pt[2]);
 }
 
 void pfo_basis_value(int kind, int li, const double *pt, double *val)
@@ -402,8 +423,8 @@ void pfo_basis_value(int kind, int li, const double *pt, double *val)
 	case PFO_Q1HEX:
 		*val = qeval(&q1_val[li], pt);
 		break;
-	case PFO_Q2HEX: /* auto_q_bases.cpp:1277-1418: tensor product of the 1-D factors (value parity to ~1 ulp) */
-		*val = q2_l(q2_node[li][0], x) * q2_l(q2_node[li][1], y) * q2_l(q2_node[li][2], z);
+	case PFO_Q2HEX: /* auto_q_bases.cpp:1277-1418, factors multiplied in the printed order (pf_q2_tables.h) */
+		*val = qeval2(&pf_q2_val[li], pt);
 		break;
 	}
 }
@@ -458,14 +479,10 @@ void pfo_basis_grad(int kind, int li, const double *pt, double *g)
 		for (int c = 0; c < 3; ++c)
 			g[c] = qeval(&q1_grad[li][c], pt);
 		break;
-	case PFO_Q2HEX: /* auto_q_bases.cpp:1420-1871 */
-	{
-		const int a = q2_node[li][0], b = q2_node[li][1], c = q2_node[li][2];
-		g[0] = q2_dl(a, x) * q2_l(b, y) * q2_l(c, z);
-		g[1] = q2_l(a, x) * q2_dl(b, y) * q2_l(c, z);
-		g[2] = q2_l(a, x) * q2_l(b, y) * q2_dl(c, z);
+	case PFO_Q2HEX: /* auto_q_bases.cpp:1420-1871, factors multiplied in the printed order (pf_q2_tables.h) */
+		for (int c = 0; c < 3; ++c)
+			g[c] = qeval2(&pf_q2_grad[li][c], pt);
 		break;
-	}
 	}
 }
 

@@ -92,6 +92,7 @@ int pfo_element_quadrature(int kind, int quad_order, pfo_quad *q);
 void pfo_basis_value(int kind, int local_index, const double *pt, double *val);
 void pfo_basis_grad(int kind, int local_index, const double *pt, double *g3);
 void pfo_basis_nodes(int kind, double *nodes /* n_loc x 3 */);
+void pfo_q2_tensor_basis(int local_index, const double *pt, double *val, double *g3); /* cross-check of the Q2 tables */
 
 double pfo_determinant3(const double *m /* row-major 3x3 */);
 

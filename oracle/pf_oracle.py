@@ -140,6 +140,14 @@ def basis_grad(kind: int, li: int, pt):
     return np.array(list(g))
 
 
+def q2_tensor_basis(li: int, pt):
+    p = np.ascontiguousarray(pt, dtype=np.float64)
+    v = C.c_double()
+    g = np.zeros(3)
+    lib().pfo_q2_tensor_basis(int(li), _dp(p), C.byref(v), _dp(g))
+    return v.value, g
+
+
 def basis_nodes(kind: int):
     n = lib().pfo_n_loc(kind)
     out = np.zeros((n, 3))

@@ -4,12 +4,13 @@
 // Built with -ffp-contract=off: the linear assembler's sparsity pattern depends on exact zeros, so every
 // expression is written in the operation order of the reference's generated code
 //   tets : src/polyfem/autogen/auto_p_bases.cpp:1000-1078 (P1), :1152-1326 (P2)
-//   hexes: src/polyfem/autogen/auto_q_bases.cpp:1115-1260 (Q1), :1420-1871 (Q2, as 1-D factor products)
+//   hexes: src/polyfem/autogen/auto_q_bases.cpp:1115-1260 (Q1), :1277-1871 (Q2, factor order recorded in pf_q2_tables.h)
 // and of the quadrature set-up
 //   src/polyfem/quadrature/TetQuadrature.cpp:31-43, LineQuadrature.cpp:4707-4734, HexQuadrature.cpp:17-45,
 //   order rule src/polyfem/basis/FEBasis3d.cpp:1467,1506.
 #include "pfx_internal.h"
 #include "pf_quad_tables.h"
+#include "pf_q2_tables.h"
 
 #include <cstring>
 
@@ -180,43 +181,48 @@ namespace
 		}
 	}
 
-	const int q2n[27][3] = {
-		{0, 0, 0}, {2, 0, 0}, {2, 2, 0}, {0, 2, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2},
-		{1, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 1, 0}, {0, 0, 1}, {2, 0, 1}, {2, 2, 1}, {0, 2, 1},
-		{1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {0, 1, 1}, {2, 1, 1}, {1, 0, 1}, {1, 2, 1},
-		{1, 1, 0}, {1, 1, 2}, {1, 1, 1}};
-
-	double q2_l(int a, double t)
+	// one factor of a generated Q expression (codes of pf_q2_tables.h)
+	double q_factor(int code, double t)
 	{
-		switch (a)
+		switch (code)
 		{
 		case 0:
-			return (t - 1) * (2.0 * t - 1.0);
+			return t;
+		case 1:
+			return t - 1;
 		case 2:
-			return t * (2.0 * t - 1.0);
+			return 2.0 * t - 1.0;
+		case 3:
+			return 4.0 * t - 3.0;
+		case 4:
+			return 4.0 * t - 1.0;
+		case 5:
+			return 16.0 * t - 12.0;
+		case 6:
+			return 16.0 * t - 4.0;
+		case 7:
+			return 64.0 * t - 48.0;
 		default:
-			return -4.0 * t * (t - 1);
+			return 64.0 * t - 16.0;
 		}
 	}
-	double q2_dl(int a, double t)
+
+	// coef * f0 * f1 * ... from left to right, the way the generated C++ expression is evaluated
+	double q_eval(const pf_qexpr &e, const double *pt)
 	{
-		switch (a)
+		double r = e.coef;
+		for (int k = 0; k < 8 && e.f[k] != 0xff; ++k)
 		{
-		case 0:
-			return 4.0 * t - 3.0;
-		case 2:
-			return 4.0 * t - 1.0;
-		default:
-			return -4.0 * (2.0 * t - 1.0);
+			const double v = q_factor(e.f[k] & 15, pt[e.f[k] >> 4]);
+			r = (k == 0) ? (e.coef * v) : (r * v);
 		}
+		return r;
 	}
 
 	void q2_grad(int li, const double *pt, double *g)
 	{
-		const int a = q2n[li][0], b = q2n[li][1], c = q2n[li][2];
-		g[0] = q2_dl(a, pt[0]) * q2_l(b, pt[1]) * q2_l(c, pt[2]);
-		g[1] = q2_l(a, pt[0]) * q2_dl(b, pt[1]) * q2_l(c, pt[2]);
-		g[2] = q2_l(a, pt[0]) * q2_l(b, pt[1]) * q2_dl(c, pt[2]);
+		for (int c = 0; c < 3; ++c)
+			g[c] = q_eval(pf_q2_grad[li][c], pt);
 	}
 
 	void basis_grad(int kind, int li, const double *pt, double *g)
@@ -238,7 +244,7 @@ namespace
 		}
 	}
 	// values: auto_p_bases.cpp:967-999 (P1), :1089-1151 (P2); auto_q_bases.cpp:1067-1110 (Q1, printed factor order),
-	// :1277-1418 (Q2, as 1-D factor products)
+	// :1277-1418 (Q2, printed factor order)
 	double basis_value(int kind, int li, const double *pt)
 	{
 		const double x = pt[0], y = pt[1], z = pt[2];
@@ -285,7 +291,7 @@ namespace
 			return r;
 		}
 		default:
-			return q2_l(q2n[li][0], x) * q2_l(q2n[li][1], y) * q2_l(q2n[li][2], z);
+			return q_eval(pf_q2_val[li], pt);
 		}
 	}
 

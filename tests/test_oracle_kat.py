@@ -369,3 +369,21 @@ def test_mass_matrix_and_rhs_oracle(oracle, kind):
     vol_e = 1.0 / mesh.n_el if kind.startswith("hex") else None
     if vol_e is not None:
         assert abs(Me.sum() - rho_e.sum() * vol_e) < 1e-12
+
+
+def test_q2_generated_tables_against_tensor_products(oracle):
+    """The Q2 values/gradients evaluated in the reference's printed factor order (generated table) agree with the plain
+    tensor products of the 1-D quadratic Lagrange factors to rounding, and are Kronecker deltas on the node table."""
+    rng = np.random.default_rng(7)
+    pts = rng.random((20, 3))
+    for li in range(27):
+        for pt in pts:
+            v_ref, g_ref = oracle.q2_tensor_basis(li, pt)
+            v = oracle.basis_value(oracle.PFO_Q2HEX if hasattr(oracle, "PFO_Q2HEX") else 3, li, pt)
+            g = oracle.basis_grad(3, li, pt)
+            assert abs(v - v_ref) <= 8 * np.finfo(float).eps * max(abs(v_ref), 1e-300) + 1e-300
+            assert np.all(np.abs(g - g_ref) <= 8 * np.finfo(float).eps * np.maximum(np.abs(g_ref), 1e-300) + 1e-300)
+    nodes = oracle.basis_nodes(3)
+    for li in range(27):
+        for lj in range(27):
+            assert oracle.basis_value(3, li, nodes[lj]) == (1.0 if li == lj else 0.0)
