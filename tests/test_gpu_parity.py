@@ -420,3 +420,56 @@ def test_cpp_shim_with_reference_signatures():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "shim ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_error_behaviour_of_the_abi(oracle):
+    """Status codes instead of a CPU fallback: wrong call order, unsupported inputs and invalid arguments are reported
+    through pfx_last_error, and the context stays usable afterwards."""
+    e2 = E.Engine(0)
+    try:
+        mesh = M.cube_tets(2, 2)
+        n = mesh.n_nodes * 3
+        with pytest.raises(E.PfxError) as ei:  # nothing bound yet
+            e2.build_pattern()
+        assert ei.value.code == -1
+        e2.set_mesh(mesh)
+        with pytest.raises(E.PfxError) as ei:  # 2-D is not implemented
+            e2.set_material(E.LINEAR_ELASTICITY, 1.0, 1.0, dim=2)
+        assert ei.value.code == -3
+        with pytest.raises(E.PfxError) as ei:  # one value per element required
+            e2.set_material(E.NEOHOOKEAN, np.ones(mesh.n_el - 1), np.ones(mesh.n_el - 1))
+        assert ei.value.code == -1
+        e2.set_material(E.NEOHOOKEAN, 1e4, 1e4)
+        with pytest.raises(E.PfxError) as ei:  # pattern missing
+            e2.energy(np.zeros(n))
+        assert ei.value.code == -1 and "pfx_build_pattern" in str(ei.value)
+        e2.build_pattern()
+        with pytest.raises(E.PfxError) as ei:  # the linear assembler needs a linear model
+            e2.assemble_linear()
+        assert ei.value.code == -1
+        with pytest.raises(E.PfxError) as ei:
+            e2.hessian(np.zeros(n), project_to_psd=True)
+        assert ei.value.code == -3 and "project_to_psd" in str(ei.value)
+        with pytest.raises(E.PfxError) as ei:  # Dirichlet dofs must be sorted, unique and in range
+            e2.set_dirichlet(np.array([5, 3], dtype=np.int32))
+        assert ei.value.code == -1
+        with pytest.raises(E.PfxError) as ei:
+            e2.set_dirichlet(np.array([n], dtype=np.int32))
+        assert ei.value.code == -1
+        e2.set_material(E.LAPLACIAN)
+        e2.build_pattern()
+        with pytest.raises(E.PfxError) as ei:  # no energy for the Laplacian
+            e2.energy(np.zeros(mesh.n_nodes))
+        assert ei.value.code == -3
+        # still usable
+        e2.set_material(E.NEOHOOKEAN, 1e4, 1e4)
+        e2.build_pattern()
+        assert e2.energy(np.zeros(n)) == 0.0
+        bad = M.cube_tets(2, 2)
+        bad.conn = bad.conn.copy()
+        bad.conn[0, 0] = bad.n_nodes  # out-of-range basis index
+        with pytest.raises(E.PfxError) as ei:
+            e2.set_mesh(bad)
+        assert ei.value.code == -1
+    finally:
+        e2.close()
