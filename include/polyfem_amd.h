@@ -235,6 +235,8 @@ pfx_status pfx_newton_solve_dev(pfx_ctx *ctx, const double *d_rhs, double *d_x_i
  *   pfx_cgs_start     threshold, early exit, p = M^-1 r ; scal[2] = r.p                  -> all-reduce scal[2]
  *   pfx_cgs_start2    stores r.p
  *   per iteration it: (exchange halo of p)  pfx_cgs_spmv: tmp = A p, scal[0] = p.tmp     -> all-reduce scal[0]
+ *                       or, to hide the exchange: start it, pfx_cgs_spmv_interior (rows whose columns are all owned),
+ *                       wait for it, pfx_cgs_spmv_boundary (remaining rows, then scal[0])
  *                     pfx_cgs_update: x += a p, r -= a tmp, scal[1] = r.r, scal[2] = r.z -> all-reduce scal[1..2]
  *                     pfx_cgs_direction: convergence test, p = M^-1 r + beta p
  *   pfx_cgs_status    synchronises and reports (done, iterations, ||r||^2, ||b||^2)
@@ -249,6 +251,8 @@ pfx_status pfx_cgs_residual(pfx_ctx *ctx, const double *d_b, const double *d_x, 
 pfx_status pfx_cgs_start(pfx_ctx *ctx, double *d_x, double tol, double *d_scal);
 pfx_status pfx_cgs_start2(pfx_ctx *ctx, const double *d_scal);
 pfx_status pfx_cgs_spmv(pfx_ctx *ctx, double *d_scal);
+pfx_status pfx_cgs_spmv_interior(pfx_ctx *ctx);
+pfx_status pfx_cgs_spmv_boundary(pfx_ctx *ctx, double *d_scal);
 pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal);
 pfx_status pfx_cgs_direction(pfx_ctx *ctx, int it, const double *d_scal);
 pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);
@@ -265,7 +269,7 @@ pfx_status pfx_get_info(pfx_ctx *ctx, pfx_info *info);
 
 /* Average duration (ms) of the launches of one named kernel family since the last reset, measured with HIP events
  * on the context's stream when timing is enabled.  Families: "local", "gather" (matrix assembly), "local_grad",
- * "gather_vec", "local_energy", "spmv", "cg_update", "cg_dir", "sell_convert".  on = 1 times every launch; on = k > 1
+ * "gather_vec", "local_energy", "spmv", "spmv_boundary", "cg_update", "cg_dir", "sell_convert", "mass".  on = 1 times every launch; on = k > 1
  * times every k-th launch of each family (two event records per timed launch cost about 3 us of stream time each,
  * which is visible in a loop of sub-millisecond kernels). */
 pfx_status pfx_timing_enable(pfx_ctx *ctx, int on);

@@ -810,6 +810,16 @@ extern "C"
 		PFX_NEED(true);
 		return pfx_cgs_spmv_impl(ctx, d_scal);
 	}
+	pfx_status pfx_cgs_spmv_interior(pfx_ctx *ctx)
+	{
+		PFX_NEED(true);
+		return pfx_cgs_spmv_phase_impl(ctx, PFX_SPMV_INTERIOR, nullptr);
+	}
+	pfx_status pfx_cgs_spmv_boundary(pfx_ctx *ctx, double *d_scal)
+	{
+		PFX_NEED(true);
+		return pfx_cgs_spmv_phase_impl(ctx, PFX_SPMV_BOUNDARY, d_scal);
+	}
 	pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal)
 	{
 		PFX_NEED(d_x);

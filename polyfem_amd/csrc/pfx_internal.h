@@ -109,6 +109,8 @@ struct pfx_ctx
 
 	// solver copy of the matrix (block-SELL-64, pfx_sell.hip)
 	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
+	int32_t *d_sell_order = nullptr; // slice list, interior slices first (null: natural order, no halo)
+	int64_t sell_interior = 0;       // number of slices that read owned entries of x only
 	int64_t *d_sell_base = nullptr;
 	double *d_sell_vals = nullptr;
 	int64_t sell_slices = 0, sell_rows = 0, sell_owned = -1;
@@ -220,8 +222,15 @@ pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
 void pfx_sell_release(pfx_ctx *ctx);
 pfx_status pfx_sell_refresh(pfx_ctx *ctx);
 int pfx_sell_grid(const pfx_ctx *ctx);
-pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done);
+enum
+{
+	PFX_SPMV_ALL = 0,
+	PFX_SPMV_INTERIOR = 1,
+	PFX_SPMV_BOUNDARY = 2
+};
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL);
 pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res);
+pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal);
 pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond);
 pfx_status pfx_cgs_residual_impl(pfx_ctx *ctx, const double *d_b, const double *d_x, double *gscal);
 pfx_status pfx_cgs_start_impl(pfx_ctx *ctx, double *d_x, double tol, double *gscal);

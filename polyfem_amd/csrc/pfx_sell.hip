@@ -115,6 +115,23 @@ namespace
 		}
 	}
 
+	// flag[s] = 1 if slice s reads an entry of x that this rank does not own (column node >= n_owned)
+	__global__ __launch_bounds__(256) void k_sell_classify(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ cols,
+															int64_t n_slices, int64_t n_owned, uint8_t *__restrict__ flag)
+	{
+		const int lane = threadIdx.x & 63;
+		const int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		if (s >= n_slices)
+			return;
+		const int64_t base = slice_base[s];
+		const int len = (int)(slice_base[s + 1] - base);
+		int any = 0;
+		for (int j = 0; j < len; ++j)
+			any |= cols[(base + j) * SL + lane] >= n_owned;
+		if (__ballot(any) != 0ull && lane == 0)
+			flag[s] = 1;
+	}
+
 	__device__ __forceinline__ double wave_sum(double v)
 	{
 		for (int off = 32; off > 0; off >>= 1)
@@ -126,7 +143,8 @@ namespace
 	// faster than four waves per block); blocks b and b+8 run on the same XCD, so each XCD walks one contiguous eighth of the slices (x gathers stay in its L2).
 	template <int BS, bool DOT>
 	__global__ __launch_bounds__(64) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
-														const int32_t *__restrict__ cols, const double *__restrict__ values, int64_t n_slices,
+														const int32_t *__restrict__ cols, const double *__restrict__ values,
+														const int32_t *__restrict__ order, int first, int count,
 														const uint8_t *__restrict__ fixed, double shift, const double *__restrict__ x,
 														double *__restrict__ y, double *__restrict__ part, const int *__restrict__ done)
 	{
@@ -137,9 +155,11 @@ namespace
 		const int nblk = gridDim.x;
 		const int per = (nblk + 7) / 8;
 		const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-		const int64_t s = vb;
+		if (vb >= count)
+			return;
+		// position first+vb of the slice list (interior slices first, then those that read halo entries of x)
+		const int64_t s = order ? order[first + vb] : first + vb;
 		double dot = 0.0;
-		if (s < n_slices)
 		{
 			const int64_t base = slice_base[s];
 			const int len = (int)(slice_base[s + 1] - base);
@@ -194,7 +214,7 @@ namespace
 		{
 			dot = wave_sum(dot);
 			if (lane == 0)
-				part[blockIdx.x] = dot;
+				part[first + vb] = dot;
 		}
 	}
 
@@ -223,7 +243,9 @@ void pfx_sell_release(pfx_ctx *ctx)
 	free_dev(ctx->d_sell_base);
 	free_dev(ctx->d_sell_cols);
 	free_dev(ctx->d_sell_vals);
+	free_dev(ctx->d_sell_order);
 	ctx->sell_slices = 0;
+	ctx->sell_interior = 0;
 	ctx->sell_owned = -1;
 	ctx->sell_gen = -1;
 }
@@ -285,6 +307,34 @@ static pfx_status sell_build(pfx_ctx *ctx)
 		blocks = 1;
 	hipLaunchKernelGGL(k_sell_cols, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_sell_perm, ctx->d_sell_base, n_slices, ctx->d_sell_cols);
 	PFX_HIP(hipGetLastError());
+	// slice list: interior slices first, then the slices that need halo entries (distributed solves overlap the halo
+	// exchange with the interior part).  A mesh without halo keeps the natural order (no list).
+	free_dev(ctx->d_sell_order);
+	ctx->sell_interior = n_slices;
+	if (n_owned < ctx->n_nodes && n_slices > 0)
+	{
+		uint8_t *d_flag = nullptr;
+		PFX_HIP(hipMalloc((void **)&d_flag, (size_t)n_slices));
+		PFX_HIP(hipMemsetAsync(d_flag, 0, (size_t)n_slices, st));
+		hipLaunchKernelGGL(k_sell_classify, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, st, ctx->d_sell_base, ctx->d_sell_cols, n_slices, n_owned, d_flag);
+		std::vector<uint8_t> flag((size_t)n_slices);
+		PFX_HIP(hipMemcpyAsync(flag.data(), d_flag, (size_t)n_slices, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		(void)hipFree(d_flag);
+		std::vector<int32_t> order;
+		order.reserve((size_t)n_slices);
+		for (int64_t k = 0; k < n_slices; ++k)
+			if (!flag[(size_t)k])
+				order.push_back((int32_t)k);
+		ctx->sell_interior = (int64_t)order.size();
+		for (int64_t k = 0; k < n_slices; ++k)
+			if (flag[(size_t)k])
+				order.push_back((int32_t)k);
+		if (pfx_alloc(ctx, &ctx->d_sell_order, n_slices))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_sell_order, order.data(), sizeof(int32_t) * (size_t)n_slices, hipMemcpyHostToDevice, st));
+		PFX_HIP(hipStreamSynchronize(st));
+	}
 	ctx->sell_owned = n_owned;
 	ctx->sell_gen = -1;
 	return PFX_OK;
@@ -317,17 +367,28 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 	return PFX_OK;
 }
 
+// number of per-slice partial sums the SpMV writes
 int pfx_sell_grid(const pfx_ctx *ctx)
 {
-	return (int)((ctx->sell_slices + 7) / 8 * 8); // one slice (one wave) per block
+	return (int)ctx->sell_slices;
 }
 
-pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done)
+// phase: PFX_SPMV_ALL, or the two halves of a distributed product: PFX_SPMV_INTERIOR (slices that read owned entries of
+// x only) and PFX_SPMV_BOUNDARY (the rest, after the halo entries have arrived)
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase)
 {
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-	const int grid = pfx_sell_grid(ctx);
-	pfx_scoped_timer tm(ctx, "spmv");
-#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, ctx->sell_slices, fixed, ctx->diag_shift, d_x, d_y, part, done)
+	int first = 0, count = (int)ctx->sell_slices;
+	if (phase == PFX_SPMV_INTERIOR)
+		count = (int)ctx->sell_interior;
+	else if (phase == PFX_SPMV_BOUNDARY)
+		first = (int)ctx->sell_interior, count = (int)(ctx->sell_slices - ctx->sell_interior);
+	if (count <= 0)
+		return PFX_OK;
+	const int grid = (count + 7) / 8 * 8; // one slice (one wave) per block
+	const int32_t *order = ctx->d_sell_order;
+	pfx_scoped_timer tm(ctx, phase == PFX_SPMV_BOUNDARY ? "spmv_boundary" : "spmv");
+#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, order, first, count, fixed, ctx->diag_shift, d_x, d_y, part, done)
 	if (ctx->bs == 1)
 	{
 		if (part)

@@ -438,14 +438,22 @@ pfx_status pfx_cgs_start2_impl(pfx_ctx *ctx, const double *gscal)
 
 pfx_status pfx_cgs_spmv_impl(pfx_ctx *ctx, double *gscal)
 {
+	return pfx_cgs_spmv_phase_impl(ctx, PFX_SPMV_ALL, gscal);
+}
+
+// PFX_SPMV_INTERIOR: the part of tmp = A p that needs no halo entry of p (enqueue it while the exchange is in flight);
+// PFX_SPMV_BOUNDARY: the rest, then the sum of the per-slice partials of p.Ap -> gscal[0]
+pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal)
+{
 	cg_vecs w;
 	if (cg_workspace(ctx, &w))
 		return PFX_ERR_HIP;
-	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done);
+	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done, phase);
 	if (rc)
 		return rc;
 	// one partial per slice: summed once here rather than by every block of the update kernel
-	hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal ? gscal : ctx->d_partials + 3 * PFX_NPART);
+	if (phase != PFX_SPMV_INTERIOR)
+		hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal ? gscal : ctx->d_partials + 3 * PFX_NPART);
 	return PFX_OK;
 }
 

@@ -183,10 +183,12 @@ class HaloExchange:
     def bytes_per_exchange(self, bs: int) -> int:
         return 8 * bs * (sum(int(v.numel()) for v in self.send_idx.values()) + sum(b - a for a, b in self.recv.values()))
 
-    def __call__(self, vec_nodes):
-        """vec_nodes: (n_local, bs) tensor view of the vector."""
+    def start(self, vec_nodes):
+        """Packs the send buffers and posts the grouped sends/receives; returns a handle for finish().  Between the
+        two calls work that does not read the halo part of the vector may be enqueued: it runs concurrently with the
+        transfers (RCCL works on its own stream)."""
         if not self.comm.on:
-            return
+            return None
         torch, dist = self.torch, self.comm.dist
         ops, staged = [], []
         for s, idx in self.send_idx.items():
@@ -204,11 +206,21 @@ class HaloExchange:
                 ops.append(dist.P2POp(dist.irecv, tmp, s))
             else:
                 ops.append(dist.P2POp(dist.irecv, dst, s))
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return reqs, staged
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        reqs, staged = handle
+        for r in reqs:
+            r.wait()
         for dst, tmp in staged:
             dst.copy_(tmp)
+
+    def __call__(self, vec_nodes):
+        """vec_nodes: (n_local, bs) tensor view of the vector."""
+        self.finish(self.start(vec_nodes))
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -239,6 +251,12 @@ class HipOps:
 
     def spmv(self, scal):
         self.e.cgs_spmv(scal.data_ptr())
+
+    def spmv_interior(self):
+        self.e.cgs_spmv_interior()
+
+    def spmv_boundary(self, scal):
+        self.e.cgs_spmv_boundary(scal.data_ptr())
 
     def update(self, it, x, scal):
         self.e.cgs_update(it, x.data_ptr(), scal.data_ptr())
@@ -278,8 +296,11 @@ class DistributedCG:
         while it < max_iter and not done:
             stop = min(it + check_every, max_iter)
             while it < stop:
-                self.halo(self.p_nodes)
-                ops.spmv(scal)
+                # the rows that need no halo entry of p are multiplied while the exchange is in flight
+                pending = self.halo.start(self.p_nodes)
+                ops.spmv_interior()
+                self.halo.finish(pending)
+                ops.spmv_boundary(scal)
                 ar(scal[0:1])
                 ops.update(it, x, scal)
                 ar(scal[1:3])

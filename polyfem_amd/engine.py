@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "pfx_set_owned", "pfx_cgs_set_workspace", "pfx_cgs_prepare", "pfx_cgs_residual", "pfx_cgs_start", "pfx_cgs_start2",
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
-    "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev",
+    "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
 ]
 
 
@@ -119,6 +119,8 @@ def load():
         "pfx_cgs_start": [_vp, _vp, _dbl, _vp],
         "pfx_cgs_start2": [_vp, _vp],
         "pfx_cgs_spmv": [_vp, _vp],
+        "pfx_cgs_spmv_interior": [_vp],
+        "pfx_cgs_spmv_boundary": [_vp, _vp],
         "pfx_cgs_update": [_vp, _i32, _vp, _vp],
         "pfx_cgs_direction": [_vp, _i32, _vp],
         "pfx_cgs_status": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pd, _pd],
@@ -385,6 +387,12 @@ class Engine:
 
     def cgs_spmv(self, d_scal: int):
         self._ck(self.L.pfx_cgs_spmv(self.h, _vp(d_scal) if d_scal else None))
+
+    def cgs_spmv_interior(self):
+        self._ck(self.L.pfx_cgs_spmv_interior(self.h))
+
+    def cgs_spmv_boundary(self, d_scal: int):
+        self._ck(self.L.pfx_cgs_spmv_boundary(self.h, _vp(d_scal) if d_scal else None))
 
     def cgs_update(self, it: int, d_x: int, d_scal: int):
         self._ck(self.L.pfx_cgs_update(self.h, it, _vp(d_x), _vp(d_scal) if d_scal else None))
