@@ -118,13 +118,15 @@ pfx_status pfx_energy(pfx_ctx *ctx, const double *u, double *energy);
 /* NLAssembler<L>::assemble_grad (Assembler.cpp:427-504); g has n_nodes*dim entries */
 pfx_status pfx_gradient(pfx_ctx *ctx, const double *u, double *g);
 /* NLAssembler<L>::assemble_hessian (Assembler.cpp:506-636); values (may be NULL = keep on device) in
- * pfx_get_pattern order.  project_to_psd != 0 is not supported yet (returns PFX_ERR_UNSUPPORTED). */
+ * pfx_get_pattern order.  project_to_psd != 0 projects every element Hessian onto the positive semi-definite cone
+ * before it is added (ipc::project_to_psd at assembler/Assembler.cpp:554-555; P1/P2 tets and Q1 hexes). */
 pfx_status pfx_hessian(pfx_ctx *ctx, const double *u, int project_to_psd, double *values);
 
 /* Device-resident variants: d_u, d_energy (1 double), d_g are device pointers. */
 pfx_status pfx_energy_dev(pfx_ctx *ctx, const double *d_u, double *d_energy);
 pfx_status pfx_gradient_dev(pfx_ctx *ctx, const double *d_u, double *d_g);
 pfx_status pfx_hessian_dev(pfx_ctx *ctx, const double *d_u);
+pfx_status pfx_hessian_psd_dev(pfx_ctx *ctx, const double *d_u); /* project_to_psd = true */
 
 /* ---- Dirichlet handling --------------------------------------------------------------------------------------- */
 
@@ -177,8 +179,8 @@ pfx_status pfx_assemble_rhs_dev(pfx_ctx *ctx, const double *force, double densit
  * LineSearch.tpp:90-145) on the objective of NLProblem (solver/NLProblem.cpp:79-99) with an ElasticForm and a
  * BodyForm:  E(x) - rhs.x, the dofs of pfx_set_dirichlet held at their incoming values in x.  x, the gradient and the
  * direction never leave the device; per iteration only a handful of scalars are read back.  Parameter names and
- * defaults follow input-spec.json:1587-1647 (solver/nonlinear/...).  The reference's descent strategy 1 ("projected
- * Newton") is run WITHOUT the per-element projection to PSD: only its regularisation weights are applied. */
+ * defaults follow input-spec.json:1587-1647 (solver/nonlinear/...).  Descent strategy 1 ("projected Newton") assembles
+ * with project_to_psd and the regularisation weights, as the reference does. */
 typedef struct
 {
 	double f_delta;             /* 1e-10 */

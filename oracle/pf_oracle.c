@@ -1035,8 +1035,78 @@ typedef struct
 	tripvec tv;
 	double scalar;
 	double *vec;
-	int mode; /* 0 linear, 1 energy, 2 grad, 3 hessian */
+	int mode; /* 0 linear, 1 energy, 2 grad, 3 hessian, 4 hessian projected to PSD */
 } job;
+
+void pfo_project_to_psd(double *a, int n)
+{
+	double *w = (double *)malloc(sizeof(double) * (size_t)n * n * 2);
+	double *A = w, *V = w + (size_t)n * n;
+	double norm2 = 0;
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j < n; ++j)
+		{
+			/* the eigensolver reads the lower triangle only */
+			A[i * n + j] = (j <= i) ? a[i * n + j] : a[j * n + i];
+			V[i * n + j] = (i == j) ? 1.0 : 0.0;
+			norm2 += A[i * n + j] * A[i * n + j];
+		}
+	for (int sweep = 0; sweep < 60; ++sweep)
+	{
+		double off = 0;
+		for (int p = 0; p < n; ++p)
+			for (int q = p + 1; q < n; ++q)
+				off += A[p * n + q] * A[p * n + q];
+		if (off <= 1e-32 * norm2)
+			break;
+		for (int p = 0; p < n; ++p)
+			for (int q = p + 1; q < n; ++q)
+			{
+				const double apq = A[p * n + q];
+				if (apq == 0.0)
+					continue;
+				const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+				const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+				const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+				for (int k = 0; k < n; ++k)
+				{
+					const double akp = A[k * n + p], akq = A[k * n + q];
+					A[k * n + p] = c * akp - sn * akq;
+					A[k * n + q] = sn * akp + c * akq;
+				}
+				for (int k = 0; k < n; ++k)
+				{
+					const double apk = A[p * n + k], aqk = A[q * n + k];
+					A[p * n + k] = c * apk - sn * aqk;
+					A[q * n + k] = sn * apk + c * aqk;
+				}
+				for (int k = 0; k < n; ++k)
+				{
+					const double vkp = V[k * n + p], vkq = V[k * n + q];
+					V[k * n + p] = c * vkp - sn * vkq;
+					V[k * n + q] = sn * vkp + c * vkq;
+				}
+			}
+	}
+	double lmin = A[0];
+	for (int k = 1; k < n; ++k)
+		if (A[k * n + k] < lmin)
+			lmin = A[k * n + k];
+	if (!(lmin >= 0.0))
+		for (int i = 0; i < n; ++i)
+			for (int j = 0; j < n; ++j)
+			{
+				double s = 0;
+				for (int k = 0; k < n; ++k)
+				{
+					const double l = A[k * n + k];
+					if (l > 0.0)
+						s += l * V[i * n + k] * V[j * n + k];
+				}
+				a[i * n + j] = s;
+			}
+	free(w);
+}
 
 static void gather_local_disp(const pfo_mesh *mesh, int64_t e, int n_loc, const double *x, double *ld)
 {
@@ -1125,6 +1195,8 @@ static void *job_run(void *arg)
 				else
 					pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
 				const int N = n_loc * size;
+				if (jb->mode == 4) /* Assembler.cpp:554-555 */
+					pfo_project_to_psd(H, N);
 				for (int i = 0; i < n_loc; ++i)
 					for (int j = 0; j < n_loc; ++j)
 						for (int n = 0; n < size; ++n)
@@ -1259,6 +1331,18 @@ int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const do
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 3, &nt, 0);
+	run_jobs(jobs, nt);
+	const int rc = merge_trips(jobs, nt, (int32_t)(mesh->n_nodes * block_size(mat)), out);
+	free(jobs);
+	return rc;
+}
+
+int pfo_assemble_hessian_psd(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
+{
+	if (mat->model != PFO_NEOHOOKEAN && mat->model != PFO_LINEAR_ELASTICITY)
+		return -1;
+	int nt = n_threads;
+	job *jobs = make_jobs(mesh, mat, x, 4, &nt, 0);
 	run_jobs(jobs, nt);
 	const int rc = merge_trips(jobs, nt, (int32_t)(mesh->n_nodes * block_size(mat)), out);
 	free(jobs);
@@ -1986,8 +2070,8 @@ int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double
 			break;
 		}
 		/* SparseNewtonDescentSolver::compute_update_direction (SparseNewtonDescentSolver.tpp:63-100).
-		 * Strategy 1 is the reference's "projected Newton": the per-element projection to PSD is not restated, only
-		 * the regularisation weight schedule (:40-47, :119-122). */
+		 * Strategy 1 is the reference's "projected Newton": element Hessians projected to PSD plus the regularisation
+		 * weight schedule (:40-47, :119-122). */
 		int have_direction = 0;
 		while (!have_direction)
 		{
@@ -1999,7 +2083,8 @@ int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double
 				break;
 			}
 			pfo_csc H, Hr;
-			if (pfo_assemble_hessian(mesh, mat, x, P.n_threads, &H))
+			/* assemble_hessian (:105-123): strategy 1 projects the element Hessians to PSD */
+			if (strategy == 1 ? pfo_assemble_hessian_psd(mesh, mat, x, P.n_threads, &H) : pfo_assemble_hessian(mesh, mat, x, P.n_threads, &H))
 			{
 				rc = -1;
 				goto cleanup;

@@ -123,6 +123,14 @@ int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const doub
  * rhs[idx*size+d] += sum_q f_d rho det w phi_i(q), stiffness quadrature, serial element loop. */
 int pfo_assemble_rhs(const pfo_mesh *mesh, int size, const double *f, double density, const double *density_e, double *rhs);
 
+/* ipc::project_to_psd (ipc-toolkit, un-vendored; call site assembler/Assembler.cpp:554-555): symmetric eigendecomposition,
+ * A returned unchanged if its smallest eigenvalue is >= 0, otherwise V max(D,0) V^T.  The eigenvalues come from cyclic
+ * Jacobi rotations here (the library uses Eigen::SelfAdjointEigenSolver): same projection up to round-off, parity
+ * unpinned.  a: n x n row-major, in place. */
+void pfo_project_to_psd(double *a, int n);
+/* NLAssembler::assemble_hessian with project_to_psd = true */
+int pfo_assemble_hessian_psd(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out);
+
 /* SpareMatrixCache restatement */
 typedef struct pfo_cache pfo_cache;
 pfo_cache *pfo_cache_create(int64_t size);

@@ -242,6 +242,24 @@ def assemble_hessian(mesh, model: int, lam: float, mu: float, x, n_threads: int 
     return _csc_to_numpy(out)
 
 
+def assemble_hessian_psd(mesh, model: int, lam, mu, x, n_threads: int = 1):
+    """NLAssembler::assemble_hessian with project_to_psd = true."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    mat, _keep_mat = make_material(model, lam, mu)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = Csc()
+    rc = lib().pfo_assemble_hessian_psd(C.byref(om.s), C.byref(mat), _dp(x), int(n_threads), C.byref(out))
+    assert rc == 0
+    return _csc_to_numpy(out)
+
+
+def project_to_psd(a):
+    m = np.array(a, dtype=np.float64, copy=True, order="C")
+    assert m.ndim == 2 and m.shape[0] == m.shape[1]
+    lib().pfo_project_to_psd(_dp(m), int(m.shape[0]))
+    return m
+
+
 class Cache:
     """utils::SpareMatrixCache restatement."""
 

@@ -65,6 +65,8 @@ namespace
 		free_dev(ctx->d_values);
 		free_dev(ctx->d_mask);
 		free_dev(ctx->d_estate);
+		free_dev(ctx->d_kloc);
+		ctx->kloc_count = 0;
 		ctx->estate_count = 0;
 		ctx->estate_kind = PFX_ESTATE_NONE;
 		free_dev(ctx->d_gloc);
@@ -503,7 +505,7 @@ extern "C"
 		return pfx_launch_gather_vector(ctx, d_g);
 	}
 
-	pfx_status pfx_hessian_dev(pfx_ctx *ctx, const double *d_u)
+	static pfx_status hessian_dev_impl(pfx_ctx *ctx, const double *d_u, bool project_to_psd)
 	{
 		if (!ctx || !d_u)
 			return PFX_ERR_ARG;
@@ -517,8 +519,18 @@ extern "C"
 		}
 		ctx->have_mask = false;
 		ctx->values_gen++;
-		pfx_scoped_timer tm(ctx, "gather");
-		return pfx_launch_rows_nl(ctx);
+		pfx_scoped_timer tm(ctx, project_to_psd ? "gather_psd" : "gather");
+		return project_to_psd ? pfx_launch_rows_nl_psd(ctx) : pfx_launch_rows_nl(ctx);
+	}
+
+	pfx_status pfx_hessian_dev(pfx_ctx *ctx, const double *d_u)
+	{
+		return hessian_dev_impl(ctx, d_u, false);
+	}
+
+	pfx_status pfx_hessian_psd_dev(pfx_ctx *ctx, const double *d_u)
+	{
+		return hessian_dev_impl(ctx, d_u, true);
 	}
 
 	pfx_status pfx_energy(pfx_ctx *ctx, const double *u, double *energy)
@@ -561,13 +573,11 @@ extern "C"
 	{
 		if (!ctx || !u)
 			return PFX_ERR_ARG;
-		if (project_to_psd)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "project_to_psd is not implemented");
 		if (need_pattern(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-		pfx_status rc = pfx_hessian_dev(ctx, ctx->d_u);
+		pfx_status rc = hessian_dev_impl(ctx, ctx->d_u, project_to_psd != 0);
 		if (rc)
 			return rc;
 		if (values && (rc = pfx_values_to_csr(ctx, values)))

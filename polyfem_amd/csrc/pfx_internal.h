@@ -84,6 +84,8 @@ struct pfx_ctx
 
 	// scratch for the two-pass (local blocks, then per-row sums) assembly
 	double *d_lambda_e = nullptr, *d_mu_e = nullptr; // per-element Lame parameters (null: uniform ctx->lambda, ctx->mu)
+	double *d_kloc = nullptr;   // projected element Hessians (project_to_psd only): n_el * n_loc(n_loc+1)/2 * 9
+	int64_t kloc_count = 0;
 	double *d_estate = nullptr; // per-element state the row assembly computes its blocks from (n_el * 22 * n_pts doubles)
 	int64_t estate_count = 0;   // doubles allocated in d_estate
 	int estate_kind = 0;        // which element kernel wrote it last (PFX_ESTATE_*)
@@ -212,6 +214,7 @@ pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                               
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess); // NeoHookean
 pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask); // strict arithmetic
 pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
+pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx);
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = true);

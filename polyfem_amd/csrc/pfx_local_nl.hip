@@ -31,6 +31,7 @@
 // functor nl_block: one lane per contribution (element, i, j) evaluates H_ij from that state.
 #include "pfx_internal.h"
 #include "pfx_rowasm.h"
+#include "pfx_psd.h"
 
 namespace
 {
@@ -363,6 +364,17 @@ namespace
 		else
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, false>{ctx->d_estate, ctx->d_tab}, false);
 	}
+	template <int NLOC, int NGLOC, int NPTS>
+	void launch_psd(pfx_ctx *ctx)
+	{
+		if (ctx->model == PFX_NEOHOOKEAN)
+			hipLaunchKernelGGL((k_project_psd<NLOC, nl_block<NLOC, NGLOC, NPTS, true>>), dim3((unsigned)ctx->n_el), dim3(64), 0, ctx->stream,
+							   nl_block<NLOC, NGLOC, NPTS, true>{ctx->d_estate, ctx->d_tab}, ctx->n_el, ctx->d_kloc);
+		else
+			hipLaunchKernelGGL((k_project_psd<NLOC, nl_block<NLOC, NGLOC, NPTS, false>>), dim3((unsigned)ctx->n_el), dim3(64), 0, ctx->stream,
+							   nl_block<NLOC, NGLOC, NPTS, false>{ctx->d_estate, ctx->d_tab}, ctx->n_el, ctx->d_kloc);
+		pfx_launch_assemble_rows<NLOC, 3>(ctx, staged_block<NLOC>{ctx->d_kloc}, false);
+	}
 } // namespace
 
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess)
@@ -426,6 +438,39 @@ pfx_status pfx_launch_rows_nl(pfx_ctx *ctx)
 		break;
 	case PFX_Q2HEX:
 		launch_rows<27, 8, 27>(ctx);
+		break;
+	default:
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: unsupported element kind");
+	}
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// global Hessian with every element Hessian projected to PSD (Assembler.cpp:554-555), from the state left by
+// pfx_launch_local_nl(..., hess = true)
+pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx)
+{
+	if (ctx->estate_kind != PFX_ESTATE_NL)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: element state missing");
+	if (ctx->kind == PFX_Q2HEX)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "project_to_psd is not implemented for Q2 hexahedra (81 x 81 element matrices)");
+	const int64_t need = ctx->n_el * (int64_t)(ctx->n_loc * (ctx->n_loc + 1) / 2) * 9;
+	if (ctx->kloc_count < need)
+	{
+		if (pfx_alloc(ctx, &ctx->d_kloc, need))
+			return PFX_ERR_HIP;
+		ctx->kloc_count = need;
+	}
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		launch_psd<4, 4, 1>(ctx);
+		break;
+	case PFX_P2TET:
+		launch_psd<10, 4, 6>(ctx);
+		break;
+	case PFX_Q1HEX:
+		launch_psd<8, 8, 1>(ctx);
 		break;
 	default:
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: unsupported element kind");

@@ -374,7 +374,8 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 				have_direction = true;
 				break;
 			}
-			if ((rc = pfx_hessian_dev(ctx, d_x)))
+			// assemble_hessian (:105-123): strategy 1 projects the element Hessians to PSD
+			if ((rc = strategy == 1 ? pfx_hessian_psd_dev(ctx, d_x) : pfx_hessian_dev(ctx, d_x)))
 				return finish(rc, ctx->err.c_str());
 			ctx->diag_shift = reg_weight;
 			hipLaunchKernelGGL(k_negate, dim3(NB), dim3(256), 0, st, S.g, n, S.w);

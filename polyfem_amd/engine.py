@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
+    "pfx_hessian_psd_dev",
 ]
 
 
@@ -101,6 +102,7 @@ def load():
         "pfx_energy_dev": [_vp, _vp, _vp],
         "pfx_gradient_dev": [_vp, _vp, _vp],
         "pfx_hessian_dev": [_vp, _vp],
+        "pfx_hessian_psd_dev": [_vp, _vp],
         "pfx_set_dirichlet": [_vp, _pi32, _i64],
         "pfx_get_reduced_csr": [_vp, _pi64, _pi64, _pi64, _pi32, _pd],
         "pfx_spmv": [_vp, _pd, _pd],
@@ -273,8 +275,11 @@ class Engine:
     def gradient_dev(self, d_u: int, d_g: int):
         self._ck(self.L.pfx_gradient_dev(self.h, _vp(d_u), _vp(d_g)))
 
-    def hessian_dev(self, d_u: int):
-        self._ck(self.L.pfx_hessian_dev(self.h, _vp(d_u)))
+    def hessian_dev(self, d_u: int, project_to_psd: bool = False):
+        if project_to_psd:
+            self._ck(self.L.pfx_hessian_psd_dev(self.h, _vp(d_u)))
+        else:
+            self._ck(self.L.pfx_hessian_dev(self.h, _vp(d_u)))
 
     # ---- Dirichlet ---------------------------------------------------------------------------------------
     def set_dirichlet(self, sorted_dofs):

@@ -167,6 +167,43 @@ def test_mass_matrix_and_body_force(eng, oracle, name, size):
     assert rel_err(eng.get_linear_csr()[2], k_ref[2]) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1"])
+def test_hessian_project_to_psd(eng, oracle, name):
+    """assemble_hessian(project_to_psd = true): element Hessians projected onto the PSD cone (Assembler.cpp:554-555).
+    The eigen-solvers differ (Jacobi sweeps in different orders; the reference uses Eigen's), the projection is the
+    same: tolerance 1e-10 of the largest entry."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    nnz = _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    # a compression / stretch that makes many element Hessians indefinite
+    x = np.zeros(n)
+    x[0::3] = -0.35 * mesh.node_xyz[:, 0]
+    x[1::3] = 0.3 * mesh.node_xyz[:, 1]
+    x += M.seeded_displacement(mesh, 3, 2e-3)
+    v = eng.hessian(x)
+    vp = eng.hessian(x, project_to_psd=True)
+    ref = oracle.assemble_hessian_psd(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]
+    plain = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]
+    assert vp.size == nnz == ref.size
+    assert np.abs(plain - ref).max() > 1e-3 * np.abs(plain).max(), "test state is not indefinite anywhere"
+    assert rel_err(v, plain) <= TOL
+    assert np.abs(vp - ref).max() <= 1e-10 * np.abs(ref).max()
+    # the projected matrix is positive semi-definite
+    rp, ci = eng.get_pattern()
+    import scipy.sparse as sp
+    Hp = sp.csr_matrix((vp, ci, rp), shape=(n, n))
+    for seed in range(3):
+        z = np.random.default_rng(seed).standard_normal(n)
+        assert z @ (Hp @ z) >= -1e-9 * np.abs(vp).max() * (z @ z)
+    # at rest every element Hessian is PSD (its rigid modes have eigenvalue zero up to round-off): nothing to project
+    zero = np.zeros(n)
+    assert np.abs(eng.hessian(zero, project_to_psd=True) - eng.hessian(zero)).max() <= 1e-10 * np.abs(v).max()
+    # LinearElasticity through the same interface: PSD by construction
+    eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+    assert np.abs(eng.hessian(x, project_to_psd=True) - eng.hessian(x)).max() <= 1e-10 * np.abs(v).max()
+
+
 def test_hessian_pattern_reuse_is_deterministic(eng, oracle):
     """Newton steps reuse the pattern (SpareMatrixCache second pass == first pass) and repeated assemblies of
     the same state are bitwise identical (no atomics in the accumulation)."""
@@ -350,7 +387,10 @@ def test_newton_with_backtracking_matches_oracle(eng, oracle):
     eng.set_dirichlet(np.zeros(0, dtype=np.int32))
     assert info_ref["line_search_iterations"] > 3 * info_ref["iterations"]
     assert info["iterations"] == info_ref["iterations"] and info["status"] == info_ref["status"]
-    assert info["line_search_iterations"] == info_ref["line_search_iterations"]
+    # the run passes through the projected-Newton fallback; near convergence "energy went up" is decided by the last
+    # bits of two energies, so the number of halvings may differ by a few evaluations
+    assert abs(info["line_search_iterations"] - info_ref["line_search_iterations"]) <= 0.1 * info_ref["line_search_iterations"]
+    assert info["line_search_iterations"] > 3 * info["iterations"]
     assert np.abs(x - x_ref).max() <= 1e-7 * np.abs(x_ref).max()
 
 
@@ -447,9 +487,6 @@ def test_error_behaviour_of_the_abi(oracle):
         with pytest.raises(E.PfxError) as ei:  # the linear assembler needs a linear model
             e2.assemble_linear()
         assert ei.value.code == -1
-        with pytest.raises(E.PfxError) as ei:
-            e2.hessian(np.zeros(n), project_to_psd=True)
-        assert ei.value.code == -3 and "project_to_psd" in str(ei.value)
         with pytest.raises(E.PfxError) as ei:  # Dirichlet dofs must be sorted, unique and in range
             e2.set_dirichlet(np.array([5, 3], dtype=np.int32))
         assert ei.value.code == -1

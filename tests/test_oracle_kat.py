@@ -387,3 +387,27 @@ def test_q2_generated_tables_against_tensor_products(oracle):
     for li in range(27):
         for lj in range(27):
             assert oracle.basis_value(3, li, nodes[lj]) == (1.0 if li == lj else 0.0)
+
+
+def test_project_to_psd_oracle(oracle):
+    """ipc::project_to_psd restated with Jacobi rotations: equals V max(D,0) V^T from LAPACK, leaves PSD matrices
+    untouched (bitwise), and the projected global Hessian of an indefinite state is positive semi-definite."""
+    rng = np.random.default_rng(0)
+    for n in (12, 24, 30, 81):
+        B = rng.standard_normal((n, n))
+        A = B + B.T
+        w, V = np.linalg.eigh(A)
+        ref = (V * np.maximum(w, 0)) @ V.T
+        assert np.abs(oracle.project_to_psd(A) - ref).max() <= 1e-12 * np.abs(ref).max()
+        S = B @ B.T
+        assert np.array_equal(oracle.project_to_psd(S), S)
+    mesh = M.cube_tets(2, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    nd = mesh.n_nodes * 3
+    x = np.zeros(nd)
+    x[0::3] = -0.35 * mesh.node_xyz[:, 0]
+    x[1::3] = 0.3 * mesh.node_xyz[:, 1]
+    H = csc_to_scipy(oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x), nd).toarray()
+    Hp = csc_to_scipy(oracle.assemble_hessian_psd(mesh, oracle.NEOHOOKEAN, lam, mu, x, n_threads=3), nd).toarray()
+    assert np.linalg.eigvalsh(H)[0] < -1.0
+    assert np.linalg.eigvalsh(Hp)[0] > -1e-9 * np.abs(Hp).max()
