@@ -44,6 +44,16 @@ def assembly_bytes(n_el, n_loc, n_gloc, n_gnodes, n_nodes, nnz, nonlinear):
     return b
 
 
+def assembly_flops(n_el, n_loc, n_pts, nonlinear):
+    """FP64 operations of one row-owner assembly: every (element, i, j) contribution is evaluated once, i.e. each pair
+    for both of its blocks.  Per quadrature point (counted from the kernels' source, a multiply-add = 2): linear
+    elasticity 94 (separate multiplies and adds, the path is compiled without contraction), NeoHookean 150."""
+    return float(n_el) * n_loc * n_loc * n_pts * (150.0 if nonlinear else 94.0)
+
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (multiply-add), the rate the assembly kernels can use
+
+
 def cpu_baseline(args, oracle, M):
     """Oracle on a bounded sample of the same workload, on this host's cores."""
     n = args.cpu_n
@@ -218,6 +228,7 @@ def main():
     sb = spmv_bytes(inf.nnz, inf.n_blocks, inf.n_nodes, n)
     ab = assembly_bytes(inf.n_el, inf.n_loc, 4, mesh.xyz.shape[0], inf.n_nodes, inf.nnz, nonlinear)
     spmv_gbs = sb / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    af = assembly_flops(inf.n_el, inf.n_loc, inf.n_pts, nonlinear)
     asm_ms = loc_ms + gat_ms
     asm_gbs = ab / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0
 
@@ -256,7 +267,11 @@ def main():
             "assembly": {"elements_per_s": world * owned_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
                          "gather_ms": gat_ms, "solver_copy_ms": conv_ms,
                          "roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": asm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": ab}},
+                                      "frac": asm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": ab},
+                         "roofline_fp64": {"bound": "fp64 valu", "achieved": af / (asm_ms * 1e-3) / 1e12 if asm_ms > 0 else 0.0,
+                                           "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": af / (asm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if asm_ms > 0 else 0.0,
+                                           "flops": af}},
             "cg": {"update_ms": upd_ms, "direction_ms": dir_ms, "spmv_ms": spmv_ms,
                    "ms_per_iter": spmv_ms + upd_ms + dir_ms},
             "pattern_build_s": t_pattern,
