@@ -510,3 +510,35 @@ def test_error_behaviour_of_the_abi(oracle):
         assert ei.value.code == -1
     finally:
         e2.close()
+
+
+def test_isolated_nodes_and_single_element(eng, oracle):
+    """Ragged input: basis indices that no element uses (empty rows / columns) and a mesh of a single element."""
+    import copy
+    base = M.cube_tets(1, 2)
+    mesh = copy.copy(base)
+    mesh.n_nodes = base.n_nodes + 3  # three unused trailing basis indices
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and rel_err(v, vals) <= TOL
+    n = mesh.n_nodes * 3
+    assert rp.size == n + 1 and np.all(np.diff(rp)[-9:] == 0)
+    x = np.random.default_rng(0).standard_normal(n)
+    y = eng.spmv(x)
+    assert not y[-9:].any() and rel_err(y, oracle.spmv((outer, inner, vals), x)) <= TOL
+    # CG: the empty rows have a zero diagonal (Jacobi uses 1 there) and a zero right-hand side
+    bnd = np.concatenate([M.boundary_dofs(base, 3, "x0"), np.arange(n - 9, n)]).astype(np.int32)
+    eng.set_dirichlet(bnd)
+    b = np.random.default_rng(1).standard_normal(n)
+    xs, it, err = eng.cg(b, None, E.PRECOND_JACOBI, 500, 1e-12)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert err <= 1e-10 and not xs[bnd].any()
+    one = copy.copy(base)
+    one.conn, one.gconn = base.conn[:1].copy(), base.gconn[:1].copy()
+    _setup(eng, one, E.NEOHOOKEAN, lam, mu)
+    u = np.random.default_rng(3).standard_normal(one.n_nodes * 3) * 1e-3
+    assert rel_err(eng.hessian(u), oracle.assemble_hessian(one, oracle.NEOHOOKEAN, lam, mu, u)[2]) <= TOL
+    assert rel_err(eng.gradient(u), oracle.assemble_gradient(one, oracle.NEOHOOKEAN, lam, mu, u)) <= TOL
