@@ -259,6 +259,17 @@ pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal);
 pfx_status pfx_cgs_direction(pfx_ctx *ctx, int it, const double *d_scal);
 pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);
 
+/* Pieces a Newton iteration over the partition needs beside the step functions (the serial counterpart is
+ * pfx_newton_solve_dev; the distributed driver is polyfem_amd.distributed.DistributedNewton):
+ * pfx_set_diag_shift: from now on pfx_spmv*, pfx_cg* and the step functions work with A + shift * I on the free dofs --
+ *   the regularised Hessian `hessian += reg_weight * sparse_identity` of SparseNewtonDescentSolver.tpp:116-121 without
+ *   touching the assembled values.  shift = 0 switches it off.
+ * pfx_take_numeric_flag: *flag = 1 if an element had a non-positive deformation-gradient determinant in any
+ *   pfx_*_dev evaluation since the last call (the host variants report that as PFX_ERR_NUMERIC themselves); clears
+ *   the flag.  Synchronises the stream. */
+pfx_status pfx_set_diag_shift(pfx_ctx *ctx, double shift);
+pfx_status pfx_take_numeric_flag(pfx_ctx *ctx, int *flag);
+
 /* ---- introspection for benchmarks ----------------------------------------------------------------------------- */
 
 typedef struct

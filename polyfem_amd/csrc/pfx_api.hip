@@ -648,6 +648,25 @@ extern "C"
 		return PFX_OK;
 	}
 
+	pfx_status pfx_set_diag_shift(pfx_ctx *ctx, double shift)
+	{
+		if (!ctx || !(shift >= 0.0))
+			return PFX_ERR_ARG;
+		ctx->diag_shift = shift;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_take_numeric_flag(pfx_ctx *ctx, int *flag)
+	{
+		if (!ctx || !flag)
+			return PFX_ERR_ARG;
+		PFX_HIP(hipMemcpyAsync(flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		if (*flag)
+			PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->stream));
+		return PFX_OK;
+	}
+
 	void pfx_newton_default_params(pfx_newton_params *p)
 	{
 		if (!p)

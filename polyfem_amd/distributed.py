@@ -267,6 +267,27 @@ class HipOps:
     def status(self):
         return self.e.cgs_status()
 
+    # ---- nonlinear pieces (DistributedNewton) ----
+    def energy(self, x, out):
+        """out[0] = energy of the elements this rank sums (pfx_set_owned's flags)."""
+        self.e.energy_dev(x.data_ptr(), out.data_ptr())
+
+    def gradient(self, x, g):
+        self.e.gradient_dev(x.data_ptr(), g.data_ptr())
+
+    def hessian(self, x, project_to_psd):
+        self.e.hessian_dev(x.data_ptr(), project_to_psd)
+
+    def apply(self, v, y):
+        """y[owned rows] = (A + shift I) v with the Dirichlet rows replaced by identity; v needs a current halo."""
+        self.e.spmv_dev(v.data_ptr(), y.data_ptr())
+
+    def set_diag_shift(self, shift):
+        self.e.set_diag_shift(shift)
+
+    def clear_numeric_flag(self):
+        self.e.take_numeric_flag()
+
 
 class DistributedCG:
     """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition."""
@@ -310,3 +331,255 @@ class DistributedCG:
         if max_iter <= 0:
             done, iters, rr, bb = ops.status()
         return iters, (0.0 if bb == 0.0 else float(np.sqrt(rr / bb)))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Newton's method over the partition
+# ------------------------------------------------------------------------------------------------------------
+
+
+class NewtonFailure(RuntimeError):
+    """Raised where the reference's nonlinear solver throws; `info` holds the state reached."""
+
+    def __init__(self, msg, info):
+        super().__init__(msg)
+        self.info = info
+
+
+NEWTON_DEFAULTS = dict(f_delta=1e-10, grad_norm=1e-8, first_grad_norm_tol=1e-10, use_grad_norm_tol=1e-4,
+                       max_iterations=1000, use_grad_norm=1, relative_gradient=0, line_search=1, cg_precond=1,
+                       cg_max_iter=1000, cg_tol=1e-12, cg_check_every=25)
+
+CONTINUE, ITERATION_LIMIT, F_DELTA, GRAD_NORM, NOT_STARTED, FAILED = range(6)
+
+
+class DistributedNewton:
+    """cppoptlib::NonlinearSolver::minimize with SparseNewtonDescentSolver and BacktrackingLineSearch
+    (src/polyfem/solver/NonlinearSolver.tpp:33-275, SparseNewtonDescentSolver.tpp:40-193,
+    line_search/BacktrackingLineSearch.hpp:29-255, LineSearch.tpp:90-145) on E(x) - rhs.x, every vector distributed
+    by node rows.  Same control flow as the single-GPU pfx_newton_solve_dev (polyfem_amd/csrc/pfx_newton.hip); the
+    differences are where the numbers come from:
+
+      * energy: every rank sums its own elements, one all-reduce of (energy, rhs.x) per evaluation;
+      * gradient / Hessian: owned rows are complete after the local assembly -- no communication;
+      * linear solve: DistributedCG; afterwards ONE halo exchange of the direction, so that every trial point
+        x + a dx of the line search is consistent on the halo without further exchanges;
+      * norms and dot products: local over the owned dofs, all-reduced (batched into one small tensor per step).
+
+    All ranks take the same branches because every decision is made on all-reduced scalars.
+    """
+
+    def __init__(self, ops, part: Part, bs: int, comm: Comm, device, fixed_dofs_local):
+        import torch
+        self.torch, self.ops, self.part, self.bs, self.comm, self.device = torch, ops, part, bs, comm, device
+        self.cg = DistributedCG(ops, part, bs, comm, device)
+        self.n = part.n_local * bs
+        self.no = part.n_owned * bs
+        fixed = np.zeros(self.n, dtype=bool)
+        fixed[np.asarray(fixed_dofs_local, dtype=np.int64)] = True
+        self.fixed = torch.from_numpy(fixed[:self.no].copy()).to(device)
+        z = lambda k: torch.zeros(k, dtype=torch.float64, device=device)  # noqa: E731
+        self.g, self.dx, self.xn, self.w, self.gls = z(self.n), z(self.n), z(self.n), z(self.n), z(self.n)
+        self.e1 = z(1)
+        self.red = z(4)
+
+    # -- reductions over the ranks: sums in red[0:2], maximum in red[2]
+    def _sums(self, *vals):
+        t, red = self.torch, self.red
+        k = len(vals)
+        t.stack(vals, out=red[:k]) if k > 1 else red[:1].copy_(vals[0].reshape(1))
+        self.comm.all_reduce_sum(red[:k])
+        return [float(v) for v in red[:k].tolist()]
+
+    def _max(self, val):
+        """Maximum over the ranks of a non-negative local value; nan if it is nan anywhere (MAX reductions may drop it)."""
+        r = self.red[2:4]
+        r[0] = self.torch.nan_to_num(val, nan=0.0)
+        r[1] = self.torch.isnan(val).to(r.dtype)
+        if self.comm.on:
+            if self.comm.stage_cpu and r.is_cuda:
+                c = r.cpu()
+                self.comm.dist.all_reduce(c, op=self.comm.dist.ReduceOp.MAX)
+                r.copy_(c)
+            else:
+                self.comm.dist.all_reduce(r, op=self.comm.dist.ReduceOp.MAX)
+        m, bad = r.tolist()
+        return float("nan") if bad else float(m)
+
+    # -- NLProblem::value (solver/NLProblem.cpp:79-88): nan/inf when an element is inverted anywhere
+    def _value(self, x):
+        no = self.no
+        self.ops.energy(x, self.e1)
+        rx = (self.rhs[:no] @ x[:no]) if self.rhs is not None else self.torch.zeros((), dtype=x.dtype, device=x.device)
+        e, d = self._sums(self.e1[0], rx)
+        self.info["objective_evaluations"] += 1
+        return e - d if np.isfinite(e) else float("nan")
+
+    # -- NLProblem::gradient (:90-99) restricted to the free dofs; returns its squared norm
+    def _gradient(self, x, out):
+        no = self.no
+        self.ops.gradient(x, out)
+        if self.rhs is not None:
+            out[:no] -= self.rhs[:no]
+        out[:no].masked_fill_(self.fixed, 0.0)
+        out[no:] = 0.0
+        (n2,) = self._sums(out[:no] @ out[:no])
+        return n2
+
+    def _line_search(self, x, par):
+        """BacktrackingLineSearch::line_search without contact; nan on failure."""
+        info, t = self.info, self.torch
+        max_it, cur = 100, 0
+        old_in = self._value(x)
+        info["line_search_iterations"] += 1
+        if np.isnan(old_in):
+            return float("nan")
+        step = 1.0
+        t.add(x, self.dx, alpha=step, out=self.xn)
+        while step > 0 and cur < max_it:
+            e = self._value(self.xn)
+            info["line_search_iterations"] += 1
+            if np.isfinite(e):
+                break
+            step *= 0.5
+            t.add(x, self.dx, alpha=step, out=self.xn)
+            cur += 1
+        if cur >= max_it or step <= 0:
+            return float("nan")
+        gn2 = self._gradient(x, self.gls)
+        use_gn = np.sqrt(gn2) < par["use_grad_norm_tol"]
+        old = gn2 if use_gn else old_in
+        while step > 0 and cur < max_it:
+            t.add(x, self.dx, alpha=step, out=self.xn)
+            c = self._gradient(self.xn, self.gls) if use_gn else self._value(self.xn)
+            info["line_search_iterations"] += 1
+            if np.isfinite(c) and not c > old:
+                break
+            step /= 2.0
+            cur += 1
+        if cur >= max_it or step <= 0:
+            return float("nan")
+        return step
+
+    @staticmethod
+    def _check(par, iterations, f_delta, grad_norm, grad_tol):
+        if par["max_iterations"] > 0 and iterations > par["max_iterations"]:
+            return ITERATION_LIMIT
+        if par["f_delta"] > 0 and f_delta < par["f_delta"]:
+            return F_DELTA
+        if grad_tol > 0 and grad_norm < grad_tol:
+            return GRAD_NORM
+        return CONTINUE
+
+    def solve(self, x, rhs=None, **params):
+        """x: local vector [owned | halo] of n_local*bs doubles, starting point in, minimiser out (the halo part is
+        kept current); rhs: local vector or None.  Returns the info dict; raises NewtonFailure where the reference
+        throws."""
+        par = dict(NEWTON_DEFAULTS)
+        for k in params:
+            if k not in par:
+                raise TypeError(f"unknown Newton parameter {k!r}")
+        par.update(params)
+        ops, t, no, bs = self.ops, self.torch, self.no, self.bs
+        nl = self.part.n_local
+        self.rhs = rhs
+        info = self.info = dict(status=CONTINUE, iterations=0, line_search_iterations=0, descent_strategy=0,
+                                cg_iterations=0, energy=float("nan"), grad_norm=0.0, objective_evaluations=0)
+        self.dx.zero_()
+        self.cg.halo(x.view(nl, bs))
+        ops.clear_numeric_flag()
+        strategy, reg = 0, 0.0
+        reg_min, reg_max, reg_inc, reg_dec = 1e-8, 1e8, 10.0, 2.0
+
+        def increase():
+            nonlocal strategy, reg
+            if strategy == 0 or reg > reg_max:
+                strategy += 1
+            else:
+                reg = max(reg_inc * reg, reg_min)
+
+        def fail(msg, status=FAILED):
+            ops.set_diag_shift(0.0)
+            ops.clear_numeric_flag()
+            info["status"] = status
+            raise NewtonFailure(msg, info)
+
+        first = float(np.sqrt(self._gradient(x, self.g)))
+        grad_norm = first
+        if np.isnan(first):
+            fail("Gradient is nan; stopping")
+        info["grad_norm"] = first
+        if self._check(par, 0, float("nan"), first / (first if par["relative_gradient"] else 1.0),
+                       par["first_grad_norm_tol"]) != CONTINUE:
+            info["energy"] = self._value(x)
+            info["status"] = NOT_STARTED
+            ops.clear_numeric_flag()
+            return info
+
+        old_energy, status, iterations = float("nan"), CONTINUE, 0
+        while True:
+            energy = info["energy"] = self._value(x)
+            if not np.isfinite(energy):
+                fail("f(x) is nan or inf; stopping")
+            grad_norm = info["grad_norm"] = float(np.sqrt(self._gradient(x, self.g)))
+            if np.isnan(grad_norm):
+                fail("Gradient is nan; stopping")
+            # ---- compute_update_direction ----
+            while True:
+                if strategy > 2:
+                    fail("no descent direction found")
+                if strategy == 2:
+                    t.neg(self.g, out=self.dx)
+                    self.cg.halo(self.dx.view(nl, bs))
+                    (dg,) = self._sums(self.dx[:no] @ self.g[:no])
+                    dx_max = self._max(self.dx[:no].abs().max())
+                    break
+                ops.hessian(x, strategy == 1)
+                ops.set_diag_shift(reg)
+                t.neg(self.g, out=self.w)
+                its, _ = self.cg.solve(self.w, self.dx, par["cg_precond"], par["cg_max_iter"], par["cg_tol"],
+                                       par["cg_check_every"])
+                info["cg_iterations"] += its
+                self.cg.halo(self.dx.view(nl, bs))
+                # check_direction: || H dx + g || and g.dx
+                ops.apply(self.dx, self.w)
+                rres = self.w[:no] + self.g[:no]
+                r2, dg = self._sums(rres @ rres, self.dx[:no] @ self.g[:no])
+                dx_max = self._max(self.dx[:no].abs().max())
+                ops.set_diag_shift(0.0)
+                residual = np.sqrt(r2)
+                if np.isnan(residual) or residual > max(1e-8 * grad_norm, 1e-5) or dg >= 0:
+                    increase()
+                    continue
+                reg /= reg_dec
+                if reg < reg_min:
+                    reg = 0.0
+                break
+            if (grad_norm != 0 and dg >= 0) or np.isnan(dx_max):
+                increase()
+                status = CONTINUE
+                continue
+            cur = grad_norm / (first if par["relative_gradient"] else 1.0) if par["use_grad_norm"] else dx_max
+            status = self._check(par, iterations, abs(old_energy - energy), cur, par["grad_norm"])
+            old_energy = energy
+            rate = 1.0
+            if par["line_search"]:
+                rate = self._line_search(x, par)
+                if np.isnan(rate):
+                    if strategy < 2:
+                        increase()
+                        status = CONTINUE
+                        continue
+                    fail("Line search failed on gradient descent")
+            x.add_(self.dx, alpha=rate)  # halo included: dx carries a current halo
+            info["descent_strategy"] = strategy
+            strategy = 0
+            iterations += 1
+            info["iterations"] = iterations
+            if status != CONTINUE:
+                break
+        info["status"] = status
+        ops.clear_numeric_flag()
+        if status == ITERATION_LIMIT:
+            fail("Reached iteration limit", ITERATION_LIMIT)
+        return info

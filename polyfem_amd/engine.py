@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
-    "pfx_hessian_psd_dev",
+    "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag",
 ]
 
 
@@ -129,6 +129,8 @@ def load():
         "pfx_assemble_mass": [_vp, _dbl, _pd],
         "pfx_assemble_rhs": [_vp, _pd, _dbl, _pd, _pd],
         "pfx_assemble_rhs_dev": [_vp, _pd, _dbl, _pd, _vp],
+        "pfx_set_diag_shift": [_vp, _dbl],
+        "pfx_take_numeric_flag": [_vp, C.POINTER(C.c_int)],
         "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_newton_solve_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
     }
@@ -374,6 +376,16 @@ class Engine:
         else:
             f = np.ascontiguousarray(elem_owned, dtype=np.uint8)
             self._ck(self.L.pfx_set_owned(self.h, n_owned_nodes, f.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def set_diag_shift(self, shift: float):
+        """The solver side works with A + shift * I on the free dofs until set back to 0."""
+        self._ck(self.L.pfx_set_diag_shift(self.h, float(shift)))
+
+    def take_numeric_flag(self) -> bool:
+        """True if a *_dev evaluation met an inverted element since the last call; clears the flag."""
+        f = C.c_int(0)
+        self._ck(self.L.pfx_take_numeric_flag(self.h, C.byref(f)))
+        return bool(f.value)
 
     def cgs_set_workspace(self, d_work: int):
         self._ck(self.L.pfx_cgs_set_workspace(self.h, _vp(d_work) if d_work else None))

@@ -15,6 +15,7 @@ class OracleOps:
         self.no = n_owned_dofs
         self.fixed = np.asarray(fixed_local[:n_owned_dofs], dtype=bool)
         self.state = dict(abs_new=[0.0, 0.0], rr=0.0, thr=0.0, bb=0.0, done=False, iters=0)
+        self.shift = 0.0
 
     def set_workspace(self, work):
         n = work.numel() // 4
@@ -22,14 +23,14 @@ class OracleOps:
         self.r, self.p, self.tmp, self.invdiag = w[0:n], w[n:2 * n], w[2 * n:3 * n], w[3 * n:4 * n]
 
     def _apply(self, v):
-        y = self.A @ v
+        y = self.A @ v + self.shift * v[:self.no]
         y[self.fixed] = v[:self.no][self.fixed]
         return y
 
     def prepare(self, x, precond):
         xv = x.numpy()
         xv[:self.no][self.fixed] = 0.0
-        d = self.A.diagonal() if precond else np.ones(self.no)
+        d = self.A.diagonal() + self.shift if precond else np.ones(self.no)
         inv = np.ones(self.no)
         nz = (d != 0) & ~self.fixed
         inv[nz] = 1.0 / d[nz]
@@ -99,6 +100,43 @@ class OracleOps:
     def status(self):
         st = self.state
         return st["done"], st["iters"], st["rr"], st["bb"]
+
+
+class OracleNLOps(OracleOps):
+    """OracleOps plus the nonlinear pieces polyfem_amd.distributed.DistributedNewton asks of its back end, computed by
+    the oracle on the rank's local mesh (energy: on the sub-mesh of the elements the rank sums)."""
+
+    def __init__(self, part, model, lam, mu, fixed_local):
+        import dataclasses
+        from oracle import pf_oracle as O
+        self.O, self.part, self.model, self.lam, self.mu = O, part, model, lam, mu
+        self.nloc = part.n_local * 3
+        keep = part.elem_owned.astype(bool)
+        m = part.mesh
+        self.own_mesh = dataclasses.replace(m, conn=np.ascontiguousarray(m.conn[keep]), gconn=np.ascontiguousarray(m.gconn[keep]))
+        empty = sp.csr_matrix((self.nloc, self.nloc))
+        super().__init__(empty, part.n_owned * 3, fixed_local)
+        self.hessians = 0
+
+    def energy(self, x, out):
+        out.numpy()[0] = self.O.assemble_energy(self.own_mesh, self.model, self.lam, self.mu, x.numpy())
+
+    def gradient(self, x, g):
+        g.numpy()[:] = self.O.assemble_gradient(self.part.mesh, self.model, self.lam, self.mu, x.numpy())
+
+    def hessian(self, x, project_to_psd):
+        f = self.O.assemble_hessian_psd if project_to_psd else self.O.assemble_hessian
+        self.A = csc_tuple_to_csr(f(self.part.mesh, self.model, self.lam, self.mu, x.numpy()), self.nloc)[:self.no]
+        self.hessians += 1
+
+    def apply(self, v, y):
+        y.numpy()[:self.no] = self._apply(v.numpy())
+
+    def set_diag_shift(self, shift):
+        self.shift = float(shift)
+
+    def clear_numeric_flag(self):
+        pass
 
 
 def csc_tuple_to_csr(csc, n):

@@ -117,3 +117,81 @@ def test_slab_partition_matches_generic():
         assert part.elem_owned.sum() == ref.elem_owned.sum()
         step_bounds = bounds
     assert step_bounds[-1] == n_nodes
+
+
+def _newton_worker(rank, world, port, case, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pf_oracle as O
+        from tests.dist_helpers import OracleNLOps
+        mesh = M.cube_tets(3, 1, jitter=0.1)
+        lam, mu = O.lame(2e4, 0.3)
+        n_glob = mesh.n_nodes * 3
+        bd = M.boundary_dofs(mesh, 3, "x0")
+        rhs_g = np.zeros(n_glob)
+        if case == "soft":
+            rhs_g[2::3] = -50.0 / mesh.n_nodes      # full Newton steps
+        else:
+            rhs_g[0::3] = -2e4 / mesh.n_nodes       # compression: the line search has to backtrack
+        bounds = D.owner_ranges(mesh.n_nodes, world)
+        part = D.partition(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds, rank, mesh.node_xyz)
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * 3 + np.arange(3)[None]).reshape(-1)
+        fixed_g = np.zeros(n_glob, dtype=bool)
+        fixed_g[bd] = True
+        fixed_l = np.nonzero(fixed_g[dof_l2g])[0]
+        ops = OracleNLOps(part, O.NEOHOOKEAN, lam, mu, fixed_g[dof_l2g])
+        newton = D.DistributedNewton(ops, part, 3, D.Comm(), torch.device("cpu"), fixed_l)
+        x = torch.zeros(part.n_local * 3, dtype=torch.float64)
+        info = newton.solve(x, torch.from_numpy(rhs_g[dof_l2g].copy()), cg_check_every=9)
+        no = part.n_owned * 3
+        xs = [None] * world
+        dist.all_gather_object(xs, (int(part.lo), x.numpy()[:no].copy()))
+        xg = np.zeros(n_glob)
+        for lo, v in xs:
+            xg[lo * 3: lo * 3 + v.size] = v
+        assert np.array_equal(x.numpy(), xg[dof_l2g]), "the halo of the iterate must be current on return"
+        infos = [None] * world
+        dist.all_gather_object(infos, {k: info[k] for k in ("status", "iterations", "line_search_iterations", "cg_iterations")})
+        assert all(i == infos[0] for i in infos), "all ranks must take the same decisions"
+        if rank == 0:
+            xr, iref = O.newton_solve(mesh, O.NEOHOOKEAN, lam, mu, rhs_g, bd, np.zeros(n_glob))
+            ret["info"], ret["iref"] = dict(info), iref
+            ret["dx"] = float(np.abs(xg - xr).max() / np.abs(xr).max())
+            ret["hessians"] = ops.hessians
+        # not started: zero load at rest
+        x.zero_()
+        info = newton.solve(x, None)
+        assert info["status"] == D.NOT_STARTED and info["iterations"] == 0
+        # iteration limit -> the reference throws
+        x.zero_()
+        try:
+            newton.solve(x, torch.from_numpy(rhs_g[dof_l2g].copy()), max_iterations=1, f_delta=0.0, grad_norm=1e-300)
+            raised = False
+        except D.NewtonFailure as e:
+            raised = e.info["status"] == D.ITERATION_LIMIT
+        assert raised
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "soft"), (2, "backtrack"), (3, "backtrack")])
+def test_distributed_newton_gloo(world, case):
+    """DistributedNewton over 2 and 3 gloo ranks (oracle arithmetic per rank) against the serial restatement of the
+    reference's Newton solver: same status, iteration and line-search counts, same minimiser."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_newton_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    assert all(ret.get(f"ok{r}") for r in range(world))
+    info, iref = ret["info"], ret["iref"]
+    assert info["status"] == iref["status"] and info["status"] in (D.F_DELTA, D.GRAD_NORM)
+    assert info["iterations"] == iref["iterations"]
+    assert info["line_search_iterations"] == iref["line_search_iterations"]
+    if case == "backtrack":
+        assert info["line_search_iterations"] > 3 * info["iterations"]
+    assert abs(info["cg_iterations"] - iref["cg_iterations"]) <= max(3 * info["iterations"], 0.03 * iref["cg_iterations"])
+    assert abs(info["energy"] - iref["energy"]) <= 1e-9 * abs(iref["energy"])
+    assert ret["dx"] <= 1e-8

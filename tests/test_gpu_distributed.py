@@ -109,3 +109,87 @@ def test_two_ranks_on_one_gpu_match_single_engine():
     assert np.abs(gg - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
     assert abs(iters - it_ref) <= 2 and err < 1e-11
     assert np.abs(xg - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+
+
+def _newton_case(n_nodes, node_xyz):
+    """Load and constraint of the Newton test in global numbering: x = 0 face clamped, compression along x."""
+    fixed = np.nonzero(np.abs(node_xyz[:, 0]) < 1e-12)[0]
+    rhs = np.zeros(n_nodes * 3)
+    rhs[0::3] = -6e3 / n_nodes
+    return fixed, rhs
+
+
+def _newton_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        part, bounds, n_nodes = D.slab_part(4, 2, rank, world, 2)
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.NEOHOOKEAN, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * 3 + np.arange(3)[None]).reshape(-1)
+        fixed_l, _ = _newton_case(part.n_local, part.mesh.node_xyz)
+        fixed_dofs = np.sort((fixed_l[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32)
+        eng.set_dirichlet(fixed_dofs)
+        rhs_g = np.zeros(n_nodes * 3)
+        rhs_g[0::3] = -6e3 / n_nodes
+        newton = D.DistributedNewton(D.HipOps(eng), part, 3, D.Comm(), dev, fixed_dofs)
+        x = torch.zeros(part.n_local * 3, dtype=torch.float64, device=dev)
+        info = newton.solve(x, torch.from_numpy(rhs_g[dof_l2g]).to(dev), cg_check_every=16)
+        torch.cuda.synchronize()
+        assert not eng.take_numeric_flag(), "the driver must leave the numeric flag cleared"
+        no = part.n_owned * 3
+        out = [None] * world
+        dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no]))
+        xg = np.zeros(n_nodes * 3)
+        for lo, xv in out:
+            xg[lo * 3: lo * 3 + xv.size] = xv
+        assert np.array_equal(x.cpu().numpy(), xg[dof_l2g]), "halo of the iterate must be current"
+        if rank == 0:
+            ret["info"], ret["x"] = dict(info), xg
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_newton_two_ranks_match_single_engine():
+    """DistributedNewton (HIP kernels per rank, gloo between two ranks sharing the card) against the single-GPU
+    pfx_newton_solve on the whole mesh: same decisions, same minimiser."""
+    import torch.multiprocessing as mp
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_newton_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        info, xg = ret["info"], ret["x"]
+    part, bounds, n_nodes = D.slab_part(4, 4, 0, 1, 2)
+    eng = E.Engine(0)
+    eng.set_mesh(part.mesh)
+    eng.set_material(E.NEOHOOKEAN, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+    eng.build_pattern()
+    fixed, rhs = _newton_case(n_nodes, part.mesh.node_xyz)
+    eng.set_dirichlet(np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+    x_ref, iref = eng.newton_solve(np.zeros(n_nodes * 3), rhs)
+    eng.close()
+    assert info["status"] == iref["status"] and info["status"] in (D.F_DELTA, D.GRAD_NORM)
+    assert info["iterations"] == iref["iterations"] and info["iterations"] >= 2
+    assert info["line_search_iterations"] == iref["line_search_iterations"]
+    assert abs(info["cg_iterations"] - iref["cg_iterations"]) <= max(3 * info["iterations"], 0.03 * iref["cg_iterations"])
+    assert abs(info["energy"] - iref["energy"]) <= 1e-9 * abs(iref["energy"])
+    assert np.abs(xg - x_ref).max() <= 1e-8 * np.abs(x_ref).max()

@@ -234,6 +234,55 @@ def test_invalid_state_reports_numeric_error(eng, oracle):
     assert ei.value.code == -4
 
 
+def test_diag_shift_and_numeric_flag(eng, oracle):
+    """pfx_set_diag_shift: SpMV and CG work with A + shift I on the free dofs (the regularised Hessian of the Newton
+    solver) without touching the assembled values; pfx_take_numeric_flag reports and clears the inverted-element flag
+    of the device-pointer evaluations."""
+    import scipy.sparse as sp
+    import torch
+    mesh = M.cube_tets(3, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    u = M.seeded_displacement(mesh, 3, 2e-3, seed=5)
+    vals = eng.hessian(u).copy()
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    eng.set_dirichlet(bnd)
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    x = np.random.default_rng(0).standard_normal(n)
+    y0 = eng.spmv(x)
+    shift = 37.5
+    eng.set_diag_shift(shift)
+    try:
+        y1 = eng.spmv(x)
+        assert np.abs(y1 - (y0 + shift * np.where(free, x, 0.0))).max() <= 1e-12 * np.abs(y0).max()
+        assert np.array_equal(eng.get_values(), vals)
+        b = np.random.default_rng(1).standard_normal(n)
+        xs, its, err = eng.cg(b, None, E.PRECOND_JACOBI, 2000, 1e-12)
+        rp, ci = eng.get_pattern()
+        A = sp.csr_matrix((vals, ci, rp), shape=(n, n))
+        r = (A @ xs + shift * xs - b)[free]
+        assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b[free]) and err < 1e-11
+    finally:
+        eng.set_diag_shift(0.0)
+    assert np.array_equal(eng.spmv(x), y0)
+    with pytest.raises(E.PfxError):
+        eng.set_diag_shift(-1.0)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    # numeric flag
+    assert not eng.take_numeric_flag()
+    bad = np.zeros(n)
+    bad[0::3] = -5.0 * mesh.node_xyz[:, 0]
+    d_u = torch.from_numpy(bad).cuda()
+    d_e = torch.zeros(1, dtype=torch.float64, device="cuda")
+    eng.energy_dev(d_u.data_ptr(), d_e.data_ptr())
+    eng.synchronize()
+    assert not np.isfinite(d_e.item())
+    assert eng.take_numeric_flag() and not eng.take_numeric_flag()
+    assert abs(eng.energy(u) - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, u)) <= 1e-12 * abs(eng.energy(u))
+
+
 @pytest.mark.parametrize("case", ["laplace_p1", "elastic_p2", "neohookean_p2"])
 def test_reduced_matrix_and_cg(eng, oracle, case):
     if case == "laplace_p1":
