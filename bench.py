@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
     ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean", "newton"],
-                    help="newton: one step = a full NeoHookean Newton solve (gravity-like load, clamped x = 0 face), single GPU")
+                    help="newton: one step = a full NeoHookean Newton solve (gravity-like load, clamped x = 0 face)")
     ap.add_argument("--cg-max-iter", type=int, default=1000)
     ap.add_argument("--cg-tol", type=float, default=1e-12)
     ap.add_argument("--cpu-n", type=int, default=14)
@@ -122,8 +122,6 @@ def main():
     from polyfem_amd import distributed as D
 
     nonlinear = args.workload in ("neohookean", "newton")
-    if args.workload == "newton" and world > 1:
-        raise SystemExit("the newton workload is single-GPU")
     # weak scaling: the global grid is n x n x (n*world) cells; every rank owns the node planes of n cell layers
     # (plus one layer of its lower neighbour's elements, which it assembles redundantly instead of communicating)
     part, bounds, n_nodes_global = D.slab_part(args.n, args.n, rank, world, 2)
@@ -145,7 +143,8 @@ def main():
     inf = eng.info()
     eng.set_owned(part.n_owned, part.elem_owned)
     fixed_nodes = np.nonzero(np.abs(mesh.node_xyz[:, 0]) < 1e-12)[0]
-    eng.set_dirichlet(np.sort((fixed_nodes[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+    fixed_dofs = np.sort((fixed_nodes[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32)
+    eng.set_dirichlet(fixed_dofs)
 
     n = inf.n_dofs
     # torch owns the vectors; the engine enqueues on the same (non-default) stream, so no cross-stream syncs
@@ -169,13 +168,19 @@ def main():
     torch.cuda.synchronize()
 
     comm = D.Comm()
-    dcg = D.DistributedCG(D.HipOps(eng), part, 3, comm, dev) if world > 1 else None
+    dcg = D.DistributedCG(D.HipOps(eng), part, 3, comm, dev) if world > 1 and args.workload != "newton" else None
 
     newton_info = {}
     load = torch.zeros(n, dtype=torch.float64, device=dev)
-    load[2::3] = -50.0 / inf.n_nodes
+    load[2::3] = -50.0 / (n_nodes_global / world)
+    dnewton = (D.DistributedNewton(D.HipOps(eng), part, 3, comm, dev, fixed_dofs)
+               if world > 1 and args.workload == "newton" else None)
 
     def step():
+        if dnewton is not None:
+            x.zero_()
+            newton_info.update(dnewton.solve(x, load, cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol, cg_check_every=50))
+            return newton_info["cg_iterations"], newton_info["grad_norm"]
         if args.workload == "newton":
             x.zero_()
             newton_info.update(eng.newton_solve_dev(x.data_ptr(), load.data_ptr(), cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol))
