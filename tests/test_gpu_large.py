@@ -166,3 +166,59 @@ def test_config4_q2_hex_full_size_properties():
         assert abs(eng.energy(u) - (lam / 2 + mu) * a * a) <= 1e-10 * (lam / 2 + mu) * a * a
     finally:
         eng.close()
+
+
+def test_ten_million_p2_tets_on_one_gpu():
+    """10.1 M P2 tets (119^3 Kuhn grid, 41 M dofs, 3.5e9 non-zeros: past 2^31 entries, 30 GB of values) on ONE device,
+    through size-independent properties: NeoHookean at rest, null space and symmetry of the Hessian, agreement of the
+    row assembly with the element energy kernel, a closed-form energy and a finite-difference check."""
+    n_side = 119
+    mesh = M.cube_tets(n_side, 2)
+    assert mesh.n_el == 6 * n_side ** 3 == 10110954 and mesh.n_nodes == (2 * n_side + 1) ** 3
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        lam, mu = 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        nnz = eng.build_pattern()
+        assert nnz == 3505892805 and nnz > 2 ** 31
+        n = mesh.n_nodes * 3
+        zero = np.zeros(n)
+        assert abs(eng.energy(zero)) < 1e-6 and np.abs(eng.gradient(zero)).max() < 1e-9
+        eng.hessian(zero, fetch=False)
+        rng = np.random.default_rng(11)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        Ax, Ay = eng.spmv(x), eng.spmv(y)
+        scale = np.abs(Ax).max()
+        assert abs(y @ Ax - x @ Ay) <= 1e-11 * abs(y @ Ax)
+        for c in range(3):
+            t = np.zeros(n)
+            t[c::3] = 1.0
+            assert np.abs(eng.spmv(t)).max() <= 1e-10 * scale
+        rot = np.zeros(n)
+        rot[0::3], rot[1::3] = -mesh.node_xyz[:, 1], mesh.node_xyz[:, 0]
+        assert np.abs(eng.spmv(rot)).max() <= 1e-9 * scale
+        del Ay, y, rot
+        # Hessian at rest == linear elasticity: x^T H x = 2 * (linear-elastic energy of x), closed-form stretch energy
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        assert abs(x @ Ax - 2.0 * eng.energy(x)) <= 1e-10 * abs(x @ Ax)
+        a = 1e-3
+        u = np.zeros(n)
+        u[0::3] = a * mesh.node_xyz[:, 0]
+        assert abs(eng.energy(u) - (lam / 2 + mu) * a * a) <= 1e-10 * (lam / 2 + mu) * a * a
+        eng.assemble_linear()
+        assert np.abs(eng.spmv(x) - Ax).max() <= 1e-11 * scale
+        # deformed state: energy / gradient / Hessian agree by central differences along the gradient
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        u = M.seeded_displacement(mesh, 3, 1e-2 / n_side)
+        g = eng.gradient(u)
+        d = g / np.abs(g).max()
+        hh = 1e-6
+        fd = (eng.energy(u + hh * d) - eng.energy(u - hh * d)) / (2 * hh)
+        assert abs(fd - g @ d) <= 1e-5 * abs(g @ d)
+        eng.hessian(u, fetch=False)
+        Hd = eng.spmv(d)
+        gfd = (eng.gradient(u + hh * d) - eng.gradient(u - hh * d)) / (2 * hh)
+        assert np.linalg.norm(gfd - Hd) <= 1e-5 * np.linalg.norm(Hd)
+    finally:
+        eng.close()
