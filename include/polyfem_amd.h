@@ -224,6 +224,32 @@ pfx_status pfx_newton_solve(pfx_ctx *ctx, const double *rhs, double *x_inout, co
 pfx_status pfx_newton_solve_dev(pfx_ctx *ctx, const double *d_rhs, double *d_x_inout, const pfx_newton_params *params,
 								pfx_newton_info *info);
 
+/* ---- transient steps: inertia term and the implicit Euler integrator ----------------------------------------------
+ *
+ * The reference's transient nonlinear solve (state/StateSolveNonlinear.cpp:355-420) minimises, per time step,
+ *   acceleration_scaling * (ElasticForm(x) + BodyForm(x)) + InertiaForm(x),
+ *   InertiaForm(x) = 1/2 (x - x_tilde)^T M (x - x_tilde)          (solver/forms/InertiaForm.cpp:14-31)
+ * with the weights set at StateSolveNonlinear.cpp:78-84 and x_tilde / acceleration_scaling from the time integrator
+ * (ImplicitEuler: x_tilde = x_prev + dt v_prev, acceleration_scaling = dt^2, time_integrator/ImplicitEuler.cpp:13-33).
+ *
+ * pfx_inertia_set_mass  assembles the mass matrix (as pfx_assemble_mass does, leaving it as the context's matrix) and
+ *                       keeps it for the inertia term: one double per node block, since Mass::assemble puts the same
+ *                       rho phi_i phi_j on the three diagonal entries of a block.  Call again after pfx_build_pattern.
+ * pfx_inertia_enable    from now on pfx_newton_solve(_dev) minimises acceleration_scaling * (E(x) - rhs.x) +
+ *                       InertiaForm(x) with the device vector d_x_tilde (which must stay valid);
+ *                       acceleration_scaling <= 0 or d_x_tilde == NULL switches back to the static objective.
+ * pfx_implicit_euler_step(_dev)  one whole step: x_tilde from x (= x_prev on input) and v, Newton solve starting at
+ *                       x_prev as the reference does, then ImplicitEuler::update_quantities: v = (x - x_prev)/dt,
+ *                       a = (v - v_prev)/dt (a may be NULL).  rhs is the body-force vector of pfx_assemble_rhs
+ *                       (may be NULL); the dofs of pfx_set_dirichlet keep their incoming values.  Errors as
+ *                       pfx_newton_solve; on error v and a are left untouched. */
+pfx_status pfx_inertia_set_mass(pfx_ctx *ctx, double density, const double *density_e);
+pfx_status pfx_inertia_enable(pfx_ctx *ctx, double acceleration_scaling, const double *d_x_tilde);
+pfx_status pfx_implicit_euler_step(pfx_ctx *ctx, double dt, const double *rhs, double *x_inout, double *v_inout, double *a_out,
+								   const pfx_newton_params *params, pfx_newton_info *info);
+pfx_status pfx_implicit_euler_step_dev(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x_inout, double *d_v_inout,
+									   double *d_a_out, const pfx_newton_params *params, pfx_newton_info *info);
+
 /* ---- multi-GPU building blocks (no counterpart in the reference, which is single-process) -------------------------
  *
  * One process per GPU holds one part of a node partition: its mesh is every element that touches an owned node,

@@ -1919,7 +1919,61 @@ typedef struct
 	int64_t n;       /* full size */
 	uint8_t *fixed;  /* n */
 	int n_threads;
+	/* transient step: InertiaForm with this mass matrix and predictor, the other forms weighted (NULL / 1: static) */
+	const pfo_csc *mass;
+	const double *x_tilde;
+	double weight;
 } nl_problem;
+
+/* 1/2 d^T M d and (optionally) g += M d for d = x - x_tilde (solver/forms/InertiaForm.cpp:14-26) */
+static double inertia_terms(const nl_problem *p, const double *x, double *g_add)
+{
+	const int64_t n = p->n;
+	double *d = (double *)malloc(sizeof(double) * (size_t)n), *md = (double *)malloc(sizeof(double) * (size_t)n);
+	for (int64_t k = 0; k < n; ++k)
+		d[k] = x[k] - p->x_tilde[k];
+	pfo_spmv(p->mass, d, md);
+	const double prod = dot(d, md, n);
+	if (g_add)
+		for (int64_t k = 0; k < n; ++k)
+			g_add[k] += md[k];
+	free(d), free(md);
+	return 0.5 * prod;
+}
+
+/* out = a * A + B, both n x n column-compressed with ascending inner indices (the sum of the weighted forms' Hessians,
+ * solver/NLProblem.cpp hessian -> FullNLProblem: hessian += each form's second_derivative) */
+static int csc_scaled_sum(double a, const pfo_csc *A, const pfo_csc *B, pfo_csc *out)
+{
+	const int32_t n = A->n;
+	out->n = n;
+	out->outer = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+	out->inner = (int32_t *)malloc(sizeof(int32_t) * (size_t)(A->nnz + B->nnz + 1));
+	out->values = (double *)malloc(sizeof(double) * (size_t)(A->nnz + B->nnz + 1));
+	if (!out->outer || !out->inner || !out->values)
+		return -1;
+	int64_t w = 0;
+	for (int32_t c = 0; c < n; ++c)
+	{
+		out->outer[c] = (int32_t)w;
+		int32_t ia = A->outer[c], ib = B->outer[c];
+		const int32_t ea = A->outer[c + 1], eb = B->outer[c + 1];
+		while (ia < ea || ib < eb)
+		{
+			const int32_t ra = ia < ea ? A->inner[ia] : INT32_MAX, rb = ib < eb ? B->inner[ib] : INT32_MAX;
+			if (ra == rb)
+				out->inner[w] = ra, out->values[w] = a * A->values[ia++] + B->values[ib++];
+			else if (ra < rb)
+				out->inner[w] = ra, out->values[w] = a * A->values[ia++];
+			else
+				out->inner[w] = rb, out->values[w] = B->values[ib++];
+			++w;
+		}
+	}
+	out->outer[n] = (int32_t)w;
+	out->nnz = w;
+	return 0;
+}
 
 /* NLProblem::value (solver/NLProblem.cpp:79-83): elastic energy + body form -x.rhs on the full vector */
 static double nlp_value(const nl_problem *p, const double *x)
@@ -1927,6 +1981,8 @@ static double nlp_value(const nl_problem *p, const double *x)
 	double e = pfo_assemble_energy(p->mesh, p->mat, x, p->n_threads);
 	if (p->rhs)
 		e -= dot(x, p->rhs, p->n);
+	if (p->mass)
+		e = p->weight * e + inertia_terms(p, x, NULL);
 	return e;
 }
 
@@ -1934,13 +1990,18 @@ static double nlp_value(const nl_problem *p, const double *x)
 static void nlp_gradient(const nl_problem *p, const double *x, double *g)
 {
 	pfo_assemble_gradient(p->mesh, p->mat, x, p->n_threads, g);
-	for (int64_t k = 0; k < p->n; ++k)
-	{
-		if (p->rhs)
+	if (p->rhs)
+		for (int64_t k = 0; k < p->n; ++k)
 			g[k] -= p->rhs[k];
+	if (p->mass)
+	{
+		for (int64_t k = 0; k < p->n; ++k)
+			g[k] *= p->weight;
+		(void)inertia_terms(p, x, g);
+	}
+	for (int64_t k = 0; k < p->n; ++k)
 		if (p->fixed[k])
 			g[k] = 0;
-	}
 }
 
 /* cppoptlib checkConvergence (meta.h, un-vendored): iteration limit, then f delta, then gradient norm */
@@ -2019,8 +2080,17 @@ static double backtracking(const nl_problem *p, const double *x, const double *d
 int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double *rhs, const int32_t *boundary_nodes, int64_t n_boundary,
 					 double *x, const pfo_newton_params *par, int n_threads, pfo_newton_info *info)
 {
+	return pfo_newton_solve_inertia(mesh, mat, rhs, boundary_nodes, n_boundary, x, par, n_threads, info, NULL, NULL, 1.0);
+}
+
+int pfo_newton_solve_inertia(const pfo_mesh *mesh, const pfo_material *mat, const double *rhs, const int32_t *boundary_nodes, int64_t n_boundary,
+							 double *x, const pfo_newton_params *par, int n_threads, pfo_newton_info *info,
+							 const pfo_csc *mass, const double *x_tilde, double weight)
+{
 	const int64_t n = mesh->n_nodes * block_size(mat);
-	nl_problem P = {mesh, mat, rhs, boundary_nodes, n_boundary, n, NULL, n_threads < 1 ? 1 : n_threads};
+	nl_problem P = {mesh, mat, rhs, boundary_nodes, n_boundary, n, NULL, n_threads < 1 ? 1 : n_threads, mass, x_tilde, weight};
+	if (mass && (!x_tilde || mass->n != n))
+		return -1;
 	P.fixed = (uint8_t *)calloc((size_t)n, 1);
 	for (int64_t k = 0; k < n_boundary; ++k)
 		P.fixed[boundary_nodes[k]] = 1;
@@ -2088,6 +2158,17 @@ int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double
 			{
 				rc = -1;
 				goto cleanup;
+			}
+			if (mass)
+			{
+				pfo_csc Hs;
+				if (csc_scaled_sum(weight, &H, mass, &Hs))
+				{
+					rc = -1;
+					goto cleanup;
+				}
+				pfo_csc_free(&H);
+				H = Hs;
 			}
 			pfo_full_to_reduced_matrix(&H, boundary_nodes, n_boundary, &Hr);
 			pfo_csc_free(&H);

@@ -197,6 +197,12 @@ typedef struct
 void pfo_newton_default_params(pfo_newton_params *p);
 int pfo_newton_solve(const pfo_mesh *mesh, const pfo_material *mat, const double *rhs, const int32_t *boundary_nodes, int64_t n_boundary,
 					 double *x, const pfo_newton_params *params, int n_threads, pfo_newton_info *info);
+/* The same solve for one implicit time step: objective  weight * (E(x) - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde),
+ * i.e. ElasticForm and BodyForm weighted with the integrator's acceleration_scaling (state/StateSolveNonlinear.cpp:78-84)
+ * plus InertiaForm (solver/forms/InertiaForm.cpp:14-31).  mass == NULL gives pfo_newton_solve. */
+int pfo_newton_solve_inertia(const pfo_mesh *mesh, const pfo_material *mat, const double *rhs, const int32_t *boundary_nodes, int64_t n_boundary,
+							 double *x, const pfo_newton_params *params, int n_threads, pfo_newton_info *info,
+							 const pfo_csc *mass, const double *x_tilde, double weight);
 
 #ifdef __cplusplus
 }

@@ -352,9 +352,12 @@ class NewtonInfo(C.Structure):
 NEWTON_STATUS = ["continue", "iteration_limit", "f_delta", "grad_norm", "not_started", "failed"]
 
 
-def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int = 1, **params):
+def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int = 1, mass=None, x_tilde=None,
+                 weight: float = 1.0, **params):
     """cppoptlib NonlinearSolver::minimize with SparseNewtonDescentSolver + BacktrackingLineSearch, restated.
-    Returns (x, info dict).  `params` override the reference's defaults (f_delta, grad_norm, max_iterations, ...)."""
+    Returns (x, info dict).  `params` override the reference's defaults (f_delta, grad_norm, max_iterations, ...).
+    With `mass` (CSC tuple) and `x_tilde` the objective is weight * (E - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde)
+    (one implicit time step: InertiaForm + weighted ElasticForm / BodyForm)."""
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
     mat, _keep_mat = make_material(model, lam, mu)
     p = NewtonParams()
@@ -365,10 +368,31 @@ def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int =
     bn = np.ascontiguousarray(boundary_nodes, dtype=np.int32)
     r = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64)
     info = NewtonInfo()
-    rc = lib().pfo_newton_solve(C.byref(om.s), C.byref(mat), _dp(r) if r is not None else None, _ip(bn), C.c_int64(bn.size),
-                                _dp(x), C.byref(p), int(n_threads), C.byref(info))
+    if mass is None:
+        rc = lib().pfo_newton_solve(C.byref(om.s), C.byref(mat), _dp(r) if r is not None else None, _ip(bn), C.c_int64(bn.size),
+                                    _dp(x), C.byref(p), int(n_threads), C.byref(info))
+    else:
+        m, _keep = _numpy_to_csc(*mass)
+        xt = np.ascontiguousarray(x_tilde, dtype=np.float64)
+        rc = lib().pfo_newton_solve_inertia(C.byref(om.s), C.byref(mat), _dp(r) if r is not None else None, _ip(bn),
+                                            C.c_int64(bn.size), _dp(x), C.byref(p), int(n_threads), C.byref(info),
+                                            C.byref(m), _dp(xt), C.c_double(weight))
     assert rc == 0
     return x, {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
+
+
+def implicit_euler_step(mesh, model, lam, mu, rhs, boundary_nodes, mass, dt, x_prev, v_prev, n_threads: int = 1, **params):
+    """One step of the reference's transient nonlinear solve with the ImplicitEuler integrator
+    (time_integrator/ImplicitEuler.cpp:5-33): x_tilde = x_prev + dt v_prev, Newton from x_prev on the weighted objective
+    (acceleration_scaling = dt^2), then v = (x - x_prev)/dt, a = (v - v_prev)/dt.  Returns (x, v, a, info)."""
+    x_prev = np.asarray(x_prev, dtype=np.float64)
+    v_prev = np.asarray(v_prev, dtype=np.float64)
+    x_tilde = x_prev + dt * v_prev
+    x, info = newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x_prev, n_threads, mass=mass, x_tilde=x_tilde,
+                           weight=dt * dt, **params)
+    v = (x - x_prev) / dt
+    a = (v - v_prev) / dt
+    return x, v, a, info
 
 
 def assemble_mass(mesh, size: int, density=1.0, n_threads: int = 1):

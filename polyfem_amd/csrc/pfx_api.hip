@@ -80,6 +80,11 @@ namespace
 		ctx->part0_count = 0;
 		free_dev(ctx->d_newton);
 		ctx->newton_count = 0;
+		free_dev(ctx->d_mass_blk);
+		free_dev(ctx->d_tstep);
+		ctx->mass_count = ctx->tstep_count = 0;
+		ctx->inertia_weight = 0.0;
+		ctx->d_x_tilde = nullptr;
 		pfx_sell_release(ctx);
 		ctx->n_blocks = ctx->nnz = 0;
 		ctx->n_dirichlet = 0;
@@ -646,6 +651,89 @@ extern "C"
 		PFX_HIP(hipMemcpyAsync(y, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
+	}
+
+	pfx_status pfx_inertia_set_mass(pfx_ctx *ctx, double density, const double *density_e)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->bs != 3)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 3)");
+		pfx_status rc = pfx_assemble_mass(ctx, density, density_e);
+		if (rc)
+			return rc;
+		return pfx_capture_mass(ctx);
+	}
+
+	pfx_status pfx_inertia_enable(pfx_ctx *ctx, double acceleration_scaling, const double *d_x_tilde)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (!(acceleration_scaling > 0.0) || !d_x_tilde)
+		{
+			ctx->inertia_weight = 0.0;
+			ctx->d_x_tilde = nullptr;
+			return PFX_OK;
+		}
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->mass_count == 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
+		ctx->inertia_weight = acceleration_scaling;
+		ctx->d_x_tilde = d_x_tilde;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_implicit_euler_step_dev(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+										   const pfx_newton_params *params, pfx_newton_info *info)
+	{
+		if (!ctx || !d_x || !d_v || !params || !info)
+			return PFX_ERR_ARG;
+		if (!(dt > 0.0))
+			PFX_FAIL(PFX_ERR_ARG, "pfx_implicit_euler_step: dt must be positive");
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->mass_count == 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
+		if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_implicit_euler_step needs the LinearElasticity or NeoHookean model");
+		if (ctx->n_owned != ctx->n_nodes)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_implicit_euler_step works on an unpartitioned mesh");
+		PFX_HIP(hipSetDevice(ctx->device));
+		return pfx_implicit_euler_run(ctx, dt, d_rhs, d_x, d_v, d_a, params, info);
+	}
+
+	pfx_status pfx_implicit_euler_step(pfx_ctx *ctx, double dt, const double *rhs, double *x, double *v, double *a,
+									   const pfx_newton_params *params, pfx_newton_info *info)
+	{
+		if (!ctx || !x || !v || !params || !info)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const int64_t n = ctx->n_dofs();
+		double *d = nullptr;
+		PFX_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(4 * n)));
+		double *d_x = d, *d_v = d + n, *d_a = d + 2 * n, *d_rhs = rhs ? d + 3 * n : nullptr;
+		hipStream_t st = ctx->stream;
+		pfx_status rc = PFX_OK;
+		if (hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_v, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess || (rhs && hipMemcpyAsync(d_rhs, rhs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess))
+			rc = PFX_ERR_HIP;
+		if (!rc)
+			rc = pfx_implicit_euler_step_dev(ctx, dt, d_rhs, d_x, d_v, d_a, params, info);
+		if (!rc)
+		{
+			if (hipMemcpyAsync(x, d_x, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(v, d_v, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess || (a && hipMemcpyAsync(a, d_a, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess)
+			{
+				ctx->err = "copy of the time-step result failed";
+				rc = PFX_ERR_HIP;
+			}
+		}
+		(void)hipStreamSynchronize(st);
+		(void)hipFree(d);
+		return rc;
 	}
 
 	pfx_status pfx_set_diag_shift(pfx_ctx *ctx, double shift)

@@ -108,6 +108,13 @@ struct pfx_ctx
 	int64_t part0_count = 0;
 	double *d_newton = nullptr;   // workspace of the Newton driver (pfx_newton.hip)
 	int64_t newton_count = 0;
+	// inertia term of a transient step: 1/2 (x - x_tilde)^T M (x - x_tilde) beside inertia_weight * (E - rhs.x)
+	double *d_mass_blk = nullptr; // n_blocks: rho phi_i phi_j of every node block (the mass matrix is that times I_3)
+	int64_t mass_count = 0;       // 0 = no mass matrix captured
+	double inertia_weight = 0.0;  // acceleration_scaling of the time integrator; 0 = static problem
+	const double *d_x_tilde = nullptr;
+	double *d_tstep = nullptr;    // x_prev and x_tilde of pfx_implicit_euler_step
+	int64_t tstep_count = 0;
 
 	// solver copy of the matrix (block-SELL-64, pfx_sell.hip)
 	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
@@ -217,6 +224,9 @@ pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
 pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx);
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info);
+pfx_status pfx_capture_mass(pfx_ctx *ctx);
+pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+								  const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = true);
 pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e);                       // strict arithmetic
 pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, double density, const double *d_density_e); // strict arithmetic

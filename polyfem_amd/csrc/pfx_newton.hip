@@ -9,6 +9,12 @@
 // cppoptlib's checkConvergence (meta.h) is not part of the reference tree; it is restated from the published
 // library: iteration limit, then f delta, then gradient norm.
 //
+// Transient steps: with an inertia term enabled (pfx_inertia_enable) the objective is
+// w (E(x) - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde), i.e. InertiaForm (src/polyfem/solver/forms/InertiaForm.cpp:14-31)
+// beside ElasticForm and BodyForm weighted with the integrator's acceleration_scaling
+// (src/polyfem/state/StateSolveNonlinear.cpp:78-84); pfx_implicit_euler_run adds the ImplicitEuler bookkeeping
+// (src/polyfem/time_integrator/ImplicitEuler.cpp:5-33).
+//
 // The reference keeps x, grad and delta_x in host Eigen vectors and crosses to the GPU for every energy evaluation
 // (its USE_NONLINEAR_GPU path copies x and delta_x per line-search step, BacktrackingLineSearch.cu).  Here the three
 // vectors live on the device for the whole solve; the host only sees the scalars that steer the iteration.
@@ -22,16 +28,77 @@ namespace
 
 	// g = gradient of the objective restricted to the free dofs: (g - rhs), 0 on constrained dofs
 	__global__ __launch_bounds__(256) void k_objective_gradient(double *__restrict__ g, const double *__restrict__ rhs,
-																const uint8_t *__restrict__ fixed, int64_t n)
+																const uint8_t *__restrict__ fixed, int64_t n, double w,
+																const double *__restrict__ md)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
 		{
 			double v = g[k];
 			if (rhs)
 				v -= rhs[k];
+			if (md) // transient step: weighted elastic + body forms, plus M (x - x_tilde)
+				v = w * v + md[k];
 			if (fixed && fixed[k])
 				v = 0.0;
 			g[k] = v;
+		}
+	}
+
+	// mass[b] = rho phi_i phi_j of node block b, read from the (0,0) entry of the assembled mass matrix
+	__global__ __launch_bounds__(256) void k_capture_mass(const double *__restrict__ values, int64_t n_blocks, double *__restrict__ mass)
+	{
+		for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (int64_t)gridDim.x * blockDim.x)
+			mass[b] = values[b * 9];
+	}
+
+	// d = x - x_tilde and md = M d, M = mass (x) I_3: one thread per node row
+	__global__ __launch_bounds__(256) void k_mass_apply(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
+														const double *__restrict__ mass, const double *__restrict__ x,
+														const double *__restrict__ xt, int64_t n_nodes, double *__restrict__ d,
+														double *__restrict__ md)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			double a0 = 0, a1 = 0, a2 = 0;
+			const int64_t b1 = node_ptr[g + 1];
+			for (int64_t b = node_ptr[g]; b < b1; ++b)
+			{
+				const int64_t c = 3 * (int64_t)node_col[b];
+				const double m = mass[b];
+				a0 += m * (x[c] - xt[c]);
+				a1 += m * (x[c + 1] - xt[c + 1]);
+				a2 += m * (x[c + 2] - xt[c + 2]);
+			}
+			md[3 * g] = a0, md[3 * g + 1] = a1, md[3 * g + 2] = a2;
+			for (int k = 0; k < 3; ++k)
+				d[3 * g + k] = x[3 * g + k] - xt[3 * g + k];
+		}
+	}
+
+	// Hessian of the transient objective: values = w * values + M (M sits on the diagonal of every node block)
+	__global__ __launch_bounds__(256) void k_add_inertia(double *__restrict__ values, int64_t nnz, double w, const double *__restrict__ mass)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t b = k / 9;
+			const int r = (int)(k - b * 9);
+			double v = w * values[k];
+			if (r == 0 || r == 4 || r == 8)
+				v += mass[b];
+			values[k] = v;
+		}
+	}
+
+	// ImplicitEuler::update_quantities: v = (x - x_prev) / dt, a = (v - v_prev) / dt
+	__global__ __launch_bounds__(256) void k_euler_update(const double *__restrict__ x, const double *__restrict__ x_prev, double dt, int64_t n,
+														  double *__restrict__ v, double *__restrict__ a)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double vn = (x[k] - x_prev[k]) / dt;
+			if (a)
+				a[k] = (vn - v[k]) / dt;
+			v[k] = vn;
 		}
 	}
 
@@ -126,6 +193,15 @@ namespace
 		const uint8_t *fixed;
 		double *g, *dx, *xn, *w, *gls; // n each
 		double *partial, *scal;        // 3*NB, 4
+		// inertia term (null mass: static problem)
+		double iw = 1.0;               // weight of the elastic and body forms
+		const double *mass = nullptr, *xt = nullptr;
+		double *d = nullptr, *md = nullptr; // n each: x - x_tilde and M (x - x_tilde)
+
+		void mass_apply(const double *x)
+		{
+			hipLaunchKernelGGL(k_mass_apply, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, x, xt, ctx->n_nodes, d, md);
+		}
 
 		// a.b, |a + c|^2 (c may be null), max|a|
 		pfx_status reduce(const double *a, const double *b, const double *c, double out[3])
@@ -163,6 +239,14 @@ namespace
 					return rc;
 				e -= r[0];
 			}
+			if (mass && std::isfinite(e))
+			{
+				double r[3];
+				mass_apply(x);
+				if ((rc = reduce(d, md, nullptr, r)))
+					return rc;
+				e = iw * e + 0.5 * r[0];
+			}
 			*val = e;
 			return PFX_OK;
 		}
@@ -174,7 +258,9 @@ namespace
 			pfx_status rc = pfx_gradient_dev(ctx, x, out);
 			if (rc)
 				return rc;
-			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, out, rhs, fixed, n);
+			if (mass)
+				mass_apply(x);
+			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, out, rhs, fixed, n, iw, (const double *)(mass ? md : nullptr));
 			double r[3];
 			if ((rc = reduce(out, out, nullptr, r)))
 				return rc;
@@ -280,17 +366,24 @@ namespace
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
 {
 	const int64_t n = ctx->n_dofs();
-	if (ctx->newton_count < 5 * n + 3 * NB + 8)
+	if (ctx->newton_count < 7 * n + 3 * NB + 8)
 	{
-		if (pfx_alloc(ctx, &ctx->d_newton, 5 * n + 3 * NB + 8))
+		if (pfx_alloc(ctx, &ctx->d_newton, 7 * n + 3 * NB + 8))
 			return PFX_ERR_HIP;
-		ctx->newton_count = 5 * n + 3 * NB + 8;
+		ctx->newton_count = 7 * n + 3 * NB + 8;
 	}
 	newton S;
 	S.ctx = ctx, S.par = par, S.info = info, S.n = n, S.rhs = d_rhs;
 	S.fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	S.g = ctx->d_newton, S.dx = S.g + n, S.xn = S.dx + n, S.w = S.xn + n, S.gls = S.w + n;
-	S.partial = S.gls + n, S.scal = S.partial + 3 * NB;
+	S.d = S.gls + n, S.md = S.d + n;
+	S.partial = S.md + n, S.scal = S.partial + 3 * NB;
+	if (ctx->inertia_weight > 0.0 && ctx->d_x_tilde && ctx->mass_count > 0)
+	{
+		if (ctx->bs != 3 || ctx->n_owned != ctx->n_nodes)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs block size 3 and an unpartitioned mesh");
+		S.iw = ctx->inertia_weight, S.mass = ctx->d_mass_blk, S.xt = ctx->d_x_tilde;
+	}
 	hipStream_t st = ctx->stream;
 	*info = pfx_newton_info{};
 	PFX_HIP(hipMemsetAsync(S.dx, 0, sizeof(double) * (size_t)n, st));
@@ -377,6 +470,11 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 			// assemble_hessian (:105-123): strategy 1 projects the element Hessians to PSD
 			if ((rc = strategy == 1 ? pfx_hessian_psd_dev(ctx, d_x) : pfx_hessian_dev(ctx, d_x)))
 				return finish(rc, ctx->err.c_str());
+			if (S.mass)
+			{
+				hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, st, ctx->d_values, ctx->nnz, S.iw, S.mass);
+				ctx->values_gen++;
+			}
 			ctx->diag_shift = reg_weight;
 			hipLaunchKernelGGL(k_negate, dim3(NB), dim3(256), 0, st, S.g, n, S.w);
 			int its = 0;
@@ -450,4 +548,47 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 	if (status == PFX_NEWTON_ITERATION_LIMIT)
 		return finish(PFX_ERR_NUMERIC, "Reached iteration limit");
 	return finish(PFX_OK, "");
+}
+
+pfx_status pfx_capture_mass(pfx_ctx *ctx)
+{
+	if (ctx->mass_count != ctx->n_blocks)
+	{
+		if (pfx_alloc(ctx, &ctx->d_mass_blk, ctx->n_blocks))
+			return PFX_ERR_HIP;
+		ctx->mass_count = ctx->n_blocks;
+	}
+	hipLaunchKernelGGL(k_capture_mass, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_values, ctx->n_blocks, ctx->d_mass_blk);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+								  const pfx_newton_params *params, pfx_newton_info *info)
+{
+	const int64_t n = ctx->n_dofs();
+	hipStream_t st = ctx->stream;
+	if (ctx->tstep_count < 2 * n)
+	{
+		if (pfx_alloc(ctx, &ctx->d_tstep, 2 * n))
+			return PFX_ERR_HIP;
+		ctx->tstep_count = 2 * n;
+	}
+	double *x_prev = ctx->d_tstep, *x_tilde = ctx->d_tstep + n;
+	PFX_HIP(hipMemcpyAsync(x_prev, d_x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+	// ImplicitEuler::x_tilde = x_prev + dt v_prev
+	hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, st, d_x, d_v, dt, n, x_tilde);
+	const double saved_w = ctx->inertia_weight;
+	const double *saved_xt = ctx->d_x_tilde;
+	ctx->inertia_weight = dt * dt; // ImplicitEuler::acceleration_scaling
+	ctx->d_x_tilde = x_tilde;
+	const pfx_status rc = pfx_newton_run(ctx, d_rhs, d_x, params, info);
+	ctx->inertia_weight = saved_w;
+	ctx->d_x_tilde = saved_xt;
+	if (rc)
+		return rc;
+	hipLaunchKernelGGL(k_euler_update, dim3(NB), dim3(256), 0, st, d_x, x_prev, dt, n, d_v, d_a);
+	PFX_HIP(hipGetLastError());
+	PFX_HIP(hipStreamSynchronize(st));
+	return PFX_OK;
 }

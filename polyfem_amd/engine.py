@@ -35,7 +35,8 @@ EXPORTED_SYMBOLS = [
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
-    "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag",
+    "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
+    "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev",
 ]
 
 
@@ -129,6 +130,10 @@ def load():
         "pfx_assemble_mass": [_vp, _dbl, _pd],
         "pfx_assemble_rhs": [_vp, _pd, _dbl, _pd, _pd],
         "pfx_assemble_rhs_dev": [_vp, _pd, _dbl, _pd, _vp],
+        "pfx_inertia_set_mass": [_vp, _dbl, _pd],
+        "pfx_inertia_enable": [_vp, _dbl, _vp],
+        "pfx_implicit_euler_step": [_vp, _dbl, _pd, _pd, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
+        "pfx_implicit_euler_step_dev": [_vp, _dbl, _vp, _vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_set_diag_shift": [_vp, _dbl],
         "pfx_take_numeric_flag": [_vp, C.POINTER(C.c_int)],
         "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
@@ -360,6 +365,51 @@ class Engine:
             setattr(p, k, v)
         info = NewtonInfo()
         self._ck(self.L.pfx_newton_solve_dev(self.h, _vp(d_rhs) if d_rhs else None, _vp(d_x), C.byref(p), C.byref(info)))
+        return {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
+
+    # ---- transient steps -------------------------------------------------------------------------------------
+    def inertia_set_mass(self, density=1.0):
+        """Assembles the mass matrix (scalar density or one value per element) and keeps it for the inertia term."""
+        if np.ndim(density) == 0:
+            self._ck(self.L.pfx_inertia_set_mass(self.h, float(density), None))
+        else:
+            d = np.ascontiguousarray(density, dtype=np.float64)
+            assert d.size == self.info().n_el
+            self._ck(self.L.pfx_inertia_set_mass(self.h, 0.0, _d(d)))
+
+    def inertia_enable(self, acceleration_scaling: float, d_x_tilde: int):
+        """Newton solves minimise acceleration_scaling * (E - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde) from now on
+        (device pointer to x_tilde); inertia_disable() restores the static objective."""
+        self._ck(self.L.pfx_inertia_enable(self.h, float(acceleration_scaling), _vp(d_x_tilde)))
+
+    def inertia_disable(self):
+        self._ck(self.L.pfx_inertia_enable(self.h, 0.0, None))
+
+    def _newton_params(self, params):
+        p = NewtonParams()
+        self.L.pfx_newton_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        return p
+
+    def implicit_euler_step(self, dt: float, x, v, rhs=None, **params):
+        """One implicit Euler step of the transient nonlinear solve (see pfx_implicit_euler_step).  Returns
+        (x, v, a, info dict)."""
+        p = self._newton_params(params)
+        x = np.array(x, dtype=np.float64, copy=True)
+        v = np.array(v, dtype=np.float64, copy=True)
+        a = np.zeros_like(x)
+        r = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64)
+        info = NewtonInfo()
+        self._ck(self.L.pfx_implicit_euler_step(self.h, float(dt), _d(r) if r is not None else None, _d(x), _d(v), _d(a),
+                                                C.byref(p), C.byref(info)))
+        return x, v, a, {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
+
+    def implicit_euler_step_dev(self, dt: float, d_x: int, d_v: int, d_a: int = 0, d_rhs: int = 0, **params):
+        p = self._newton_params(params)
+        info = NewtonInfo()
+        self._ck(self.L.pfx_implicit_euler_step_dev(self.h, float(dt), _vp(d_rhs) if d_rhs else None, _vp(d_x), _vp(d_v),
+                                                    _vp(d_a) if d_a else None, C.byref(p), C.byref(info)))
         return {f[0]: getattr(info, f[0]) for f in NewtonInfo._fields_}
 
     def dirichlet_solve(self, b, precond: int = PRECOND_JACOBI, max_iter: int = 1000, tol: float = 1e-12):

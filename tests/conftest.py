@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before the HIP library: PyTorch ships its own ROCm runtime, and the first one loaded serves the process
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -411,3 +411,38 @@ def test_project_to_psd_oracle(oracle):
     Hp = csc_to_scipy(oracle.assemble_hessian_psd(mesh, oracle.NEOHOOKEAN, lam, mu, x, n_threads=3), nd).toarray()
     assert np.linalg.eigvalsh(H)[0] < -1.0
     assert np.linalg.eigvalsh(Hp)[0] > -1e-9 * np.abs(Hp).max()
+
+
+def test_implicit_euler_step_oracle(oracle):
+    """One implicit Euler step of the transient solve (InertiaForm + dt^2-weighted elastic and body forms): for
+    LinearElasticity it solves (dt^2 K + M) x = dt^2 f + M x_tilde on the free dofs (checked with a direct solve); for
+    NeoHookean the result is a stationary point of the step objective; without load and velocity nothing moves."""
+    import scipy.sparse.linalg as spla
+    mesh = M.cube_tets(2, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    rho, dt = 1000.0, 0.05
+    mass = oracle.assemble_mass(mesh, 3, rho)
+    Mm = csc_to_scipy(mass, n)
+    rhs = oracle.assemble_rhs(mesh, 3, np.array([0.0, 0.0, -9.81]), rho)
+    rng = np.random.default_rng(5)
+    x0 = np.zeros(n)
+    v0 = np.where(free, 1e-2 * rng.standard_normal(n), 0.0)
+    x, v, a, info = oracle.implicit_euler_step(mesh, oracle.LINEAR_ELASTICITY, lam, mu, rhs, bnd, mass, dt, x0, v0)
+    K = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    A = (dt * dt * K + Mm).tocsr()
+    xd = np.zeros(n)
+    xd[free] = spla.spsolve(A[free][:, free].tocsc(), (dt * dt * rhs + Mm @ (x0 + dt * v0))[free])
+    assert info["status"] in (2, 3) and np.abs(x - xd).max() <= 1e-9 * np.abs(xd).max()
+    assert np.array_equal(v, (x - x0) / dt) and np.array_equal(a, (v - v0) / dt)
+
+    x2, v2, a2, info2 = oracle.implicit_euler_step(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, mass, dt, x, v)
+    g = dt * dt * (oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x2) - rhs) + Mm @ (x2 - (x + dt * v))
+    assert info2["status"] in (2, 3) and np.linalg.norm(g[free]) <= 1e-7 * np.linalg.norm((Mm @ v)[free]) * dt
+    assert not np.any(x2[bnd])
+
+    x3, v3, a3, info3 = oracle.implicit_euler_step(mesh, oracle.NEOHOOKEAN, lam, mu, None, bnd, mass, dt, np.zeros(n), np.zeros(n))
+    assert info3["status"] == 4 and not x3.any() and not v3.any()
