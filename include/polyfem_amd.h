@@ -48,12 +48,15 @@ enum
 	PFX_Q2HEX = 3
 };
 
-/* local assemblers: Laplacian.cpp:7-18, LinearElasticity.cpp:21-54, NeoHookeanElasticity.cpp:250-565 */
+/* local assemblers: Laplacian.cpp:7-18, LinearElasticity.cpp:21-54, NeoHookeanElasticity.cpp:250-565,
+ * SaintVenantElasticity.cpp:104-143,215-312 (nonlinear interface only; isotropic elasticity tensor from lambda, mu as
+ * ElasticityTensor::set_from_lambda_mu builds it, utils/ElasticityUtils.cpp:372-413) */
 enum
 {
 	PFX_LAPLACIAN = 0,
 	PFX_LINEAR_ELASTICITY = 1,
-	PFX_NEOHOOKEAN = 2
+	PFX_NEOHOOKEAN = 2,
+	PFX_SAINT_VENANT = 3
 };
 
 enum

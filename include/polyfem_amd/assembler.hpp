@@ -241,6 +241,10 @@ namespace polyfem_amd
 		{
 			static constexpr int model = PFX_NEOHOOKEAN;
 		};
+		struct SaintVenantElasticity : ElasticBase // isotropic tensor (young/nu or lambda/mu); no "elasticity_tensor" entries
+		{
+			static constexpr int model = PFX_SAINT_VENANT;
+		};
 
 		template <class LocalAssembler>
 		class Assembler // assembler/Assembler.hpp:26-47

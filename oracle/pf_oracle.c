@@ -758,6 +758,167 @@ void pfo_local_linear_elasticity_hessian(const pfo_vals *v, const double *da, do
 		}
 }
 
+/* ---- SaintVenantElasticity (assembler/SaintVenantElasticity.cpp), isotropic elasticity tensor ---- */
+
+/* ElasticityTensor::set_from_lambda_mu (utils/ElasticityUtils.cpp:372-413), 3-D: symmetric 6 x 6, Voigt order
+ * xx, yy, zz, yz, xz, xy with engineering shear strains */
+static void sv_tensor(double lambda, double mu, double C[6][6])
+{
+	for (int a = 0; a < 6; ++a)
+		for (int b = 0; b < 6; ++b)
+			C[a][b] = 0;
+	for (int a = 0; a < 3; ++a)
+	{
+		for (int b = 0; b < 3; ++b)
+			C[a][b] = lambda;
+		C[a][a] = 2 * mu + lambda;
+		C[3 + a][3 + a] = mu;
+	}
+}
+
+/* strain_from_disp_grad (:15-24) on G = F - I, then the Voigt strain / stress of compute_energy_aux (:276-302) */
+static void sv_strain_stress(const double *F, double C[6][6], double *E, double *S)
+{
+	double G[9];
+	for (int a = 0; a < 3; ++a)
+		for (int b = 0; b < 3; ++b)
+			M(G, a, b) = M(F, a, b) - (a == b ? 1.0 : 0.0);
+	for (int a = 0; a < 3; ++a)
+		for (int b = 0; b < 3; ++b)
+		{
+			double gtg = 0;
+			for (int k = 0; k < 3; ++k)
+				gtg += M(G, k, a) * M(G, k, b);
+			M(E, a, b) = (gtg + M(G, a, b) + M(G, b, a)) * 0.5;
+		}
+	const double eps[6] = {M(E, 0, 0), M(E, 1, 1), M(E, 2, 2), 2 * M(E, 1, 2), 2 * M(E, 0, 2), 2 * M(E, 0, 1)};
+	double sg[6];
+	for (int j = 0; j < 6; ++j)
+	{
+		double res = C[j][0] * eps[0];
+		for (int k = 1; k < 6; ++k)
+			res += C[j][k] * eps[k];
+		sg[j] = res;
+	}
+	M(S, 0, 0) = sg[0], M(S, 0, 1) = sg[5], M(S, 0, 2) = sg[4];
+	M(S, 1, 0) = sg[5], M(S, 1, 1) = sg[1], M(S, 1, 2) = sg[3];
+	M(S, 2, 0) = sg[4], M(S, 2, 1) = sg[3], M(S, 2, 2) = sg[2];
+}
+
+/* SaintVenantElasticity::compute_energy_aux<double> (:215-312): 1/2 sum_p trace(stress * strain) da_p */
+double pfo_local_saint_venant_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu)
+{
+	double C[6][6], energy = 0;
+	sv_tensor(lambda, mu, C);
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9], E[9], S[9];
+		def_grad_at(v, p, local_disp, F);
+		sv_strain_stress(F, C, E, S);
+		double tr = 0;
+		for (int a = 0; a < 3; ++a)
+			for (int k = 0; k < 3; ++k)
+				tr += M(S, a, k) * M(E, k, a);
+		energy += tr * da[p];
+	}
+	return energy * 0.5;
+}
+
+/* Voigt strain (engineering shears) of sym(f (x) g) */
+static void sv_voigt_sym(const double *f, const double *g, double *e)
+{
+	e[0] = f[0] * g[0], e[1] = f[1] * g[1], e[2] = f[2] * g[2];
+	e[3] = f[1] * g[2] + g[1] * f[2];
+	e[4] = f[0] * g[2] + g[0] * f[2];
+	e[5] = f[0] * g[1] + g[0] * f[1];
+}
+
+/* SaintVenantElasticity::assemble_grad (:104-122) differentiates compute_energy_aux with forward autodiff; written
+ * out: d/du_{i,d} = sum_p da_p (F S G_i)[d]  (first Piola-Kirchhoff stress F S, S = C : E symmetric) */
+void pfo_local_saint_venant_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G)
+{
+	double C[6][6];
+	sv_tensor(lambda, mu, C);
+	for (int k = 0; k < 3 * v->n_loc; ++k)
+		G[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9], E[9], S[9], P[9];
+		def_grad_at(v, p, local_disp, F);
+		sv_strain_stress(F, C, E, S);
+		for (int a = 0; a < 3; ++a)
+			for (int b = 0; b < 3; ++b)
+				M(P, a, b) = M(F, a, 0) * M(S, 0, b) + M(F, a, 1) * M(S, 1, b) + M(F, a, 2) * M(S, 2, b);
+		for (int i = 0; i < v->n_loc; ++i)
+		{
+			double Gi[3];
+			phys_grad(v, i, p, Gi);
+			for (int d = 0; d < 3; ++d)
+				G[3 * i + d] += (M(P, d, 0) * Gi[0] + M(P, d, 1) * Gi[1] + M(P, d, 2) * Gi[2]) * da[p];
+		}
+	}
+}
+
+/* SaintVenantElasticity::assemble_hessian (:124-143, second-order autodiff in the reference), written out: the
+ * variation of E along dof (j,b) is sym(f_b (x) G_j) with f_b = row b of F, so
+ * d2/du_{i,a} du_{j,b} = sum_p da_p [ delta_ab G_i^T S G_j + voigt(f_a, G_i)^T C voigt(f_b, G_j) ] */
+void pfo_local_saint_venant_hessian(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H)
+{
+	const int N = 3 * v->n_loc;
+	double C[6][6];
+	sv_tensor(lambda, mu, C);
+	for (int k = 0; k < N * N; ++k)
+		H[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[9], E[9], S[9];
+		def_grad_at(v, p, local_disp, F);
+		sv_strain_stress(F, C, E, S);
+		for (int i = 0; i < v->n_loc; ++i)
+		{
+			double Gi[3];
+			phys_grad(v, i, p, Gi);
+			for (int j = 0; j < v->n_loc; ++j)
+			{
+				double Gj[3], SGj[3];
+				phys_grad(v, j, p, Gj);
+				for (int a = 0; a < 3; ++a)
+					SGj[a] = M(S, a, 0) * Gj[0] + M(S, a, 1) * Gj[1] + M(S, a, 2) * Gj[2];
+				const double gsg = Gi[0] * SGj[0] + Gi[1] * SGj[1] + Gi[2] * SGj[2];
+				for (int a = 0; a < 3; ++a)
+				{
+					double va[6];
+					sv_voigt_sym(&M(F, a, 0), Gi, va);
+					for (int b = 0; b < 3; ++b)
+					{
+						double vb[6], acc = (a == b) ? gsg : 0.0;
+						sv_voigt_sym(&M(F, b, 0), Gj, vb);
+						for (int r = 0; r < 6; ++r)
+						{
+							double cv = 0;
+							for (int c = 0; c < 6; ++c)
+								cv += C[r][c] * vb[c];
+							acc += va[r] * cv;
+						}
+						H[(3 * i + a) * N + 3 * j + b] += acc * da[p];
+					}
+				}
+			}
+		}
+	}
+}
+
+/* the three nonlinear local assemblers behind one switch */
+static int is_nl_model(int model) { return model == PFO_NEOHOOKEAN || model == PFO_LINEAR_ELASTICITY || model == PFO_SAINT_VENANT; }
+static double nl_local_energy(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu)
+{
+	if (model == PFO_NEOHOOKEAN)
+		return pfo_local_neohookean_energy(v, da, ld, lambda, mu);
+	if (model == PFO_SAINT_VENANT)
+		return pfo_local_saint_venant_energy(v, da, ld, lambda, mu);
+	return pfo_local_linear_elasticity_energy(v, da, ld, lambda, mu);
+}
+
 static void cross3(const double *x, const double *y, double *z)
 {
 	z[0] = x[1] * y[2] - x[2] * y[1];
@@ -1168,7 +1329,7 @@ static void *job_run(void *arg)
 			if (jb->mode == 1)
 			{
 				/* Assembler.cpp:657-668 */
-				const double val = mat->model == PFO_NEOHOOKEAN ? pfo_local_neohookean_energy(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e)) : pfo_local_linear_elasticity_energy(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
+				const double val = nl_local_energy(mat->model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
 				jb->scalar += val;
 			}
 			else if (jb->mode == 2)
@@ -1176,6 +1337,8 @@ static void *job_run(void *arg)
 				/* Assembler.cpp:465-492 */
 				if (mat->model == PFO_NEOHOOKEAN)
 					pfo_local_neohookean_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
+				else if (mat->model == PFO_SAINT_VENANT)
+					pfo_local_saint_venant_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
 				else
 					pfo_local_linear_elasticity_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
 				for (int j = 0; j < n_loc; ++j)
@@ -1192,6 +1355,8 @@ static void *job_run(void *arg)
 				/* Assembler.cpp:550-616 : every entry, order (i, j, n, m) */
 				if (mat->model == PFO_NEOHOOKEAN)
 					pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
+				else if (mat->model == PFO_SAINT_VENANT)
+					pfo_local_saint_venant_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
 				else
 					pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
 				const int N = n_loc * size;
@@ -1306,7 +1471,7 @@ double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const 
 /* assembler/Assembler.cpp:427-504 */
 int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, double *rhs)
 {
-	if (mat->model != PFO_NEOHOOKEAN && mat->model != PFO_LINEAR_ELASTICITY)
+	if (!is_nl_model(mat->model))
 		return -1;
 	const int64_t N = mesh->n_nodes * block_size(mat);
 	int nt = n_threads;
@@ -1327,7 +1492,7 @@ int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const d
 /* assembler/Assembler.cpp:506-636, first (pattern-building) pass: triplets of every local entry */
 int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
 {
-	if (mat->model != PFO_NEOHOOKEAN && mat->model != PFO_LINEAR_ELASTICITY)
+	if (!is_nl_model(mat->model))
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 3, &nt, 0);
@@ -1339,7 +1504,7 @@ int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const do
 
 int pfo_assemble_hessian_psd(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
 {
-	if (mat->model != PFO_NEOHOOKEAN && mat->model != PFO_LINEAR_ELASTICITY)
+	if (!is_nl_model(mat->model))
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 4, &nt, 0);
@@ -1703,6 +1868,8 @@ int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, c
 		gather_local_disp(mesh, e, n_loc, x, ld);
 		if (mat->model == PFO_NEOHOOKEAN)
 			pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
+		else if (mat->model == PFO_SAINT_VENANT)
+			pfo_local_saint_venant_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
 		else
 			pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
 		const int32_t *idx = mesh->conn + e * n_loc;
@@ -1929,7 +2096,7 @@ typedef struct
 static double inertia_terms(const nl_problem *p, const double *x, double *g_add)
 {
 	const int64_t n = p->n;
-	double *d = (double *)malloc(sizeof(double) * (size_t)n), *md = (double *)malloc(sizeof(double) * (size_t)n);
+	double *d = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)), *md = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
 	for (int64_t k = 0; k < n; ++k)
 		d[k] = x[k] - p->x_tilde[k];
 	pfo_spmv(p->mass, d, md);

@@ -21,7 +21,7 @@ extern "C" {
 /* element kinds: number of local bases 4 / 10 / 8 / 27 */
 enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3 };
 /* local assemblers */
-enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2 };
+enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2, PFO_SAINT_VENANT = 3 };
 
 #define PFO_MAX_PTS 125
 #define PFO_MAX_LOC 27

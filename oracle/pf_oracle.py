@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpf_oracle.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN = 0, 1, 2
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT = 0, 1, 2, 3
 MAX_PTS, MAX_LOC = 125, 27
 
 

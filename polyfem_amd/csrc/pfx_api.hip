@@ -310,7 +310,7 @@ extern "C"
 	{
 		if (!ctx)
 			return PFX_ERR_ARG;
-		if (model < PFX_LAPLACIAN || model > PFX_NEOHOOKEAN)
+		if (model < PFX_LAPLACIAN || model > PFX_SAINT_VENANT)
 			PFX_FAIL(PFX_ERR_ARG, "unknown model");
 		if (dim != 3)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "only dim = 3 is implemented");
@@ -697,8 +697,8 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (ctx->mass_count == 0)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
-		if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY)
-			PFX_FAIL(PFX_ERR_ARG, "pfx_implicit_euler_step needs the LinearElasticity or NeoHookean model");
+		if (ctx->model == PFX_LAPLACIAN)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_implicit_euler_step needs an elastic model");
 		if (ctx->n_owned != ctx->n_nodes)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_implicit_euler_step works on an unpartitioned mesh");
 		PFX_HIP(hipSetDevice(ctx->device));
@@ -778,7 +778,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_pattern(ctx))
 			return PFX_ERR_ARG;
-		if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY)
+		if (ctx->model == PFX_LAPLACIAN)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_newton_solve needs an elastic model");
 		if (ctx->n_owned != ctx->n_nodes)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_newton_solve runs on an unpartitioned mesh");

@@ -1,5 +1,5 @@
 // pfx_local_nl.hip -- per-element energy, gradient and Hessian blocks of the nonlinear-assembler interface
-// (NeoHookean, and LinearElasticity used through that interface).
+// (NeoHookean, SaintVenant, and LinearElasticity used through that interface).
 //
 // Reference: NLAssembler<NeoHookeanElasticity>::assemble / assemble_grad / assemble_hessian element loops
 // (src/polyfem/assembler/Assembler.cpp:638-678, 427-504, 506-636) and the local kernels
@@ -21,6 +21,12 @@
 //   energy += da [ mu eps:eps + lambda/2 tr(eps)^2 ]      grad_i += da sigma G_i
 //   H_ij   += da [ mu (G_i . G_j) I + mu G_j G_i^T + lambda G_i G_j^T ]
 //
+// SaintVenantElasticity (SaintVenantElasticity.cpp:215-312, isotropic elasticity tensor of
+// utils/ElasticityUtils.cpp:372-413; gradient and Hessian are autodiff in the reference, written out here): with
+// E = (F^T F - I)/2, S = lambda tr(E) I + 2 mu E (second Piola-Kirchhoff stress) and f_m = row m of F:
+//   energy += da/2 S:E        grad_i += da F S G_i
+//   H_ij   += da [ (G_i^T S G_j) I + lambda (F G_i)(F G_j)^T + mu ( (G_i.G_j) F F^T + (F G_j)(F G_i)^T ) ]
+//
 // Element kernel (TPE lanes per element, all intermediate data in LDS):
 //   1 geometry nodes, connectivity, displacements -> LDS      4 F per point (9 lanes per point)
 //   2 J^{-T}, det per quadrature point                       5 per-point scalars, cofactors, energy
@@ -35,6 +41,14 @@
 
 namespace
 {
+	// material behind the kernels' MODEL parameter
+	enum
+	{
+		M_LINEAR = 0,
+		M_NEO = 1,
+		M_STVK = 2
+	};
+
 	template <int NLOC, int NGLOC, int NPTS>
 	struct nl_smem
 	{
@@ -76,7 +90,7 @@ namespace
 		__host__ __device__ static constexpr int f_at(int k) { return affine ? 10 + 12 * k : 22 * k + 10; }
 	};
 
-	template <int NLOC, int NGLOC, int NPTS, int TPE, bool NEO>
+	template <int NLOC, int NGLOC, int NPTS, int TPE, int MODEL>
 	__global__ __launch_bounds__(256) void k_local_nl(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
 																   const double *__restrict__ xyz, const double *__restrict__ u,
 																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u, double mu_u,
@@ -137,7 +151,7 @@ namespace
 			for (int t = lane; t < NPTS * 9; t += TPE)
 			{
 				const int k = t / 9, d = (t % 9) / 3, c = t % 3;
-				double acc = (NEO && d == c) ? 1.0 : 0.0;
+				double acc = (MODEL != M_LINEAR && d == c) ? 1.0 : 0.0;
 				for (int i = 0; i < NLOC; ++i)
 					acc += s.ul[3 * i + d] * s.G[3 * (k * NLOC + i) + c];
 				s.F[t] = acc; // F(d,c) row-major
@@ -150,7 +164,7 @@ namespace
 				const double *F = &s.F[9 * k];
 				double *dJ = &s.dJ[9 * k];
 				const double da = s.da[k];
-				if (NEO)
+				if (MODEL == M_NEO)
 				{
 					// cofactor matrix: dJ(r,c) = d det / d F(r,c)
 					dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
@@ -167,6 +181,30 @@ namespace
 					s.coef[4 * k + 1] = (mu + lambda * (1.0 - lj)) / (J * J) * da;
 					s.coef[4 * k + 2] = (lambda * lj - mu) / J * da;
 					s.coef[4 * k + 3] = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+				}
+				else if (MODEL == M_STVK)
+				{
+					// dJ receives the first Piola-Kirchhoff stress F S
+					double E[9], S[9];
+					for (int r = 0; r < 3; ++r)
+						for (int c = 0; c < 3; ++c)
+							E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
+					const double tr = E[0] + E[4] + E[8];
+					double se = 0;
+					for (int q = 0; q < 9; ++q)
+					{
+						S[q] = 2 * mu * E[q];
+						if (q == 0 || q == 4 || q == 8)
+							S[q] += lambda * tr;
+						se += S[q] * E[q];
+					}
+					for (int r = 0; r < 3; ++r)
+						for (int c = 0; c < 3; ++c)
+							dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
+					s.coef[4 * k + 0] = mu * da;
+					s.coef[4 * k + 1] = lambda * da;
+					s.coef[4 * k + 2] = da;
+					s.coef[4 * k + 3] = se / 2 * da;
 				}
 				else
 				{
@@ -200,7 +238,7 @@ namespace
 		if (active && lane == 0 && s.bad)
 			atomicOr(flag, 1);
 
-		if (NEO && active && want_g)
+		if (MODEL == M_NEO && active && want_g)
 			for (int t = lane; t < NPTS * NLOC; t += TPE)
 			{
 				const int k = t / NLOC;
@@ -220,7 +258,7 @@ namespace
 					const double *F = &s.F[9 * k];
 					const double *Gi = &s.G[3 * (k * NLOC + i)], *Wi = &s.W[3 * (k * NLOC + i)];
 					const double a = s.coef[4 * k + 0], c2 = s.coef[4 * k + 2];
-					if (NEO)
+					if (MODEL == M_NEO)
 						for (int d = 0; d < 3; ++d)
 							g[d] += a * (F[3 * d] * Gi[0] + F[3 * d + 1] * Gi[1] + F[3 * d + 2] * Gi[2]) + c2 * Wi[d];
 					else
@@ -254,7 +292,7 @@ namespace
 	}
 
 	// H_ij for the pair (i, j), j <= i : out[m*3+n] = d2 E / d u_{i,m} d u_{j,n}
-	template <int NLOC, int NGLOC, int NPTS, bool NEO>
+	template <int NLOC, int NGLOC, int NPTS, int MODEL>
 	struct nl_block
 	{
 		const double *estate;
@@ -302,12 +340,43 @@ namespace
 					Gj[c] = rj[0] * jt[c] + rj[1] * jt[3 + c] + rj[2] * jt[6 + c];
 				}
 				const double dot = a * (Gi[0] * Gj[0] + Gi[1] * Gj[1] + Gi[2] * Gj[2]);
-				if (!NEO)
+				if (MODEL == M_LINEAR)
 				{
 					// a = mu da, c1 = lambda da
 					for (int m = 0; m < 3; ++m)
 						for (int n = 0; n < 3; ++n)
 							b[3 * m + n] += a * Gi[n] * Gj[m] + c1 * Gi[m] * Gj[n] + (m == n ? dot : 0.0);
+					continue;
+				}
+				if (MODEL == M_STVK)
+				{
+					// a = mu da, c1 = lambda da; S da = c1 tr(E) I + 2 a E from F
+					double E[6]; // xx, yy, zz, yz, xz, xy of (F^T F - I)/2
+					E[0] = (F[0] * F[0] + F[3] * F[3] + F[6] * F[6] - 1.0) / 2;
+					E[1] = (F[1] * F[1] + F[4] * F[4] + F[7] * F[7] - 1.0) / 2;
+					E[2] = (F[2] * F[2] + F[5] * F[5] + F[8] * F[8] - 1.0) / 2;
+					E[3] = (F[1] * F[2] + F[4] * F[5] + F[7] * F[8]) / 2;
+					E[4] = (F[0] * F[2] + F[3] * F[5] + F[6] * F[8]) / 2;
+					E[5] = (F[0] * F[1] + F[3] * F[4] + F[6] * F[7]) / 2;
+					const double ltr = c1 * (E[0] + E[1] + E[2]);
+					const double s0 = ltr + 2 * a * E[0], s1 = ltr + 2 * a * E[1], s2 = ltr + 2 * a * E[2];
+					const double s3 = 2 * a * E[3], s4 = 2 * a * E[4], s5 = 2 * a * E[5];
+					const double sg0 = s0 * Gj[0] + s5 * Gj[1] + s4 * Gj[2];
+					const double sg1 = s5 * Gj[0] + s1 * Gj[1] + s3 * Gj[2];
+					const double sg2 = s4 * Gj[0] + s3 * Gj[1] + s2 * Gj[2];
+					const double gsg = Gi[0] * sg0 + Gi[1] * sg1 + Gi[2] * sg2;
+					double fgi[3], fgj[3];
+					for (int m = 0; m < 3; ++m)
+					{
+						fgi[m] = F[3 * m] * Gi[0] + F[3 * m + 1] * Gi[1] + F[3 * m + 2] * Gi[2];
+						fgj[m] = F[3 * m] * Gj[0] + F[3 * m + 1] * Gj[1] + F[3 * m + 2] * Gj[2];
+					}
+					for (int m = 0; m < 3; ++m)
+						for (int n = 0; n < 3; ++n)
+						{
+							const double fft = F[3 * m] * F[3 * n] + F[3 * m + 1] * F[3 * n + 1] + F[3 * m + 2] * F[3 * n + 2];
+							b[3 * m + n] += c1 * fgi[m] * fgj[n] + dot * fft + a * fgj[m] * fgi[n] + (m == n ? gsg : 0.0);
+						}
 					continue;
 				}
 				const double f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
@@ -346,41 +415,52 @@ namespace
 	{
 		constexpr int EPB = 256 / TPE;
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
+#define PFX_LOCAL_NL(MODEL_)                                                                                                              \
+	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
+					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, (int)en, (int)gr, (int)he,     \
+					   ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
 		if (ctx->model == PFX_NEOHOOKEAN)
-			hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e,
-							   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag);
+			PFX_LOCAL_NL(M_NEO);
+		else if (ctx->model == PFX_SAINT_VENANT)
+			PFX_LOCAL_NL(M_STVK);
 		else
-			hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-							   ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e,
-							   (int)en, (int)gr, (int)he, ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag);
+			PFX_LOCAL_NL(M_LINEAR);
+#undef PFX_LOCAL_NL
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_rows(pfx_ctx *ctx)
 	{
 		if (ctx->model == PFX_NEOHOOKEAN)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, true>{ctx->d_estate, ctx->d_tab}, false);
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
+		else if (ctx->model == PFX_SAINT_VENANT)
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab}, false);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, false>{ctx->d_estate, ctx->d_tab}, false);
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
+	}
+	template <int NLOC, int NGLOC, int NPTS, int MODEL>
+	void launch_psd_model(pfx_ctx *ctx)
+	{
+		typedef nl_block<NLOC, NGLOC, NPTS, MODEL> Op;
+		hipLaunchKernelGGL((k_project_psd<NLOC, Op>), dim3((unsigned)ctx->n_el), dim3(64), 0, ctx->stream, Op{ctx->d_estate, ctx->d_tab}, ctx->n_el, ctx->d_kloc);
 	}
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_psd(pfx_ctx *ctx)
 	{
 		if (ctx->model == PFX_NEOHOOKEAN)
-			hipLaunchKernelGGL((k_project_psd<NLOC, nl_block<NLOC, NGLOC, NPTS, true>>), dim3((unsigned)ctx->n_el), dim3(64), 0, ctx->stream,
-							   nl_block<NLOC, NGLOC, NPTS, true>{ctx->d_estate, ctx->d_tab}, ctx->n_el, ctx->d_kloc);
+			launch_psd_model<NLOC, NGLOC, NPTS, M_NEO>(ctx);
+		else if (ctx->model == PFX_SAINT_VENANT)
+			launch_psd_model<NLOC, NGLOC, NPTS, M_STVK>(ctx);
 		else
-			hipLaunchKernelGGL((k_project_psd<NLOC, nl_block<NLOC, NGLOC, NPTS, false>>), dim3((unsigned)ctx->n_el), dim3(64), 0, ctx->stream,
-							   nl_block<NLOC, NGLOC, NPTS, false>{ctx->d_estate, ctx->d_tab}, ctx->n_el, ctx->d_kloc);
+			launch_psd_model<NLOC, NGLOC, NPTS, M_LINEAR>(ctx);
 		pfx_launch_assemble_rows<NLOC, 3>(ctx, staged_block<NLOC>{ctx->d_kloc}, false);
 	}
 } // namespace
 
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess)
 {
-	if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the nonlinear-assembler interface is implemented for NeoHookean and LinearElasticity");
+	if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY && ctx->model != PFX_SAINT_VENANT)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the nonlinear-assembler interface is implemented for NeoHookean, SaintVenant and LinearElasticity");
 	const int np = ctx->n_pts;
 	bool ok = true;
 	switch (ctx->kind)

@@ -21,9 +21,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpolyfem_amd.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN = 0, 1, 2
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT = 0, 1, 2, 3
 PRECOND_IDENTITY, PRECOND_JACOBI = 0, 1
-MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN}
+MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN,
+                 "SaintVenant": SAINT_VENANT}
 
 EXPORTED_SYMBOLS = [
     "pfx_create", "pfx_destroy", "pfx_last_error", "pfx_set_stream", "pfx_synchronize", "pfx_set_mesh",
@@ -572,7 +573,7 @@ class Assembler(_AssemblerBase):
 
 
 class NLAssembler(_AssemblerBase):
-    """assembler::NLAssembler<LocalAssembler> for NeoHookean."""
+    """assembler::NLAssembler<LocalAssembler> for NeoHookean, SaintVenant (and LinearElasticity)."""
 
     def assemble(self, is_volume, bases, gbases, cache, dt, displacement, displacement_prev=None) -> float:
         self._bind(bases)

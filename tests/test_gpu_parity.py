@@ -84,6 +84,58 @@ def test_neohookean_energy_gradient_hessian(eng, oracle, name):
         assert rel_err(v, vals) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "p2_stretched", "q1", "q2"])
+def test_saint_venant_energy_gradient_hessian(eng, oracle, name):
+    """SaintVenantElasticity (SaintVenantElasticity.cpp:104-143, 215-312; isotropic tensor): energy, gradient, Hessian
+    (plain and project_to_psd) at rest, at a moderate and at a large deformation, per-element materials, and a Newton
+    solve, against the oracle."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    nnz = _setup(eng, mesh, E.SAINT_VENANT, lam, mu)
+    n = mesh.n_nodes * 3
+    h = 1.0 / round((mesh.n_el / (6 if mesh.kind < 2 else 1)) ** (1 / 3))
+    for amp in (0.0, 1e-2 * h, 0.3 * h):
+        x = M.seeded_displacement(mesh, 3, amp)
+        e_ref = oracle.assemble_energy(mesh, oracle.SAINT_VENANT, lam, mu, x)
+        g_ref = oracle.assemble_gradient(mesh, oracle.SAINT_VENANT, lam, mu, x)
+        outer, inner, vals = oracle.assemble_hessian(mesh, oracle.SAINT_VENANT, lam, mu, x)
+        e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and nnz == inner.size
+        if amp == 0.0:
+            assert e == 0.0 and e_ref == 0.0 and not g.any()
+        else:
+            assert abs(e - e_ref) <= TOL * abs(e_ref)
+            assert rel_err(g, g_ref) <= TOL
+        assert rel_err(v, vals) <= TOL
+    if name != "q2":
+        vp = eng.hessian(x, project_to_psd=True)
+        ref = oracle.assemble_hessian_psd(mesh, oracle.SAINT_VENANT, lam, mu, x)
+        assert np.abs(vp - ref[2]).max() <= 1e-10 * np.abs(ref[2]).max()
+    # one (lambda, mu) per element
+    half = np.arange(mesh.n_el) < mesh.n_el // 2
+    l2, m2 = oracle.lame(5e4, 0.2)
+    lam_e, mu_e = np.where(half, lam, l2), np.where(half, mu, m2)
+    eng.set_material(E.SAINT_VENANT, lam_e, mu_e)
+    x = M.seeded_displacement(mesh, 3, 0.1 * h, seed=4)
+    assert abs(eng.energy(x) - oracle.assemble_energy(mesh, oracle.SAINT_VENANT, lam_e, mu_e, x)) <= TOL * abs(eng.energy(x))
+    assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.SAINT_VENANT, lam_e, mu_e, x)) <= TOL
+    assert rel_err(eng.hessian(x), oracle.assemble_hessian(mesh, oracle.SAINT_VENANT, lam_e, mu_e, x)[2]) <= TOL
+    # Newton solve (the Q1 one-point rule leaves the clamped static problem singular: skipped there)
+    if name != "q1":
+        eng.set_material(E.SAINT_VENANT, lam, mu)
+        bnd = M.boundary_dofs(mesh, 3, "x0")
+        eng.set_dirichlet(bnd)
+        rhs = np.zeros(n)
+        rhs[2::3] = -100.0 / mesh.n_nodes
+        xs, info = eng.newton_solve(np.zeros(n), rhs)
+        xr, iref = oracle.newton_solve(mesh, oracle.SAINT_VENANT, lam, mu, rhs, bnd, np.zeros(n))
+        eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+        assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+        assert info["line_search_iterations"] == iref["line_search_iterations"]
+        assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
 @pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
 def test_linear_elasticity_through_nonlinear_interface(eng, oracle, name):
     """LinearElasticity::compute_energy / assemble_grad / assemble_hessian (LinearElasticity.cpp:56-169) against the

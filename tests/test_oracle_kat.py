@@ -446,3 +446,38 @@ def test_implicit_euler_step_oracle(oracle):
 
     x3, v3, a3, info3 = oracle.implicit_euler_step(mesh, oracle.NEOHOOKEAN, lam, mu, None, bnd, mass, dt, np.zeros(n), np.zeros(n))
     assert info3["status"] == 4 and not x3.any() and not v3.any()
+
+
+@pytest.mark.parametrize("kind", ["tet2", "hex2", "tet1"])
+def test_saint_venant_oracle(oracle, kind):
+    """SaintVenant restatement: the written-out gradient / Hessian are the derivatives of the reference's energy
+    (central differences), the Hessian is symmetric, small strains reproduce linear elasticity, a rigid rotation stores
+    no energy (the linear model does), and a uniaxial stretch has the closed-form energy."""
+    mesh = {"tet2": lambda: M.cube_tets(2, 2, jitter=0.1), "hex2": lambda: M.cube_hexes(2, 2), "tet1": lambda: M.cube_tets(2, 1)}[kind]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    SV, LE = oracle.SAINT_VENANT, oracle.LINEAR_ELASTICITY
+    u = M.seeded_displacement(mesh, 3, 5e-2, seed=3)
+    g = oracle.assemble_gradient(mesh, SV, lam, mu, u)
+    H = csc_to_scipy(oracle.assemble_hessian(mesh, SV, lam, mu, u), n)
+    d = np.random.default_rng(0).standard_normal(n)
+    h = 1e-6
+    fd = (oracle.assemble_energy(mesh, SV, lam, mu, u + h * d) - oracle.assemble_energy(mesh, SV, lam, mu, u - h * d)) / (2 * h)
+    gfd = (oracle.assemble_gradient(mesh, SV, lam, mu, u + h * d) - oracle.assemble_gradient(mesh, SV, lam, mu, u - h * d)) / (2 * h)
+    assert abs(fd - g @ d) <= 1e-7 * abs(g @ d)
+    assert np.linalg.norm(gfd - H @ d) <= 1e-7 * np.linalg.norm(H @ d)
+    assert abs(H - H.T).max() <= 1e-13 * abs(H).max()
+    us = 1e-7 * u
+    assert abs(oracle.assemble_energy(mesh, SV, lam, mu, us) / oracle.assemble_energy(mesh, LE, lam, mu, us) - 1) <= 1e-6
+    if kind != "tet2":  # (the jittered mesh keeps lattice node positions: no exact rigid motion of its geometry)
+        th = 0.7
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        ur = (mesh.node_xyz @ R.T - mesh.node_xyz).reshape(-1)
+        assert abs(oracle.assemble_energy(mesh, SV, lam, mu, ur)) <= 1e-20 * lam
+        assert np.abs(oracle.assemble_gradient(mesh, SV, lam, mu, ur)).max() <= 1e-10
+        assert oracle.assemble_energy(mesh, LE, lam, mu, ur) > 1.0
+        a = 0.2  # x -> (1+a) x: E_xx = a + a^2/2, energy density (lambda/2 + mu) E_xx^2, unit volume
+        ux = np.zeros(n)
+        ux[0::3] = a * mesh.node_xyz[:, 0]
+        exx = a + a * a / 2
+        assert abs(oracle.assemble_energy(mesh, SV, lam, mu, ux) - (lam / 2 + mu) * exx * exx) <= 1e-12 * lam * exx * exx
