@@ -190,12 +190,11 @@ extern "C"
 			return PFX_ERR_HIP;
 		}
 		ctx->own_stream = true;
-		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_tab_mass, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess)
+		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_tab_mass, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess || hipMemset(ctx->d_flag, 0, sizeof(int)) != hipSuccess)
 		{
-			delete ctx;
+			pfx_destroy(ctx); // releases whatever was allocated so far, and the stream
 			return PFX_ERR_HIP;
 		}
-		(void)hipMemset(ctx->d_flag, 0, sizeof(int));
 		*out = ctx;
 		return PFX_OK;
 	}
@@ -714,9 +713,9 @@ extern "C"
 			return PFX_ERR_ARG;
 		PFX_HIP(hipSetDevice(ctx->device));
 		const int64_t n = ctx->n_dofs();
-		double *d = nullptr;
-		PFX_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(4 * n)));
-		double *d_x = d, *d_v = d + n, *d_a = d + 2 * n, *d_rhs = rhs ? d + 3 * n : nullptr;
+		pfx_tmp<double> d;
+		PFX_HIP(d.alloc((size_t)(4 * n)));
+		double *d_x = d.p, *d_v = d.p + n, *d_a = d.p + 2 * n, *d_rhs = rhs ? d.p + 3 * n : nullptr;
 		hipStream_t st = ctx->stream;
 		pfx_status rc = PFX_OK;
 		if (hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_v, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess || (rhs && hipMemcpyAsync(d_rhs, rhs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess))
@@ -732,7 +731,6 @@ extern "C"
 			}
 		}
 		(void)hipStreamSynchronize(st);
-		(void)hipFree(d);
 		return rc;
 	}
 
@@ -793,15 +791,14 @@ extern "C"
 		if (need_pattern(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
-		double *d = nullptr;
-		PFX_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(2 * n)));
-		PFX_HIP(hipMemcpyAsync(d, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		pfx_tmp<double> d;
+		PFX_HIP(d.alloc((size_t)(2 * n)));
+		PFX_HIP(hipMemcpyAsync(d.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
 		if (rhs)
-			PFX_HIP(hipMemcpyAsync(d + n, rhs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-		const pfx_status rc = pfx_newton_solve_dev(ctx, rhs ? d + n : nullptr, d, params, info);
-		(void)hipMemcpyAsync(x, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+			PFX_HIP(hipMemcpyAsync(d.p + n, rhs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		const pfx_status rc = pfx_newton_solve_dev(ctx, rhs ? d.p + n : nullptr, d.p, params, info);
+		(void)hipMemcpyAsync(x, d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
 		(void)hipStreamSynchronize(ctx->stream);
-		(void)hipFree(d);
 		return rc;
 	}
 
@@ -841,9 +838,10 @@ extern "C"
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		hipStream_t st = ctx->stream;
-		double *d_b = nullptr, *d_g = nullptr;
-		PFX_HIP(hipMalloc((void **)&d_b, sizeof(double) * (size_t)n));
-		PFX_HIP(hipMalloc((void **)&d_g, sizeof(double) * (size_t)n));
+		pfx_tmp<double> tb, tg;
+		PFX_HIP(tb.alloc((size_t)n));
+		PFX_HIP(tg.alloc((size_t)n));
+		double *d_b = tb.p, *d_g = tg.p;
 		PFX_HIP(hipMemcpyAsync(d_b, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
 		// lift: g holds the prescribed values; A g with the UNMASKED operator moves them to the right-hand side
 		hipLaunchKernelGGL(k_dirichlet_lift, dim3(grid_for(n)), dim3(256), 0, st, d_b, ctx->d_fixed, n, d_g);
@@ -863,8 +861,7 @@ extern "C"
 			PFX_HIP(hipMemcpyAsync(x, ctx->d_vec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
 			PFX_HIP(hipStreamSynchronize(st));
 		}
-		(void)hipFree(d_b);
-		(void)hipFree(d_g);
+		(void)hipStreamSynchronize(st); // the temporaries are released on return
 		return rc;
 	}
 

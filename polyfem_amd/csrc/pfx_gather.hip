@@ -224,13 +224,12 @@ pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy)
 // copies the matrix values to the host in the order of the scalar CSR returned by pfx_export_pattern
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values)
 {
-	double *d_csr = nullptr;
-	PFX_HIP(hipMalloc((void **)&d_csr, sizeof(double) * (size_t)(ctx->nnz ? ctx->nnz : 1)));
+	pfx_tmp<double> d_csr;
+	PFX_HIP(d_csr.alloc((size_t)ctx->nnz));
 	hipLaunchKernelGGL(k_values_to_csr, dim3(grid_for(ctx->n_nodes * 64)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->n_nodes, ctx->bs,
-					   ctx->d_values, d_csr);
-	PFX_HIP(hipMemcpyAsync(host_values, d_csr, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+					   ctx->d_values, d_csr.p);
+	PFX_HIP(hipMemcpyAsync(host_values, d_csr.p, sizeof(double) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
 	PFX_HIP(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_csr);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
@@ -247,63 +246,51 @@ pfx_status pfx_export_compressed(pfx_ctx *ctx, bool use_mask, bool drop_fixed, i
 	hipStream_t st = ctx->stream;
 	const uint8_t *mask = use_mask ? ctx->d_mask : nullptr;
 	const uint8_t *fixed = (drop_fixed && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
-	int64_t *cnt = nullptr, *off = nullptr, *newrow = nullptr, *fl = nullptr;
-	void *tmp = nullptr;
+	pfx_tmp<int64_t> cnt, off, newrow, fl;
+	pfx_tmp<char> tmp;
 	size_t tb = 0;
-	PFX_HIP(hipMalloc((void **)&cnt, sizeof(int64_t) * (size_t)(n_rows + 1)));
-	PFX_HIP(hipMalloc((void **)&off, sizeof(int64_t) * (size_t)(n_rows + 1)));
-	PFX_HIP(hipMemsetAsync(cnt, 0, sizeof(int64_t) * (size_t)(n_rows + 1), st));
-	hipLaunchKernelGGL(k_count_kept, dim3(grid_for(n_rows)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, mask, fixed, cnt);
-	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, cnt, off, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
-	PFX_HIP(hipMalloc(&tmp, tb));
-	PFX_HIP(rocprim::exclusive_scan(tmp, tb, cnt, off, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(cnt.alloc((size_t)(n_rows + 1)));
+	PFX_HIP(off.alloc((size_t)(n_rows + 1)));
+	PFX_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int64_t) * (size_t)(n_rows + 1), st));
+	hipLaunchKernelGGL(k_count_kept, dim3(grid_for(n_rows)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, mask, fixed, cnt.p);
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, cnt.p, off.p, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(tmp.alloc(tb));
+	PFX_HIP(rocprim::exclusive_scan(tmp.p, tb, cnt.p, off.p, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
 	int64_t total = 0, n_red = n_rows;
-	PFX_HIP(hipMemcpyAsync(&total, off + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PFX_HIP(hipMemcpyAsync(&total, off.p + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	tmp = nullptr;
 	if (fixed)
 	{
-		PFX_HIP(hipMalloc((void **)&fl, sizeof(int64_t) * (size_t)(n_rows + 1)));
-		PFX_HIP(hipMalloc((void **)&newrow, sizeof(int64_t) * (size_t)(n_rows + 1)));
-		PFX_HIP(hipMemsetAsync(fl, 0, sizeof(int64_t) * (size_t)(n_rows + 1), st));
-		hipLaunchKernelGGL(k_free_flag, dim3(grid_for(n_rows)), dim3(256), 0, st, fixed, n_rows, fl);
+		PFX_HIP(fl.alloc((size_t)(n_rows + 1)));
+		PFX_HIP(newrow.alloc((size_t)(n_rows + 1)));
+		PFX_HIP(hipMemsetAsync(fl.p, 0, sizeof(int64_t) * (size_t)(n_rows + 1), st));
+		hipLaunchKernelGGL(k_free_flag, dim3(grid_for(n_rows)), dim3(256), 0, st, fixed, n_rows, fl.p);
 		tb = 0;
-		PFX_HIP(rocprim::exclusive_scan(nullptr, tb, fl, newrow, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
-		PFX_HIP(hipMalloc(&tmp, tb));
-		PFX_HIP(rocprim::exclusive_scan(tmp, tb, fl, newrow, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
-		PFX_HIP(hipMemcpyAsync(&n_red, newrow + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+		PFX_HIP(rocprim::exclusive_scan(nullptr, tb, fl.p, newrow.p, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(tmp.alloc(tb));
+		PFX_HIP(rocprim::exclusive_scan(tmp.p, tb, fl.p, newrow.p, (int64_t)0, (size_t)(n_rows + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(hipMemcpyAsync(&n_red, newrow.p + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
 		PFX_HIP(hipStreamSynchronize(st));
-		(void)hipFree(tmp);
-		tmp = nullptr;
 	}
+	tmp.reset();
 	*n_rows_out = n_red;
 	*nnz_out = total;
 	if (row_ptr)
 	{
-		int64_t *d_rp = nullptr;
-		int32_t *d_ci = nullptr;
-		double *d_v = nullptr;
-		PFX_HIP(hipMalloc((void **)&d_rp, sizeof(int64_t) * (size_t)(n_red + 1)));
-		PFX_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * (size_t)(total ? total : 1)));
-		PFX_HIP(hipMalloc((void **)&d_v, sizeof(double) * (size_t)(total ? total : 1)));
+		pfx_tmp<int64_t> d_rp;
+		pfx_tmp<int32_t> d_ci;
+		pfx_tmp<double> d_v;
+		PFX_HIP(d_rp.alloc((size_t)(n_red + 1)));
+		PFX_HIP(d_ci.alloc((size_t)total));
+		PFX_HIP(d_v.alloc((size_t)total));
 		hipLaunchKernelGGL(k_write_kept, dim3(grid_for(n_rows)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, mask, fixed,
-						   newrow, off, ctx->d_values, d_rp, d_ci, d_v);
-		PFX_HIP(hipMemcpyAsync(row_ptr, d_rp, sizeof(int64_t) * (size_t)n_red, hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipMemcpyAsync(col_idx, d_ci, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipMemcpyAsync(values, d_v, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, st));
+						   (const int64_t *)newrow.p, (const int64_t *)off.p, ctx->d_values, d_rp.p, d_ci.p, d_v.p);
+		PFX_HIP(hipMemcpyAsync(row_ptr, d_rp.p, sizeof(int64_t) * (size_t)n_red, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(col_idx, d_ci.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(values, d_v.p, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, st));
 		PFX_HIP(hipStreamSynchronize(st));
 		row_ptr[n_red] = total;
-		(void)hipFree(d_rp);
-		(void)hipFree(d_ci);
-		(void)hipFree(d_v);
 	}
-	(void)hipFree(cnt);
-	(void)hipFree(off);
-	if (fl)
-		(void)hipFree(fl);
-	if (newrow)
-		(void)hipFree(newrow);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

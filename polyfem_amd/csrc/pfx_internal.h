@@ -177,6 +177,29 @@ pfx_status pfx_alloc(pfx_ctx *ctx, T **p, int64_t count)
 	return PFX_OK;
 }
 
+// Temporary device buffer of the host-side sequencing code: released when it goes out of scope, i.e. also on the early
+// returns of PFX_HIP / PFX_FAIL.  Kernel launches take the raw pointer (.p).
+template <typename T>
+struct pfx_tmp
+{
+	T *p = nullptr;
+	pfx_tmp() = default;
+	pfx_tmp(const pfx_tmp &) = delete;
+	pfx_tmp &operator=(const pfx_tmp &) = delete;
+	~pfx_tmp() { reset(); }
+	hipError_t alloc(size_t count)
+	{
+		reset();
+		return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1));
+	}
+	void reset()
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+	}
+};
+
 // Times one kernel family with a pair of HIP events recorded on the context's stream; nothing synchronises
 // until pfx_timing_get()/pfx_timing_reset() resolves the pending pairs.
 struct pfx_scoped_timer

@@ -155,43 +155,41 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	hipStream_t st = ctx->stream;
 
 	// ---- node-pair blocks ----------------------------------------------------------------------------------
-	uint64_t *keys_a = nullptr, *keys_b = nullptr;
-	uint32_t *vals_a = nullptr;
-	int64_t *pos = nullptr, *deg = nullptr;
-	void *tmp = nullptr;
+	pfx_tmp<uint64_t> keys_a, keys_b;
+	pfx_tmp<uint32_t> vals_a;
+	pfx_tmp<int64_t> pos, deg;
+	pfx_tmp<char> tmp;
 	size_t tmp_bytes = 0;
-	PFX_HIP(hipMalloc((void **)&keys_a, sizeof(uint64_t) * (size_t)n_pair));
-	PFX_HIP(hipMalloc((void **)&keys_b, sizeof(uint64_t) * (size_t)n_pair));
-	PFX_HIP(hipMalloc((void **)&vals_a, sizeof(uint32_t) * (size_t)n_pair));
+	PFX_HIP(keys_a.alloc((size_t)n_pair));
+	PFX_HIP(keys_b.alloc((size_t)n_pair));
+	PFX_HIP(vals_a.alloc((size_t)n_pair));
 	if (pfx_alloc(ctx, &ctx->d_blk_src, n_pair))
 		return PFX_ERR_HIP;
-	hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, ctx->d_conn, n_pair, n_loc, n_nodes, keys_a, vals_a);
+	hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, ctx->d_conn, n_pair, n_loc, n_nodes, keys_a.p, vals_a.p);
 	const int end_bit = bits_for((uint64_t)n_nodes * (uint64_t)n_nodes);
-	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
-	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
-	PFX_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, vals_a.p, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
+	PFX_HIP(tmp.alloc(tmp_bytes));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_a.p, keys_b.p, vals_a.p, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	tmp = nullptr;
-	(void)hipFree(keys_a);
-	(void)hipFree(vals_a);
+	tmp.reset();
+	keys_a.reset();
+	vals_a.reset();
 
 	// positions of run heads
-	PFX_HIP(hipMalloc((void **)&pos, sizeof(int64_t) * (size_t)(n_pair + 1)));
-	auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), head_flag{keys_b});
+	PFX_HIP(pos.alloc((size_t)(n_pair + 1)));
+	auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), head_flag{keys_b.p});
 	tmp_bytes = 0;
-	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pos, (int64_t)0, (size_t)n_pair, rocprim::plus<int64_t>(), st));
-	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
-	PFX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pos, (int64_t)0, (size_t)n_pair, rocprim::plus<int64_t>(), st));
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pos.p, (int64_t)0, (size_t)n_pair, rocprim::plus<int64_t>(), st));
+	PFX_HIP(tmp.alloc(tmp_bytes));
+	PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, flags, pos.p, (int64_t)0, (size_t)n_pair, rocprim::plus<int64_t>(), st));
 	int64_t last_pos = 0;
-	PFX_HIP(hipMemcpyAsync(&last_pos, pos + (n_pair - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
+	PFX_HIP(hipMemcpyAsync(&last_pos, pos.p + (n_pair - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	tmp = nullptr;
+	tmp.reset();
 	// the last item is a head iff its key differs from its predecessor; count = pos[last] + flag[last]
 	uint64_t k_last[2] = {0, 0};
 	if (n_pair >= 2)
-		PFX_HIP(hipMemcpy(k_last, keys_b + (n_pair - 2), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+		PFX_HIP(hipMemcpy(k_last, keys_b.p + (n_pair - 2), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	const int64_t last_flag = (n_pair == 1) ? 1 : (k_last[0] != k_last[1] ? 1 : 0);
 	const int64_t n_blocks = last_pos + last_flag;
 	ctx->n_blocks = n_blocks;
@@ -199,74 +197,62 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 
 	if (pfx_alloc(ctx, &ctx->d_blk_ptr, n_blocks + 1) || pfx_alloc(ctx, &ctx->d_node_col, n_blocks) || pfx_alloc(ctx, &ctx->d_node_ptr, n_nodes + 1))
 		return PFX_ERR_HIP;
-	PFX_HIP(hipMalloc((void **)&deg, sizeof(int64_t) * (size_t)(n_nodes + 1)));
-	PFX_HIP(hipMemsetAsync(deg, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
-	hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b, pos, n_pair, n_nodes, ctx->d_blk_ptr, ctx->d_node_col, deg);
+	PFX_HIP(deg.alloc((size_t)(n_nodes + 1)));
+	PFX_HIP(hipMemsetAsync(deg.p, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
+	hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, pos.p, n_pair, n_nodes, ctx->d_blk_ptr, ctx->d_node_col, deg.p);
 	hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, st, ctx->d_blk_ptr + n_blocks, n_pair);
 	tmp_bytes = 0;
-	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
-	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
-	PFX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, deg, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg.p, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(tmp.alloc(tmp_bytes));
+	PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	tmp = nullptr;
-	(void)hipFree(pos);
+	tmp.reset();
+	pos.reset();
 
 	// ---- compute order of the contributions inside each assembly window -----------------------------------------
 	{
-		uint64_t *wk_a = nullptr, *wk_b = nullptr, *wv_a = nullptr, *wv_b = nullptr;
-		PFX_HIP(hipMalloc((void **)&wk_a, sizeof(uint64_t) * (size_t)n_pair));
-		PFX_HIP(hipMalloc((void **)&wk_b, sizeof(uint64_t) * (size_t)n_pair));
-		PFX_HIP(hipMalloc((void **)&wv_a, sizeof(uint64_t) * (size_t)n_pair));
-		PFX_HIP(hipMalloc((void **)&wv_b, sizeof(uint64_t) * (size_t)n_pair));
+		pfx_tmp<uint64_t> wk_a, wk_b, wv_a, wv_b;
+		PFX_HIP(wk_a.alloc((size_t)n_pair));
+		PFX_HIP(wk_b.alloc((size_t)n_pair));
+		PFX_HIP(wv_a.alloc((size_t)n_pair));
+		PFX_HIP(wv_b.alloc((size_t)n_pair));
 		if (pfx_alloc(ctx, &ctx->d_blk_slot, n_pair))
 			return PFX_ERR_HIP;
-		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b, ctx->d_blk_src, ctx->d_node_ptr, ctx->d_blk_ptr, n_pair,
-						   n_nodes, (uint32_t)(n_loc * n_loc), wk_a, wv_a);
+		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, ctx->d_blk_src, ctx->d_node_ptr, ctx->d_blk_ptr, n_pair,
+						   n_nodes, (uint32_t)(n_loc * n_loc), wk_a.p, wv_a.p);
 		const int wbits = 28 + bits_for((uint64_t)n_pair);
 		tmp_bytes = 0;
-		PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, wk_a, wk_b, wv_a, wv_b, (size_t)n_pair, 0, wbits, st));
-		PFX_HIP(hipMalloc(&tmp, tmp_bytes));
-		PFX_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, wk_a, wk_b, wv_a, wv_b, (size_t)n_pair, 0, wbits, st));
-		hipLaunchKernelGGL(k_split_window_vals, dim3(grid_for(n_pair)), dim3(256), 0, st, wv_b, n_pair, ctx->d_blk_src, ctx->d_blk_slot);
+		PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, wk_a.p, wk_b.p, wv_a.p, wv_b.p, (size_t)n_pair, 0, wbits, st));
+		PFX_HIP(tmp.alloc(tmp_bytes));
+		PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, wk_a.p, wk_b.p, wv_a.p, wv_b.p, (size_t)n_pair, 0, wbits, st));
+		hipLaunchKernelGGL(k_split_window_vals, dim3(grid_for(n_pair)), dim3(256), 0, st, wv_b.p, n_pair, ctx->d_blk_src, ctx->d_blk_slot);
 		PFX_HIP(hipStreamSynchronize(st));
-		(void)hipFree(tmp);
-		tmp = nullptr;
-		(void)hipFree(wk_a);
-		(void)hipFree(wk_b);
-		(void)hipFree(wv_a);
-		(void)hipFree(wv_b);
+		tmp.reset();
 	}
-	(void)hipFree(keys_b);
+	keys_b.reset();
 
 	// ---- node -> (element, local index) incidences ---------------------------------------------------------
-	uint32_t *nk_a = nullptr, *nk_b = nullptr, *nv_a = nullptr;
-	PFX_HIP(hipMalloc((void **)&nk_a, sizeof(uint32_t) * (size_t)n_inc));
-	PFX_HIP(hipMalloc((void **)&nk_b, sizeof(uint32_t) * (size_t)n_inc));
-	PFX_HIP(hipMalloc((void **)&nv_a, sizeof(uint32_t) * (size_t)n_inc));
+	pfx_tmp<uint32_t> nk_a, nk_b, nv_a;
+	PFX_HIP(nk_a.alloc((size_t)n_inc));
+	PFX_HIP(nk_b.alloc((size_t)n_inc));
+	PFX_HIP(nv_a.alloc((size_t)n_inc));
 	if (pfx_alloc(ctx, &ctx->d_ne_src, n_inc) || pfx_alloc(ctx, &ctx->d_ne_ptr, n_nodes + 1))
 		return PFX_ERR_HIP;
-	hipLaunchKernelGGL(k_node_keys, dim3(grid_for(n_inc)), dim3(256), 0, st, ctx->d_conn, n_inc, nk_a, nv_a);
+	hipLaunchKernelGGL(k_node_keys, dim3(grid_for(n_inc)), dim3(256), 0, st, ctx->d_conn, n_inc, nk_a.p, nv_a.p);
 	const int nb = bits_for((uint64_t)n_nodes);
 	tmp_bytes = 0;
-	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, nk_a, nk_b, nv_a, ctx->d_ne_src, (size_t)n_inc, 0, nb, st));
-	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
-	PFX_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, nk_a, nk_b, nv_a, ctx->d_ne_src, (size_t)n_inc, 0, nb, st));
-	PFX_HIP(hipMemsetAsync(deg, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
-	hipLaunchKernelGGL(k_count_u32, dim3(grid_for(n_inc)), dim3(256), 0, st, nk_b, n_inc, deg);
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, nk_a.p, nk_b.p, nv_a.p, ctx->d_ne_src, (size_t)n_inc, 0, nb, st));
+	PFX_HIP(tmp.alloc(tmp_bytes));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, nk_a.p, nk_b.p, nv_a.p, ctx->d_ne_src, (size_t)n_inc, 0, nb, st));
+	PFX_HIP(hipMemsetAsync(deg.p, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
+	hipLaunchKernelGGL(k_count_u32, dim3(grid_for(n_inc)), dim3(256), 0, st, nk_b.p, n_inc, deg.p);
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	tmp = nullptr;
+	tmp.reset();
 	tmp_bytes = 0;
-	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
-	PFX_HIP(hipMalloc(&tmp, tmp_bytes));
-	PFX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, deg, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg.p, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(tmp.alloc(tmp_bytes));
+	PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	(void)hipFree(deg);
-	(void)hipFree(nk_a);
-	(void)hipFree(nk_b);
-	(void)hipFree(nv_a);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
@@ -274,15 +260,13 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 pfx_status pfx_export_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx)
 {
 	const int64_t n_rows = ctx->n_dofs();
-	int64_t *d_rp = nullptr;
-	int32_t *d_ci = nullptr;
-	PFX_HIP(hipMalloc((void **)&d_rp, sizeof(int64_t) * (size_t)(n_rows + 1)));
-	PFX_HIP(hipMalloc((void **)&d_ci, sizeof(int32_t) * (size_t)(ctx->nnz ? ctx->nnz : 1)));
-	hipLaunchKernelGGL(k_export_pattern, dim3(grid_for(n_rows + 1)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, d_rp, d_ci);
-	PFX_HIP(hipMemcpyAsync(row_ptr, d_rp, sizeof(int64_t) * (size_t)(n_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
-	PFX_HIP(hipMemcpyAsync(col_idx, d_ci, sizeof(int32_t) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
+	pfx_tmp<int64_t> d_rp;
+	pfx_tmp<int32_t> d_ci;
+	PFX_HIP(d_rp.alloc((size_t)(n_rows + 1)));
+	PFX_HIP(d_ci.alloc((size_t)ctx->nnz));
+	hipLaunchKernelGGL(k_export_pattern, dim3(grid_for(n_rows + 1)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, d_rp.p, d_ci.p);
+	PFX_HIP(hipMemcpyAsync(row_ptr, d_rp.p, sizeof(int64_t) * (size_t)(n_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
+	PFX_HIP(hipMemcpyAsync(col_idx, d_ci.p, sizeof(int32_t) * (size_t)ctx->nnz, hipMemcpyDeviceToHost, ctx->stream));
 	PFX_HIP(hipStreamSynchronize(ctx->stream));
-	(void)hipFree(d_rp);
-	(void)hipFree(d_ci);
 	return PFX_OK;
 }

@@ -261,40 +261,33 @@ static pfx_status sell_build(pfx_ctx *ctx)
 		sigma = atoi(e) > 0 ? (atoi(e) + SL - 1) / SL * SL : sigma;
 	const int64_t n_slices = (n_owned + SL - 1) / SL;
 	const int64_t n_pad = n_slices * SL;
-	uint64_t *ka = nullptr, *kb = nullptr;
-	uint32_t *va = nullptr, *vb = nullptr;
-	int64_t *len = nullptr;
-	void *tmp = nullptr;
+	pfx_tmp<uint64_t> ka, kb;
+	pfx_tmp<uint32_t> va, vb;
+	pfx_tmp<int64_t> len;
+	pfx_tmp<char> tmp;
 	size_t tb = 0;
-	PFX_HIP(hipMalloc((void **)&ka, sizeof(uint64_t) * (size_t)(n_owned + 1)));
-	PFX_HIP(hipMalloc((void **)&kb, sizeof(uint64_t) * (size_t)(n_owned + 1)));
-	PFX_HIP(hipMalloc((void **)&va, sizeof(uint32_t) * (size_t)(n_owned + 1)));
-	PFX_HIP(hipMalloc((void **)&vb, sizeof(uint32_t) * (size_t)(n_owned + 1)));
-	PFX_HIP(hipMalloc((void **)&len, sizeof(int64_t) * (size_t)(n_slices + 1)));
-	PFX_HIP(hipMemsetAsync(len, 0, sizeof(int64_t) * (size_t)(n_slices + 1), st));
-	hipLaunchKernelGGL(k_sell_keys, dim3(grid_for(n_owned)), dim3(256), 0, st, ctx->d_node_ptr, n_owned, sigma, ka, va);
-	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tb, ka, kb, va, vb, (size_t)n_owned, 0, 64, st));
-	PFX_HIP(hipMalloc(&tmp, tb));
-	PFX_HIP(rocprim::radix_sort_pairs(tmp, tb, ka, kb, va, vb, (size_t)n_owned, 0, 64, st));
+	PFX_HIP(ka.alloc((size_t)(n_owned + 1)));
+	PFX_HIP(kb.alloc((size_t)(n_owned + 1)));
+	PFX_HIP(va.alloc((size_t)(n_owned + 1)));
+	PFX_HIP(vb.alloc((size_t)(n_owned + 1)));
+	PFX_HIP(len.alloc((size_t)(n_slices + 1)));
+	PFX_HIP(hipMemsetAsync(len.p, 0, sizeof(int64_t) * (size_t)(n_slices + 1), st));
+	hipLaunchKernelGGL(k_sell_keys, dim3(grid_for(n_owned)), dim3(256), 0, st, ctx->d_node_ptr, n_owned, sigma, ka.p, va.p);
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tb, ka.p, kb.p, va.p, vb.p, (size_t)n_owned, 0, 64, st));
+	PFX_HIP(tmp.alloc(tb));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tb, ka.p, kb.p, va.p, vb.p, (size_t)n_owned, 0, 64, st));
 	if (pfx_alloc(ctx, &ctx->d_sell_perm, n_pad) || pfx_alloc(ctx, &ctx->d_sell_base, n_slices + 1))
 		return PFX_ERR_HIP;
-	hipLaunchKernelGGL(k_sell_perm, dim3(grid_for(n_pad)), dim3(256), 0, st, vb, n_owned, n_pad, ctx->d_node_ptr, ctx->d_sell_perm, len);
+	hipLaunchKernelGGL(k_sell_perm, dim3(grid_for(n_pad)), dim3(256), 0, st, vb.p, n_owned, n_pad, ctx->d_node_ptr, ctx->d_sell_perm, len.p);
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	tmp = nullptr;
 	tb = 0;
-	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, len, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
-	PFX_HIP(hipMalloc(&tmp, tb));
-	PFX_HIP(rocprim::exclusive_scan(tmp, tb, len, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, len.p, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
+	PFX_HIP(tmp.alloc(tb));
+	PFX_HIP(rocprim::exclusive_scan(tmp.p, tb, len.p, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
 	int64_t total = 0;
 	PFX_HIP(hipMemcpyAsync(&total, ctx->d_sell_base + n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
 	PFX_HIP(hipStreamSynchronize(st));
-	(void)hipFree(tmp);
-	(void)hipFree(ka);
-	(void)hipFree(kb);
-	(void)hipFree(va);
-	(void)hipFree(vb);
-	(void)hipFree(len);
+	tmp.reset(), ka.reset(), kb.reset(), va.reset(), vb.reset(), len.reset();
 	ctx->sell_rows = total;
 	ctx->sell_slices = n_slices;
 	const int b2 = ctx->bs * ctx->bs;
@@ -313,14 +306,14 @@ static pfx_status sell_build(pfx_ctx *ctx)
 	ctx->sell_interior = n_slices;
 	if (n_owned < ctx->n_nodes && n_slices > 0)
 	{
-		uint8_t *d_flag = nullptr;
-		PFX_HIP(hipMalloc((void **)&d_flag, (size_t)n_slices));
-		PFX_HIP(hipMemsetAsync(d_flag, 0, (size_t)n_slices, st));
-		hipLaunchKernelGGL(k_sell_classify, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, st, ctx->d_sell_base, ctx->d_sell_cols, n_slices, n_owned, d_flag);
+		pfx_tmp<uint8_t> d_flag;
+		PFX_HIP(d_flag.alloc((size_t)n_slices));
+		PFX_HIP(hipMemsetAsync(d_flag.p, 0, (size_t)n_slices, st));
+		hipLaunchKernelGGL(k_sell_classify, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, st, ctx->d_sell_base, ctx->d_sell_cols, n_slices, n_owned, d_flag.p);
 		std::vector<uint8_t> flag((size_t)n_slices);
-		PFX_HIP(hipMemcpyAsync(flag.data(), d_flag, (size_t)n_slices, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(flag.data(), d_flag.p, (size_t)n_slices, hipMemcpyDeviceToHost, st));
 		PFX_HIP(hipStreamSynchronize(st));
-		(void)hipFree(d_flag);
+		d_flag.reset();
 		std::vector<int32_t> order;
 		order.reserve((size_t)n_slices);
 		for (int64_t k = 0; k < n_slices; ++k)
