@@ -1,0 +1,72 @@
+"""Gmsh reader / flattening (input side of the path): round trips through both ASCII formats, the first-touch P2
+numbering against the generator that follows the same rule, body ids, re-orientation, rejected inputs.  The reference
+parses MSH files with the un-vendored MshIO library and holds no mesh fixture: parity unpinned, checked for
+self-consistency only."""
+import numpy as np
+import pytest
+
+from polyfem_amd import mesh as M
+from polyfem_amd import meshio as IO
+
+
+@pytest.mark.parametrize("version", ["2.2", "4.1"])
+def test_msh_round_trip_and_p2_numbering(tmp_path, version):
+    ref1 = M.cube_tets(2, 1, jitter=0.1)
+    body = (np.arange(ref1.n_el) >= ref1.n_el // 3).astype(np.int32) * 7 + 1  # two bodies, contiguous in the file
+    path = tmp_path / "cube.msh"
+    IO.write_msh(path, ref1.xyz, ref1.gconn, body, version)
+    v, c, b = IO.read_msh(path)
+    assert np.array_equal(v, ref1.xyz) and np.array_equal(c, ref1.gconn) and np.array_equal(b, body)
+    m1 = IO.flatten(v, ref1.gconn, 1)
+    assert m1.kind == M.P1TET and np.array_equal(m1.conn, ref1.conn) and m1.n_nodes == ref1.n_nodes
+    # P2: vertices first, then edge nodes in first-touch order == the generator's "polyfem" numbering
+    ref2 = M.cube_tets(2, 2, numbering="polyfem", jitter=0.1)
+    m2 = IO.flatten(v, ref1.gconn, 2)
+    assert m2.kind == M.P2TET and m2.n_nodes == ref2.n_nodes
+    assert np.array_equal(m2.conn, ref2.conn) and np.array_equal(m2.gconn, ref2.gconn)
+    mid = 0.5 * (v[m2.gconn[:, 0]] + v[m2.gconn[:, 1]])
+    assert np.allclose(m2.node_xyz[m2.conn[:, 4]], mid)
+    mesh, b2 = IO.load(path, 2)
+    assert mesh.n_nodes == ref2.n_nodes and b2.size == ref1.n_el
+
+
+def test_msh_hexes_sparse_tags_and_orientation(tmp_path):
+    ref = M.cube_hexes(2, 1)
+    path = tmp_path / "hex.msh"
+    IO.write_msh(path, ref.xyz, ref.gconn, None, "4.1")
+    m, body = IO.load(path, 1)
+    assert m.kind == M.Q1HEX and np.array_equal(m.conn, ref.conn) and not body.any()
+    with pytest.raises(ValueError):
+        IO.flatten(ref.xyz, ref.gconn, 2)
+    # node tags with gaps are condensed in file order; lower-dimensional elements are ignored; higher-order
+    # tetrahedra contribute their four vertices
+    path = tmp_path / "sparse.msh"
+    path.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n5\n10 0 0 0\n20 1 0 0\n30 0 1 0\n40 0 0 1\n50 1 1 1\n$EndNodes\n"
+                    "$Elements\n3\n1 2 2 5 5 10 20 30\n2 4 2 3 3 10 30 20 40\n3 4 2 4 4 20 30 40 50\n$EndElements\n")
+    v, c, b = IO.read_msh(path)
+    assert v.shape == (5, 3) and np.array_equal(c, [[0, 2, 1, 3], [1, 2, 3, 4]]) and np.array_equal(b, [3, 4])
+    m = IO.flatten(v, c, 1)
+    p = v[m.gconn]
+    det = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0])
+    assert np.all(det > 0), "inverted tetrahedra are re-oriented"
+    bad = tmp_path / "bad.msh"
+    bad.write_text("$MeshFormat\n2.2 1 8\n$EndMeshFormat\n")
+    with pytest.raises(ValueError):
+        IO.read_msh(bad)
+    surf = tmp_path / "surf.msh"
+    surf.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n3\n1 0 0 0\n2 1 0 0\n3 0 1 0\n$EndNodes\n$Elements\n1\n1 2 2 0 0 1 2 3\n$EndElements\n")
+    with pytest.raises(ValueError):
+        IO.read_msh(surf)
+
+
+def test_flattened_file_mesh_assembles_like_the_generated_one(tmp_path, oracle):
+    """The oracle's stiffness matrix of the mesh read from a file equals that of the generated mesh (same numbering)."""
+    ref = M.cube_tets(2, 2, numbering="polyfem", jitter=0.15)
+    base = M.cube_tets(2, 1, jitter=0.15)
+    path = tmp_path / "c.msh"
+    IO.write_msh(path, base.xyz, base.gconn, None, "4.1")
+    mesh, _ = IO.load(path, 2)
+    lam, mu = oracle.lame(1e5, 0.3)
+    a = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    b = oracle.assemble_linear(ref, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
