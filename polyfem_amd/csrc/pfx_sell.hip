@@ -71,18 +71,19 @@ namespace
 		return c * SL + lane;
 	}
 
-	// node-block values -> slice layout.  One wave per slice; for every slot j the 64 blocks (one per row of the slice,
-	// bs*bs contiguous doubles each) are read with the lanes running over consecutive doubles, transposed through LDS
-	// and written as the slot's contiguous run of the slice.
-	template <int BS>
-	__global__ __launch_bounds__(256) void k_sell_values(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
-														  const int64_t *__restrict__ slice_base, int64_t n_slices, const double *__restrict__ blocks,
-														  double *__restrict__ out)
+	// node-block values -> slice layout.  One wave per slice; JB slots at a time: the JB blocks of each of the 64 rows
+	// (JB * bs*bs contiguous doubles per row) are read with the lanes running over consecutive doubles -- cached loads, so
+	// that a 128-byte line shared by two neighbouring blocks of a row is fetched once --, transposed through LDS and
+	// written with streaming stores as the slots' contiguous runs of the slice.
+	template <int BS, int JB, int WPB>
+	__global__ __launch_bounds__(64 * WPB) void k_sell_values(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
+															   const int64_t *__restrict__ slice_base, int64_t n_slices,
+															   const double *__restrict__ blocks, double *__restrict__ out)
 	{
-		constexpr int B2 = BS * BS;
-		__shared__ double tile[4][SL * B2];
+		constexpr int B2 = BS * BS, RUN = JB * B2; // doubles per row and pass
+		__shared__ double tile[WPB][JB * SL * B2];
 		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-		const int64_t s = (int64_t)blockIdx.x * 4 + w;
+		const int64_t s = (int64_t)blockIdx.x * WPB + w;
 		const bool active = s < n_slices;
 		const int64_t base = active ? slice_base[s] : 0;
 		const int len = active ? (int)(slice_base[s + 1] - base) : 0;
@@ -90,25 +91,26 @@ namespace
 		const int64_t b0_mine = g_mine >= 0 ? node_ptr[g_mine] : 0;
 		const int deg_mine = g_mine >= 0 ? (int)(node_ptr[g_mine + 1] - b0_mine) : 0;
 		double *o = out + base * (SL * B2);
-		for (int j = 0; j < len; ++j)
+		for (int j = 0; j < len; j += JB)
 		{
 #pragma unroll
-			for (int it = 0; it < B2; ++it)
+			for (int it = 0; it < RUN; ++it)
 			{
 				const int t = it * 64 + lane;
-				const int l = t / B2, c = t - l * B2;
+				const int l = t / RUN, r = t - l * RUN; // row of the slice, position in its run
+				const int jj = r / B2, c = r - jj * B2;
 				const int64_t b0 = __shfl(b0_mine, l);
 				const int deg = __shfl(deg_mine, l);
-				const double v = j < deg ? __builtin_nontemporal_load(blocks + (b0 + j) * B2 + c) : 0.0;
-				tile[w][entry_offset<BS>(c, l)] = v;
+				const double v = j + jj < deg ? blocks[(b0 + j) * B2 + r] : 0.0;
+				tile[w][jj * (SL * B2) + entry_offset<BS>(c, l)] = v;
 			}
 			// one wave reads back what it wrote itself: LDS operations of a wave complete in order
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-			for (int it = 0; it < B2; ++it)
-				o[(int64_t)j * (SL * B2) + it * 64 + lane] = tile[w][it * 64 + lane];
+			const int nj = len - j < JB ? len - j : JB; // slots of this pass that exist in the slice
+			for (int it = 0; it < nj * B2; ++it)
+				__builtin_nontemporal_store(tile[w][it * 64 + lane], o + (int64_t)j * (SL * B2) + it * 64 + lane);
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -345,15 +347,18 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 	if (ctx->sell_gen != ctx->values_gen)
 	{
 		pfx_scoped_timer tm(ctx, "sell_convert");
-		int64_t blocks = (ctx->sell_slices + 3) / 4; // one wave per slice
-		if (blocks < 1)
-			blocks = 1;
+		// one wave per slice
+#define PFX_CONVERT(BS_, JB_, WPB_)                                                                                                         \
+	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_>), dim3((unsigned)((ctx->sell_slices + WPB_ - 1) / WPB_ > 0 ? (ctx->sell_slices + WPB_ - 1) / WPB_ : 1)), \
+					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, ctx->d_sell_vals)
+		// (measured at 1 M P2 tets: one slot per pass 1.68 ms, two 1.70 ms, four with half the waves 2.40 ms)
 		if (ctx->bs == 1)
-			hipLaunchKernelGGL((k_sell_values<1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, ctx->d_sell_vals);
+			PFX_CONVERT(1, 4, 4);
 		else if (ctx->bs == 3)
-			hipLaunchKernelGGL((k_sell_values<3>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, ctx->d_sell_vals);
+			PFX_CONVERT(3, 1, 4);
 		else
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+#undef PFX_CONVERT
 		PFX_HIP(hipGetLastError());
 		ctx->sell_gen = ctx->values_gen;
 	}
