@@ -9,7 +9,7 @@ import pytest
 from polyfem_amd import mesh as M
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
-MODEL = {"Laplacian": 0, "LinearElasticity": 1, "NeoHookean": 2}
+MODEL = {"Laplacian": 0, "LinearElasticity": 1, "NeoHookean": 2, "SaintVenant": 3}
 
 
 def _mesh(d):
@@ -18,7 +18,7 @@ def _mesh(d):
 
 
 def test_fixtures_present():
-    assert len(GOLDEN) >= 6
+    assert len(GOLDEN) >= 8
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -26,7 +26,7 @@ def test_oracle_reproduces_golden(oracle, path):
     d = np.load(path, allow_pickle=False)
     mesh, model = _mesh(d), MODEL[str(d["model"])]
     lam, mu = float(d["lam"]), float(d["mu"])
-    if model == 2:
+    if model >= 2:
         outer, inner, vals = oracle.assemble_hessian(mesh, model, lam, mu, d["x"])
         assert oracle.assemble_energy(mesh, model, lam, mu, d["x"]) == float(d["energy"])
         assert np.array_equal(oracle.assemble_gradient(mesh, model, lam, mu, d["x"]), d["gradient"])
@@ -50,7 +50,7 @@ def test_hip_matches_golden(path):
     eng.set_material(model, float(d["lam"]), float(d["mu"]))
     eng.build_pattern()
     scale = np.abs(d["values"]).max()
-    if model == 2:
+    if model >= 2:
         v = eng.hessian(d["x"])
         rp, ci = eng.get_pattern()
         assert abs(eng.energy(d["x"]) - float(d["energy"])) <= 1e-12 * abs(float(d["energy"]))

@@ -4,7 +4,7 @@
 The reference itself cannot be built or imported in this environment (C++ with un-vendored Eigen/TBB/polysolve), and
 its own test meshes live in the un-vendored polyfem-data repository, so these vectors pin the ORACLE (a regression
 guard for it, and a second, file-based target for the HIP path); the oracle in turn is pinned by the reference's
-self-contained known-answer tests (tests/test_oracle_kat.py).  Usage: python tools/make_golden.py"""
+self-contained known-answer tests (tests/test_oracle_kat.py).  Usage: python tools/make_golden.py [--force]   (without --force only missing fixtures are written)"""
 import os
 import sys
 
@@ -22,21 +22,27 @@ CASES = {
     "p1_n3_neohookean": (lambda: M.cube_tets(3, 1, jitter=0.1, seed=5), "NeoHookean"),
     "q1_n2_linear_elasticity": (lambda: M.cube_hexes(2, 1), "LinearElasticity"),
     "q2_n1_neohookean": (lambda: M.cube_hexes(1, 2), "NeoHookean"),
+    "p2_n2_jitter_saint_venant": (lambda: M.cube_tets(2, 2, jitter=0.2, seed=6), "SaintVenant"),
+    "q2_n1_saint_venant": (lambda: M.cube_hexes(1, 2), "SaintVenant"),
 }
+NONLINEAR = {"NeoHookean": O.NEOHOOKEAN, "SaintVenant": O.SAINT_VENANT}
 
 
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    force = "--force" in sys.argv
     for name, (mk, model) in CASES.items():
+        if os.path.exists(os.path.join(out_dir, name + ".npz")) and not force:
+            continue  # committed fixtures are only rewritten on request
         mesh = mk()
         d = dict(kind=mesh.kind, conn=mesh.conn, gconn=mesh.gconn, xyz=mesh.xyz, n_nodes=mesh.n_nodes, model=model)
-        if model == "NeoHookean":
+        if model in NONLINEAR:
+            mid = NONLINEAR[model]
             lam, mu = O.lame(2e4, 0.3)
-            x = M.seeded_displacement(mesh, 3, 2e-3)
-            outer, inner, vals = O.assemble_hessian(mesh, O.NEOHOOKEAN, lam, mu, x)
-            d.update(x=x, energy=O.assemble_energy(mesh, O.NEOHOOKEAN, lam, mu, x),
-                     gradient=O.assemble_gradient(mesh, O.NEOHOOKEAN, lam, mu, x))
+            x = M.seeded_displacement(mesh, 3, 2e-3 if model == "NeoHookean" else 5e-2)
+            outer, inner, vals = O.assemble_hessian(mesh, mid, lam, mu, x)
+            d.update(x=x, energy=O.assemble_energy(mesh, mid, lam, mu, x), gradient=O.assemble_gradient(mesh, mid, lam, mu, x))
         else:
             lam, mu = O.lame(1e5, 0.3)
             mid = O.LAPLACIAN if model == "Laplacian" else O.LINEAR_ELASTICITY
