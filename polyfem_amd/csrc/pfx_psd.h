@@ -4,14 +4,18 @@
 // calls ipc::project_to_psd on every local (n_loc*3)^2 matrix: symmetric eigendecomposition, the matrix is returned
 // unchanged if its smallest eigenvalue is >= 0, otherwise V max(D, 0) V^T.  The Newton solver switches this on when a
 // plain Newton step fails (SparseNewtonDescentSolver.tpp:105-123, descent strategy 1).  ipc-toolkit and Eigen's
-// SelfAdjointEigenSolver are not part of the reference tree; the eigenvalues are computed here with cyclic Jacobi
-// rotations (round-robin ordering: n/2 independent rotations per step), which yields the same projection up to
-// round-off.  The tournament schedule is tabulated in LDS once per element and the rotation passes give every lane a
-// fixed matrix row, so the inner loops contain no integer division.  Elements whose Hessian is positive definite after
-// a shift of 1e-12 of its largest diagonal entry skip the eigendecomposition (elimination test, see the kernel).
+// SelfAdjointEigenSolver are not part of the reference tree.  Like that solver, the kernel reduces the matrix to
+// tridiagonal form with Householder reflections and diagonalises it with implicitly shifted QL sweeps (the classical
+// tred2 / tql2 pair), which yields the same projection up to round-off:
+//   * Householder phase: one lane per matrix row, the dot products of a step are wave reductions;
+//   * QL phase: the scalar recurrence of the rotations is evaluated redundantly by every lane (identical stores to d
+//     and e), and lane k applies each rotation to row k of the eigenvector matrix -- no lane reads anything it has not
+//     also written itself, so the phase needs no barrier and the elements resident on a CU hide each other's latencies.
+// Elements whose Hessian is positive definite after a shift of 1e-12 of its largest diagonal entry skip the
+// eigendecomposition (elimination test, see the kernel).
 //
 // This is the only assembly path that materialises local matrices: one 64-lane workgroup per element builds the local
-// Hessian in LDS from the contribution functor, diagonalises it there and writes the projected blocks of the pairs
+// Hessian in LDS from the contribution functor, factorises it there and writes the (projected) blocks of the pairs
 // j <= i to HBM (n_loc(n_loc+1)/2 * 9 doubles per element); the row assembly then reads them through staged_block.
 #pragma once
 #include "pfx_internal.h"
@@ -40,52 +44,218 @@ namespace pfx_psd_detail
 			v += __shfl_xor(v, off, 64);
 		return v;
 	}
-	__device__ __forceinline__ double wave_min_all(double v)
+	__device__ __forceinline__ double wave_max_all(double v)
 	{
 		for (int off = 32; off > 0; off >>= 1)
 		{
 			const double o = __shfl_xor(v, off, 64);
-			v = o < v ? o : v;
+			v = o > v ? o : v;
 		}
 		return v;
 	}
-	// pair k of step t of the round-robin tournament on n players (n even): p < q
-	__device__ __forceinline__ void rr_pair(int n, int t, int k, int &p, int &q)
+
+	// Householder reduction of the symmetric N x N matrix in Z (row stride LD, lower triangle referenced) to tridiagonal
+	// form; on return Z holds the orthogonal transformation, d the diagonal, e[1..N-1] the sub-diagonal.  Called by all
+	// 64 lanes of a single-wave workgroup.
+	template <int N, int LD>
+	__device__ void householder_tridiagonal(double *Z, double *d, double *e, int lane)
 	{
-		int a, b;
-		if (k == 0)
-			a = n - 1, b = t;
-		else
-			a = (t + k) % (n - 1), b = (t - k + (n - 1)) % (n - 1);
-		p = a < b ? a : b;
-		q = a < b ? b : a;
+		for (int i = N - 1; i >= 1; --i)
+		{
+			const int l = i - 1;
+			double h = 0.0;
+			if (l > 0)
+			{
+				const double scale = wave_sum_all(lane <= l ? fabs(Z[i * LD + lane]) : 0.0);
+				if (scale == 0.0)
+				{
+					if (lane == 0)
+						e[i] = Z[i * LD + l];
+				}
+				else
+				{
+					double v = 0.0;
+					if (lane <= l)
+					{
+						v = Z[i * LD + lane] / scale;
+						Z[i * LD + lane] = v;
+					}
+					h = wave_sum_all(v * v);
+					__syncthreads();
+					const double f0 = Z[i * LD + l];
+					const double g0 = f0 >= 0.0 ? -sqrt(h) : sqrt(h);
+					h -= f0 * g0;
+					__syncthreads();
+					if (lane == 0)
+					{
+						e[i] = scale * g0;
+						Z[i * LD + l] = f0 - g0;
+					}
+					__syncthreads();
+					// e[j] = (A u)_j / h for the rows j <= l, u = row i
+					double fpart = 0.0;
+					if (lane <= l)
+					{
+						const int j = lane;
+						const double uj = Z[i * LD + j];
+						Z[j * LD + i] = uj / h;
+						double g = 0.0;
+						for (int k = 0; k <= j; ++k)
+							g += Z[j * LD + k] * Z[i * LD + k];
+						for (int k = j + 1; k <= l; ++k)
+							g += Z[k * LD + j] * Z[i * LD + k];
+						const double ej = g / h;
+						e[j] = ej;
+						fpart = ej * uj;
+					}
+					const double hh = wave_sum_all(fpart) / (h + h);
+					__syncthreads();
+					if (lane <= l)
+						e[lane] -= hh * Z[i * LD + lane];
+					__syncthreads();
+					if (lane <= l)
+					{
+						const int j = lane;
+						const double f = Z[i * LD + j], g = e[j];
+						for (int k = 0; k <= j; ++k)
+							Z[j * LD + k] -= f * e[k] + g * Z[i * LD + k];
+					}
+				}
+			}
+			else if (lane == 0)
+				e[i] = Z[i * LD + l];
+			if (lane == 0)
+				d[i] = h;
+			__syncthreads();
+		}
+		if (lane == 0)
+			d[0] = 0.0, e[0] = 0.0;
+		__syncthreads();
+		// accumulate the reflections
+		for (int i = 0; i < N; ++i)
+		{
+			const int l = i - 1;
+			if (d[i] != 0.0 && lane <= l)
+			{
+				const int j = lane;
+				double g = 0.0;
+				for (int k = 0; k <= l; ++k)
+					g += Z[i * LD + k] * Z[k * LD + j];
+				for (int k = 0; k <= l; ++k)
+					Z[k * LD + j] -= g * Z[k * LD + i];
+			}
+			__syncthreads();
+			if (lane == 0)
+			{
+				d[i] = Z[i * LD + i];
+				Z[i * LD + i] = 1.0;
+			}
+			if (lane <= l)
+				Z[lane * LD + i] = 0.0, Z[i * LD + lane] = 0.0;
+			__syncthreads();
+		}
+	}
+
+	// Implicit QL with Wilkinson shifts on the tridiagonal (d, e); the rotations are applied to the rows of Z, lane k
+	// owning row k.  Every lane runs the same scalar recurrence on d and e and stores the same values (a lane only ever
+	// reads what it has also written itself), so the phase needs no barrier.  Returns false if an eigenvalue needs more
+	// than 60 sweeps.
+	template <int N, int LD>
+	__device__ bool ql_implicit(double *Z, double *dl, double *el, int lane)
+	{
+		for (int i = 1; i < N; ++i)
+			el[i - 1] = el[i];
+		el[N - 1] = 0.0;
+		const bool has_row = lane < N;
+		double *zr = Z + (has_row ? lane : 0) * LD;
+		for (int l = 0; l < N; ++l)
+		{
+			int iter = 0, m;
+			do
+			{
+				// first m >= l whose sub-diagonal entry is negligible (N - 1 if there is none): one candidate per lane
+				{
+					const double dd = lane < N - 1 ? fabs(dl[lane]) + fabs(dl[lane + 1]) : 0.0;
+					const bool negligible = lane >= N - 1 || fabs(el[lane]) + dd == dd;
+					m = __ffsll((long long)__ballot(negligible && lane >= l)) - 1;
+				}
+				if (m != l)
+				{
+					if (iter++ == 60)
+						return false;
+					double g = (dl[l + 1] - dl[l]) / (2.0 * el[l]);
+					double r = sqrt(g * g + 1.0);
+					g = dl[m] - dl[l] + el[l] / (g + (g >= 0.0 ? r : -r));
+					double s = 1.0, c = 1.0, p = 0.0;
+					int i;
+					// The rotations form one dependent chain; everything that does not depend on the previous rotation
+					// (e[i-1], d[i-1] and this lane's z[i-1] of the next step) is loaded one step ahead, and d[i], z[i]
+					// are carried over in registers, so that only arithmetic is left on the chain.
+					double e_i = el[m - 1], d_i = dl[m - 1], d_ip1 = dl[m];
+					double z_i = has_row ? zr[m - 1] : 0.0, z_ip1 = has_row ? zr[m] : 0.0;
+					for (i = m - 1; i >= l; --i)
+					{
+						const double e_nx = i > l ? el[i - 1] : 0.0, d_nx = i > l ? dl[i - 1] : 0.0;
+						const double z_nx = (has_row && i > l) ? zr[i - 1] : 0.0;
+						const double f = s * e_i;
+						const double b = c * e_i;
+						// |(f, g)| and its reciprocal from one reciprocal square root (entries of an element Hessian: no
+						// overflow, and an underflow to zero deflates)
+						const double t2 = f * f + g * g;
+						const double inv = t2 > 0.0 ? rsqrt(t2) : 0.0;
+						r = t2 * inv;
+						el[i + 1] = r;
+						if (r == 0.0)
+						{
+							dl[i + 1] = d_ip1 - p;
+							el[m] = 0.0;
+							if (has_row)
+								zr[i + 1] = z_ip1;
+							break;
+						}
+						s = f * inv;
+						c = g * inv;
+						g = d_ip1 - p;
+						r = (d_i - g) * s + 2.0 * c * b;
+						p = s * r;
+						dl[i + 1] = g + p;
+						g = c * r - b;
+						if (has_row)
+							zr[i + 1] = s * z_i + c * z_ip1;
+						z_ip1 = c * z_i - s * z_ip1; // becomes z[i], the upper member of the next pair
+						z_i = z_nx;
+						d_ip1 = d_i, d_i = d_nx, e_i = e_nx;
+					}
+					if (has_row && i < l)
+						zr[l] = z_ip1;
+					if (r == 0.0 && i >= l)
+						continue;
+					dl[l] -= p;
+					el[l] = g;
+					el[m] = 0.0;
+				}
+			} while (m != l);
+		}
+		return true;
 	}
 } // namespace pfx_psd_detail
 
 template <int NLOC, class Op>
-__global__ __launch_bounds__(64) void k_project_psd(Op op, int64_t n_el, double *__restrict__ kloc)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_project_psd(Op op, int64_t n_el, double *__restrict__ kloc)
 {
 	using namespace pfx_psd_detail;
-	constexpr int N = NLOC * 3, NPAIR = NLOC * (NLOC + 1) / 2, H = N / 2;
-	static_assert(N % 2 == 0 && N <= 64, "round-robin ordering needs an even size; one lane per row");
-	// lanes are laid out as (pair slot, row): RW rows per pair, PPI pairs per pass over the wave
-	constexpr int RW = N <= 16 ? 16 : (N <= 32 ? 32 : 64), PPI = 64 / RW;
-	constexpr int LD = N + 1; // odd row stride: the column passes (one row per lane) stay free of bank conflicts
-	__shared__ double A[N * LD], V[N * LD], cs[N];
-	__shared__ uint8_t pq[(N - 1) * H * 2]; // tournament schedule: pair k of step t
-	__shared__ uint8_t ij[NPAIR * 2];       // (i, j) of the local block q = i(i+1)/2 + j
+	constexpr int N = NLOC * 3, NPAIR = NLOC * (NLOC + 1) / 2;
+	static_assert(N <= 32, "one lane per matrix row, two lanes per row in the elimination pass");
+	constexpr int RW = N <= 16 ? 16 : 32, PPI = 64 / RW; // elimination pass: lanes laid out as (column slot, row)
+	constexpr int LD = N + 1;                              // odd row stride: one row per lane without bank conflicts
+	__shared__ double W[N * LD], d[N], e[N];
+	__shared__ uint8_t ij[NPAIR * 2]; // (i, j) of the local block q = i(i+1)/2 + j
 	__shared__ double optab[Op::LDS_DOUBLES];
 	const int lane = threadIdx.x;
-	const int64_t e = blockIdx.x;
-	if (e >= n_el)
+	const int64_t el = blockIdx.x;
+	if (el >= n_el)
 		return;
 	op.load_tables(optab, lane);
-	for (int idx = lane; idx < (N - 1) * H; idx += 64)
-	{
-		int p, q;
-		rr_pair(N, idx / H, idx % H, p, q);
-		pq[2 * idx] = (uint8_t)p, pq[2 * idx + 1] = (uint8_t)q;
-	}
 	for (int q = lane; q < NPAIR; q += 64)
 	{
 		int i = 0;
@@ -94,170 +264,95 @@ __global__ __launch_bounds__(64) void k_project_psd(Op op, int64_t n_el, double 
 		ij[2 * q] = (uint8_t)i, ij[2 * q + 1] = (uint8_t)(q - i * (i + 1) / 2);
 	}
 	__syncthreads();
-	// local Hessian, both triangles
-	for (int q = lane; q < NPAIR; q += 64)
-	{
-		const int i = ij[2 * q], j = ij[2 * q + 1];
-		double b[9];
-		op(optab, (uint32_t)e, i, j, b);
-		for (int m = 0; m < 3; ++m)
-			for (int n = 0; n < 3; ++n)
-			{
-				A[(3 * i + m) * LD + 3 * j + n] = b[3 * m + n];
-				A[(3 * j + n) * LD + 3 * i + m] = b[3 * m + n];
-			}
-	}
-	const int row = lane & (RW - 1), slot = lane / RW; // this lane's matrix row and column / pair slot in the passes below
-	double *out = kloc + e * (int64_t)(NPAIR * 9);
+	// local Hessian into W, both triangles (evaluated again whenever a fresh copy is needed: cheaper than a second
+	// matrix in LDS, which would halve the number of elements a CU works on at a time)
+	auto fill = [&]() {
+		for (int q = lane; q < NPAIR; q += 64)
+		{
+			const int i = ij[2 * q], j = ij[2 * q + 1];
+			double b[9];
+			op(optab, (uint32_t)el, i, j, b);
+			for (int m = 0; m < 3; ++m)
+				for (int n = 0; n < 3; ++n)
+				{
+					W[(3 * i + m) * LD + 3 * j + n] = b[3 * m + n];
+					W[(3 * j + n) * LD + 3 * i + m] = b[3 * m + n];
+				}
+		}
+		__syncthreads();
+	};
+	fill();
+	const int row = lane & (RW - 1), slot = lane / RW;
+	double *out = kloc + el * (int64_t)(NPAIR * 9);
+	const double dmax = wave_max_all(lane < N ? W[lane * LD + lane] : 0.0);
 
 	// Fast path.  If A + shift I (shift = 1e-12 max diag) can be eliminated without pivoting with positive pivots, it is
 	// positive definite, so lambda_min(A) > -shift and the projection leaves A as it is up to that shift -- which is the
 	// size of the round-off that decides the sign of the zero eigenvalues (rigid translations) in the exact test anyway.
-	// Costs N eliminations steps against some thirteen Jacobi sweeps of N - 1 steps; V is the work copy.
+	__syncthreads();
+	if (lane < N)
+		W[lane * LD + lane] += 1e-12 * dmax;
+	__syncthreads();
+	bool keep = dmax > 0.0;
+	for (int k = 0; k < N - 1 && keep; ++k)
 	{
-		double dmax = lane < N ? A[lane * LD + lane] : 0.0;
-		for (int o = 32; o > 0; o >>= 1)
+		const double piv = W[k * LD + k];
+		if (!(piv > 0.0))
 		{
-			const double other = __shfl_xor(dmax, o, 64);
-			dmax = other > dmax ? other : dmax;
+			keep = false; // the same value in every lane
+			break;
 		}
-		for (int t = lane; t < N * LD; t += 64)
-			V[t] = A[t];
-		__syncthreads();
-		if (lane < N)
-			V[lane * LD + lane] += 1e-12 * dmax;
-		__syncthreads();
-		bool definite = dmax > 0.0;
-		for (int k = 0; k < N - 1 && definite; ++k)
+		if (row > k && row < N)
 		{
-			const double d = V[k * LD + k];
-			if (!(d > 0.0))
-			{
-				definite = false; // the same value in every lane
-				break;
-			}
-			if (row > k && row < N)
-			{
-				const double l = V[row * LD + k] / d;
-				for (int c = k + 1 + slot; c < N; c += PPI)
-					V[row * LD + c] -= l * V[k * LD + c];
-			}
+			const double l = W[row * LD + k] / piv;
+			for (int c = k + 1 + slot; c < N; c += PPI)
+				W[row * LD + c] -= l * W[k * LD + c];
+		}
+		__syncthreads();
+	}
+	keep = keep && W[(N - 1) * LD + N - 1] > 0.0;
+	__syncthreads();
+
+	if (!keep)
+	{
+		fill();
+		householder_tridiagonal<N, LD>(W, d, e, lane);
+		const bool ok = ql_implicit<N, LD>(W, d, e, lane);
+		__syncthreads();
+		double lmin = lane < N ? d[lane] : 1e300;
+		lmin = -wave_max_all(-lmin);
+		keep = ok && lmin >= 0.0;
+		if (!keep)
+		{
+			// V max(D, 0) V^T (not-a-number where the iteration did not converge, which finite input does not produce)
 			__syncthreads();
-		}
-		if (definite && V[(N - 1) * LD + N - 1] > 0.0)
-		{
-			for (int idx = lane; idx < NPAIR * 9; idx += 64)
+			if (lane < N)
+				e[lane] = !ok ? 0.0 / 0.0 : (d[lane] > 0.0 ? d[lane] : 0.0);
+			__syncthreads();
+			for (int q = lane; q < NPAIR; q += 64)
 			{
-				const int q = idx / 9, mn = idx - q * 9;
-				out[idx] = A[(3 * ij[2 * q] + mn / 3) * LD + 3 * ij[2 * q + 1] + mn % 3];
+				const int i = ij[2 * q], j = ij[2 * q + 1];
+				double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+				for (int k = 0; k < N; ++k)
+				{
+					const double l = e[k];
+					const double vi0 = l * W[(3 * i) * LD + k], vi1 = l * W[(3 * i + 1) * LD + k], vi2 = l * W[(3 * i + 2) * LD + k];
+					const double vj0 = W[(3 * j) * LD + k], vj1 = W[(3 * j + 1) * LD + k], vj2 = W[(3 * j + 2) * LD + k];
+					b[0] += vi0 * vj0, b[1] += vi0 * vj1, b[2] += vi0 * vj2;
+					b[3] += vi1 * vj0, b[4] += vi1 * vj1, b[5] += vi1 * vj2;
+					b[6] += vi2 * vj0, b[7] += vi2 * vj1, b[8] += vi2 * vj2;
+				}
+				for (int k = 0; k < 9; ++k)
+					out[q * 9 + k] = b[k];
 			}
 			return;
 		}
-		__syncthreads();
 	}
-
-	for (int t = lane; t < N * LD; t += 64)
-		V[t] = 0.0;
-	__syncthreads();
-	if (lane < N)
-		V[lane * LD + lane] = 1.0;
-	double norm2 = 0;
-	if (lane < N)
-		for (int c = 0; c < N; ++c)
-			norm2 += A[lane * LD + c] * A[lane * LD + c];
-	norm2 = wave_sum_all(norm2);
-	__syncthreads();
-
-	double prev_off = 1e300;
-	for (int sweep = 0; sweep < 60; ++sweep)
-	{
-		// off-diagonal mass: lane r sums row r right of the diagonal
-		double off = 0;
-		if (lane < N)
-			for (int c = lane + 1; c < N; ++c)
-				off += A[lane * LD + c] * A[lane * LD + c];
-		off = wave_sum_all(off);
-		// converged, or stagnating at the round-off floor (N^2/2 entries of size eps |A| keep the sum near 1e-30 |A|^2:
-		// without the second test every element would run all 60 sweeps)
-		if (off <= 1e-32 * norm2 || (off <= 1e-24 * norm2 && off > 0.25 * prev_off))
-			break;
-		prev_off = off;
-		for (int t = 0; t < N - 1; ++t)
-		{
-			const uint8_t *sched = pq + 2 * t * H;
-			if (lane < H)
-			{
-				const int p = sched[2 * lane], q = sched[2 * lane + 1];
-				const double apq = A[p * LD + q];
-				double c = 1.0, s = 0.0;
-				if (apq != 0.0)
-				{
-					const double theta = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
-					const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-					c = 1.0 / sqrt(tt * tt + 1.0);
-					s = tt * c;
-				}
-				cs[2 * lane] = c, cs[2 * lane + 1] = s;
-			}
-			__syncthreads();
-			// columns p, q of A and V
-			if (row < N)
-				for (int k = slot; k < H; k += PPI)
-				{
-					const int p = sched[2 * k], q = sched[2 * k + 1];
-					const double c = cs[2 * k], s = cs[2 * k + 1];
-					const double ap = A[row * LD + p], aq = A[row * LD + q];
-					A[row * LD + p] = c * ap - s * aq;
-					A[row * LD + q] = s * ap + c * aq;
-					const double vp = V[row * LD + p], vq = V[row * LD + q];
-					V[row * LD + p] = c * vp - s * vq;
-					V[row * LD + q] = s * vp + c * vq;
-				}
-			__syncthreads();
-			// rows p, q of A
-			if (row < N)
-				for (int k = slot; k < H; k += PPI)
-				{
-					const int p = sched[2 * k], q = sched[2 * k + 1];
-					const double c = cs[2 * k], s = cs[2 * k + 1];
-					const double ap = A[p * LD + row], aq = A[q * LD + row];
-					A[p * LD + row] = c * ap - s * aq;
-					A[q * LD + row] = s * ap + c * aq;
-				}
-			__syncthreads();
-		}
-	}
-	double lmin = lane < N ? A[lane * LD + lane] : 1e300;
-	lmin = wave_min_all(lmin);
-	if (lmin >= 0.0)
-	{
-		// already positive semi-definite: the matrix is kept as it is
-		for (int q = lane; q < NPAIR; q += 64)
-		{
-			double b[9];
-			op(optab, (uint32_t)e, ij[2 * q], ij[2 * q + 1], b);
-			for (int k = 0; k < 9; ++k)
-				out[q * 9 + k] = b[k];
-		}
-		return;
-	}
-	// V max(D, 0) V^T: scale the columns of the negative eigenvalues away once, then one dot product per entry
-	if (lane < N)
-		cs[lane] = A[lane * LD + lane] > 0.0 ? A[lane * LD + lane] : 0.0;
-	__syncthreads();
+	// the matrix is kept as it is
 	for (int q = lane; q < NPAIR; q += 64)
 	{
-		const int i = ij[2 * q], j = ij[2 * q + 1];
-		double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-		for (int k = 0; k < N; ++k)
-		{
-			const double l = cs[k];
-			const double vi0 = l * V[(3 * i) * LD + k], vi1 = l * V[(3 * i + 1) * LD + k], vi2 = l * V[(3 * i + 2) * LD + k];
-			const double vj0 = V[(3 * j) * LD + k], vj1 = V[(3 * j + 1) * LD + k], vj2 = V[(3 * j + 2) * LD + k];
-			b[0] += vi0 * vj0, b[1] += vi0 * vj1, b[2] += vi0 * vj2;
-			b[3] += vi1 * vj0, b[4] += vi1 * vj1, b[5] += vi1 * vj2;
-			b[6] += vi2 * vj0, b[7] += vi2 * vj1, b[8] += vi2 * vj2;
-		}
+		double b[9];
+		op(optab, (uint32_t)el, ij[2 * q], ij[2 * q + 1], b);
 		for (int k = 0; k < 9; ++k)
 			out[q * 9 + k] = b[k];
 	}
