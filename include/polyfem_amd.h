@@ -122,7 +122,7 @@ pfx_status pfx_energy(pfx_ctx *ctx, const double *u, double *energy);
 pfx_status pfx_gradient(pfx_ctx *ctx, const double *u, double *g);
 /* NLAssembler<L>::assemble_hessian (Assembler.cpp:506-636); values (may be NULL = keep on device) in
  * pfx_get_pattern order.  project_to_psd != 0 projects every element Hessian onto the positive semi-definite cone
- * before it is added (ipc::project_to_psd at assembler/Assembler.cpp:554-555; P1/P2 tets and Q1 hexes). */
+ * before it is added (ipc::project_to_psd at assembler/Assembler.cpp:554-555). */
 pfx_status pfx_hessian(pfx_ctx *ctx, const double *u, int project_to_psd, double *values);
 
 /* Device-resident variants: d_u, d_energy (1 double), d_g are device pointers. */

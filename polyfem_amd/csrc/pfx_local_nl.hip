@@ -438,22 +438,20 @@ namespace
 		else
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
 	}
-	template <int NLOC, int NGLOC, int NPTS, int MODEL>
-	void launch_psd_model(pfx_ctx *ctx)
-	{
-		typedef nl_block<NLOC, NGLOC, NPTS, MODEL> Op;
-		hipLaunchKernelGGL((k_project_psd<NLOC, Op>), dim3((unsigned)ctx->n_el), dim3(64), 0, ctx->stream, Op{ctx->d_estate, ctx->d_tab}, ctx->n_el, ctx->d_kloc);
-	}
 	template <int NLOC, int NGLOC, int NPTS>
-	void launch_psd(pfx_ctx *ctx)
+	pfx_status launch_psd(pfx_ctx *ctx)
 	{
+		pfx_status rc;
 		if (ctx->model == PFX_NEOHOOKEAN)
-			launch_psd_model<NLOC, NGLOC, NPTS, M_NEO>(ctx);
+			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_SAINT_VENANT)
-			launch_psd_model<NLOC, NGLOC, NPTS, M_STVK>(ctx);
+			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
 		else
-			launch_psd_model<NLOC, NGLOC, NPTS, M_LINEAR>(ctx);
+			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
+		if (rc)
+			return rc;
 		pfx_launch_assemble_rows<NLOC, 3>(ctx, staged_block<NLOC>{ctx->d_kloc}, false);
+		return PFX_OK;
 	}
 } // namespace
 
@@ -535,8 +533,6 @@ pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx)
 {
 	if (ctx->estate_kind != PFX_ESTATE_NL)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: element state missing");
-	if (ctx->kind == PFX_Q2HEX)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "project_to_psd is not implemented for Q2 hexahedra (81 x 81 element matrices)");
 	const int64_t need = ctx->n_el * (int64_t)(ctx->n_loc * (ctx->n_loc + 1) / 2) * 9;
 	if (ctx->kloc_count < need)
 	{
@@ -544,20 +540,26 @@ pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx)
 			return PFX_ERR_HIP;
 		ctx->kloc_count = need;
 	}
+	pfx_status rc;
 	switch (ctx->kind)
 	{
 	case PFX_P1TET:
-		launch_psd<4, 4, 1>(ctx);
+		rc = launch_psd<4, 4, 1>(ctx);
 		break;
 	case PFX_P2TET:
-		launch_psd<10, 4, 6>(ctx);
+		rc = launch_psd<10, 4, 6>(ctx);
 		break;
 	case PFX_Q1HEX:
-		launch_psd<8, 8, 1>(ctx);
+		rc = launch_psd<8, 8, 1>(ctx);
+		break;
+	case PFX_Q2HEX:
+		rc = launch_psd<27, 8, 27>(ctx);
 		break;
 	default:
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: unsupported element kind");
 	}
+	if (rc)
+		return rc;
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -56,8 +56,8 @@ namespace pfx_psd_detail
 
 	// Householder reduction of the symmetric N x N matrix in Z (row stride LD, lower triangle referenced) to tridiagonal
 	// form; on return Z holds the orthogonal transformation, d the diagonal, e[1..N-1] the sub-diagonal.  Called by all
-	// 64 lanes of a single-wave workgroup.
-	template <int N, int LD>
+	// 64 lanes of a single-wave workgroup; lane t owns the rows / columns t, t + 64, ... (R of them).
+	template <int N, int LD, int R>
 	__device__ void householder_tridiagonal(double *Z, double *d, double *e, int lane)
 	{
 		for (int i = N - 1; i >= 1; --i)
@@ -66,7 +66,12 @@ namespace pfx_psd_detail
 			double h = 0.0;
 			if (l > 0)
 			{
-				const double scale = wave_sum_all(lane <= l ? fabs(Z[i * LD + lane]) : 0.0);
+				double part = 0.0;
+#pragma unroll
+				for (int rr = 0; rr < R; ++rr)
+					if (lane + 64 * rr <= l)
+						part += fabs(Z[i * LD + lane + 64 * rr]);
+				const double scale = wave_sum_all(part);
 				if (scale == 0.0)
 				{
 					if (lane == 0)
@@ -74,13 +79,16 @@ namespace pfx_psd_detail
 				}
 				else
 				{
-					double v = 0.0;
-					if (lane <= l)
-					{
-						v = Z[i * LD + lane] / scale;
-						Z[i * LD + lane] = v;
-					}
-					h = wave_sum_all(v * v);
+					part = 0.0;
+#pragma unroll
+					for (int rr = 0; rr < R; ++rr)
+						if (lane + 64 * rr <= l)
+						{
+							const double v = Z[i * LD + lane + 64 * rr] / scale;
+							Z[i * LD + lane + 64 * rr] = v;
+							part += v * v;
+						}
+					h = wave_sum_all(part);
 					__syncthreads();
 					const double f0 = Z[i * LD + l];
 					const double g0 = f0 >= 0.0 ? -sqrt(h) : sqrt(h);
@@ -94,31 +102,41 @@ namespace pfx_psd_detail
 					__syncthreads();
 					// e[j] = (A u)_j / h for the rows j <= l, u = row i
 					double fpart = 0.0;
-					if (lane <= l)
+#pragma unroll
+					for (int rr = 0; rr < R; ++rr)
 					{
-						const int j = lane;
-						const double uj = Z[i * LD + j];
-						Z[j * LD + i] = uj / h;
-						double g = 0.0;
-						for (int k = 0; k <= j; ++k)
-							g += Z[j * LD + k] * Z[i * LD + k];
-						for (int k = j + 1; k <= l; ++k)
-							g += Z[k * LD + j] * Z[i * LD + k];
-						const double ej = g / h;
-						e[j] = ej;
-						fpart = ej * uj;
+						const int j = lane + 64 * rr;
+						if (j <= l)
+						{
+							const double uj = Z[i * LD + j];
+							Z[j * LD + i] = uj / h;
+							double g = 0.0;
+							for (int k = 0; k <= j; ++k)
+								g += Z[j * LD + k] * Z[i * LD + k];
+							for (int k = j + 1; k <= l; ++k)
+								g += Z[k * LD + j] * Z[i * LD + k];
+							const double ej = g / h;
+							e[j] = ej;
+							fpart += ej * uj;
+						}
 					}
 					const double hh = wave_sum_all(fpart) / (h + h);
 					__syncthreads();
-					if (lane <= l)
-						e[lane] -= hh * Z[i * LD + lane];
+#pragma unroll
+					for (int rr = 0; rr < R; ++rr)
+						if (lane + 64 * rr <= l)
+							e[lane + 64 * rr] -= hh * Z[i * LD + lane + 64 * rr];
 					__syncthreads();
-					if (lane <= l)
+#pragma unroll
+					for (int rr = 0; rr < R; ++rr)
 					{
-						const int j = lane;
-						const double f = Z[i * LD + j], g = e[j];
-						for (int k = 0; k <= j; ++k)
-							Z[j * LD + k] -= f * e[k] + g * Z[i * LD + k];
+						const int j = lane + 64 * rr;
+						if (j <= l)
+						{
+							const double f = Z[i * LD + j], g = e[j];
+							for (int k = 0; k <= j; ++k)
+								Z[j * LD + k] -= f * e[k] + g * Z[i * LD + k];
+						}
 					}
 				}
 			}
@@ -135,14 +153,21 @@ namespace pfx_psd_detail
 		for (int i = 0; i < N; ++i)
 		{
 			const int l = i - 1;
-			if (d[i] != 0.0 && lane <= l)
+			if (d[i] != 0.0)
 			{
-				const int j = lane;
-				double g = 0.0;
-				for (int k = 0; k <= l; ++k)
-					g += Z[i * LD + k] * Z[k * LD + j];
-				for (int k = 0; k <= l; ++k)
-					Z[k * LD + j] -= g * Z[k * LD + i];
+#pragma unroll
+				for (int rr = 0; rr < R; ++rr)
+				{
+					const int j = lane + 64 * rr;
+					if (j <= l)
+					{
+						double g = 0.0;
+						for (int k = 0; k <= l; ++k)
+							g += Z[i * LD + k] * Z[k * LD + j];
+						for (int k = 0; k <= l; ++k)
+							Z[k * LD + j] -= g * Z[k * LD + i];
+					}
+				}
 			}
 			__syncthreads();
 			if (lane == 0)
@@ -150,34 +175,48 @@ namespace pfx_psd_detail
 				d[i] = Z[i * LD + i];
 				Z[i * LD + i] = 1.0;
 			}
-			if (lane <= l)
-				Z[lane * LD + i] = 0.0, Z[i * LD + lane] = 0.0;
+#pragma unroll
+			for (int rr = 0; rr < R; ++rr)
+				if (lane + 64 * rr <= l)
+					Z[(lane + 64 * rr) * LD + i] = 0.0, Z[i * LD + lane + 64 * rr] = 0.0;
 			__syncthreads();
 		}
 	}
 
-	// Implicit QL with Wilkinson shifts on the tridiagonal (d, e); the rotations are applied to the rows of Z, lane k
-	// owning row k.  Every lane runs the same scalar recurrence on d and e and stores the same values (a lane only ever
-	// reads what it has also written itself), so the phase needs no barrier.  Returns false if an eigenvalue needs more
-	// than 60 sweeps.
-	template <int N, int LD>
+	// Implicit QL with Wilkinson shifts on the tridiagonal (d, e); the rotations are applied to the rows of Z, lane t
+	// owning the rows t, t + 64, ...  Every lane runs the same scalar recurrence on d and e and stores the same values (a
+	// lane only ever reads what it has also written itself), so the phase needs no barrier.  Returns false if an
+	// eigenvalue needs more than 60 sweeps.
+	template <int N, int LD, int R>
 	__device__ bool ql_implicit(double *Z, double *dl, double *el, int lane)
 	{
 		for (int i = 1; i < N; ++i)
 			el[i - 1] = el[i];
 		el[N - 1] = 0.0;
-		const bool has_row = lane < N;
-		double *zr = Z + (has_row ? lane : 0) * LD;
+		bool has_row[R];
+		double *zr[R];
+#pragma unroll
+		for (int rr = 0; rr < R; ++rr)
+		{
+			has_row[rr] = lane + 64 * rr < N;
+			zr[rr] = Z + (has_row[rr] ? lane + 64 * rr : 0) * LD;
+		}
 		for (int l = 0; l < N; ++l)
 		{
 			int iter = 0, m;
 			do
 			{
-				// first m >= l whose sub-diagonal entry is negligible (N - 1 if there is none): one candidate per lane
+				// first m >= l whose sub-diagonal entry is negligible (N - 1 if there is none): one candidate per lane and pass
+				m = N - 1;
+#pragma unroll
+				for (int rr = R - 1; rr >= 0; --rr)
 				{
-					const double dd = lane < N - 1 ? fabs(dl[lane]) + fabs(dl[lane + 1]) : 0.0;
-					const bool negligible = lane >= N - 1 || fabs(el[lane]) + dd == dd;
-					m = __ffsll((long long)__ballot(negligible && lane >= l)) - 1;
+					const int t = lane + 64 * rr;
+					const double dd = t < N - 1 ? fabs(dl[t]) + fabs(dl[t + 1]) : 0.0;
+					const bool negligible = t < N - 1 && fabs(el[t]) + dd == dd;
+					const unsigned long long hit = __ballot(negligible && t >= l);
+					if (hit)
+						m = 64 * rr + __ffsll((long long)hit) - 1;
 				}
 				if (m != l)
 				{
@@ -192,11 +231,17 @@ namespace pfx_psd_detail
 					// (e[i-1], d[i-1] and this lane's z[i-1] of the next step) is loaded one step ahead, and d[i], z[i]
 					// are carried over in registers, so that only arithmetic is left on the chain.
 					double e_i = el[m - 1], d_i = dl[m - 1], d_ip1 = dl[m];
-					double z_i = has_row ? zr[m - 1] : 0.0, z_ip1 = has_row ? zr[m] : 0.0;
+					double z_i[R], z_ip1[R];
+#pragma unroll
+					for (int rr = 0; rr < R; ++rr)
+						z_i[rr] = has_row[rr] ? zr[rr][m - 1] : 0.0, z_ip1[rr] = has_row[rr] ? zr[rr][m] : 0.0;
 					for (i = m - 1; i >= l; --i)
 					{
 						const double e_nx = i > l ? el[i - 1] : 0.0, d_nx = i > l ? dl[i - 1] : 0.0;
-						const double z_nx = (has_row && i > l) ? zr[i - 1] : 0.0;
+						double z_nx[R];
+#pragma unroll
+						for (int rr = 0; rr < R; ++rr)
+							z_nx[rr] = (has_row[rr] && i > l) ? zr[rr][i - 1] : 0.0;
 						const double f = s * e_i;
 						const double b = c * e_i;
 						// |(f, g)| and its reciprocal from one reciprocal square root (entries of an element Hessian: no
@@ -209,8 +254,10 @@ namespace pfx_psd_detail
 						{
 							dl[i + 1] = d_ip1 - p;
 							el[m] = 0.0;
-							if (has_row)
-								zr[i + 1] = z_ip1;
+#pragma unroll
+							for (int rr = 0; rr < R; ++rr)
+								if (has_row[rr])
+									zr[rr][i + 1] = z_ip1[rr];
 							break;
 						}
 						s = f * inv;
@@ -220,14 +267,23 @@ namespace pfx_psd_detail
 						p = s * r;
 						dl[i + 1] = g + p;
 						g = c * r - b;
-						if (has_row)
-							zr[i + 1] = s * z_i + c * z_ip1;
-						z_ip1 = c * z_i - s * z_ip1; // becomes z[i], the upper member of the next pair
-						z_i = z_nx;
+#pragma unroll
+						for (int rr = 0; rr < R; ++rr)
+						{
+							if (has_row[rr])
+								zr[rr][i + 1] = s * z_i[rr] + c * z_ip1[rr];
+							z_ip1[rr] = c * z_i[rr] - s * z_ip1[rr]; // becomes z[i], the upper member of the next pair
+							z_i[rr] = z_nx[rr];
+						}
 						d_ip1 = d_i, d_i = d_nx, e_i = e_nx;
 					}
-					if (has_row && i < l)
-						zr[l] = z_ip1;
+					if (i < l)
+					{
+#pragma unroll
+						for (int rr = 0; rr < R; ++rr)
+							if (has_row[rr])
+								zr[rr][l] = z_ip1[rr];
+					}
 					if (r == 0.0 && i >= l)
 						continue;
 					dl[l] -= p;
@@ -240,15 +296,18 @@ namespace pfx_psd_detail
 	}
 } // namespace pfx_psd_detail
 
+// W: N x LD doubles of dynamic shared memory (N = 3 NLOC, LD = N rounded up to odd)
 template <int NLOC, class Op>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_project_psd(Op op, int64_t n_el, double *__restrict__ kloc)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLOC <= 10 ? 4 : 1, NLOC <= 10 ? 4 : 8))) void k_project_psd(Op op, int64_t n_el, double *__restrict__ kloc)
 {
 	using namespace pfx_psd_detail;
 	constexpr int N = NLOC * 3, NPAIR = NLOC * (NLOC + 1) / 2;
-	static_assert(N <= 32, "one lane per matrix row, two lanes per row in the elimination pass");
-	constexpr int RW = N <= 16 ? 16 : 32, PPI = 64 / RW; // elimination pass: lanes laid out as (column slot, row)
-	constexpr int LD = N + 1;                              // odd row stride: one row per lane without bank conflicts
-	__shared__ double W[N * LD], d[N], e[N];
+	constexpr int R = (N + 63) / 64;                                   // matrix rows per lane
+	constexpr int RW = N <= 16 ? 16 : (N <= 32 ? 32 : 64), PPI = 64 / RW; // elimination pass: lanes laid out as (column slot, row)
+	constexpr int LD = N | 1;                                            // odd row stride: one row per lane without bank conflicts
+	extern __shared__ double pfx_psd_dyn[];
+	double *W = pfx_psd_dyn;
+	__shared__ double d[N], e[N];
 	__shared__ uint8_t ij[NPAIR * 2]; // (i, j) of the local block q = i(i+1)/2 + j
 	__shared__ double optab[Op::LDS_DOUBLES];
 	const int lane = threadIdx.x;
@@ -284,14 +343,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	fill();
 	const int row = lane & (RW - 1), slot = lane / RW;
 	double *out = kloc + el * (int64_t)(NPAIR * 9);
-	const double dmax = wave_max_all(lane < N ? W[lane * LD + lane] : 0.0);
+	double dloc = 0.0;
+#pragma unroll
+	for (int rr = 0; rr < R; ++rr)
+		if (lane + 64 * rr < N)
+			dloc = fmax(dloc, W[(lane + 64 * rr) * LD + lane + 64 * rr]);
+	const double dmax = wave_max_all(dloc);
 
 	// Fast path.  If A + shift I (shift = 1e-12 max diag) can be eliminated without pivoting with positive pivots, it is
 	// positive definite, so lambda_min(A) > -shift and the projection leaves A as it is up to that shift -- which is the
 	// size of the round-off that decides the sign of the zero eigenvalues (rigid translations) in the exact test anyway.
 	__syncthreads();
-	if (lane < N)
-		W[lane * LD + lane] += 1e-12 * dmax;
+#pragma unroll
+	for (int rr = 0; rr < R; ++rr)
+		if (lane + 64 * rr < N)
+			W[(lane + 64 * rr) * LD + lane + 64 * rr] += 1e-12 * dmax;
 	__syncthreads();
 	bool keep = dmax > 0.0;
 	for (int k = 0; k < N - 1 && keep; ++k)
@@ -302,11 +368,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			keep = false; // the same value in every lane
 			break;
 		}
-		if (row > k && row < N)
+#pragma unroll
+		for (int rr = 0; rr < R; ++rr)
 		{
-			const double l = W[row * LD + k] / piv;
-			for (int c = k + 1 + slot; c < N; c += PPI)
-				W[row * LD + c] -= l * W[k * LD + c];
+			const int r = row + 64 * rr;
+			if (r > k && r < N)
+			{
+				const double l = W[r * LD + k] / piv;
+				for (int c = k + 1 + slot; c < N; c += PPI)
+					W[r * LD + c] -= l * W[k * LD + c];
+			}
 		}
 		__syncthreads();
 	}
@@ -316,18 +387,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 	if (!keep)
 	{
 		fill();
-		householder_tridiagonal<N, LD>(W, d, e, lane);
-		const bool ok = ql_implicit<N, LD>(W, d, e, lane);
+		householder_tridiagonal<N, LD, R>(W, d, e, lane);
+		const bool ok = ql_implicit<N, LD, R>(W, d, e, lane);
 		__syncthreads();
-		double lmin = lane < N ? d[lane] : 1e300;
+		double lmin = 1e300;
+#pragma unroll
+		for (int rr = 0; rr < R; ++rr)
+			if (lane + 64 * rr < N)
+				lmin = fmin(lmin, d[lane + 64 * rr]);
 		lmin = -wave_max_all(-lmin);
 		keep = ok && lmin >= 0.0;
 		if (!keep)
 		{
 			// V max(D, 0) V^T (not-a-number where the iteration did not converge, which finite input does not produce)
 			__syncthreads();
-			if (lane < N)
-				e[lane] = !ok ? 0.0 / 0.0 : (d[lane] > 0.0 ? d[lane] : 0.0);
+#pragma unroll
+			for (int rr = 0; rr < R; ++rr)
+				if (lane + 64 * rr < N)
+					e[lane + 64 * rr] = !ok ? 0.0 / 0.0 : (d[lane + 64 * rr] > 0.0 ? d[lane + 64 * rr] : 0.0);
 			__syncthreads();
 			for (int q = lane; q < NPAIR; q += 64)
 			{
@@ -356,4 +433,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		for (int k = 0; k < 9; ++k)
 			out[q * 9 + k] = b[k];
 	}
+}
+
+// launches k_project_psd for all elements; the matrix lives in dynamic shared memory (more than the 64 KB a kernel may
+// claim statically for 27-node elements)
+template <int NLOC, class Op>
+pfx_status pfx_launch_project_psd(pfx_ctx *ctx, Op op)
+{
+	constexpr int N = NLOC * 3, LD = N | 1;
+	const size_t bytes = sizeof(double) * N * LD;
+	auto kernel = k_project_psd<NLOC, Op>;
+	if (bytes > 32 * 1024)
+		PFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->n_el), dim3(64), bytes, ctx->stream, op, ctx->n_el, ctx->d_kloc);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
 }
