@@ -297,6 +297,14 @@ pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, doubl
  *   pfx_*_dev evaluation since the last call (the host variants report that as PFX_ERR_NUMERIC themselves); clears
  *   the flag.  Synchronises the stream. */
 pfx_status pfx_set_diag_shift(pfx_ctx *ctx, double shift);
+/* The inertia term for a driver that runs the Newton loop itself (on a partition: the rows this rank owns):
+ * pfx_mass_apply_dev       d_y[owned rows] = M d_v with the mass matrix kept by pfx_inertia_set_mass -- InertiaForm's
+ *                          first derivative M (x - x_tilde) when d_v holds x - x_tilde (solver/forms/InertiaForm.cpp:23-26);
+ * pfx_hessian_add_mass_dev matrix := weight * matrix + M, the weighted sum of ElasticForm's and InertiaForm's second
+ *                          derivatives (:28-31, weights at state/StateSolveNonlinear.cpp:78-84); call it after
+ *                          pfx_hessian_dev / pfx_hessian_psd_dev. */
+pfx_status pfx_mass_apply_dev(pfx_ctx *ctx, const double *d_v, double *d_y);
+pfx_status pfx_hessian_add_mass_dev(pfx_ctx *ctx, double weight);
 pfx_status pfx_take_numeric_flag(pfx_ctx *ctx, int *flag);
 
 /* ---- introspection for benchmarks ----------------------------------------------------------------------------- */

@@ -685,6 +685,28 @@ extern "C"
 		return PFX_OK;
 	}
 
+	pfx_status pfx_mass_apply_dev(pfx_ctx *ctx, const double *d_v, double *d_y)
+	{
+		if (!ctx || !d_v || !d_y)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->mass_count == 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
+		return pfx_mass_apply_run(ctx, d_v, d_y);
+	}
+
+	pfx_status pfx_hessian_add_mass_dev(pfx_ctx *ctx, double weight)
+	{
+		if (!ctx || !(weight >= 0.0))
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->mass_count == 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
+		return pfx_add_mass_run(ctx, weight);
+	}
+
 	pfx_status pfx_implicit_euler_step_dev(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
 										   const pfx_newton_params *params, pfx_newton_info *info)
 	{

@@ -248,6 +248,8 @@ pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx);
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_capture_mass(pfx_ctx *ctx);
+pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y);
+pfx_status pfx_add_mass_run(pfx_ctx *ctx, double w);
 pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
 								  const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = true);

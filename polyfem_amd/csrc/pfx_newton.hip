@@ -51,13 +51,13 @@ namespace
 			mass[b] = values[b * 9];
 	}
 
-	// d = x - x_tilde and md = M d, M = mass (x) I_3: one thread per node row
+	// d = x - x_tilde and md = M d, M = mass (x) I_3: one thread per node row (xt and d may be null: md = M x)
 	__global__ __launch_bounds__(256) void k_mass_apply(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
 														const double *__restrict__ mass, const double *__restrict__ x,
-														const double *__restrict__ xt, int64_t n_nodes, double *__restrict__ d,
+														const double *__restrict__ xt, int64_t n_rows, double *__restrict__ d,
 														double *__restrict__ md)
 	{
-		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_rows; g += (int64_t)gridDim.x * blockDim.x)
 		{
 			double a0 = 0, a1 = 0, a2 = 0;
 			const int64_t b1 = node_ptr[g + 1];
@@ -65,13 +65,14 @@ namespace
 			{
 				const int64_t c = 3 * (int64_t)node_col[b];
 				const double m = mass[b];
-				a0 += m * (x[c] - xt[c]);
-				a1 += m * (x[c + 1] - xt[c + 1]);
-				a2 += m * (x[c + 2] - xt[c + 2]);
+				a0 += m * (x[c] - (xt ? xt[c] : 0.0));
+				a1 += m * (x[c + 1] - (xt ? xt[c + 1] : 0.0));
+				a2 += m * (x[c + 2] - (xt ? xt[c + 2] : 0.0));
 			}
 			md[3 * g] = a0, md[3 * g + 1] = a1, md[3 * g + 2] = a2;
-			for (int k = 0; k < 3; ++k)
-				d[3 * g + k] = x[3 * g + k] - xt[3 * g + k];
+			if (d)
+				for (int k = 0; k < 3; ++k)
+					d[3 * g + k] = x[3 * g + k] - (xt ? xt[3 * g + k] : 0.0);
 		}
 	}
 
@@ -590,5 +591,24 @@ pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, 
 	hipLaunchKernelGGL(k_euler_update, dim3(NB), dim3(256), 0, st, d_x, x_prev, dt, n, d_v, d_a);
 	PFX_HIP(hipGetLastError());
 	PFX_HIP(hipStreamSynchronize(st));
+	return PFX_OK;
+}
+
+// y[owned rows] = M v with the captured mass matrix (v needs a current halo on a partitioned mesh)
+pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y)
+{
+	hipLaunchKernelGGL(k_mass_apply, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_mass_blk, d_v,
+					   (const double *)nullptr, ctx->n_owned, (double *)nullptr, d_y);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// values = w * values + M on the resident matrix
+pfx_status pfx_add_mass_run(pfx_ctx *ctx, double w)
+{
+	hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_values, ctx->nnz, w, ctx->d_mass_blk);
+	ctx->values_gen++;
+	ctx->have_mask = false;
+	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

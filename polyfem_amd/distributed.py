@@ -288,6 +288,13 @@ class HipOps:
     def clear_numeric_flag(self):
         self.e.take_numeric_flag()
 
+    def mass_apply(self, v, y):
+        """y[owned rows] = M v (mass matrix kept by Engine.inertia_set_mass); v needs a current halo."""
+        self.e.mass_apply_dev(v.data_ptr(), y.data_ptr())
+
+    def hessian_add_mass(self, weight):
+        self.e.hessian_add_mass_dev(weight)
+
 
 class DistributedCG:
     """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition."""
@@ -380,8 +387,10 @@ class DistributedNewton:
         self.fixed = torch.from_numpy(fixed[:self.no].copy()).to(device)
         z = lambda k: torch.zeros(k, dtype=torch.float64, device=device)  # noqa: E731
         self.g, self.dx, self.xn, self.w, self.gls = z(self.n), z(self.n), z(self.n), z(self.n), z(self.n)
+        self.dd, self.md = z(self.n), z(self.n)  # x - x_tilde and M (x - x_tilde) of a transient step
         self.e1 = z(1)
-        self.red = z(4)
+        self.red = z(6)
+        self.x_tilde, self.weight = None, 1.0
 
     # -- reductions over the ranks: sums in red[0:2], maximum in red[2]
     def _sums(self, *vals):
@@ -393,7 +402,7 @@ class DistributedNewton:
 
     def _max(self, val):
         """Maximum over the ranks of a non-negative local value; nan if it is nan anywhere (MAX reductions may drop it)."""
-        r = self.red[2:4]
+        r = self.red[4:6]
         r[0] = self.torch.nan_to_num(val, nan=0.0)
         r[1] = self.torch.isnan(val).to(r.dtype)
         if self.comm.on:
@@ -411,9 +420,16 @@ class DistributedNewton:
         no = self.no
         self.ops.energy(x, self.e1)
         rx = (self.rhs[:no] @ x[:no]) if self.rhs is not None else self.torch.zeros((), dtype=x.dtype, device=x.device)
-        e, d = self._sums(self.e1[0], rx)
+        if self.x_tilde is None:
+            e, d = self._sums(self.e1[0], rx)
+            self.info["objective_evaluations"] += 1
+            return e - d if np.isfinite(e) else float("nan")
+        # transient step: weight * (E - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde)   (InertiaForm.cpp:14-21)
+        self.torch.sub(x, self.x_tilde, out=self.dd)
+        self.ops.mass_apply(self.dd, self.md)
+        e, d, q = self._sums(self.e1[0], rx, self.dd[:no] @ self.md[:no])
         self.info["objective_evaluations"] += 1
-        return e - d if np.isfinite(e) else float("nan")
+        return self.weight * (e - d) + 0.5 * q if np.isfinite(e) else float("nan")
 
     # -- NLProblem::gradient (:90-99) restricted to the free dofs; returns its squared norm
     def _gradient(self, x, out):
@@ -421,6 +437,10 @@ class DistributedNewton:
         self.ops.gradient(x, out)
         if self.rhs is not None:
             out[:no] -= self.rhs[:no]
+        if self.x_tilde is not None:
+            self.torch.sub(x, self.x_tilde, out=self.dd)
+            self.ops.mass_apply(self.dd, self.md)
+            out[:no].mul_(self.weight).add_(self.md[:no])
         out[:no].masked_fill_(self.fixed, 0.0)
         out[no:] = 0.0
         (n2,) = self._sums(out[:no] @ out[:no])
@@ -471,10 +491,13 @@ class DistributedNewton:
             return GRAD_NORM
         return CONTINUE
 
-    def solve(self, x, rhs=None, **params):
+    def solve(self, x, rhs=None, x_tilde=None, weight: float = 1.0, **params):
         """x: local vector [owned | halo] of n_local*bs doubles, starting point in, minimiser out (the halo part is
-        kept current); rhs: local vector or None.  Returns the info dict; raises NewtonFailure where the reference
+        kept current); rhs: local vector or None.  With `x_tilde` (local vector with a current halo) the objective is
+        weight * (E(x) - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde), M being the mass matrix the back end holds
+        (Engine.inertia_set_mass on every rank).  Returns the info dict; raises NewtonFailure where the reference
         throws."""
+        self.x_tilde, self.weight = x_tilde, (float(weight) if x_tilde is not None else 1.0)
         par = dict(NEWTON_DEFAULTS)
         for k in params:
             if k not in par:
@@ -535,6 +558,8 @@ class DistributedNewton:
                     dx_max = self._max(self.dx[:no].abs().max())
                     break
                 ops.hessian(x, strategy == 1)
+                if self.x_tilde is not None:
+                    ops.hessian_add_mass(self.weight)
                 ops.set_diag_shift(reg)
                 t.neg(self.g, out=self.w)
                 its, _ = self.cg.solve(self.w, self.dx, par["cg_precond"], par["cg_max_iter"], par["cg_tol"],
@@ -582,4 +607,33 @@ class DistributedNewton:
         ops.clear_numeric_flag()
         if status == ITERATION_LIMIT:
             fail("Reached iteration limit", ITERATION_LIMIT)
+        return info
+
+
+class DistributedImplicitEuler:
+    """The reference's transient nonlinear solve with the ImplicitEuler integrator over the partition
+    (time_integrator/ImplicitEuler.cpp:5-33, state/StateSolveNonlinear.cpp:78-84): per step x_tilde = x + dt v, a Newton
+    solve of dt^2 (E(x) - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde) starting at x, then v = (x_new - x)/dt,
+    a = (v_new - v)/dt.  x, v, a are local vectors [owned | halo]; their halos stay consistent without extra exchanges
+    because the Newton driver returns x with a current halo."""
+
+    def __init__(self, newton: DistributedNewton, dt: float):
+        import torch
+        assert dt > 0
+        self.torch, self.newton, self.dt = torch, newton, float(dt)
+        n, dev = newton.n, newton.device
+        self.x_prev = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.x_tilde = torch.zeros(n, dtype=torch.float64, device=dev)
+
+    def step(self, x, v, a=None, rhs=None, **params):
+        """Advances (x, v) in place; writes the acceleration into `a` if given.  Returns the Newton info dict."""
+        t, dt = self.torch, self.dt
+        self.x_prev.copy_(x)
+        t.add(x, v, alpha=dt, out=self.x_tilde)
+        info = self.newton.solve(x, rhs, x_tilde=self.x_tilde, weight=dt * dt, **params)
+        v_new = (x - self.x_prev) / dt
+        if a is not None:
+            t.sub(v_new, v, out=a)
+            a.div_(dt)
+        v.copy_(v_new)
         return info

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
-    "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev",
+    "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
 ]
 
 
@@ -136,6 +136,8 @@ def load():
         "pfx_implicit_euler_step": [_vp, _dbl, _pd, _pd, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_implicit_euler_step_dev": [_vp, _dbl, _vp, _vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_set_diag_shift": [_vp, _dbl],
+        "pfx_mass_apply_dev": [_vp, _vp, _vp],
+        "pfx_hessian_add_mass_dev": [_vp, _dbl],
         "pfx_take_numeric_flag": [_vp, C.POINTER(C.c_int)],
         "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_newton_solve_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
@@ -431,6 +433,14 @@ class Engine:
     def set_diag_shift(self, shift: float):
         """The solver side works with A + shift * I on the free dofs until set back to 0."""
         self._ck(self.L.pfx_set_diag_shift(self.h, float(shift)))
+
+    def mass_apply_dev(self, d_v: int, d_y: int):
+        """y[owned rows] = M v with the mass matrix of inertia_set_mass (device pointers)."""
+        self._ck(self.L.pfx_mass_apply_dev(self.h, _vp(d_v), _vp(d_y)))
+
+    def hessian_add_mass_dev(self, weight: float):
+        """Resident matrix := weight * matrix + M (after hessian_dev)."""
+        self._ck(self.L.pfx_hessian_add_mass_dev(self.h, float(weight)))
 
     def take_numeric_flag(self) -> bool:
         """True if a *_dev evaluation met an inverted element since the last call; clears the flag."""

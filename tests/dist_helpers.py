@@ -138,6 +138,16 @@ class OracleNLOps(OracleOps):
     def clear_numeric_flag(self):
         pass
 
+    def set_mass(self, density):
+        """Counterpart of Engine.inertia_set_mass: owned rows of the mass matrix of the local mesh."""
+        self.M = csc_tuple_to_csr(self.O.assemble_mass(self.part.mesh, 3, density), self.nloc)[:self.no]
+
+    def mass_apply(self, v, y):
+        y.numpy()[:self.no] = self.M @ v.numpy()
+
+    def hessian_add_mass(self, weight):
+        self.A = (weight * self.A + self.M).tocsr()
+
 
 def csc_tuple_to_csr(csc, n):
     outer, inner, values = csc

@@ -195,3 +195,65 @@ def test_distributed_newton_gloo(world, case):
     assert abs(info["cg_iterations"] - iref["cg_iterations"]) <= max(3 * info["iterations"], 0.03 * iref["cg_iterations"])
     assert abs(info["energy"] - iref["energy"]) <= 1e-9 * abs(iref["energy"])
     assert ret["dx"] <= 1e-8
+
+
+def _euler_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pf_oracle as O
+        from tests.dist_helpers import OracleNLOps
+        mesh = M.cube_tets(3, 1, jitter=0.1)
+        lam, mu = O.lame(2e4, 0.3)
+        n_glob = mesh.n_nodes * 3
+        bd = M.boundary_dofs(mesh, 3, "x0")
+        rho, dt = 1000.0, 0.02
+        rhs_g = O.assemble_rhs(mesh, 3, np.array([0.0, 3.0, -9.81]), rho)
+        bounds = D.owner_ranges(mesh.n_nodes, world)
+        part = D.partition(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds, rank, mesh.node_xyz)
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * 3 + np.arange(3)[None]).reshape(-1)
+        fixed_g = np.zeros(n_glob, dtype=bool)
+        fixed_g[bd] = True
+        ops = OracleNLOps(part, O.NEOHOOKEAN, lam, mu, fixed_g[dof_l2g])
+        ops.set_mass(rho)
+        newton = D.DistributedNewton(ops, part, 3, D.Comm(), torch.device("cpu"), np.nonzero(fixed_g[dof_l2g])[0])
+        stepper = D.DistributedImplicitEuler(newton, dt)
+        v0_g = np.where(fixed_g, 0.0, 0.05 * np.random.default_rng(9).standard_normal(n_glob))
+        x = torch.zeros(part.n_local * 3, dtype=torch.float64)
+        v = torch.from_numpy(v0_g[dof_l2g].copy())
+        a = torch.zeros_like(x)
+        rhs = torch.from_numpy(rhs_g[dof_l2g].copy())
+        infos = [stepper.step(x, v, a, rhs, cg_check_every=11) for _ in range(2)]
+        no = part.n_owned * 3
+        out = [None] * world
+        dist.all_gather_object(out, (int(part.lo), x.numpy()[:no].copy(), v.numpy()[:no].copy(), a.numpy()[:no].copy()))
+        xg, vg, ag = np.zeros(n_glob), np.zeros(n_glob), np.zeros(n_glob)
+        for lo, xv, vv, av in out:
+            xg[lo * 3: lo * 3 + xv.size], vg[lo * 3: lo * 3 + vv.size], ag[lo * 3: lo * 3 + av.size] = xv, vv, av
+        assert np.array_equal(x.numpy(), xg[dof_l2g]) and np.array_equal(v.numpy(), vg[dof_l2g])
+        if rank == 0:
+            mass = O.assemble_mass(mesh, 3, rho)
+            xo, vo, irefs = np.zeros(n_glob), v0_g.copy(), []
+            for _ in range(2):
+                xo, vo, ao, iref = O.implicit_euler_step(mesh, O.NEOHOOKEAN, lam, mu, rhs_g, bd, mass, dt, xo, vo)
+                irefs.append(iref)
+            ret["ok_counts"] = all(i["iterations"] == r["iterations"] and i["status"] == r["status"]
+                                   and i["line_search_iterations"] == r["line_search_iterations"] for i, r in zip(infos, irefs))
+            ret["dx"] = float(np.abs(xg - xo).max() / np.abs(xo).max())
+            ret["dv"] = float(np.abs(vg - vo).max() / np.abs(vo).max())
+            ret["da"] = float(np.abs(ag - ao).max() / np.abs(ao).max())
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_implicit_euler_gloo():
+    """Two implicit Euler steps over 2 gloo ranks (oracle arithmetic per rank) against the serial restatement."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_euler_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(f"ok{r}") for r in range(world))
+    assert ret["ok_counts"] and ret["dx"] <= 1e-8 and ret["dv"] <= 1e-7 and ret["da"] <= 1e-6

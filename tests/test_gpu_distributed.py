@@ -193,3 +193,93 @@ def test_distributed_newton_two_ranks_match_single_engine():
     assert abs(info["cg_iterations"] - iref["cg_iterations"]) <= max(3 * info["iterations"], 0.03 * iref["cg_iterations"])
     assert abs(info["energy"] - iref["energy"]) <= 1e-9 * abs(iref["energy"])
     assert np.abs(xg - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+
+
+def _euler_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        part, bounds, n_nodes = D.slab_part(4, 2, rank, world, 2)
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.NEOHOOKEAN, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        rho, dt = 1000.0, 0.02
+        f = np.array([0.0, 3.0, -9.81])
+        rhs_l = eng.assemble_rhs(f, rho)            # owned rows are complete
+        eng.inertia_set_mass(rho)
+        fixed_l, _ = _newton_case(part.n_local, part.mesh.node_xyz)
+        fixed_dofs = np.sort((fixed_l[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32)
+        eng.set_dirichlet(fixed_dofs)
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * 3 + np.arange(3)[None]).reshape(-1)
+        v_g = 0.05 * np.random.default_rng(9).standard_normal(n_nodes * 3)
+        v_l = v_g[dof_l2g].copy()
+        v_l[fixed_dofs] = 0.0
+        newton = D.DistributedNewton(D.HipOps(eng), part, 3, D.Comm(), dev, fixed_dofs)
+        stepper = D.DistributedImplicitEuler(newton, dt)
+        x = torch.zeros(part.n_local * 3, dtype=torch.float64, device=dev)
+        v = torch.from_numpy(v_l).to(dev)
+        a = torch.zeros_like(x)
+        rhs = torch.from_numpy(rhs_l).to(dev)
+        infos = [dict(stepper.step(x, v, a, rhs, cg_check_every=16)) for _ in range(2)]
+        torch.cuda.synchronize()
+        no = part.n_owned * 3
+        out = [None] * world
+        dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no], v.cpu().numpy()[:no], a.cpu().numpy()[:no]))
+        if rank == 0:
+            xg, vg, ag = np.zeros(n_nodes * 3), np.zeros(n_nodes * 3), np.zeros(n_nodes * 3)
+            for lo, xv, vv, av in out:
+                xg[lo * 3: lo * 3 + xv.size], vg[lo * 3: lo * 3 + vv.size], ag[lo * 3: lo * 3 + av.size] = xv, vv, av
+            ret["infos"], ret["x"], ret["v"], ret["a"] = infos, xg, vg, ag
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_implicit_euler_two_ranks_match_single_engine():
+    """Two implicit Euler steps with the mesh split over two ranks (HIP kernels per rank, gloo in between) against
+    pfx_implicit_euler_step on the whole mesh."""
+    import torch.multiprocessing as mp
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_euler_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        infos, xg, vg, ag = ret["infos"], ret["x"], ret["v"], ret["a"]
+    part, bounds, n_nodes = D.slab_part(4, 4, 0, 1, 2)
+    eng = E.Engine(0)
+    eng.set_mesh(part.mesh)
+    eng.set_material(E.NEOHOOKEAN, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+    eng.build_pattern()
+    rho, dt = 1000.0, 0.02
+    rhs = eng.assemble_rhs(np.array([0.0, 3.0, -9.81]), rho)
+    eng.inertia_set_mass(rho)
+    fixed, _ = _newton_case(n_nodes, part.mesh.node_xyz)
+    fixed_dofs = np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32)
+    eng.set_dirichlet(fixed_dofs)
+    x = np.zeros(n_nodes * 3)
+    v = 0.05 * np.random.default_rng(9).standard_normal(n_nodes * 3)
+    v[fixed_dofs] = 0.0
+    for step in range(2):
+        x, v, a, iref = eng.implicit_euler_step(dt, x, v, rhs)
+        assert infos[step]["status"] == iref["status"] and infos[step]["iterations"] == iref["iterations"]
+        assert infos[step]["line_search_iterations"] == iref["line_search_iterations"]
+    eng.close()
+    assert np.abs(xg - x).max() <= 1e-8 * np.abs(x).max()
+    assert np.abs(vg - v).max() <= 1e-7 * np.abs(v).max()
+    assert np.abs(ag - a).max() <= 1e-6 * np.abs(a).max()
