@@ -248,6 +248,8 @@ pfx_status pfx_newton_solve_dev(pfx_ctx *ctx, const double *d_rhs, double *d_x_i
  *                       pfx_newton_solve; on error v and a are left untouched. */
 pfx_status pfx_inertia_set_mass(pfx_ctx *ctx, double density, const double *density_e);
 pfx_status pfx_inertia_enable(pfx_ctx *ctx, double acceleration_scaling, const double *d_x_tilde);
+/* the same with x_tilde on the host: it is copied into a buffer of the context */
+pfx_status pfx_inertia_enable_host(pfx_ctx *ctx, double acceleration_scaling, const double *x_tilde);
 pfx_status pfx_implicit_euler_step(pfx_ctx *ctx, double dt, const double *rhs, double *x_inout, double *v_inout, double *a_out,
 								   const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_implicit_euler_step_dev(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x_inout, double *d_v_inout,

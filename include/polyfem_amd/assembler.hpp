@@ -23,6 +23,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace polyfem_amd
@@ -90,6 +91,7 @@ namespace polyfem_amd
 		const void *bound_bases = nullptr;
 		size_t bound_count = 0;
 		int bound_model = -1, bound_bs = 0;
+		long pattern_generation = 0; // bumped whenever the device pattern is rebuilt (per-pattern device state must follow)
 		double bound_lambda = 0, bound_mu = 0;
 		const double *bound_lambda_e = nullptr;
 
@@ -125,6 +127,7 @@ namespace polyfem_amd
 			{
 				int64_t nnz = 0;
 				check(pfx_build_pattern(h, &nnz)); // once per mesh and block size; reused by every assembly afterwards
+				++pattern_generation;
 			}
 			bound_bases = bases.data();
 			bound_count = bases.size();
@@ -246,6 +249,26 @@ namespace polyfem_amd
 			static constexpr int model = PFX_SAINT_VENANT;
 		};
 
+		// assembler/Mass.hpp: rho phi_i phi_j on the diagonal of every size x size block; density uniform or one value
+		// per element (Density with one entry per body id, utils/ElasticityUtils.cpp:561-570)
+		struct Mass
+		{
+			int size_ = 3;
+			double density = 1.0;
+			std::vector<double> density_e;
+			int size() const { return size_; }
+			void set_size(int s)
+			{
+				if (s != 1 && s != 3)
+					throw std::runtime_error("polyfem_amd: the mass matrix is implemented for size 1 and 3");
+				size_ = s;
+			}
+			// the block size decides the layout of the device pattern: bound like the stiffness of the same size
+			int model_for_binding() const { return size_ == 1 ? PFX_LAPLACIAN : PFX_LINEAR_ELASTICITY; }
+			double lambda = 1, mu = 1;
+			std::vector<double> lambda_e, mu_e; // unused
+		};
+
 		template <class LocalAssembler>
 		class Assembler // assembler/Assembler.hpp:26-47
 		{
@@ -254,11 +277,25 @@ namespace polyfem_amd
 						  const std::vector<basis::ElementBases> &gbases, const AssemblyValsCache &, StiffnessMatrix &stiffness,
 						  const bool is_mass = false) const
 			{
-				if (!is_volume || is_mass)
-					throw std::runtime_error("polyfem_amd: only 3-D stiffness assembly is implemented");
+				if (!is_volume)
+					throw std::runtime_error("polyfem_amd: only 3-D problems are implemented");
 				Context &c = Context::instance();
-				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
-				c.check(pfx_assemble_linear(c.h));
+				if constexpr (std::is_same<LocalAssembler, Mass>::value)
+				{
+					if (!is_mass)
+						throw std::runtime_error("polyfem_amd: Assembler<Mass>::assemble is called with is_mass = true");
+					if (!local_assembler_.density_e.empty() && local_assembler_.density_e.size() != bases.size())
+						throw std::runtime_error("polyfem_amd: one density per element expected");
+					c.bind(bases, gbases, n_basis, local_assembler_.model_for_binding(), 3, 1.0, 1.0);
+					c.check(pfx_assemble_mass(c.h, local_assembler_.density, local_assembler_.density_e.empty() ? nullptr : local_assembler_.density_e.data()));
+				}
+				else
+				{
+					if (is_mass)
+						throw std::runtime_error("polyfem_amd: is_mass = true belongs to Assembler<Mass>");
+					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
+					c.check(pfx_assemble_linear(c.h));
+				}
 				int64_t nnz = 0;
 				c.check(pfx_get_linear_csr(c.h, &nnz, nullptr, nullptr, nullptr));
 				stiffness.n = n_basis * local_assembler_.size();
@@ -273,6 +310,17 @@ namespace polyfem_amd
 		private:
 			LocalAssembler local_assembler_;
 		};
+
+		// RhsAssembler::assemble (assembler/RhsAssembler.cpp:55-98) for a constant body force: rhs[node*3 + c] =
+		// sum_e sum_q force_c rho det w phi_i(q).  The mesh must be bound (any assembler call binds it).
+		inline void assemble_body_force(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, const int n_basis,
+										const double (&force)[3], const Mass &density, VectorXd &rhs)
+		{
+			Context &c = Context::instance();
+			c.bind(bases, gbases, n_basis, PFX_LINEAR_ELASTICITY, 3, 1.0, 1.0);
+			rhs.assign((size_t)n_basis * 3, 0.0);
+			c.check(pfx_assemble_rhs(c.h, force, density.density, density.density_e.empty() ? nullptr : density.density_e.data(), rhs.data()));
+		}
 
 		template <class LocalAssembler>
 		class NLAssembler // assembler/Assembler.hpp:70-118
@@ -388,6 +436,48 @@ namespace polyfem_amd
 		};
 	} // namespace polysolve
 
+	namespace time_integrator
+	{
+		// time_integrator::ImplicitEuler (time_integrator/ImplicitEuler.cpp:5-33, ImplicitTimeIntegrator.cpp:16-30): host
+		// vectors, as in the reference
+		class ImplicitEuler
+		{
+		public:
+			void init(const VectorXd &x_prev, const VectorXd &v_prev, const VectorXd &a_prev, double dt)
+			{
+				if (!(dt > 0))
+					throw std::runtime_error("polyfem_amd: dt must be positive");
+				x_prev_ = x_prev, v_prev_ = v_prev, a_prev_ = a_prev, dt_ = dt;
+			}
+			double dt() const { return dt_; }
+			const VectorXd &x_prev() const { return x_prev_; }
+			const VectorXd &v_prev() const { return v_prev_; }
+			const VectorXd &a_prev() const { return a_prev_; }
+			VectorXd x_tilde() const
+			{
+				VectorXd t(x_prev_.size());
+				for (size_t k = 0; k < t.size(); ++k)
+					t[k] = x_prev_[k] + dt_ * v_prev_[k];
+				return t;
+			}
+			double acceleration_scaling() const { return dt_ * dt_; }
+			void update_quantities(const VectorXd &x)
+			{
+				for (size_t k = 0; k < x.size(); ++k)
+				{
+					const double v = (x[k] - x_prev_[k]) / dt_;
+					a_prev_[k] = (v - v_prev_[k]) / dt_;
+					v_prev_[k] = v;
+					x_prev_[k] = x[k];
+				}
+			}
+
+		private:
+			VectorXd x_prev_, v_prev_, a_prev_;
+			double dt_ = 0;
+		};
+	} // namespace time_integrator
+
 	namespace solver
 	{
 		// solver::NLProblem (solver/NLProblem.hpp, NLProblem.cpp:79-211) for one ElasticForm plus one BodyForm: the
@@ -424,11 +514,33 @@ namespace polyfem_amd
 					f[(size_t)k] = is_fixed_[(size_t)k] ? (boundary_values_.empty() ? 0.0 : boundary_values_[(size_t)k]) : reduced[w++];
 				return f;
 			}
-			void bind() const
+			// InertiaForm (solver/forms/InertiaForm.cpp) with the mass matrix of `mass` and the predictor of `integrator`;
+			// the elastic and body forms are then weighted with its acceleration_scaling (state/StateSolveNonlinear.cpp:
+			// 78-84).  nullptr: static problem.
+			void set_inertia(const assembler::Mass &mass, const time_integrator::ImplicitEuler *integrator)
+			{
+				mass_ = mass;
+				integrator_ = integrator;
+				mass_generation_ = -1;
+			}
+			void bind()
 			{
 				Context &c = Context::instance();
 				c.bind(bases_, gbases_, n_basis_, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
 				c.check(pfx_set_dirichlet(c.h, boundary_nodes_.data(), (int64_t)boundary_nodes_.size()));
+				if (!integrator_)
+				{
+					c.check(pfx_inertia_enable(c.h, 0.0, nullptr));
+					return;
+				}
+				if (mass_generation_ != c.pattern_generation)
+				{
+					// the mass matrix lives with the device pattern: assembled once per pattern
+					c.check(pfx_inertia_set_mass(c.h, mass_.density, mass_.density_e.empty() ? nullptr : mass_.density_e.data()));
+					mass_generation_ = c.pattern_generation;
+				}
+				const VectorXd xt = integrator_->x_tilde();
+				c.check(pfx_inertia_enable_host(c.h, integrator_->acceleration_scaling(), xt.data()));
 			}
 			const VectorXd &rhs() const { return rhs_; }
 
@@ -439,6 +551,9 @@ namespace polyfem_amd
 			std::vector<int> boundary_nodes_;
 			VectorXd rhs_, boundary_values_;
 			std::vector<char> is_fixed_;
+			assembler::Mass mass_;
+			const time_integrator::ImplicitEuler *integrator_ = nullptr;
+			long mass_generation_ = -1;
 		};
 	} // namespace solver
 } // namespace polyfem_amd

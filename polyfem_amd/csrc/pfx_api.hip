@@ -685,6 +685,26 @@ extern "C"
 		return PFX_OK;
 	}
 
+	pfx_status pfx_inertia_enable_host(pfx_ctx *ctx, double acceleration_scaling, const double *x_tilde)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (!(acceleration_scaling > 0.0) || !x_tilde)
+			return pfx_inertia_enable(ctx, 0.0, nullptr);
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		if (ctx->tstep_count < 2 * n)
+		{
+			if (pfx_alloc(ctx, &ctx->d_tstep, 2 * n))
+				return PFX_ERR_HIP;
+			ctx->tstep_count = 2 * n;
+		}
+		PFX_HIP(hipMemcpyAsync(ctx->d_tstep + n, x_tilde, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return pfx_inertia_enable(ctx, acceleration_scaling, ctx->d_tstep + n);
+	}
+
 	pfx_status pfx_mass_apply_dev(pfx_ctx *ctx, const double *d_v, double *d_y)
 	{
 		if (!ctx || !d_v || !d_y)

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
+    "pfx_inertia_enable_host",
 ]
 
 
@@ -133,6 +134,7 @@ def load():
         "pfx_assemble_rhs_dev": [_vp, _pd, _dbl, _pd, _vp],
         "pfx_inertia_set_mass": [_vp, _dbl, _pd],
         "pfx_inertia_enable": [_vp, _dbl, _vp],
+        "pfx_inertia_enable_host": [_vp, _dbl, _pd],
         "pfx_implicit_euler_step": [_vp, _dbl, _pd, _pd, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_implicit_euler_step_dev": [_vp, _dbl, _vp, _vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_set_diag_shift": [_vp, _dbl],
@@ -384,6 +386,11 @@ class Engine:
         """Newton solves minimise acceleration_scaling * (E - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde) from now on
         (device pointer to x_tilde); inertia_disable() restores the static objective."""
         self._ck(self.L.pfx_inertia_enable(self.h, float(acceleration_scaling), _vp(d_x_tilde)))
+
+    def inertia_enable_host(self, acceleration_scaling: float, x_tilde):
+        xt = np.ascontiguousarray(x_tilde, dtype=np.float64)
+        assert xt.size == self.info().n_dofs
+        self._ck(self.L.pfx_inertia_enable_host(self.h, float(acceleration_scaling), _d(xt)))
 
     def inertia_disable(self):
         self._ck(self.L.pfx_inertia_enable(self.h, 0.0, None))

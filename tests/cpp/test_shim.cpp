@@ -220,6 +220,74 @@ int main()
 		REQUIRE(limit);
 		std::printf("newton ok: %d iterations, %ld cg iterations\n", newton.solver_info.iterations, (long)newton.solver_info.cg_iterations);
 	}
+	// mass matrix, body force and two implicit Euler steps (solve_transient_tensor_nonlinear: minimize, then
+	// update_quantities), against the one-call time step of the C ABI
+	{
+		assembler::Mass mass;
+		mass.density = 1000.0;
+		assembler::Assembler<assembler::Mass> mass_assembler;
+		mass_assembler.local_assembler() = mass;
+		StiffnessMatrix Mm;
+		mass_assembler.assemble(true, n_basis, bases, gbases, cache, Mm, true);
+		double total = 0; // 1^T M 1 = 3 * rho * volume
+		for (double v : Mm.values)
+			total += v;
+		REQUIRE(std::fabs(total - 3.0 * 1000.0) <= 1e-9 * 3000.0);
+		const double force[3] = {0.0, 3.0, -9.81};
+		VectorXd rhs;
+		assembler::assemble_body_force(bases, gbases, n_basis, force, mass, rhs);
+		double fz = 0;
+		for (int i = 0; i < n_basis; ++i)
+			fz += rhs[3 * i + 2];
+		REQUIRE(std::fabs(fz + 9810.0) <= 1e-9 * 9810.0);
+
+		assembler::NeoHookeanElasticity mat;
+		mat.set_E_nu(2e4, 0.3);
+		VectorXd bc(N, 0.0), x0(N, 0.0), v0(N, 0.0), a0(N, 0.0);
+		std::vector<char> is_fixed(N, 0);
+		for (int b : fixed)
+			is_fixed[b] = 1;
+		for (int k = 0; k < N; ++k)
+			v0[k] = is_fixed[k] ? 0.0 : 0.05 * std::sin(0.37 * k);
+		const double dt = 0.02;
+		time_integrator::ImplicitEuler integrator;
+		integrator.init(x0, v0, a0, dt);
+		solver::NLProblem<assembler::NeoHookeanElasticity> problem(bases, gbases, n_basis, mat, fixed, rhs, bc);
+		problem.set_inertia(mass, &integrator);
+		cppoptlib::SparseNewtonDescentSolver<solver::NLProblem<assembler::NeoHookeanElasticity>> newton;
+		VectorXd xr = problem.full_to_reduced(x0);
+		int its[2];
+		for (int step = 0; step < 2; ++step)
+		{
+			newton.minimize(problem, xr);
+			its[step] = newton.solver_info.iterations;
+			integrator.update_quantities(problem.reduced_to_full(xr));
+		}
+		// the same two steps through pfx_implicit_euler_step
+		Context &c = Context::instance();
+		VectorXd x1 = x0, v1 = v0, a1(N, 0.0);
+		pfx_newton_params par;
+		pfx_newton_default_params(&par);
+		pfx_newton_info info;
+		for (int step = 0; step < 2; ++step)
+		{
+			c.check(pfx_implicit_euler_step(c.h, dt, rhs.data(), x1.data(), v1.data(), a1.data(), &par, &info));
+			REQUIRE(info.iterations == its[step]);
+		}
+		double dx = 0, xm = 0, dv = 0, vm = 0;
+		for (int k = 0; k < N; ++k)
+		{
+			dx = std::fmax(dx, std::fabs(integrator.x_prev()[k] - x1[k])), xm = std::fmax(xm, std::fabs(x1[k]));
+			dv = std::fmax(dv, std::fabs(integrator.v_prev()[k] - v1[k])), vm = std::fmax(vm, std::fabs(v1[k]));
+		}
+		REQUIRE(xm > 0 && dx <= 1e-10 * xm && dv <= 1e-9 * vm);
+		// back to a static problem: the inertia term is switched off again
+		problem.set_inertia(mass, nullptr);
+		VectorXd xs((size_t)problem.reduced_size(), 0.0);
+		newton.minimize(problem, xs);
+		REQUIRE(newton.solver_info.status == PFX_NEWTON_F_DELTA || newton.solver_info.status == PFX_NEWTON_GRAD_NORM);
+		std::printf("transient ok: %d + %d newton iterations\n", its[0], its[1]);
+	}
 	std::printf("shim ok: nnz(K)=%ld energy=%.6e cg_iters=%d err=%.2e\n", (long)K.nonZeros(), e0, solver->solver_iter(), solver->solver_error());
 	return 0;
 }
