@@ -572,6 +572,40 @@ def test_implicit_euler_steps_match_oracle(eng, oracle, name, model):
         eng.set_dirichlet(np.zeros(0, dtype=np.int32))
 
 
+@pytest.mark.parametrize("name", ["p2_jitter_polyfem", "q2"])
+def test_inertia_form_pieces(eng, oracle, name):
+    """The pieces of InertiaForm a caller-driven Newton loop uses (the reference checks the form by finite differences,
+    tests/test_form_derivatives.cpp:290-305; its value is quadratic, so the pieces are compared directly): M v against
+    the oracle's mass matrix, the value 1/2 d^T M d, and weight * H + M."""
+    import scipy.sparse as sp
+    import torch
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 3
+    rho_e = 500.0 + 100.0 * (np.arange(mesh.n_el) % 4)
+    mo = oracle.assemble_mass(mesh, 3, rho_e)
+    Mo = sp.csc_matrix((mo[2], mo[1], mo[0]), shape=(n, n)).tocsr()
+    eng.inertia_set_mass(rho_e)
+    v = np.random.default_rng(3).standard_normal(n)
+    d_v = torch.from_numpy(v).cuda()
+    d_y = torch.zeros_like(d_v)
+    eng.mass_apply_dev(d_v.data_ptr(), d_y.data_ptr())
+    eng.synchronize()
+    y = d_y.cpu().numpy()
+    assert rel_err(y, Mo @ v) <= TOL
+    assert abs(0.5 * v @ y - 0.5 * v @ (Mo @ v)) <= TOL * abs(v @ y)
+    u = M.seeded_displacement(mesh, 3, 2e-3, seed=8)
+    h = eng.hessian(u).copy()
+    eng.hessian_add_mass_dev(2.5e-4)
+    hm = eng.get_values()
+    rp, ci = eng.get_pattern()
+    H = sp.csr_matrix((h, ci, rp), shape=(n, n))
+    Hm = sp.csr_matrix((hm, ci, rp), shape=(n, n))
+    ref = 2.5e-4 * H + Mo
+    assert abs(Hm - ref).max() <= TOL * abs(ref).max()
+
+
 def test_inertia_error_behaviour(eng, oracle):
     mesh = M.cube_tets(2, 1)
     lam, mu = oracle.lame(2e4, 0.3)
