@@ -1,0 +1,126 @@
+"""Time integrators (polyfem_amd/time_integrator.py, mirrors of time_integrator/*.cpp of the reference).
+CPU: the formulas on a scalar oscillator, where the minimiser of the step objective is known in closed form
+(convergence orders, energy behaviour, BDF start-up, factory).  GPU: device-resident transient solves with every
+integrator against the oracle's Newton solve of the same step objective."""
+import numpy as np
+import pytest
+
+from polyfem_amd import time_integrator as TI
+
+
+def _oscillator(integrator, dt, steps, k=4.0, m=1.0):
+    """m x'' = -k x, x(0) = 1, v(0) = 0; per step x minimises w * k x^2 / 2 + m (x - x_tilde)^2 / 2."""
+    integrator.init(np.array([1.0]), np.array([0.0]), np.array([-k / m]), dt)
+    xs = []
+    for _ in range(steps):
+        w, xt = integrator.acceleration_scaling(), integrator.x_tilde()
+        x = m * xt / (m + w * k)
+        integrator.update_quantities(x)
+        xs.append(float(x[0]))
+    return np.array(xs), integrator
+
+
+def test_integrator_formulas_and_orders():
+    k, T = 4.0, 1.0
+    exact = np.cos(np.sqrt(k) * T)
+    errs = {}
+    for name, mk in (("euler", TI.ImplicitEuler), ("bdf1", lambda: TI.BDF(1)), ("bdf2", lambda: TI.BDF(2)),
+                     ("bdf3", lambda: TI.BDF(3)), ("newmark", lambda: TI.ImplicitNewmark(0.5, 0.25))):
+        e = []
+        for n in (100, 200, 400):
+            xs, _ = _oscillator(mk(), T / n, n, k)
+            e.append(abs(xs[-1] - exact))
+        errs[name] = e
+    order = {n: np.log2(e[1] / e[2]) for n, e in errs.items()}
+    assert abs(order["euler"] - 1) < 0.1 and abs(order["bdf1"] - 1) < 0.1
+    assert abs(order["bdf2"] - 2) < 0.15 and abs(order["newmark"] - 2) < 0.1
+    assert errs["bdf3"][2] < errs["bdf2"][2] < errs["bdf1"][2]
+    # BDF1 is implicit Euler
+    a, _ = _oscillator(TI.ImplicitEuler(), 0.01, 50)
+    b, _ = _oscillator(TI.BDF(1), 0.01, 50)
+    assert np.array_equal(a, b)
+    # the trapezoidal Newmark scheme conserves the energy of the linear oscillator, implicit Euler dissipates it
+    xs, ti = _oscillator(TI.ImplicitNewmark(0.5, 0.25), 0.01, 500, k)
+    en = 0.5 * ti.v_prev()[0] ** 2 + 0.5 * k * ti.x_prev()[0] ** 2
+    assert abs(en - 0.5 * k) < 1e-10
+    xs, ti = _oscillator(TI.ImplicitEuler(), 0.01, 500, k)
+    assert 0.5 * ti.v_prev()[0] ** 2 + 0.5 * k * ti.x_prev()[0] ** 2 < 0.5 * k * 0.95
+    # history: BDF(3) knows one state after init and at most three later
+    ti = TI.BDF(3)
+    ti.init(np.zeros(2), np.ones(2), np.zeros(2), 0.1)
+    assert len(ti.x_prevs) == 1 and ti.acceleration_scaling() == pytest.approx(0.01)
+    for _ in range(5):
+        ti.update_quantities(ti.x_tilde())
+    assert len(ti.x_prevs) == len(ti.v_prevs) == len(ti.a_prevs) == 3
+    assert ti.acceleration_scaling() == pytest.approx((6.0 / 11.0 * 0.1) ** 2)
+    assert sum(TI.BDF_ALPHAS[2]) == pytest.approx(1.0) and all(abs(sum(a) - 1.0) < 1e-14 for a in TI.BDF_ALPHAS)
+
+
+def test_factory():
+    assert isinstance(TI.construct_time_integrator("ImplicitEuler"), TI.ImplicitEuler)
+    assert isinstance(TI.construct_time_integrator("implict_euler"), TI.ImplicitEuler)
+    nm = TI.construct_time_integrator({"type": "ImplicitNewmark", "gamma": 0.6, "beta": 0.3})
+    assert isinstance(nm, TI.ImplicitNewmark) and nm.gamma == 0.6 and nm.beta == 0.3
+    assert TI.construct_time_integrator({"type": "BDF", "steps": 4}).steps == 4
+    assert TI.construct_time_integrator({"type": "BDF", "steps": 9}).steps == 1
+    with pytest.raises(RuntimeError):
+        TI.construct_time_integrator("RK4")
+    with pytest.raises(ValueError):
+        TI.ImplicitEuler().init(np.zeros(1), np.zeros(1), np.zeros(1), 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ImplicitEuler", "ImplicitNewmark", "BDF2", "BDF3"])
+def test_transient_solver_matches_oracle(oracle, kind):
+    """Four device-resident time steps of a NeoHookean body under gravity with each integrator; the reference run is
+    the same integrator class on numpy vectors with the oracle's Newton solve of the step objective."""
+    import torch
+    from polyfem_amd import engine as E
+    from polyfem_amd import mesh as M
+
+    def make():
+        return {"ImplicitEuler": TI.ImplicitEuler, "ImplicitNewmark": TI.ImplicitNewmark, "BDF2": lambda: TI.BDF(2),
+                "BDF3": lambda: TI.BDF(3)}[kind]()
+
+    mesh = M.cube_tets(3, 2, numbering="polyfem", jitter=0.2, seed=2)
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    rho, dt = 1000.0, 0.02
+    rhs = oracle.assemble_rhs(mesh, 3, np.array([0.0, 3.0, -9.81]), rho)
+    mass = oracle.assemble_mass(mesh, 3, rho)
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    v0 = np.where(free, 0.05 * np.random.default_rng(9).standard_normal(n), 0.0)
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.build_pattern()
+        eng.set_dirichlet(bnd)
+        eng.inertia_set_mass(rho)
+        dev = torch.device("cuda", 0)
+        ti = make()
+        ti.init(torch.zeros(n, dtype=torch.float64, device=dev), torch.from_numpy(v0).to(dev),
+                torch.zeros(n, dtype=torch.float64, device=dev), dt)
+        solver = TI.TransientSolver(eng, ti, torch.from_numpy(rhs).to(dev))
+        ref = make()
+        ref.init(np.zeros(n), v0.copy(), np.zeros(n), dt)
+        for step in range(4):
+            x, info = solver.step()
+            xr, iref = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, ref.x_prev(), mass=mass,
+                                           x_tilde=ref.x_tilde(), weight=ref.acceleration_scaling())
+            ref.update_quantities(xr)
+            assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 1
+            xs = x.cpu().numpy()
+            assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+            assert np.abs(ti.v_prev().cpu().numpy() - ref.v_prev()).max() <= 1e-6 * np.abs(ref.v_prev()).max()
+            assert not xs[bnd].any()
+        if kind == "ImplicitEuler":
+            # the one-call time step of the C ABI does the same
+            x1, v1 = np.zeros(n), v0.copy()
+            for step in range(4):
+                x1, v1, a1, _ = eng.implicit_euler_step(dt, x1, v1, rhs)
+            assert np.abs(x1 - xs).max() <= 1e-10 * np.abs(xs).max()
+    finally:
+        eng.close()
