@@ -98,8 +98,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
-    ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean", "newton"],
-                    help="newton: one step = a full NeoHookean Newton solve (gravity-like load, clamped x = 0 face)")
+    ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean", "newton", "transient"],
+                    help="newton: one step = a full NeoHookean Newton solve (gravity-like load, clamped x = 0 face); "
+                         "transient: one step = one implicit Euler time step of the same body falling under gravity (single GPU)")
+    ap.add_argument("--dt", type=float, default=1e-3, help="time step of the transient workload")
     ap.add_argument("--cg-max-iter", type=int, default=1000)
     ap.add_argument("--cg-tol", type=float, default=1e-12)
     ap.add_argument("--cpu-n", type=int, default=14)
@@ -129,7 +131,9 @@ def main():
 
     from polyfem_amd import distributed as D
 
-    nonlinear = args.workload in ("neohookean", "newton")
+    nonlinear = args.workload in ("neohookean", "newton", "transient")
+    if args.workload == "transient" and world > 1:
+        raise SystemExit("the transient workload of bench.py is single-GPU (DistributedImplicitEuler covers the partitioned case)")
     # weak scaling: the global grid is n x n x (n*world) cells; every rank owns the node planes of n cell layers
     # (plus one layer of its lower neighbour's elements, which it assembles redundantly instead of communicating)
     part, bounds, n_nodes_global = D.slab_part(args.n, args.n, rank, world, 2)
@@ -184,7 +188,19 @@ def main():
     dnewton = (D.DistributedNewton(D.HipOps(eng), part, 3, comm, dev, fixed_dofs)
                if world > 1 and args.workload == "newton" else None)
 
+    if args.workload == "transient":
+        rho = 1000.0
+        eng.inertia_set_mass(rho)
+        gravity = torch.from_numpy(eng.assemble_rhs(np.array([0.0, 0.0, -9.81]), rho)).to(dev)
+        vel = torch.zeros(n, dtype=torch.float64, device=dev)
+        acc = torch.zeros(n, dtype=torch.float64, device=dev)
+
     def step():
+        if args.workload == "transient":
+            # consecutive time steps of one simulation: x and vel carry over
+            newton_info.update(eng.implicit_euler_step_dev(args.dt, x.data_ptr(), vel.data_ptr(), acc.data_ptr(), gravity.data_ptr(),
+                                                           cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol))
+            return newton_info["cg_iterations"], newton_info["grad_norm"]
         if dnewton is not None:
             x.zero_()
             newton_info.update(dnewton.solve(x, load, cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol, cg_check_every=50))
@@ -295,11 +311,15 @@ def main():
                    "ms_per_iter": spmv_ms + upd_ms + dir_ms},
             "pattern_build_s": t_pattern,
         }
+        if args.workload == "transient":
+            out["config"]["workload"] = (f"NeoHookean implicit Euler time step (dt {args.dt:g}, Newton + backtracking, Jacobi-CG tol {args.cg_tol:g} "
+                                         f"max_iter {args.cg_max_iter}), P2 tets, {args.n}^3 Kuhn grid")
+            out["newton"] = dict(newton_info)
         if args.workload == "newton":
             out["config"]["workload"] = (f"NeoHookean Newton solve (backtracking line search, Jacobi-CG tol {args.cg_tol:g} max_iter "
                                          f"{args.cg_max_iter} per step), P2 tets, {args.n}^3 Kuhn grid")
             out["newton"] = dict(newton_info)
-        if not args.no_cpu_baseline and world == 1 and args.workload != "newton":  # the CPU column is reported with the single-GPU line only
+        if not args.no_cpu_baseline and world == 1 and args.workload not in ("newton", "transient"):  # the CPU column is reported with the single-GPU line only
             from oracle import pf_oracle
             pf_oracle.build()
             out["cpu_baseline"] = cpu_baseline(args, pf_oracle, M)

@@ -509,6 +509,33 @@ extern "C"
 		return pfx_launch_gather_vector(ctx, d_g);
 	}
 
+} // extern "C"
+
+pfx_status pfx_eval_all_dev(pfx_ctx *ctx, const double *d_u, double *d_energy, double *d_g)
+{
+	{
+		pfx_scoped_timer tm(ctx, "local");
+		pfx_status rc = pfx_launch_local_nl(ctx, d_u, true, true, true);
+		if (rc)
+			return rc;
+	}
+	pfx_status rc = pfx_launch_reduce_energy(ctx, d_energy);
+	if (rc)
+		return rc;
+	pfx_scoped_timer tm(ctx, "gather_vec");
+	return pfx_launch_gather_vector(ctx, d_g);
+}
+
+pfx_status pfx_hessian_from_state(pfx_ctx *ctx, bool project_to_psd)
+{
+	ctx->have_mask = false;
+	ctx->values_gen++;
+	pfx_scoped_timer tm(ctx, project_to_psd ? "gather_psd" : "gather");
+	return project_to_psd ? pfx_launch_rows_nl_psd(ctx) : pfx_launch_rows_nl(ctx);
+}
+
+extern "C"
+{
 	static pfx_status hessian_dev_impl(pfx_ctx *ctx, const double *d_u, bool project_to_psd)
 	{
 		if (!ctx || !d_u)

@@ -247,6 +247,10 @@ pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
 pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx);
 pfx_status pfx_values_to_csr(pfx_ctx *ctx, double *host_values);
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info);
+// energy + gradient + Hessian state of one displacement in ONE element-kernel launch, and the Hessian assembled from
+// that state afterwards (the Newton driver evaluates all three at every iterate)
+pfx_status pfx_eval_all_dev(pfx_ctx *ctx, const double *d_u, double *d_energy, double *d_g);
+pfx_status pfx_hessian_from_state(pfx_ctx *ctx, bool project_to_psd);
 pfx_status pfx_capture_mass(pfx_ctx *ctx);
 pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y);
 pfx_status pfx_add_mass_run(pfx_ctx *ctx, double w);

@@ -51,28 +51,38 @@ namespace
 			mass[b] = values[b * 9];
 	}
 
-	// d = x - x_tilde and md = M d, M = mass (x) I_3: one thread per node row (xt and d may be null: md = M x)
+	// md = M v on the rows [0, n_rows), M = mass (x) I_3.  Eight lanes share a node row: they walk the row's blocks side by
+	// side (mass and column index are read in 64-byte runs) and combine their partial sums with shuffles.
 	__global__ __launch_bounds__(256) void k_mass_apply(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
-														const double *__restrict__ mass, const double *__restrict__ x,
-														const double *__restrict__ xt, int64_t n_rows, double *__restrict__ d,
+														const double *__restrict__ mass, const double *__restrict__ v, int64_t n_rows,
 														double *__restrict__ md)
 	{
-		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_rows; g += (int64_t)gridDim.x * blockDim.x)
+		const int sub = threadIdx.x & 7;
+		const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 3);
+		for (int64_t g0 = (int64_t)blockIdx.x * (blockDim.x >> 3); g0 < n_rows; g0 += stride) // uniform trip count per wave
 		{
+			const int64_t g = g0 + (threadIdx.x >> 3);
 			double a0 = 0, a1 = 0, a2 = 0;
-			const int64_t b1 = node_ptr[g + 1];
-			for (int64_t b = node_ptr[g]; b < b1; ++b)
+			if (g < n_rows)
 			{
-				const int64_t c = 3 * (int64_t)node_col[b];
-				const double m = mass[b];
-				a0 += m * (x[c] - (xt ? xt[c] : 0.0));
-				a1 += m * (x[c + 1] - (xt ? xt[c + 1] : 0.0));
-				a2 += m * (x[c + 2] - (xt ? xt[c + 2] : 0.0));
+				const int64_t b1 = node_ptr[g + 1];
+				for (int64_t b = node_ptr[g] + sub; b < b1; b += 8)
+				{
+					const int64_t c = 3 * (int64_t)node_col[b];
+					const double m = mass[b];
+					a0 += m * v[c];
+					a1 += m * v[c + 1];
+					a2 += m * v[c + 2];
+				}
 			}
-			md[3 * g] = a0, md[3 * g + 1] = a1, md[3 * g + 2] = a2;
-			if (d)
-				for (int k = 0; k < 3; ++k)
-					d[3 * g + k] = x[3 * g + k] - (xt ? xt[3 * g + k] : 0.0);
+			for (int o = 4; o > 0; o >>= 1)
+			{
+				a0 += __shfl_xor(a0, o, 64);
+				a1 += __shfl_xor(a1, o, 64);
+				a2 += __shfl_xor(a2, o, 64);
+			}
+			if (g < n_rows && sub < 3)
+				md[3 * g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
 		}
 	}
 
@@ -199,9 +209,11 @@ namespace
 		const double *mass = nullptr, *xt = nullptr;
 		double *d = nullptr, *md = nullptr; // n each: x - x_tilde and M (x - x_tilde)
 
+		// d = x - x_tilde, md = M d
 		void mass_apply(const double *x)
 		{
-			hipLaunchKernelGGL(k_mass_apply, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, x, xt, ctx->n_nodes, d, md);
+			hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, ctx->stream, x, xt, -1.0, n, d);
+			hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, (const double *)d, ctx->n_nodes, md);
 		}
 
 		// a.b, |a + c|^2 (c may be null), max|a|
@@ -212,6 +224,55 @@ namespace
 			hipLaunchKernelGGL(k_reduce3_finish, dim3(1), dim3(256), 0, st, partial, scal);
 			PFX_HIP(hipMemcpyAsync(out, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
 			PFX_HIP(hipStreamSynchronize(st));
+			return PFX_OK;
+		}
+
+		// Values at the current iterate, from one fused element-kernel launch (energy, gradient rows and the per-element
+		// state the Hessian is assembled from); the line search asks for the same numbers again and gets them from here.
+		double x_energy = 0.0, x_gn2 = 0.0;
+		bool x_valid = false, x_state_valid = false;
+		// last trial point of the line search: step size and objective
+		double trial_step = -1.0, trial_energy = 0.0;
+
+		// objective and gradient at the iterate x (into g), Hessian state left on the device
+		pfx_status eval_iterate(const double *x, double *val, double *norm2)
+		{
+			hipStream_t st = ctx->stream;
+			pfx_status rc = pfx_eval_all_dev(ctx, x, scal + 3, g);
+			if (rc)
+				return rc;
+			double e = 0;
+			int flag = 0;
+			PFX_HIP(hipMemcpyAsync(&e, scal + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+			if (flag)
+			{
+				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+				e = std::nan("");
+			}
+			double r[3];
+			if (rhs && std::isfinite(e))
+			{
+				if ((rc = reduce(x, rhs, nullptr, r)))
+					return rc;
+				e -= r[0];
+			}
+			if (mass)
+				mass_apply(x);
+			if (mass && std::isfinite(e))
+			{
+				if ((rc = reduce(d, md, nullptr, r)))
+					return rc;
+				e = iw * e + 0.5 * r[0];
+			}
+			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, g, rhs, fixed, n, iw, (const double *)(mass ? md : nullptr));
+			if ((rc = reduce(g, g, nullptr, r)))
+				return rc;
+			*val = e;
+			*norm2 = flag ? std::nan("") : r[0];
+			x_energy = *val, x_gn2 = *norm2;
+			x_valid = x_state_valid = true;
 			return PFX_OK;
 		}
 
@@ -293,7 +354,10 @@ namespace
 			pfx_status rc;
 			double old_energy_in = 0;
 			*rate = std::nan("");
-			if ((rc = value(x, &old_energy_in)))
+			trial_step = -1.0;
+			if (x_valid)
+				old_energy_in = x_energy; // evaluated with the gradient at the top of the iteration
+			else if ((rc = value(x, &old_energy_in)))
 				return rc;
 			info->line_search_iterations++;
 			if (std::isnan(old_energy_in))
@@ -308,6 +372,7 @@ namespace
 				double energy = 0;
 				if ((rc = value(xn, &energy)))
 					return rc;
+				trial_step = step_size, trial_energy = energy;
 				info->line_search_iterations++;
 				if (!std::isfinite(energy))
 				{
@@ -323,21 +388,28 @@ namespace
 				return PFX_OK;
 			// descent step (BacktrackingLineSearch.hpp:157-255)
 			double gn2 = 0;
-			if ((rc = gradient(x, gls, &gn2)))
+			if (x_valid)
+				gn2 = x_gn2; // |gradient(x)|^2, known from the top of the iteration
+			else if ((rc = gradient(x, gls, &gn2)))
 				return rc;
 			const bool use_grad_norm = std::sqrt(gn2) < par->use_grad_norm_tol;
 			const double old_energy = use_grad_norm ? gn2 : old_energy_in;
 			double cur_energy = std::nan("");
 			while (step_size > min_step_size && cur_iter < max_step_size_iter)
 			{
-				if ((rc = step(x, step_size, xn)))
-					return rc;
-				if (use_grad_norm)
-					rc = gradient(xn, gls, &cur_energy);
+				if (!use_grad_norm && step_size == trial_step)
+					cur_energy = trial_energy; // the point the finite-energy loop ended on: same objective value
 				else
-					rc = value(xn, &cur_energy);
-				if (rc)
-					return rc;
+				{
+					if ((rc = step(x, step_size, xn)))
+						return rc;
+					if (use_grad_norm)
+						rc = gradient(xn, gls, &cur_energy);
+					else
+						rc = value(xn, &cur_energy);
+					if (rc)
+						return rc;
+				}
 				info->line_search_iterations++;
 				if (!std::isfinite(cur_energy) || cur_energy > old_energy)
 					step_size /= 2.0;
@@ -432,15 +504,15 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 
 	do
 	{
-		if ((rc = S.value(d_x, &energy)))
+		if (S.x_valid) // the iterate did not move (a descent strategy was escalated): same values
+			energy = S.x_energy, gn2 = S.x_gn2;
+		else if ((rc = S.eval_iterate(d_x, &energy, &gn2)))
 			return finish(rc, ctx->err.c_str());
 		if (!std::isfinite(energy))
 		{
 			status = PFX_NEWTON_FAILED;
 			return finish(PFX_ERR_NUMERIC, "f(x) is nan or inf; stopping");
 		}
-		if ((rc = S.gradient(d_x, S.g, &gn2)))
-			return finish(rc, ctx->err.c_str());
 		grad_norm = std::sqrt(gn2);
 		if (std::isnan(grad_norm))
 		{
@@ -469,7 +541,7 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 				break;
 			}
 			// assemble_hessian (:105-123): strategy 1 projects the element Hessians to PSD
-			if ((rc = strategy == 1 ? pfx_hessian_psd_dev(ctx, d_x) : pfx_hessian_dev(ctx, d_x)))
+			if ((rc = S.x_state_valid ? pfx_hessian_from_state(ctx, strategy == 1) : (strategy == 1 ? pfx_hessian_psd_dev(ctx, d_x) : pfx_hessian_dev(ctx, d_x))))
 				return finish(rc, ctx->err.c_str());
 			if (S.mass)
 			{
@@ -539,6 +611,7 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 			}
 		}
 		hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, st, d_x, S.dx, rate, n, d_x);
+		S.x_valid = S.x_state_valid = false;
 		info->descent_strategy = strategy;
 		strategy = 0;
 		++iterations;
@@ -597,8 +670,7 @@ pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, 
 // y[owned rows] = M v with the captured mass matrix (v needs a current halo on a partitioned mesh)
 pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y)
 {
-	hipLaunchKernelGGL(k_mass_apply, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_mass_blk, d_v,
-					   (const double *)nullptr, ctx->n_owned, (double *)nullptr, d_y);
+	hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_mass_blk, d_v, ctx->n_owned, d_y);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
