@@ -56,7 +56,8 @@ enum
 	PFX_LAPLACIAN = 0,
 	PFX_LINEAR_ELASTICITY = 1,
 	PFX_NEOHOOKEAN = 2,
-	PFX_SAINT_VENANT = 3
+	PFX_SAINT_VENANT = 3,
+	PFX_HOOKE_LINEAR = 4 /* HookeLinearElasticity.cpp:75-190: linear assembler with a general elasticity tensor */
 };
 
 enum
@@ -93,6 +94,10 @@ pfx_status pfx_set_material(pfx_ctx *ctx, int model, int dim, double lambda, dou
  * Call after pfx_set_mesh; a later pfx_set_mesh or pfx_set_material drops the arrays. */
 pfx_status pfx_set_material_per_element(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu,
 										int64_t n_el);
+/* HookeLinearElasticity with its `elasticity_tensor`: the symmetric 6 x 6 tensor in Voigt order xx yy zz yz xz xy,
+ * row-major, as ElasticityTensor holds it after set_from_entries / set_from_lambda_mu / set_from_young_poisson
+ * (utils/ElasticityUtils.cpp:298-413).  Selects the model PFX_HOOKE_LINEAR (pfx_assemble_linear only). */
+pfx_status pfx_set_elasticity_tensor(pfx_ctx *ctx, int dim, const double *tensor36);
 
 /* ---- sparsity pattern (utils::SpareMatrixCache, utils/MatrixUtils.cpp:108-264) --------------------------------- */
 

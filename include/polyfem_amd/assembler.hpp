@@ -249,6 +249,92 @@ namespace polyfem_amd
 			static constexpr int model = PFX_SAINT_VENANT;
 		};
 
+		// utils/ElasticityUtils.hpp ElasticityTensor for size 3: only the upper triangle is ever written or read
+		// (operator() swaps its indices, ElasticityUtils.cpp:276-296), so full() mirrors it.
+		class ElasticityTensor
+		{
+		public:
+			double &operator()(int i, int j) { return i <= j ? upper_[i * 6 + j] : upper_[j * 6 + i]; }
+			double operator()(int i, int j) const { return i <= j ? upper_[i * 6 + j] : upper_[j * 6 + i]; }
+			void set_from_entries(const std::vector<double> &entries) // ElasticityUtils.cpp:298-370
+			{
+				if (entries.size() == 9)
+				{
+					set_orthotropic(entries[0], entries[1], entries[2], entries[3], entries[4], entries[5], entries[6], entries[7], entries[8]);
+					return;
+				}
+				if (entries.size() < 21)
+					throw std::runtime_error("polyfem_amd: the elasticity tensor takes 21 (or 9 orthotropic) entries");
+				int k = 0;
+				for (int i = 0; i < 6; ++i)
+					for (int j = i; j < 6; ++j)
+						(*this)(i, j) = entries[k++];
+			}
+			void set_from_lambda_mu(const double lambda, const double mu) // ElasticityUtils.cpp:372-413
+			{
+				for (double &v : upper_)
+					v = 0;
+				for (int i = 0; i < 3; ++i)
+				{
+					(*this)(i, i) = 2 * mu + lambda;
+					for (int j = i + 1; j < 3; ++j)
+						(*this)(i, j) = lambda;
+					(*this)(3 + i, 3 + i) = mu;
+				}
+			}
+			void set_from_young_poisson(const double young, const double nu) // ElasticityUtils.cpp:416-437
+			{
+				const double v = nu, f = young / ((1. + v) * (1. - 2. * v));
+				for (double &x : upper_)
+					x = 0;
+				for (int i = 0; i < 3; ++i)
+				{
+					(*this)(i, i) = (1. - v) * f;
+					for (int j = i + 1; j < 3; ++j)
+						(*this)(i, j) = v * f;
+					(*this)(3 + i, 3 + i) = ((1. - 2. * v) / 2.) * f;
+				}
+			}
+			// ElasticityUtils.cpp:439-455: the reference stores these reciprocals as they are (no inversion follows)
+			void set_orthotropic(double Ex, double Ey, double Ez, double nuYX, double nuZX, double nuZY, double muYZ, double muZX, double muXY)
+			{
+				for (double &x : upper_)
+					x = 0;
+				(*this)(0, 0) = 1.0 / Ex, (*this)(0, 1) = -nuYX / Ey, (*this)(0, 2) = -nuZX / Ez;
+				(*this)(1, 1) = 1.0 / Ey, (*this)(1, 2) = -nuZY / Ez;
+				(*this)(2, 2) = 1.0 / Ez;
+				(*this)(3, 3) = 1.0 / muYZ, (*this)(4, 4) = 1.0 / muZX, (*this)(5, 5) = 1.0 / muXY;
+			}
+			void full(double (&out)[36]) const
+			{
+				for (int i = 0; i < 6; ++i)
+					for (int j = 0; j < 6; ++j)
+						out[i * 6 + j] = (*this)(i, j);
+			}
+
+		private:
+			double upper_[36] = {};
+		};
+		// assembler/HookeLinearElasticity.hpp: linear assembler with a general elasticity tensor ("elasticity_tensor"
+		// entries, else young/nu, else lambda/mu: HookeLinearElasticity.cpp:24-49)
+		struct HookeLinearElasticity
+		{
+			static constexpr int model = PFX_HOOKE_LINEAR;
+			int size() const { return 3; }
+			void set_size(int s)
+			{
+				if (s != 3)
+					throw std::runtime_error("polyfem_amd: only 3-D elasticity is implemented");
+			}
+			ElasticityTensor &elasticity_tensor() { return tensor_; }
+			const ElasticityTensor &elasticity_tensor() const { return tensor_; }
+			double lambda = 0, mu = 0;
+			std::vector<double> lambda_e, mu_e; // unused
+
+		private:
+			ElasticityTensor tensor_;
+		};
+
 		// assembler/Mass.hpp: rho phi_i phi_j on the diagonal of every size x size block; density uniform or one value
 		// per element (Density with one entry per body id, utils/ElasticityUtils.cpp:561-570)
 		struct Mass
@@ -288,6 +374,17 @@ namespace polyfem_amd
 						throw std::runtime_error("polyfem_amd: one density per element expected");
 					c.bind(bases, gbases, n_basis, local_assembler_.model_for_binding(), 3, 1.0, 1.0);
 					c.check(pfx_assemble_mass(c.h, local_assembler_.density, local_assembler_.density_e.empty() ? nullptr : local_assembler_.density_e.data()));
+				}
+				else if constexpr (std::is_same<LocalAssembler, HookeLinearElasticity>::value)
+				{
+					if (is_mass)
+						throw std::runtime_error("polyfem_amd: is_mass = true belongs to Assembler<Mass>");
+					c.bind(bases, gbases, n_basis, PFX_LINEAR_ELASTICITY, 3, 0.0, 0.0); // mesh and pattern of block size 3
+					double t[36];
+					local_assembler_.elasticity_tensor().full(t);
+					c.check(pfx_set_elasticity_tensor(c.h, 3, t));
+					c.bound_model = -1; // the next bind passes its own material again
+					c.check(pfx_assemble_linear(c.h));
 				}
 				else
 				{

@@ -625,6 +625,64 @@ void pfo_local_linear_elasticity(const pfo_vals *v, int i, int j, const double *
 	}
 }
 
+/* assembler/HookeLinearElasticity.cpp:75-190 (3-D branch) ; res index jj*3+ii.  strain<3>(grad, jac_it, k, coo) puts
+ * the physical gradient into row coo of a zero matrix and symmetrises it; the Voigt strain (engineering shears) goes
+ * through ElasticityTensor::compute_stress (utils/ElasticityUtils.cpp:469-477) and the entry is trace(sigma_i * eps_j). */
+static void hooke_strain(const double *g, int coo, double *eps)
+{
+	double J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	for (int c = 0; c < 3; ++c)
+		M(J, coo, c) = g[c];
+	for (int r = 0; r < 3; ++r)
+		for (int c = 0; c < 3; ++c)
+			M(eps, r, c) = (M(J, r, c) + M(J, c, r)) * 0.5;
+}
+
+void pfo_local_hooke(const pfo_vals *v, int i, int j, const double *da, const double *C, double *res)
+{
+	for (int c = 0; c < 9; ++c)
+		res[c] = 0;
+	for (int k = 0; k < v->n_pts; ++k)
+	{
+		const double *gi = v->grad_t_m[i][k], *gj = v->grad_t_m[j][k];
+		double sigma[3][9], epsj[3][9];
+		for (int coo = 0; coo < 3; ++coo)
+		{
+			double ei[9];
+			hooke_strain(gi, coo, ei);
+			hooke_strain(gj, coo, epsj[coo]);
+			const double e6[6] = {M(ei, 0, 0), M(ei, 1, 1), M(ei, 2, 2), 2 * M(ei, 1, 2), 2 * M(ei, 0, 2), 2 * M(ei, 0, 1)};
+			double s6[6];
+			for (int a = 0; a < 6; ++a)
+			{
+				double r = 0;
+				for (int b = 0; b < 6; ++b)
+					r += C[a * 6 + b] * e6[b];
+				s6[a] = r;
+			}
+			double *sg = sigma[coo];
+			M(sg, 0, 0) = s6[0], M(sg, 0, 1) = s6[5], M(sg, 0, 2) = s6[4];
+			M(sg, 1, 0) = s6[5], M(sg, 1, 1) = s6[1], M(sg, 1, 2) = s6[3];
+			M(sg, 2, 0) = s6[4], M(sg, 2, 1) = s6[3], M(sg, 2, 2) = s6[2];
+		}
+		double res_k[9];
+		for (int ci = 0; ci < 3; ++ci)
+			for (int cj = 0; cj < 3; ++cj)
+			{
+				const double *sg = sigma[ci], *ej = epsj[cj];
+				double tr = 0;
+				for (int r = 0; r < 3; ++r)
+				{
+					const double dr = (M(sg, r, 0) * M(ej, 0, r) + M(sg, r, 1) * M(ej, 1, r)) + M(sg, r, 2) * M(ej, 2, r);
+					tr = r == 0 ? dr : tr + dr;
+				}
+				res_k[cj * 3 + ci] = tr;
+			}
+		for (int c = 0; c < 9; ++c)
+			res[c] += res_k[c] * da[k];
+	}
+}
+
 /* F = local_disp^T * grad(p) * jac_it(p) + I ; local_disp is n_loc x 3 (row i = displacement of basis i).
  * NeoHookeanElasticity.cpp:402 / :491 (dense products).  F row-major. */
 static void def_grad_at_id(const pfo_vals *v, int p, const double *local_disp, double *F, double id)
@@ -1307,6 +1365,8 @@ static void *job_run(void *arg)
 					double sv[9];
 					if (mat->model == PFO_LAPLACIAN)
 						pfo_local_laplacian(v, i, j, da, sv);
+					else if (mat->model == PFO_HOOKE_LINEAR)
+						pfo_local_hooke(v, i, j, da, mat->tensor, sv);
 					else
 						pfo_local_linear_elasticity(v, i, j, da, mat_lambda(mat, e), mat_mu(mat, e), sv);
 					for (int n = 0; n < size; ++n)
@@ -1445,7 +1505,7 @@ static int merge_trips(job *jobs, int nt, int32_t n, pfo_csc *out)
 /* assembler/Assembler.cpp:100-317 */
 int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_threads, pfo_csc *out)
 {
-	if (mat->model != PFO_LAPLACIAN && mat->model != PFO_LINEAR_ELASTICITY)
+	if (mat->model != PFO_LAPLACIAN && mat->model != PFO_LINEAR_ELASTICITY && !(mat->model == PFO_HOOKE_LINEAR && mat->tensor))
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, NULL, 0, &nt, 0);

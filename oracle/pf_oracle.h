@@ -21,7 +21,7 @@ extern "C" {
 /* element kinds: number of local bases 4 / 10 / 8 / 27 */
 enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3 };
 /* local assemblers */
-enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2, PFO_SAINT_VENANT = 3 };
+enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2, PFO_SAINT_VENANT = 3, PFO_HOOKE_LINEAR = 4 };
 
 #define PFO_MAX_PTS 125
 #define PFO_MAX_LOC 27
@@ -65,6 +65,8 @@ typedef struct
 	double lambda, mu; /* uniform Lame parameters */
 	const double *lambda_e, *mu_e; /* optional per-element values (LameParameters with one entry per element,
 	                                  utils/ElasticityUtils.cpp:490-517); NULL = uniform */
+	const double *tensor;          /* PFO_HOOKE_LINEAR: the symmetric 6 x 6 elasticity tensor, row-major, Voigt order
+	                                  xx yy zz yz xz xy (ElasticityTensor, utils/ElasticityUtils.cpp:298-413) */
 } pfo_material;
 
 /* compressed column storage with int32 indices = Eigen::SparseMatrix<double, ColMajor, int> */

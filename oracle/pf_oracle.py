@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpf_oracle.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT = 0, 1, 2, 3
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR = 0, 1, 2, 3, 4
 MAX_PTS, MAX_LOC = 125, 27
 
 
@@ -42,16 +42,37 @@ class MeshS(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("model", C.c_int), ("dim", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double),
-                ("lambda_e", C.POINTER(C.c_double)), ("mu_e", C.POINTER(C.c_double))]
+                ("lambda_e", C.POINTER(C.c_double)), ("mu_e", C.POINTER(C.c_double)), ("tensor", C.POINTER(C.c_double))]
 
 
 def make_material(model: int, lam, mu):
-    """Uniform Lame parameters (scalars) or one value per element (arrays).  Returns (Material, keep-alive)."""
+    """Uniform Lame parameters (scalars) or one value per element (arrays); for HOOKE_LINEAR `lam` is the symmetric
+    6 x 6 elasticity tensor (and `mu` is ignored).  Returns (Material, keep-alive)."""
+    if model == HOOKE_LINEAR:
+        t = np.ascontiguousarray(lam, dtype=np.float64).reshape(6, 6)
+        assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
+        return Material(model, 3, 0.0, 0.0, None, None, _dp(t)), t
     if np.ndim(lam) == 0:
-        return Material(model, 3, float(lam), float(mu), None, None), None
+        return Material(model, 3, float(lam), float(mu), None, None, None), None
     la = np.ascontiguousarray(lam, dtype=np.float64)
     ma = np.ascontiguousarray(mu, dtype=np.float64)
-    return Material(model, 3, float(la[0]), float(ma[0]), _dp(la), _dp(ma)), (la, ma)
+    return Material(model, 3, float(la[0]), float(ma[0]), _dp(la), _dp(ma), None), (la, ma)
+
+
+def elasticity_tensor(lam=None, mu=None, entries=None):
+    """ElasticityTensor (utils/ElasticityUtils.cpp): set_from_lambda_mu (:372-413) or set_from_entries with the 21
+    upper-triangular entries row by row (:298-370); returns the full symmetric 6 x 6 matrix."""
+    t = np.zeros((6, 6))
+    if entries is not None:
+        entries = np.asarray(entries, dtype=np.float64)
+        assert entries.size == 21
+        t[np.triu_indices(6)] = entries
+        t = t + np.triu(t, 1).T
+        return t
+    t[:3, :3] = lam
+    t[np.arange(3), np.arange(3)] = 2 * mu + lam
+    t[np.arange(3, 6), np.arange(3, 6)] = mu
+    return t
 
 
 class Csc(C.Structure):

@@ -216,6 +216,7 @@ extern "C"
 		free_dev(ctx->d_elem_owned);
 		free_dev(ctx->d_lambda_e);
 		free_dev(ctx->d_mu_e);
+		free_dev(ctx->d_tensor);
 		free_dev(ctx->d_partials);
 		free_dev(ctx->d_cgstate);
 		resolve_timers(ctx);
@@ -310,7 +311,7 @@ extern "C"
 		if (!ctx)
 			return PFX_ERR_ARG;
 		if (model < PFX_LAPLACIAN || model > PFX_SAINT_VENANT)
-			PFX_FAIL(PFX_ERR_ARG, "unknown model");
+			PFX_FAIL(PFX_ERR_ARG, "unknown model (PFX_HOOKE_LINEAR is selected by pfx_set_elasticity_tensor)");
 		if (dim != 3)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "only dim = 3 is implemented");
 		const int bs = (model == PFX_LAPLACIAN) ? 1 : dim;
@@ -323,6 +324,28 @@ extern "C"
 		ctx->mu = mu;
 		free_dev(ctx->d_lambda_e);
 		free_dev(ctx->d_mu_e);
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_elasticity_tensor(pfx_ctx *ctx, int dim, const double *tensor36)
+	{
+		if (!ctx || !tensor36)
+			return PFX_ERR_ARG;
+		if (dim != 3)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "only dim = 3 is implemented");
+		for (int a = 0; a < 6; ++a)
+			for (int b = 0; b < a; ++b)
+				if (tensor36[a * 6 + b] != tensor36[b * 6 + a])
+					PFX_FAIL(PFX_ERR_ARG, "the elasticity tensor must be symmetric");
+		pfx_status rc = pfx_set_material(ctx, PFX_LINEAR_ELASTICITY, dim, 0.0, 0.0);
+		if (rc)
+			return rc;
+		PFX_HIP(hipSetDevice(ctx->device));
+		if (!ctx->d_tensor && pfx_alloc(ctx, &ctx->d_tensor, 36))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_tensor, tensor36, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		ctx->model = PFX_HOOKE_LINEAR;
 		return PFX_OK;
 	}
 
@@ -393,8 +416,8 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_pattern(ctx))
 			return PFX_ERR_ARG;
-		if (ctx->model != PFX_LAPLACIAN && ctx->model != PFX_LINEAR_ELASTICITY)
-			PFX_FAIL(PFX_ERR_ARG, "pfx_assemble_linear needs the Laplacian or LinearElasticity model");
+		if (ctx->model != PFX_LAPLACIAN && ctx->model != PFX_LINEAR_ELASTICITY && ctx->model != PFX_HOOKE_LINEAR)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_assemble_linear needs the Laplacian, LinearElasticity or HookeLinearElasticity model");
 		{
 			pfx_scoped_timer tm(ctx, "local");
 			pfx_status rc = pfx_launch_local_linear(ctx);

@@ -62,6 +62,7 @@ struct pfx_ctx
 	// material
 	int model = -1, dim = 3, bs = 0; // bs = block size (1 or dim)
 	double lambda = 0, mu = 0;
+	double *d_tensor = nullptr; // PFX_HOOKE_LINEAR: symmetric 6 x 6 elasticity tensor (36 doubles)
 
 	// pattern: node-block structure; the scalar CSR is implied (row gi*bs+m holds, for every neighbour slot s,
 	// the bs columns node_col[s]*bs+n) and the values array IS that CSR's value array.

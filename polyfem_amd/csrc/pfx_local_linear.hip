@@ -1,4 +1,5 @@
-// pfx_local_linear.hip -- local stiffness blocks of the LINEAR assemblers (Laplacian, LinearElasticity).
+// pfx_local_linear.hip -- local stiffness blocks of the LINEAR assemblers (Laplacian, LinearElasticity,
+// HookeLinearElasticity).
 //
 // Reference: Assembler<L>::assemble element loop (src/polyfem/assembler/Assembler.cpp:127-209),
 // ElementAssemblyValues::compute/finalize3d (ElementAssemblyValues.cpp:94-133, 205-351),
@@ -158,6 +159,100 @@ namespace
 		}
 	};
 
+	// HookeLinearElasticity::assemble (assembler/HookeLinearElasticity.cpp:75-190, 3-D branch) for the pair (i, j): per
+	// point, strain<3>() puts the physical gradient into row `coo` of a zero matrix and symmetrises it, the Voigt strain
+	// (engineering shears) goes through ElasticityTensor::compute_stress (utils/ElasticityUtils.cpp:469-477), and entry
+	// (coo_j * 3 + coo_i) is trace(sigma_i * eps_j).  Every operation of the reference is kept (including the products
+	// with the structural zeros), in its order.
+	template <int NLOC, int NPTS, int SP>
+	struct hooke_block
+	{
+		const double *geo;
+		const pfx_tables *tab;
+		const double *tensor; // device, 36 doubles, symmetric 6 x 6
+		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + NPTS + 36; // grad[k][i][3], w[k], tensor
+
+		__device__ __forceinline__ void load_tables(double *lds, int lane) const
+		{
+			for (int t = lane; t < NPTS * NLOC * 3; t += 64)
+				lds[t] = tab->grad[t / (NLOC * 3)][(t / 3) % NLOC][t % 3];
+			for (int t = lane; t < NPTS; t += 64)
+				lds[NPTS * NLOC * 3 + t] = tab->w[t];
+			if (lane < 36)
+				lds[NPTS * NLOC * 3 + NPTS + lane] = tensor[lane];
+		}
+
+		__device__ __forceinline__ static void strain(const double *g, int coo, double *eps)
+		{
+			double J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (int c = 0; c < 3; ++c)
+				J[3 * coo + c] = g[c];
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c)
+					eps[3 * r + c] = (J[3 * r + c] + J[3 * c + r]) * 0.5;
+		}
+
+		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[9]) const
+		{
+			const double *C = lds + NPTS * NLOC * 3 + NPTS;
+			const double *ge = geo + (int64_t)e * (SP * 10);
+			double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (int k = 0; k < NPTS; ++k)
+			{
+				const double *jt = ge + (SP == 1 ? 0 : k * 10);
+				const double dak = jt[9] * lds[NPTS * NLOC * 3 + k];
+				const double *ri = lds + (k * NLOC + i) * 3, *rj = lds + (k * NLOC + j) * 3;
+				double gi[3], gj[3];
+				for (int c = 0; c < 3; ++c)
+				{
+					gi[c] = (ri[0] * jt[c] + ri[1] * jt[3 + c]) + ri[2] * jt[6 + c];
+					gj[c] = (rj[0] * jt[c] + rj[1] * jt[3 + c]) + rj[2] * jt[6 + c];
+				}
+				double sigma[3][9], epsj[3][9];
+#pragma unroll
+				for (int coo = 0; coo < 3; ++coo)
+				{
+					double ei[9];
+					strain(gi, coo, ei);
+					strain(gj, coo, epsj[coo]);
+					const double e6[6] = {ei[0], ei[4], ei[8], 2 * ei[5], 2 * ei[2], 2 * ei[1]};
+					double s6[6];
+#pragma unroll
+					for (int a = 0; a < 6; ++a)
+					{
+						double r = 0;
+#pragma unroll
+						for (int b = 0; b < 6; ++b)
+							r += C[a * 6 + b] * e6[b];
+						s6[a] = r;
+					}
+					double *sg = sigma[coo];
+					sg[0] = s6[0], sg[1] = s6[5], sg[2] = s6[4];
+					sg[3] = s6[5], sg[4] = s6[1], sg[5] = s6[3];
+					sg[6] = s6[4], sg[7] = s6[3], sg[8] = s6[2];
+				}
+#pragma unroll
+				for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+					for (int cj = 0; cj < 3; ++cj)
+					{
+						const double *sg = sigma[ci], *ej = epsj[cj];
+						const double d0 = (sg[0] * ej[0] + sg[1] * ej[3]) + sg[2] * ej[6];
+						const double d1 = (sg[3] * ej[1] + sg[4] * ej[4]) + sg[5] * ej[7];
+						const double d2 = (sg[6] * ej[2] + sg[7] * ej[5]) + sg[8] * ej[8];
+						res[cj * 3 + ci] += ((d0 + d1) + d2) * dak;
+					}
+			}
+			// entry (row comp m, col comp n) of block (i,j) is res[n*3+m]  (Assembler.cpp:169,177,182)
+			for (int m = 0; m < 3; ++m)
+				for (int n = 0; n < 3; ++n)
+				{
+					const double v = res[n * 3 + m];
+					out[m * 3 + n] = fabs(v) < 1e-30 ? 0.0 : v;
+				}
+		}
+	};
+
 	// Mass::assemble (assembler/Mass.cpp:5-20) for the pair (i, j): rho * phi_i * phi_j integrated with the mass
 	// quadrature, on the diagonal of the bs x bs block; |v| < 1e-30 replaced by an exact zero as for the stiffness
 	template <int NLOC, int NPTS, int BS, int SP>
@@ -264,7 +359,9 @@ namespace
 	void launch_rows(pfx_ctx *ctx, bool write_mask)
 	{
 		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
-		if (ctx->bs == 1)
+		if (ctx->model == PFX_HOOKE_LINEAR)
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, hooke_block<NLOC, NPTS, SP>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, write_mask);
+		else if (ctx->bs == 1)
 			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 		else
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpolyfem_amd.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT = 0, 1, 2, 3
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR = 0, 1, 2, 3, 4
 PRECOND_IDENTITY, PRECOND_JACOBI = 0, 1
 MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN,
                  "SaintVenant": SAINT_VENANT}
@@ -38,8 +38,32 @@ EXPORTED_SYMBOLS = [
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
-    "pfx_inertia_enable_host",
+    "pfx_inertia_enable_host", "pfx_set_elasticity_tensor",
 ]
+
+
+def elasticity_tensor(entries=None, lam=None, mu=None, young=None, nu=None):
+    """The 6 x 6 tensor of the reference's ElasticityTensor for size 3 (utils/ElasticityUtils.cpp): from the 21
+    upper-triangular entries row by row (set_from_entries, :298-370), from (lambda, mu) (:372-413) or from
+    (young, nu) (:416-437); the precedence is HookeLinearElasticity::add_multimaterial's (entries, young/nu, lambda/mu)."""
+    t = np.zeros((6, 6))
+    if entries is not None:
+        entries = np.asarray(entries, dtype=np.float64).reshape(-1)
+        if entries.size < 21:
+            raise ValueError("21 upper-triangular entries expected")
+        t[np.triu_indices(6)] = entries[:21]
+    elif young is not None:
+        f = young / ((1.0 + nu) * (1.0 - 2.0 * nu))
+        t[:3, :3] = nu * f
+        t[np.arange(3), np.arange(3)] = (1.0 - nu) * f
+        t[np.arange(3, 6), np.arange(3, 6)] = ((1.0 - 2.0 * nu) / 2.0) * f
+        return t
+    else:
+        t[:3, :3] = lam
+        t[np.arange(3), np.arange(3)] = 2 * mu + lam
+        t[np.arange(3, 6), np.arange(3, 6)] = mu
+        return t
+    return np.triu(t) + np.triu(t, 1).T
 
 
 class PfxError(RuntimeError):
@@ -94,6 +118,7 @@ def load():
         "pfx_set_mesh": [_vp, _i32, _i64, _i64, _i64, _pi32, _pi32, _pd, _i32],
         "pfx_set_material": [_vp, _i32, _i32, _dbl, _dbl],
         "pfx_set_material_per_element": [_vp, _i32, _i32, _pd, _pd, _i64],
+        "pfx_set_elasticity_tensor": [_vp, _i32, _pd],
         "pfx_build_pattern": [_vp, _pi64],
         "pfx_get_pattern": [_vp, _pi64, _pi32],
         "pfx_get_values": [_vp, _pd],
@@ -220,6 +245,11 @@ class Engine:
             assert la.shape == ma.shape and la.ndim == 1
             self._ck(self.L.pfx_set_material_per_element(self.h, model, dim, _d(la), _d(ma), la.size))
         self.model = model
+
+    def set_elasticity_tensor(self, tensor, dim: int = 3):
+        """HookeLinearElasticity: symmetric 6 x 6 tensor (Voigt order xx yy zz yz xz xy); linear assembly only."""
+        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(36)
+        self._ck(self.L.pfx_set_elasticity_tensor(self.h, dim, _d(t)))
 
     def build_pattern(self) -> int:
         nnz = C.c_int64()

@@ -153,6 +153,37 @@ int main()
 	}
 	REQUIRE(threw);
 
+	// HookeLinearElasticity with the tensor of the same (E, nu) acts like LinearElasticity; both tensor setters agree
+	{
+		assembler::Assembler<assembler::HookeLinearElasticity> hooke;
+		hooke.local_assembler().set_size(3);
+		hooke.local_assembler().elasticity_tensor().set_from_young_poisson(1e5, 0.3);
+		assembler::ElasticityTensor t2;
+		t2.set_from_lambda_mu(lin.local_assembler().lambda, lin.local_assembler().mu);
+		for (int a = 0; a < 6; ++a)
+			for (int b = 0; b < 6; ++b)
+				REQUIRE(std::fabs(t2(a, b) - hooke.local_assembler().elasticity_tensor()(a, b)) <= 1e-10 * 1e5);
+		StiffnessMatrix KH;
+		hooke.assemble(true, n_basis, bases, gbases, cache, KH);
+		REQUIRE(KH.rows() == N);
+		double worst = 0, ymax = 0;
+		for (int r = 0; r < N; ++r)
+		{
+			double y1 = 0, y2 = 0;
+			for (int64_t k = K.outer[r]; k < K.outer[r + 1]; ++k)
+				y1 += K.values[k] * x[K.inner[k]];
+			for (int64_t k = KH.outer[r]; k < KH.outer[r + 1]; ++k)
+				y2 += KH.values[k] * x[KH.inner[k]];
+			worst = std::fmax(worst, std::fabs(y1 - y2));
+			ymax = std::fmax(ymax, std::fabs(y1));
+		}
+		REQUIRE(worst <= 1e-10 * ymax);
+		// the scalar-material assemblers still bind their own material afterwards
+		StiffnessMatrix K2;
+		lin.assemble(true, n_basis, bases, gbases, cache, K2);
+		REQUIRE(K2.values == K.values && K2.inner == K.inner);
+	}
+
 	// "hessian_lin" (tests/test_assembler.cpp:12-64): LinearElasticity through the nonlinear interface reproduces the
 	// stiffness matrix for any displacement
 	{

@@ -37,3 +37,18 @@ def test_no_cpu_fallback_when_no_device():
     assert rc < 0 and not h
     with pytest.raises(engine.PfxError):
         engine.Engine(0)
+
+
+def test_elasticity_tensor_host_helper(oracle):
+    """engine.elasticity_tensor follows ElasticityTensor's three setters (utils/ElasticityUtils.cpp:298-437)."""
+    import numpy as np
+    lam, mu = oracle.lame(1e5, 0.3)
+    a = engine.elasticity_tensor(lam=lam, mu=mu)
+    b = engine.elasticity_tensor(young=1e5, nu=0.3)
+    assert np.array_equal(a, a.T) and np.allclose(a, b, rtol=1e-14, atol=0)
+    assert np.array_equal(a, oracle.elasticity_tensor(lam, mu))
+    e = np.arange(1.0, 22.0)
+    c = engine.elasticity_tensor(entries=e)
+    assert np.array_equal(c, c.T) and np.array_equal(c[np.triu_indices(6)], e)
+    assert np.array_equal(c, oracle.elasticity_tensor(entries=e))
+    assert c[0, 5] == 6.0 and c[1, 1] == 7.0 and c[5, 5] == 21.0  # row by row, as set_from_entries

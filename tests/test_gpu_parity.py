@@ -57,6 +57,44 @@ def test_linear_assembly_pattern_bit_exact_and_values(eng, oracle, name, model):
     assert v.size <= eng.info().nnz
 
 
+def _orthotropic_tensor(seed):
+    """A random symmetric positive-definite 6 x 6 tensor (fully anisotropic)."""
+    a = np.random.default_rng(seed).standard_normal((6, 6))
+    return 1e4 * (a @ a.T + 6 * np.eye(6))
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_aligned", "p2_jitter_polyfem", "p2_stretched", "q1", "q2"])
+@pytest.mark.parametrize("tensor", ["isotropic", "anisotropic"])
+def test_hooke_linear_assembly(eng, oracle, name, tensor):
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(1e5, 0.3)
+    C = oracle.elasticity_tensor(lam, mu) if tensor == "isotropic" else _orthotropic_tensor(3)
+    eng.set_mesh(mesh)
+    eng.set_elasticity_tensor(C)
+    eng.build_pattern()
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, oracle.HOOKE_LINEAR, C, 0.0)
+    n = mesh.n_nodes * 3
+    # the local blocks of this assembler are symmetric only up to rounding, so an entry can be exactly zero (dropped)
+    # while its mirror image is not: compare row-major with row-major
+    ref = csc_to_scipy((outer, inner, vals), n).tocsr()
+    ref.sort_indices()
+    assert np.array_equal(rp, ref.indptr), "row_ptr differs from the oracle"
+    assert np.array_equal(ci, ref.indices), "col_idx differs from the oracle"
+    assert rel_err(v, ref.data) <= TOL
+    if tensor == "isotropic":
+        # the isotropic tensor is LinearElasticity: same action on a vector (the value-dependent patterns may differ)
+        xv = np.random.default_rng(5).standard_normal(n)
+        a = ref
+        b = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n)
+        assert rel_err(a @ xv, b @ xv) <= 1e-12
+    with pytest.raises(E.PfxError):
+        eng.energy(np.zeros(mesh.n_nodes * 3))  # the tensor model is a linear assembler only here
+    with pytest.raises(E.PfxError):
+        eng.set_elasticity_tensor(C + np.triu(np.ones((6, 6)), 1))  # not symmetric
+
+
 @pytest.mark.parametrize("name", ["p1_jitter", "p2_aligned", "p2_jitter_polyfem", "p2_stretched", "q1", "q2"])
 def test_neohookean_energy_gradient_hessian(eng, oracle, name):
     mesh = MESHES[name]()

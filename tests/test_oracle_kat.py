@@ -481,3 +481,41 @@ def test_saint_venant_oracle(oracle, kind):
         ux[0::3] = a * mesh.node_xyz[:, 0]
         exx = a + a * a / 2
         assert abs(oracle.assemble_energy(mesh, SV, lam, mu, ux) - (lam / 2 + mu) * exx * exx) <= 1e-12 * lam * exx * exx
+
+
+@pytest.mark.parametrize("kind", ["p1", "p2", "q1", "q2"])
+def test_hooke_linear_oracle(oracle, kind):
+    """HookeLinearElasticity (assembler/HookeLinearElasticity.cpp:75-190).  The reference holds no self-contained
+    vector for it, so the restatement is pinned through identities: with the isotropic tensor of set_from_lambda_mu
+    it is LinearElasticity (pinned above); for any symmetric tensor the matrix is symmetric, annihilates the six
+    rigid-body modes, and x^T K x equals the quadrature sum of eps(x) : C : eps(x)."""
+    mesh = {"p1": lambda: M.cube_tets(3, 1, jitter=0.2, seed=2), "p2": lambda: M.cube_tets(2, 2, jitter=0.2, seed=3),
+            "q1": lambda: M.cube_hexes(2, 1), "q2": lambda: M.cube_hexes(1, 2)}[kind]()
+    n = mesh.n_nodes * 3
+    lam, mu = oracle.lame(1e5, 0.3)
+    iso = oracle.elasticity_tensor(lam, mu)
+    kh = csc_to_scipy(oracle.assemble_linear(mesh, oracle.HOOKE_LINEAR, iso, 0.0), n)
+    kl = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    assert abs(kh - kl).max() <= 1e-13 * abs(kl).max()
+
+    a = np.random.default_rng(7).standard_normal((6, 6))
+    C = 1e4 * (a @ a.T + 6 * np.eye(6))
+    assert np.array_equal(oracle.elasticity_tensor(entries=C[np.triu_indices(6)]), C)
+    k = csc_to_scipy(oracle.assemble_linear(mesh, oracle.HOOKE_LINEAR, C, 0.0), n)
+    scale = abs(k).max()
+    assert abs(k - k.T).max() <= 1e-13 * scale
+    p = mesh.xyz[:mesh.n_nodes] if mesh.xyz.shape[0] == mesh.n_nodes else None
+    modes = [np.tile(np.eye(3)[c], mesh.n_nodes) for c in range(3)]
+    if p is not None:  # rotations need the node positions (geometry nodes = solution nodes only for P1 / Q1)
+        for w in np.eye(3):
+            modes.append(np.cross(w, p).reshape(-1))
+    for m in modes:
+        assert abs(k @ m).max() <= 1e-12 * scale * max(1.0, abs(m).max())
+    # a linear displacement u = G x has constant strain: x^T K x = vol * eps : C : eps
+    if p is not None:
+        G = np.random.default_rng(8).standard_normal((3, 3))
+        u = (p @ G.T).reshape(-1)
+        eps = 0.5 * (G + G.T)
+        e6 = np.array([eps[0, 0], eps[1, 1], eps[2, 2], 2 * eps[1, 2], 2 * eps[0, 2], 2 * eps[0, 1]])
+        vol = 1.0  # the unit cube
+        assert abs(u @ (k @ u) - vol * e6 @ C @ e6) <= 1e-11 * abs(e6 @ C @ e6)
