@@ -64,8 +64,9 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (multiply-add), the rate the assem
 
 def cpu_baseline(args, oracle, M):
     """Oracle on a bounded sample of the same workload, on this host's cores."""
-    n = args.cpu_n
-    mesh = M.cube_tets(n, 2)
+    hexes = args.element == "q2hex"
+    n = max(args.cpu_n // 2, 2) if hexes else args.cpu_n
+    mesh = M.cube_hexes(n, 2) if hexes else M.cube_tets(n, 2)
     lam, mu = oracle.lame(1e5, 0.3)
     cores = min(os.cpu_count() or 1, 16)
     om = oracle.OMesh(mesh)
@@ -86,7 +87,7 @@ def cpu_baseline(args, oracle, M):
     t_cg = (time.perf_counter() - t0) * (args.cg_max_iter / max(it, 1))
     return {
         "value": mesh.n_el / (t_asm + t_cg), "unit": "elements/s", "cores": cores, "kind": "port",
-        "sample": f"P2 tets {n}^3 grid ({mesh.n_el} elements): assembly with {cores} threads {t_asm:.3f}s + "
+        "sample": f"{'Q2 hexes' if hexes else 'P2 tets'} {n}^3 grid ({mesh.n_el} elements): assembly with {cores} threads {t_asm:.3f}s + "
                   f"{it} single-thread CG iterations scaled to {args.cg_max_iter} ({t_cg:.3f}s)",
         "assembly_elements_per_s": mesh.n_el / t_asm,
     }
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", dest="n", type=int, default=55, help="grid cells per side (55 -> 998 250 P2 tets)")
+    ap.add_argument("--element", default="p2tet", choices=["p2tet", "q2hex"],
+                    help="q2hex: n^3 Q2 hexahedra per GPU on trilinear geometry (--grid 100 is the Q2 configuration of the scope table)")
     ap.add_argument("--workload", default="linear_elasticity", choices=["linear_elasticity", "neohookean", "newton", "transient"],
                     help="newton: one step = a full NeoHookean Newton solve (gravity-like load, clamped x = 0 face); "
                          "transient: one step = one implicit Euler time step of the same body falling under gravity (single GPU)")
@@ -136,7 +139,8 @@ def main():
         raise SystemExit("the transient workload of bench.py is single-GPU (DistributedImplicitEuler covers the partitioned case)")
     # weak scaling: the global grid is n x n x (n*world) cells; every rank owns the node planes of n cell layers
     # (plus one layer of its lower neighbour's elements, which it assembles redundantly instead of communicating)
-    part, bounds, n_nodes_global = D.slab_part(args.n, args.n, rank, world, 2)
+    hexes = args.element == "q2hex"
+    part, bounds, n_nodes_global = D.slab_part(args.n, args.n, rank, world, 2, "hex" if hexes else "tet")
     mesh = part.mesh
     eng = E.Engine(local_rank)
     eng.set_mesh(mesh)
@@ -256,7 +260,7 @@ def main():
 
     sb = spmv_bytes(inf.nnz, n)
     sb_stored = spmv_stored_bytes(inf.nnz, inf.n_blocks, inf.n_nodes, n)
-    ab = assembly_bytes(inf.n_el, inf.n_loc, 4, mesh.xyz.shape[0], inf.n_nodes, inf.nnz, nonlinear)
+    ab = assembly_bytes(inf.n_el, inf.n_loc, 8 if hexes else 4, mesh.xyz.shape[0], inf.n_nodes, inf.nnz, nonlinear)
     spmv_gbs = sb / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     af = assembly_flops(inf.n_el, inf.n_loc, inf.n_pts, nonlinear)
     asm_ms = loc_ms + gat_ms
@@ -266,13 +270,14 @@ def main():
     # same workload; null when no recording matches the grid or the run is partitioned.
     traffic, traffic_src = None, None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r1_pmc_traffic_grid{args.n}.json")
-    if world == 1 and not nonlinear and os.path.exists(tpath):
+    if world == 1 and not nonlinear and not hexes and os.path.exists(tpath):
         rec = json.load(open(tpath)).get("k_sell_spmv<3, true>")
         if rec:
             traffic, traffic_src = rec["hbm_bytes"], os.path.relpath(tpath, os.path.dirname(os.path.abspath(__file__)))
 
-    n_el_global = 6 * args.n * args.n * args.n * world
+    n_el_global = (1 if hexes else 6) * args.n * args.n * args.n * world
     owned_el = int(part.elem_owned.sum())
+    shape = f"Q2 hexes, {args.n}^3 grid" if hexes else f"P2 tets, {args.n}^3 Kuhn grid"
     if rank == 0:
         out = {
             "metric": "elements/s Hessian assembly + CG SpMV GB/s, P2 elasticity tets, 1-8 GPUs",
@@ -284,8 +289,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": ("NeoHookean Hessian+gradient" if nonlinear else "LinearElasticity stiffness")
-                            + f" assembly + Jacobi-CG (tol {args.cg_tol:g}, max_iter {args.cg_max_iter}), P2 tets, "
-                              f"{args.n}^3 Kuhn grid",
+                            + f" assembly + Jacobi-CG (tol {args.cg_tol:g}, max_iter {args.cg_max_iter}), {shape}",
                 "elements": n_el_global, "elements_per_gpu_owned": owned_el, "elements_per_gpu_assembled": inf.n_el,
                 "dofs_per_gpu": part.n_owned * 3, "nnz_per_gpu": inf.nnz, "cg_iters": it, "cg_rel_residual": err,
                 "parallelism": f"row/element partition over {world} GPUs, RCCL halo exchange + all-reduce"
@@ -313,11 +317,11 @@ def main():
         }
         if args.workload == "transient":
             out["config"]["workload"] = (f"NeoHookean implicit Euler time step (dt {args.dt:g}, Newton + backtracking, Jacobi-CG tol {args.cg_tol:g} "
-                                         f"max_iter {args.cg_max_iter}), P2 tets, {args.n}^3 Kuhn grid")
+                                         f"max_iter {args.cg_max_iter}), {shape}")
             out["newton"] = dict(newton_info)
         if args.workload == "newton":
             out["config"]["workload"] = (f"NeoHookean Newton solve (backtracking line search, Jacobi-CG tol {args.cg_tol:g} max_iter "
-                                         f"{args.cg_max_iter} per step), P2 tets, {args.n}^3 Kuhn grid")
+                                         f"{args.cg_max_iter} per step), {shape}")
             out["newton"] = dict(newton_info)
         if not args.no_cpu_baseline and world == 1 and args.workload not in ("newton", "transient"):  # the CPU column is reported with the single-GPU line only
             from oracle import pf_oracle

@@ -103,13 +103,33 @@ def cube_tets_slab(n: int, nz: int, zc0: int, zc1: int, order: int = 2):
     return M.P2TET, conn.astype(np.int64), gconn, xyz, L * L * (2 * nz + 1), L
 
 
-def slab_part(n: int, cells_per_rank: int, rank: int, world: int, order: int = 2) -> tuple[Part, np.ndarray, int]:
-    """Weak-scaling decomposition used by the benchmark: the global grid is n x n x (cells_per_rank*world) cells,
-    rank r owns the lattice planes of its cell layers (the last rank also the top plane)."""
+def cube_hexes_slab(n: int, nz: int, zc0: int, zc1: int, order: int = 2):
+    """Cells z in [zc0, zc1) of the n x n x nz grid of hexahedra on [0,1]^2 x [0, nz/n], Q1/Q2 bases on trilinear
+    geometry, GLOBAL lattice numbering (x fastest); same return values as cube_tets_slab."""
+    kz, ky, kx = np.meshgrid(np.arange(zc0, zc1), np.arange(n), np.arange(n), indexing="ij")
+    cell = np.stack([kx, ky, kz], axis=-1).reshape(-1, 1, 3)
+    nv = n + 1
+    corners = cell + M._Q1_CORNERS[None]
+    gconn = corners[..., 0] + nv * (corners[..., 1] + nv * corners[..., 2])
+    gz, gy, gx = np.meshgrid(np.arange(nz + 1), np.arange(nv), np.arange(nv), indexing="ij")
+    xyz = np.stack([gx, gy, gz], axis=-1).reshape(-1, 3).astype(np.float64) / n
+    if order == 1:
+        return M.Q1HEX, gconn.astype(np.int64), gconn, xyz, nv * nv * (nz + 1), nv
+    L = 2 * n + 1
+    loc = 2 * cell + M._Q2_NODES[None]
+    conn = loc[..., 0] + L * (loc[..., 1] + L * loc[..., 2])
+    return M.Q2HEX, conn.astype(np.int64), gconn, xyz, L * L * (2 * nz + 1), L
+
+
+def slab_part(n: int, cells_per_rank: int, rank: int, world: int, order: int = 2, element: str = "tet") -> tuple[Part, np.ndarray, int]:
+    """Weak-scaling decomposition used by the benchmark: the global grid is n x n x (cells_per_rank*world) cells
+    (Kuhn-split into tetrahedra, or hexahedra), rank r owns the lattice planes of its cell layers (the last rank also
+    the top plane)."""
     nz = cells_per_rank * world
     step = 2 if order == 2 else 1
     z0, z1 = rank * cells_per_rank, (rank + 1) * cells_per_rank
-    kind, conn, gconn, xyz, n_nodes, L = cube_tets_slab(n, nz, max(z0 - 1, 0), z1, order)
+    slab = {"tet": cube_tets_slab, "hex": cube_hexes_slab}[element]
+    kind, conn, gconn, xyz, n_nodes, L = slab(n, nz, max(z0 - 1, 0), z1, order)
     bounds = np.array([step * r * cells_per_rank * L * L for r in range(world)] + [n_nodes], dtype=np.int64)
     h = (0.5 if order == 2 else 1.0) / n
 

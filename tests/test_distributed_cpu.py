@@ -257,3 +257,31 @@ def test_distributed_implicit_euler_gloo():
     mp.spawn(_euler_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(f"ok{r}") for r in range(world))
     assert ret["ok_counts"] and ret["dx"] <= 1e-8 and ret["dv"] <= 1e-7 and ret["da"] <= 1e-6
+
+
+def test_hex_slab_partition_covers_the_global_mesh():
+    """The hexahedral slab decomposition of the benchmark: every global element is energy-owned by exactly one rank,
+    owned node ranges tile the lattice, and local connectivity maps back to the global lattice numbering."""
+    from polyfem_amd import distributed as D
+    from polyfem_amd import mesh as M
+    n, world = 3, 2
+    ref = M.cube_hexes(n, 2)  # one rank's worth; the global grid is n x n x (n*world)
+    owned_total, seen = 0, []
+    for rank in range(world):
+        part, bounds, n_nodes = D.slab_part(n, n, rank, world, 2, "hex")
+        assert part.mesh.kind == M.Q2HEX and part.mesh.conn.shape[1] == 27
+        L = 2 * n + 1
+        assert n_nodes == L * L * (2 * n * world + 1)
+        assert part.lo == bounds[rank] and part.n_owned == bounds[rank + 1] - bounds[rank]
+        l2g = part.local_to_global()
+        gl = l2g[part.mesh.conn]
+        own = part.elem_owned.astype(bool)
+        owned_total += int(own.sum())
+        seen.append(np.sort(gl[own], axis=1))
+        # node coordinates follow the lattice
+        assert np.allclose(part.mesh.node_xyz[:, 2], (l2g // (L * L)) * 0.5 / n)
+    assert owned_total == n * n * n * world
+    allc = np.concatenate(seen)
+    assert np.unique(allc, axis=0).shape[0] == allc.shape[0]
+    if world == 1:
+        assert ref.n_el == owned_total
