@@ -30,15 +30,16 @@
 //      ascending order.  A block cut by the window boundary hands its partial sums to the next window through
 //      `carry`, so the order of the additions does not depend on where the windows fall.
 // The index data of a window are loaded one window ahead.
-template <int NLOC, int BS, int RPG, class Op>
+// MASK: also record, per entry, whether any of its contributions is non-zero (the value-dependent pattern of the
+// linear assemblers); the Hessian keeps every structural entry and skips that bookkeeping.
+template <int NLOC, int BS, int RPG, bool MASK, class Op>
 __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr,
 													   const uint32_t *__restrict__ blk_src, const uint8_t *__restrict__ blk_slot, Op op, int64_t n_nodes,
-													   double *__restrict__ values, uint8_t *__restrict__ mask, int write_mask)
+													   double *__restrict__ values, uint8_t *__restrict__ mask)
 {
 	constexpr int B2 = BS * BS;
 	constexpr uint32_t NL2 = NLOC * NLOC;
 	__shared__ double stage[64 * B2];
-	__shared__ uint8_t src_tr[64];
 	__shared__ int bp[66]; // start of block bl+s in the window, clamped to [-1, nw+1]
 	__shared__ double carry[2][B2];
 	__shared__ uint8_t carry_any[2][B2];
@@ -96,10 +97,13 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 			const int i = (int)(ij / NLOC), j = (int)(ij - (ij / NLOC) * NLOC);
 			double out[B2];
 			op(optab, e, i > j ? i : j, i > j ? j : i, out);
+			const bool tr = i < j; // the functor computed the mirror image: stage its transpose
 #pragma unroll
 			for (int k = 0; k < B2; ++k)
-				stage[slot_now * B2 + k] = out[k];
-			src_tr[slot_now] = (uint8_t)(i < j);
+			{
+				const int kt = (k % BS) * BS + k / BS;
+				stage[slot_now * B2 + k] = (kt != k && tr) ? out[kt] : out[k];
+			}
 		}
 		__syncthreads();
 		// C: consecutive lanes own consecutive entries of the run [bl*B2, (bl+nb)*B2) of the value array
@@ -107,29 +111,39 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 		for (int o = lane; o < n_items; o += 64)
 		{
 			const int s = o / B2, mn = o - s * B2;
-			const int m = mn / BS, n = mn - m * BS;
-			const int nm = n * BS + m;
 			const int cb0 = bp[s], cb1 = bp[s + 1];
 			const bool cont_in = cb0 < 0, cont_out = cb1 > nw;
 			const int c0 = cont_in ? 0 : cb0, c1 = cont_out ? nw : cb1;
 			double acc = cont_in ? carry[cur][mn] : 0.0;
-			int any = cont_in ? carry_any[cur][mn] : 0;
-			for (int c = c0; c < c1; ++c)
+			int any = (MASK && cont_in) ? carry_any[cur][mn] : 0;
+			const double *sp = stage + c0 * B2 + mn;
+			int c = c0;
+			for (; c + 1 < c1; c += 2, sp += 2 * B2) // two contributions per trip, added in list order
 			{
-				const double v = stage[c * B2 + (src_tr[c] ? nm : mn)];
+				const double v0 = sp[0], v1 = sp[B2];
+				acc += v0;
+				acc += v1;
+				if (MASK)
+					any |= (v0 != 0.0) | (v1 != 0.0);
+			}
+			if (c < c1)
+			{
+				const double v = sp[0];
 				acc += v;
-				any |= (v != 0.0);
+				if (MASK)
+					any |= (v != 0.0);
 			}
 			if (cont_out)
 			{
 				carry[cur ^ 1][mn] = acc;
-				carry_any[cur ^ 1][mn] = (uint8_t)any;
+				if (MASK)
+					carry_any[cur ^ 1][mn] = (uint8_t)any;
 			}
 			else
 			{
 				const int64_t at = bl * B2 + o;
 				values[at] = acc;
-				if (write_mask)
+				if (MASK)
 					mask[at] = (uint8_t)any;
 			}
 		}
@@ -144,6 +158,10 @@ inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask
 {
 	constexpr int RPG = PFX_ROWS_PER_GROUP;
 	const int64_t groups = (ctx->n_nodes + RPG - 1) / RPG;
-	hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
-					   ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask, write_mask ? 1 : 0);
+	if (write_mask)
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, true, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
+						   ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
+	else
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, false, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
+						   ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
 }
