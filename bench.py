@@ -53,10 +53,10 @@ def assembly_bytes(n_el, n_loc, n_gloc, n_gnodes, n_nodes, nnz, nonlinear):
 
 
 def assembly_flops(n_el, n_loc, n_pts, nonlinear):
-    """FP64 operations of one row-owner assembly: every (element, i, j) contribution is evaluated once, i.e. each pair
-    for both of its blocks.  Per quadrature point (counted from the kernels' source, a multiply-add = 2): linear
+    """FP64 operations of one row-owner assembly: every pair (i >= j) of an element is evaluated once (its mirror image
+    is a transposed store).  Per quadrature point (counted from the kernels' source, a multiply-add = 2): linear
     elasticity 94 (separate multiplies and adds, the path is compiled without contraction), NeoHookean 150."""
-    return float(n_el) * n_loc * n_loc * n_pts * (150.0 if nonlinear else 94.0)
+    return float(n_el) * (n_loc * (n_loc + 1) // 2) * n_pts * (150.0 if nonlinear else 94.0)
 
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (multiply-add), the rate the assembly kernels can use

@@ -60,6 +60,10 @@ namespace
 		free_dev(ctx->d_blk_ptr);
 		free_dev(ctx->d_blk_src);
 		free_dev(ctx->d_blk_slot);
+		free_dev(ctx->d_unode_ptr);
+		free_dev(ctx->d_ublk_off);
+		free_dev(ctx->d_ublk_low);
+		ctx->n_ublocks = ctx->n_upair = 0;
 		free_dev(ctx->d_ne_ptr);
 		free_dev(ctx->d_ne_src);
 		free_dev(ctx->d_values);

@@ -69,9 +69,16 @@ struct pfx_ctx
 	int64_t n_blocks = 0, nnz = 0;
 	int64_t *d_node_ptr = nullptr; // n_nodes+1
 	int32_t *d_node_col = nullptr; // n_blocks, ascending per node
-	int64_t *d_blk_ptr = nullptr;  // n_blocks+1 -> contribution list
-	// contribution lists (n_el*n_loc^2 entries).  Position c of the block-ordered list belongs to the block b with
-	// blk_ptr[b] <= c < blk_ptr[b+1] (ascending element inside a block).  The assembly kernel walks that list in windows
+	// Only the blocks on and above the diagonal (column node >= row node, "upper" blocks, n_ublocks of them, numbered in
+	// block order) are assembled from contributions; the lane that finishes an entry of an upper block also writes it,
+	// transposed, into the block's mirror image below the diagonal (d_ublk_low).
+	int64_t n_ublocks = 0, n_upair = 0;
+	int64_t *d_unode_ptr = nullptr; // n_nodes+1: upper blocks of the rows before each row
+	int64_t *d_blk_ptr = nullptr;   // n_ublocks+1 -> contribution list of each upper block
+	uint32_t *d_ublk_off = nullptr; // n_ublocks: (index among all blocks) - (index among the upper blocks)
+	uint32_t *d_ublk_low = nullptr; // n_ublocks: index (among all blocks) of the mirror image, 0xFFFFFFFF on the diagonal
+	// contribution lists (n_upair entries: n_loc(n_loc+1)/2 per element).  Position c of the block-ordered list belongs to the upper block ub with
+	// blk_ptr[ub] <= c < blk_ptr[ub+1] (ascending element inside a block).  The assembly kernel walks that list in windows
 	// of 64 per group of PFX_ROWS_PER_GROUP node rows; inside each window the contributions are stored reordered by
 	// element (lanes that read the same element state sit next to each other): d_blk_src[c] = e*n_loc^2 + i*n_loc + j of
 	// the contribution computed by lane c - window start, d_blk_slot[c] = its position in the window in block order.

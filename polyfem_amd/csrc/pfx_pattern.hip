@@ -9,7 +9,10 @@
 //      element order (a fixed summation order, so assembly is deterministic);
 //   2. run heads of the sorted keys are the node blocks: node_ptr / node_col (ascending columns per row, as in
 //      Eigen's compressed storage), and blk_ptr delimits each block's contribution list;
-//   3. the same is done per node for (element, local index) incidences, used by the gradient.
+//   3. only the blocks on and above the diagonal (column node >= row node) keep a contribution list: the reference
+//      evaluates the pairs j <= i only and mirrors them (Assembler.cpp:179-184), and so does the assembly here -- the
+//      blocks below the diagonal receive the transpose of their mirror image (d_ublk_low);
+//   4. the same grouping is done per node for (element, local index) incidences, used by the gradient.
 // The scalar CSR of a block size bs > 1 is implied: row node*bs+m owns, per neighbour slot s, the bs columns
 // node_col[s]*bs+n; it is materialised only when the caller asks for it (pfx_export_pattern).
 #include "pfx_internal.h"
@@ -49,7 +52,7 @@ namespace
 	};
 
 	__global__ void k_fill_blocks(const uint64_t *__restrict__ keys, const int64_t *__restrict__ pos, int64_t n_items, int64_t n_nodes,
-								  int64_t *__restrict__ blk_ptr, int32_t *__restrict__ node_col, int64_t *__restrict__ deg)
+								  int32_t *__restrict__ node_col, int64_t *__restrict__ deg)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * blockDim.x)
 		{
@@ -57,10 +60,92 @@ namespace
 			if (k == 0 || key != keys[k - 1])
 			{
 				const int64_t b = pos[k];
-				blk_ptr[b] = k;
 				const uint64_t gi = key / (uint64_t)n_nodes;
 				node_col[b] = (int32_t)(key - gi * (uint64_t)n_nodes);
 				atomicAdd((unsigned long long *)&deg[gi], 1ull);
+			}
+		}
+	}
+
+	// 1 for a contribution to a block on or above the diagonal; index n_items (one past the end) counts as 0 so that an
+	// exclusive scan over n_items + 1 flags ends with the total
+	struct upper_flag
+	{
+		const uint64_t *keys;
+		int64_t n_items;
+		uint64_t n_nodes;
+		bool heads_only;
+		__host__ __device__ int64_t operator()(int64_t k) const
+		{
+			if (k >= n_items)
+				return 0;
+			const uint64_t key = keys[k];
+			const uint64_t gi = key / n_nodes, gj = key - gi * n_nodes;
+			if (gi > gj)
+				return 0;
+			return (!heads_only || k == 0 || key != keys[k - 1]) ? 1 : 0;
+		}
+	};
+
+	// keeps the contributions of the upper blocks: their keys and sources in list order, the start of every upper block's
+	// run, the distance between its index among all blocks and among the upper ones, and the upper blocks per row
+	__global__ void k_compact_upper(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ src, const int64_t *__restrict__ upos,
+									const int64_t *__restrict__ ubpos, const int64_t *__restrict__ pos, int64_t n_items, int64_t n_nodes,
+									uint64_t *__restrict__ ukeys, uint32_t *__restrict__ usrc, int64_t *__restrict__ ublk_ptr,
+									uint32_t *__restrict__ ublk_off, int64_t *__restrict__ udeg)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const uint64_t key = keys[k];
+			const uint64_t gi = key / (uint64_t)n_nodes, gj = key - gi * (uint64_t)n_nodes;
+			if (gi > gj)
+				continue;
+			const int64_t u = upos[k];
+			ukeys[u] = key;
+			usrc[u] = src[k];
+			if (k == 0 || key != keys[k - 1])
+			{
+				const int64_t ub = ubpos[k];
+				ublk_ptr[ub] = u;
+				ublk_off[ub] = (uint32_t)(pos[k] - ub);
+				atomicAdd((unsigned long long *)&udeg[gi], 1ull);
+			}
+		}
+	}
+
+	// for every block above the diagonal, the index of its mirror image (row = its column node, column = its row node);
+	// 0xFFFFFFFF for the diagonal blocks
+	__global__ void k_mirror_index(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, const int64_t *__restrict__ unode_ptr,
+								   int64_t n_nodes, uint32_t *__restrict__ ulow, int *__restrict__ bad)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t ub0 = unode_ptr[g], n_up = unode_ptr[g + 1] - ub0;
+			const int64_t b0 = node_ptr[g + 1] - n_up; // the upper blocks are the last ones of the row
+			for (int64_t k = 0; k < n_up; ++k)
+			{
+				const int64_t c = node_col[b0 + k];
+				if (c == g)
+				{
+					ulow[ub0 + k] = 0xFFFFFFFFu;
+					continue;
+				}
+				int64_t lo = node_ptr[c], hi = node_ptr[c + 1]; // first position of row c with column >= g
+				while (lo < hi)
+				{
+					const int64_t mid = (lo + hi) >> 1;
+					if (node_col[mid] < g)
+						lo = mid + 1;
+					else
+						hi = mid;
+				}
+				if (c < g || lo >= node_ptr[c + 1] || node_col[lo] != g)
+				{
+					*bad = 1; // cannot happen for a pattern built from element pairs
+					ulow[ub0 + k] = 0xFFFFFFFFu;
+				}
+				else
+					ulow[ub0 + k] = (uint32_t)lo;
 			}
 		}
 	}
@@ -156,20 +241,19 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 
 	// ---- node-pair blocks ----------------------------------------------------------------------------------
 	pfx_tmp<uint64_t> keys_a, keys_b;
-	pfx_tmp<uint32_t> vals_a;
+	pfx_tmp<uint32_t> vals_a, vals_b;
 	pfx_tmp<int64_t> pos, deg;
 	pfx_tmp<char> tmp;
 	size_t tmp_bytes = 0;
 	PFX_HIP(keys_a.alloc((size_t)n_pair));
 	PFX_HIP(keys_b.alloc((size_t)n_pair));
 	PFX_HIP(vals_a.alloc((size_t)n_pair));
-	if (pfx_alloc(ctx, &ctx->d_blk_src, n_pair))
-		return PFX_ERR_HIP;
+	PFX_HIP(vals_b.alloc((size_t)n_pair));
 	hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, ctx->d_conn, n_pair, n_loc, n_nodes, keys_a.p, vals_a.p);
 	const int end_bit = bits_for((uint64_t)n_nodes * (uint64_t)n_nodes);
-	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, vals_a.p, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
+	PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)n_pair, 0, end_bit, st));
 	PFX_HIP(tmp.alloc(tmp_bytes));
-	PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_a.p, keys_b.p, vals_a.p, ctx->d_blk_src, (size_t)n_pair, 0, end_bit, st));
+	PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_a.p, keys_b.p, vals_a.p, vals_b.p, (size_t)n_pair, 0, end_bit, st));
 	PFX_HIP(hipStreamSynchronize(st));
 	tmp.reset();
 	keys_a.reset();
@@ -195,41 +279,95 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	ctx->n_blocks = n_blocks;
 	ctx->nnz = n_blocks * ctx->bs * ctx->bs;
 
-	if (pfx_alloc(ctx, &ctx->d_blk_ptr, n_blocks + 1) || pfx_alloc(ctx, &ctx->d_node_col, n_blocks) || pfx_alloc(ctx, &ctx->d_node_ptr, n_nodes + 1))
+	if (n_blocks >= ((int64_t)1 << 32))
+		PFX_FAIL(PFX_ERR_SIZE, "more than 2^32 node blocks on one device; partition the mesh over more devices");
+	if (pfx_alloc(ctx, &ctx->d_node_col, n_blocks) || pfx_alloc(ctx, &ctx->d_node_ptr, n_nodes + 1))
 		return PFX_ERR_HIP;
 	PFX_HIP(deg.alloc((size_t)(n_nodes + 1)));
 	PFX_HIP(hipMemsetAsync(deg.p, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
-	hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, pos.p, n_pair, n_nodes, ctx->d_blk_ptr, ctx->d_node_col, deg.p);
-	hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, st, ctx->d_blk_ptr + n_blocks, n_pair);
+	hipLaunchKernelGGL(k_fill_blocks, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, pos.p, n_pair, n_nodes, ctx->d_node_col, deg.p);
 	tmp_bytes = 0;
 	PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg.p, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 	PFX_HIP(tmp.alloc(tmp_bytes));
 	PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_node_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 	PFX_HIP(hipStreamSynchronize(st));
 	tmp.reset();
+
+	// ---- blocks on and above the diagonal: the only ones with a contribution list ------------------------------
+	int64_t n_upair = 0, n_ublocks = 0;
+	pfx_tmp<uint64_t> ukeys;
+	{
+		pfx_tmp<int64_t> upos, ubpos;
+		PFX_HIP(upos.alloc((size_t)(n_pair + 1)));
+		PFX_HIP(ubpos.alloc((size_t)(n_pair + 1)));
+		for (int pass = 0; pass < 2; ++pass)
+		{
+			auto uf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), upper_flag{keys_b.p, n_pair, (uint64_t)n_nodes, pass == 1});
+			int64_t *dst = pass == 0 ? upos.p : ubpos.p;
+			tmp_bytes = 0;
+			PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, uf, dst, (int64_t)0, (size_t)(n_pair + 1), rocprim::plus<int64_t>(), st));
+			PFX_HIP(tmp.alloc(tmp_bytes));
+			PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, uf, dst, (int64_t)0, (size_t)(n_pair + 1), rocprim::plus<int64_t>(), st));
+			PFX_HIP(hipMemcpyAsync(pass == 0 ? &n_upair : &n_ublocks, dst + n_pair, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+			tmp.reset();
+		}
+		ctx->n_ublocks = n_ublocks;
+		ctx->n_upair = n_upair;
+		PFX_HIP(ukeys.alloc((size_t)n_upair));
+		if (pfx_alloc(ctx, &ctx->d_blk_src, n_upair) || pfx_alloc(ctx, &ctx->d_blk_ptr, n_ublocks + 1) || pfx_alloc(ctx, &ctx->d_ublk_off, n_ublocks)
+			|| pfx_alloc(ctx, &ctx->d_unode_ptr, n_nodes + 1))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemsetAsync(deg.p, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
+		hipLaunchKernelGGL(k_compact_upper, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, vals_b.p, upos.p, ubpos.p, pos.p, n_pair, n_nodes, ukeys.p,
+						   ctx->d_blk_src, ctx->d_blk_ptr, ctx->d_ublk_off, deg.p);
+		hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, st, ctx->d_blk_ptr + n_ublocks, n_upair);
+		tmp_bytes = 0;
+		PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg.p, ctx->d_unode_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(tmp.alloc(tmp_bytes));
+		PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_unode_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(hipStreamSynchronize(st));
+		tmp.reset();
+	}
 	pos.reset();
+	keys_b.reset();
+	vals_b.reset();
+	{
+		if (pfx_alloc(ctx, &ctx->d_ublk_low, n_ublocks))
+			return PFX_ERR_HIP;
+		pfx_tmp<int> bad;
+		PFX_HIP(bad.alloc(1));
+		PFX_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+		hipLaunchKernelGGL(k_mirror_index, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_unode_ptr, n_nodes,
+						   ctx->d_ublk_low, bad.p);
+		int h_bad = 0;
+		PFX_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		if (h_bad)
+			PFX_FAIL(PFX_ERR_SIZE, "internal: the node-block pattern is not structurally symmetric");
+	}
 
 	// ---- compute order of the contributions inside each assembly window -----------------------------------------
 	{
 		pfx_tmp<uint64_t> wk_a, wk_b, wv_a, wv_b;
-		PFX_HIP(wk_a.alloc((size_t)n_pair));
-		PFX_HIP(wk_b.alloc((size_t)n_pair));
-		PFX_HIP(wv_a.alloc((size_t)n_pair));
-		PFX_HIP(wv_b.alloc((size_t)n_pair));
-		if (pfx_alloc(ctx, &ctx->d_blk_slot, n_pair))
+		PFX_HIP(wk_a.alloc((size_t)n_upair));
+		PFX_HIP(wk_b.alloc((size_t)n_upair));
+		PFX_HIP(wv_a.alloc((size_t)n_upair));
+		PFX_HIP(wv_b.alloc((size_t)n_upair));
+		if (pfx_alloc(ctx, &ctx->d_blk_slot, n_upair))
 			return PFX_ERR_HIP;
-		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, ctx->d_blk_src, ctx->d_node_ptr, ctx->d_blk_ptr, n_pair,
+		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_upair)), dim3(256), 0, st, ukeys.p, ctx->d_blk_src, ctx->d_unode_ptr, ctx->d_blk_ptr, n_upair,
 						   n_nodes, (uint32_t)(n_loc * n_loc), wk_a.p, wv_a.p);
-		const int wbits = 28 + bits_for((uint64_t)n_pair);
+		const int wbits = 28 + bits_for((uint64_t)n_upair);
 		tmp_bytes = 0;
-		PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, wk_a.p, wk_b.p, wv_a.p, wv_b.p, (size_t)n_pair, 0, wbits, st));
+		PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, wk_a.p, wk_b.p, wv_a.p, wv_b.p, (size_t)n_upair, 0, wbits, st));
 		PFX_HIP(tmp.alloc(tmp_bytes));
-		PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, wk_a.p, wk_b.p, wv_a.p, wv_b.p, (size_t)n_pair, 0, wbits, st));
-		hipLaunchKernelGGL(k_split_window_vals, dim3(grid_for(n_pair)), dim3(256), 0, st, wv_b.p, n_pair, ctx->d_blk_src, ctx->d_blk_slot);
+		PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, wk_a.p, wk_b.p, wv_a.p, wv_b.p, (size_t)n_upair, 0, wbits, st));
+		hipLaunchKernelGGL(k_split_window_vals, dim3(grid_for(n_upair)), dim3(256), 0, st, wv_b.p, n_upair, ctx->d_blk_src, ctx->d_blk_slot);
 		PFX_HIP(hipStreamSynchronize(st));
 		tmp.reset();
 	}
-	keys_b.reset();
+	ukeys.reset();
 
 	// ---- node -> (element, local index) incidences ---------------------------------------------------------
 	pfx_tmp<uint32_t> nk_a, nk_b, nv_a;

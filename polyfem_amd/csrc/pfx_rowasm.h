@@ -10,7 +10,10 @@
 // scheduling (bitwise reproducible), needs no zero-fill of the value array and no FP64 atomics.
 //
 // The contribution functor computes the block of the pair (hi, lo), hi >= lo, exactly as the reference's loop over
-// j <= i does; the block of (lo, hi) is its transpose (Assembler.cpp:179-184 mirrors the same values).  It keeps its
+// j <= i does; the block of (lo, hi) is its transpose (Assembler.cpp:179-184 mirrors the same values).  Only the blocks
+// on and above the diagonal (column node >= row node) have contribution lists and are summed here; the lane that
+// finishes an entry also stores it, transposed, into the block's mirror image below the diagonal, so each pair is
+// evaluated once and every entry of the value array is still written exactly once.  It keeps its
 // constant tables (reference gradients of the bases at the quadrature points, weights) in LDS: they are indexed by
 // the lane's own (i, j), and reading them through the vector memory path would cost more than the arithmetic.
 //
@@ -33,7 +36,7 @@
 // MASK: also record, per entry, whether any of its contributions is non-zero (the value-dependent pattern of the
 // linear assemblers); the Hessian keeps every structural entry and skips that bookkeeping.
 template <int NLOC, int BS, int RPG, bool MASK, class Op>
-__global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr,
+__global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr, const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_low,
 													   const uint32_t *__restrict__ blk_src, const uint8_t *__restrict__ blk_slot, Op op, int64_t n_nodes,
 													   double *__restrict__ values, uint8_t *__restrict__ mask)
 {
@@ -41,6 +44,8 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 	constexpr uint32_t NL2 = NLOC * NLOC;
 	__shared__ double stage[64 * B2];
 	__shared__ int bp[66]; // start of block bl+s in the window, clamped to [-1, nw+1]
+	__shared__ uint32_t boff[64]; // block bl+s is block bl+s+boff[s] of the whole matrix
+	__shared__ uint32_t blow[64]; // its mirror image below the diagonal (0xFFFFFFFF: none)
 	__shared__ double carry[2][B2];
 	__shared__ uint8_t carry_any[2][B2];
 	__shared__ double optab[Op::LDS_DOUBLES]; // the functor's constant tables (reference gradients, weights)
@@ -60,6 +65,8 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 	int slot = (w_begin + lane < c_end) ? __builtin_nontemporal_load(blk_slot + w_begin + lane) : 0;
 	int64_t bptr = (bl + lane <= b_end) ? blk_ptr[bl + lane] : c_end + 128;
 	int64_t bptr2 = (lane < 2 && bl + 64 + lane <= b_end) ? blk_ptr[bl + 64 + lane] : c_end + 128;
+	uint32_t off = (bl + lane < b_end) ? blk_off[bl + lane] : 0u;
+	uint32_t low = (bl + lane < b_end) ? blk_low[bl + lane] : 0xFFFFFFFFu;
 	for (int64_t w0 = w_begin; w0 < c_end; w0 += 64)
 	{
 		const int64_t w1 = (w0 + 64 < c_end) ? w0 + 64 : c_end;
@@ -68,6 +75,8 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 		const int64_t d = bptr - w0;
 		const int rel = d < 0 ? -1 : (d > nw ? nw + 1 : (int)d);
 		bp[lane] = rel;
+		boff[lane] = off;
+		blow[lane] = low;
 		if (lane < 2)
 		{
 			const int64_t d2 = bptr2 - w0;
@@ -88,6 +97,8 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 			slot = (w1 + lane < c_end) ? __builtin_nontemporal_load(blk_slot + w1 + lane) : 0;
 			bptr = (bl_next + lane <= b_end) ? blk_ptr[bl_next + lane] : c_end + 128;
 			bptr2 = (lane < 2 && bl_next + 64 + lane <= b_end) ? blk_ptr[bl_next + 64 + lane] : c_end + 128;
+			off = (bl_next + lane < b_end) ? blk_off[bl_next + lane] : 0u;
+			low = (bl_next + lane < b_end) ? blk_low[bl_next + lane] : 0xFFFFFFFFu;
 		}
 		// B
 		if (lane < nw)
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 			}
 		}
 		__syncthreads();
-		// C: consecutive lanes own consecutive entries of the run [bl*B2, (bl+nb)*B2) of the value array
+		// C: consecutive lanes own consecutive entries of the blocks bl .. bl+nb-1 (contiguous in the value array row by row)
 		const int n_items = nb * B2;
 		for (int o = lane; o < n_items; o += 64)
 		{
@@ -141,10 +152,18 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 			}
 			else
 			{
-				const int64_t at = bl * B2 + o;
+				const int64_t at = (bl + (int64_t)boff[s]) * B2 + o;
 				values[at] = acc;
 				if (MASK)
 					mask[at] = (uint8_t)any;
+				const uint32_t lw = blow[s];
+				if (lw != 0xFFFFFFFFu)
+				{
+					const int64_t at2 = (int64_t)lw * B2 + (mn % BS) * BS + mn / BS;
+					values[at2] = acc;
+					if (MASK)
+						mask[at2] = (uint8_t)any;
+				}
 			}
 		}
 		bl = bl_next;
@@ -159,9 +178,9 @@ inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask
 	constexpr int RPG = PFX_ROWS_PER_GROUP;
 	const int64_t groups = (ctx->n_nodes + RPG - 1) / RPG;
 	if (write_mask)
-		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, true, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
-						   ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, true, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
+						   ctx->d_ublk_off, ctx->d_ublk_low, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
 	else
-		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, false, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_node_ptr, ctx->d_blk_ptr,
-						   ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, false, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
+						   ctx->d_ublk_off, ctx->d_ublk_low, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
 }
