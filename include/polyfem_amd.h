@@ -57,7 +57,8 @@ enum
 	PFX_LINEAR_ELASTICITY = 1,
 	PFX_NEOHOOKEAN = 2,
 	PFX_SAINT_VENANT = 3,
-	PFX_HOOKE_LINEAR = 4 /* HookeLinearElasticity.cpp:75-190: linear assembler with a general elasticity tensor */
+	PFX_HOOKE_LINEAR = 4, /* HookeLinearElasticity.cpp:75-190: linear assembler with a general elasticity tensor */
+	PFX_MULTI_MODEL = 5   /* MultiModel.cpp:42-96: LinearElasticity, NeoHookean or SaintVenant chosen per element */
 };
 
 enum
@@ -98,6 +99,11 @@ pfx_status pfx_set_material_per_element(pfx_ctx *ctx, int model, int dim, const 
  * row-major, as ElasticityTensor holds it after set_from_entries / set_from_lambda_mu / set_from_young_poisson
  * (utils/ElasticityUtils.cpp:298-413).  Selects the model PFX_HOOKE_LINEAR (pfx_assemble_linear only). */
 pfx_status pfx_set_elasticity_tensor(pfx_ctx *ctx, int dim, const double *tensor36);
+/* MultiModel (assembler/MultiModel.cpp:42-96, `multi_material_models_[el_id]`): after pfx_set_material(_per_element) with
+ * any of the three elastic models, gives every element its own model -- PFX_LINEAR_ELASTICITY, PFX_NEOHOOKEAN or
+ * PFX_SAINT_VENANT -- for the nonlinear interface (energy, gradient, Hessian, Newton, time steps).  The Lame parameters
+ * stay those of pfx_set_material(_per_element).  A later pfx_set_material call returns to one model. */
+pfx_status pfx_set_element_models(pfx_ctx *ctx, const int32_t *model_per_element, int64_t n_el);
 
 /* ---- sparsity pattern (utils::SpareMatrixCache, utils/MatrixUtils.cpp:108-264) --------------------------------- */
 

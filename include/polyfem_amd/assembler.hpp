@@ -94,6 +94,8 @@ namespace polyfem_amd
 		long pattern_generation = 0; // bumped whenever the device pattern is rebuilt (per-pattern device state must follow)
 		double bound_lambda = 0, bound_mu = 0;
 		const double *bound_lambda_e = nullptr;
+		const void *bound_models = nullptr; // MultiModel: the per-element model list that is bound ...
+		long bound_models_version = 0;      // ... and its edit counter (the list may be refilled in place)
 
 		void check(pfx_status rc) const
 		{
@@ -105,11 +107,13 @@ namespace polyfem_amd
 		// when the mesh changed, passes the material when it changed and (re)builds the device pattern when needed.
 		// lambda_e / mu_e: one value per element (multi-material bodies) or null.
 		void bind(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis, int model, int dim, double lambda, double mu,
-				  const std::vector<double> *lambda_e = nullptr, const std::vector<double> *mu_e = nullptr)
+				  const std::vector<double> *lambda_e = nullptr, const std::vector<double> *mu_e = nullptr, const std::vector<int32_t> *models = nullptr,
+				  long models_version = 0)
 		{
 			const bool per_element = lambda_e && !lambda_e->empty();
 			const bool same_mesh = bound_bases == (const void *)bases.data() && bound_count == bases.size();
-			const bool same_material = same_mesh && bound_model == model && bound_lambda == lambda && bound_mu == mu && bound_lambda_e == (per_element ? lambda_e->data() : nullptr);
+			const bool same_material = same_mesh && bound_model == model && bound_lambda == lambda && bound_mu == mu && bound_lambda_e == (per_element ? lambda_e->data() : nullptr)
+									   && bound_models == (models ? (const void *)models->data() : nullptr) && bound_models_version == models_version;
 			if (same_material)
 				return;
 			if (!same_mesh)
@@ -122,6 +126,8 @@ namespace polyfem_amd
 			}
 			else
 				check(pfx_set_material(h, model, dim, lambda, mu));
+			if (models)
+				check(pfx_set_element_models(h, models->data(), (int64_t)models->size()));
 			const int bs = model == PFX_LAPLACIAN ? 1 : dim;
 			if (!same_mesh || bs != bound_bs)
 			{
@@ -136,6 +142,8 @@ namespace polyfem_amd
 			bound_lambda = lambda;
 			bound_mu = mu;
 			bound_lambda_e = per_element ? lambda_e->data() : nullptr;
+			bound_models = models ? (const void *)models->data() : nullptr;
+			bound_models_version = models_version;
 		}
 
 	private:
@@ -335,6 +343,31 @@ namespace polyfem_amd
 			ElasticityTensor tensor_;
 		};
 
+		// assembler/MultiModel.hpp: one of the three elastic models per element ("multi_material_models_[el_id]",
+		// MultiModel.cpp:42-96); the Lame parameters are shared by the member assemblers (add_multimaterial, :22-29)
+		struct MultiModel : ElasticBase
+		{
+			static constexpr int model = PFX_NEOHOOKEAN; // what pfx_set_material receives before pfx_set_element_models
+			void init_multimodels(const std::vector<std::string> &mats)
+			{
+				models.clear();
+				++version;
+				for (const std::string &m : mats)
+				{
+					if (m == "LinearElasticity")
+						models.push_back(PFX_LINEAR_ELASTICITY);
+					else if (m == "NeoHookean")
+						models.push_back(PFX_NEOHOOKEAN);
+					else if (m == "SaintVenant")
+						models.push_back(PFX_SAINT_VENANT);
+					else
+						throw std::runtime_error("polyfem_amd: MultiModel knows LinearElasticity, NeoHookean and SaintVenant, not " + m);
+				}
+			}
+			std::vector<int32_t> models;
+			long version = 0;
+		};
+
 		// assembler/Mass.hpp: rho phi_i phi_j on the diagonal of every size x size block; density uniform or one value
 		// per element (Density with one entry per body id, utils/ElasticityUtils.cpp:561-570)
 		struct Mass
@@ -472,7 +505,15 @@ namespace polyfem_amd
 				if (!is_volume)
 					throw std::runtime_error("polyfem_amd: only 3-D problems are implemented");
 				Context &c = Context::instance();
-				c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
+				if constexpr (std::is_same<LocalAssembler, MultiModel>::value)
+				{
+					if (local_assembler_.models.size() != bases.size())
+						throw std::runtime_error("polyfem_amd: MultiModel needs one model per element (init_multimodels)");
+					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e,
+						   &local_assembler_.models, local_assembler_.version);
+				}
+				else
+					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
 				return c;
 			}
 			LocalAssembler local_assembler_;

@@ -967,7 +967,9 @@ void pfo_local_saint_venant_hessian(const pfo_vals *v, const double *da, const d
 }
 
 /* the three nonlinear local assemblers behind one switch */
-static int is_nl_model(int model) { return model == PFO_NEOHOOKEAN || model == PFO_LINEAR_ELASTICITY || model == PFO_SAINT_VENANT; }
+static int is_nl_model(int model) { return model == PFO_NEOHOOKEAN || model == PFO_LINEAR_ELASTICITY || model == PFO_SAINT_VENANT || model == PFO_MULTI_MODEL; }
+/* MultiModel (assembler/MultiModel.cpp:42-96) picks the local assembler by the element id */
+static int mat_model(const pfo_material *mat, int64_t e) { return (mat->model == PFO_MULTI_MODEL && mat->model_e) ? mat->model_e[e] : mat->model; }
 static double nl_local_energy(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu)
 {
 	if (model == PFO_NEOHOOKEAN)
@@ -1389,15 +1391,15 @@ static void *job_run(void *arg)
 			if (jb->mode == 1)
 			{
 				/* Assembler.cpp:657-668 */
-				const double val = nl_local_energy(mat->model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
+				const double val = nl_local_energy(mat_model(mat, e), v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
 				jb->scalar += val;
 			}
 			else if (jb->mode == 2)
 			{
 				/* Assembler.cpp:465-492 */
-				if (mat->model == PFO_NEOHOOKEAN)
+				if (mat_model(mat, e) == PFO_NEOHOOKEAN)
 					pfo_local_neohookean_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
-				else if (mat->model == PFO_SAINT_VENANT)
+				else if (mat_model(mat, e) == PFO_SAINT_VENANT)
 					pfo_local_saint_venant_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
 				else
 					pfo_local_linear_elasticity_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
@@ -1413,9 +1415,9 @@ static void *job_run(void *arg)
 			else
 			{
 				/* Assembler.cpp:550-616 : every entry, order (i, j, n, m) */
-				if (mat->model == PFO_NEOHOOKEAN)
+				if (mat_model(mat, e) == PFO_NEOHOOKEAN)
 					pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
-				else if (mat->model == PFO_SAINT_VENANT)
+				else if (mat_model(mat, e) == PFO_SAINT_VENANT)
 					pfo_local_saint_venant_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
 				else
 					pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
@@ -1926,9 +1928,9 @@ int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, c
 		for (int k = 0; k < quad.n_pts; ++k)
 			da[k] = v->det[k] * quad.w[k];
 		gather_local_disp(mesh, e, n_loc, x, ld);
-		if (mat->model == PFO_NEOHOOKEAN)
+		if (mat_model(mat, e) == PFO_NEOHOOKEAN)
 			pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
-		else if (mat->model == PFO_SAINT_VENANT)
+		else if (mat_model(mat, e) == PFO_SAINT_VENANT)
 			pfo_local_saint_venant_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
 		else
 			pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);

@@ -21,7 +21,7 @@ extern "C" {
 /* element kinds: number of local bases 4 / 10 / 8 / 27 */
 enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3 };
 /* local assemblers */
-enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2, PFO_SAINT_VENANT = 3, PFO_HOOKE_LINEAR = 4 };
+enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2, PFO_SAINT_VENANT = 3, PFO_HOOKE_LINEAR = 4, PFO_MULTI_MODEL = 5 };
 
 #define PFO_MAX_PTS 125
 #define PFO_MAX_LOC 27
@@ -67,6 +67,8 @@ typedef struct
 	                                  utils/ElasticityUtils.cpp:490-517); NULL = uniform */
 	const double *tensor;          /* PFO_HOOKE_LINEAR: the symmetric 6 x 6 elasticity tensor, row-major, Voigt order
 	                                  xx yy zz yz xz xy (ElasticityTensor, utils/ElasticityUtils.cpp:298-413) */
+	const int32_t *model_e;        /* PFO_MULTI_MODEL: the model of every element (MultiModel::multi_material_models_,
+	                                  assembler/MultiModel.cpp:42-96): LINEAR_ELASTICITY, NEOHOOKEAN or SAINT_VENANT */
 } pfo_material;
 
 /* compressed column storage with int32 indices = Eigen::SparseMatrix<double, ColMajor, int> */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpf_oracle.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR = 0, 1, 2, 3, 4
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
 MAX_PTS, MAX_LOC = 125, 27
 
 
@@ -42,21 +42,28 @@ class MeshS(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("model", C.c_int), ("dim", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double),
-                ("lambda_e", C.POINTER(C.c_double)), ("mu_e", C.POINTER(C.c_double)), ("tensor", C.POINTER(C.c_double))]
+                ("lambda_e", C.POINTER(C.c_double)), ("mu_e", C.POINTER(C.c_double)), ("tensor", C.POINTER(C.c_double)),
+                ("model_e", C.POINTER(C.c_int32))]
 
 
 def make_material(model: int, lam, mu):
     """Uniform Lame parameters (scalars) or one value per element (arrays); for HOOKE_LINEAR `lam` is the symmetric
     6 x 6 elasticity tensor (and `mu` is ignored).  Returns (Material, keep-alive)."""
+    if np.ndim(model) == 1:  # MultiModel: one model id per element
+        me = np.ascontiguousarray(model, dtype=np.int32)
+        assert np.isin(me, (LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT)).all()
+        mat, keep = make_material(MULTI_MODEL, lam, mu)
+        mat.model_e = me.ctypes.data_as(C.POINTER(C.c_int32))
+        return mat, (keep, me)
     if model == HOOKE_LINEAR:
         t = np.ascontiguousarray(lam, dtype=np.float64).reshape(6, 6)
         assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
-        return Material(model, 3, 0.0, 0.0, None, None, _dp(t)), t
+        return Material(model, 3, 0.0, 0.0, None, None, _dp(t), None), t
     if np.ndim(lam) == 0:
-        return Material(model, 3, float(lam), float(mu), None, None, None), None
+        return Material(model, 3, float(lam), float(mu), None, None, None, None), None
     la = np.ascontiguousarray(lam, dtype=np.float64)
     ma = np.ascontiguousarray(mu, dtype=np.float64)
-    return Material(model, 3, float(la[0]), float(ma[0]), _dp(la), _dp(ma), None), (la, ma)
+    return Material(model, 3, float(la[0]), float(ma[0]), _dp(la), _dp(ma), None, None), (la, ma)
 
 
 def elasticity_tensor(lam=None, mu=None, entries=None):

@@ -220,6 +220,7 @@ extern "C"
 		free_dev(ctx->d_elem_owned);
 		free_dev(ctx->d_lambda_e);
 		free_dev(ctx->d_mu_e);
+		free_dev(ctx->d_model_e);
 		free_dev(ctx->d_tensor);
 		free_dev(ctx->d_partials);
 		free_dev(ctx->d_cgstate);
@@ -298,6 +299,7 @@ extern "C"
 		free_dev(ctx->d_elem_owned);
 		free_dev(ctx->d_lambda_e);
 		free_dev(ctx->d_mu_e);
+		free_dev(ctx->d_model_e);
 		ctx->n_gnodes = n_gnodes;
 		if (pfx_alloc(ctx, &ctx->d_conn, n_el * n_loc) || pfx_alloc(ctx, &ctx->d_gconn, n_el * n_gloc) || pfx_alloc(ctx, &ctx->d_xyz, n_gnodes * 3))
 			return PFX_ERR_HIP;
@@ -328,6 +330,7 @@ extern "C"
 		ctx->mu = mu;
 		free_dev(ctx->d_lambda_e);
 		free_dev(ctx->d_mu_e);
+		free_dev(ctx->d_model_e);
 		return PFX_OK;
 	}
 
@@ -350,6 +353,34 @@ extern "C"
 		PFX_HIP(hipMemcpyAsync(ctx->d_tensor, tensor36, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		ctx->model = PFX_HOOKE_LINEAR;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_element_models(pfx_ctx *ctx, const int32_t *model_per_element, int64_t n_el)
+	{
+		if (!ctx || !model_per_element)
+			return PFX_ERR_ARG;
+		if (ctx->n_el <= 0 || n_el != ctx->n_el)
+			PFX_FAIL(PFX_ERR_ARG, "one model per element of the current mesh expected");
+		if (ctx->bs != 3)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_material(_per_element) with an elastic model must come first");
+		std::vector<uint8_t> m((size_t)n_el);
+		for (int64_t e = 0; e < n_el; ++e)
+			switch (model_per_element[e])
+			{
+			case PFX_LINEAR_ELASTICITY: m[e] = 0; break;
+			case PFX_NEOHOOKEAN: m[e] = 1; break;
+			case PFX_SAINT_VENANT: m[e] = 2; break;
+			default: PFX_FAIL(PFX_ERR_ARG, "element models are PFX_LINEAR_ELASTICITY, PFX_NEOHOOKEAN or PFX_SAINT_VENANT");
+			}
+		PFX_HIP(hipSetDevice(ctx->device));
+		free_dev(ctx->d_model_e);
+		if (pfx_alloc(ctx, &ctx->d_model_e, n_el))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_model_e, m.data(), (size_t)n_el, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		ctx->model = PFX_MULTI_MODEL;
+		ctx->estate_kind = PFX_ESTATE_NONE;
 		return PFX_OK;
 	}
 

@@ -46,7 +46,8 @@ namespace
 	{
 		M_LINEAR = 0,
 		M_NEO = 1,
-		M_STVK = 2
+		M_STVK = 2,
+		M_MULTI = 3 // one of the three per element (MultiModel, assembler/MultiModel.cpp:42-96): the branches become run-time tests
 	};
 
 	template <int NLOC, int NGLOC, int NPTS>
@@ -94,7 +95,7 @@ namespace
 	__global__ __launch_bounds__(BLOCK) void k_local_nl(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
 																   const double *__restrict__ xyz, const double *__restrict__ u,
 																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u, double mu_u,
-																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
+																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e, const uint8_t *__restrict__ model_e,
 																   int want_e, int want_g, int want_h,
 																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
 																   int *__restrict__ flag)
@@ -110,6 +111,7 @@ namespace
 		nl_smem<NLOC, NGLOC, NPTS> &s = sm[grp];
 		// LameParameters::lambda_mu (utils/ElasticityUtils.cpp:490-517): one value, or one per element
 		const double lambda = (lambda_e && active) ? lambda_e[e] : lambda_u, mu = (mu_e && active) ? mu_e[e] : mu_u;
+		const int model = (MODEL == M_MULTI) ? (active ? (int)model_e[e] : (int)M_LINEAR) : MODEL;
 
 		if (active)
 		{
@@ -151,7 +153,7 @@ namespace
 			for (int t = lane; t < NPTS * 9; t += TPE)
 			{
 				const int k = t / 9, d = (t % 9) / 3, c = t % 3;
-				double acc = (MODEL != M_LINEAR && d == c) ? 1.0 : 0.0;
+				double acc = (model != M_LINEAR && d == c) ? 1.0 : 0.0;
 				for (int i = 0; i < NLOC; ++i)
 					acc += s.ul[3 * i + d] * s.G[3 * (k * NLOC + i) + c];
 				s.F[t] = acc; // F(d,c) row-major
@@ -164,7 +166,7 @@ namespace
 				const double *F = &s.F[9 * k];
 				double *dJ = &s.dJ[9 * k];
 				const double da = s.da[k];
-				if (MODEL == M_NEO)
+				if (model == M_NEO)
 				{
 					// cofactor matrix: dJ(r,c) = d det / d F(r,c)
 					dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
@@ -182,7 +184,7 @@ namespace
 					s.coef[4 * k + 2] = (lambda * lj - mu) / J * da;
 					s.coef[4 * k + 3] = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
 				}
-				else if (MODEL == M_STVK)
+				else if (model == M_STVK)
 				{
 					// dJ receives the first Piola-Kirchhoff stress F S
 					double E[9], S[9];
@@ -238,7 +240,7 @@ namespace
 		if (active && lane == 0 && s.bad)
 			atomicOr(flag, 1);
 
-		if (MODEL == M_NEO && active && want_g)
+		if (model == M_NEO && active && want_g)
 			for (int t = lane; t < NPTS * NLOC; t += TPE)
 			{
 				const int k = t / NLOC;
@@ -258,7 +260,7 @@ namespace
 					const double *F = &s.F[9 * k];
 					const double *Gi = &s.G[3 * (k * NLOC + i)], *Wi = &s.W[3 * (k * NLOC + i)];
 					const double a = s.coef[4 * k + 0], c2 = s.coef[4 * k + 2];
-					if (MODEL == M_NEO)
+					if (model == M_NEO)
 						for (int d = 0; d < 3; ++d)
 							g[d] += a * (F[3 * d] * Gi[0] + F[3 * d + 1] * Gi[1] + F[3 * d + 2] * Gi[2]) + c2 * Wi[d];
 					else
@@ -281,7 +283,7 @@ namespace
 				if (q < 10)
 				{
 					if (!ST::affine || k == 0)
-						st[ST::jt_at(k) + q] = q < 9 ? s.jt[9 * k + q] : 0.0;
+						st[ST::jt_at(k) + q] = q < 9 ? s.jt[9 * k + q] : (double)model; // the tenth slot tells the row functor the element's model
 				}
 				else if (q < 19)
 					st[ST::f_at(k) + q - 10] = s.F[9 * k + q - 10];
@@ -340,7 +342,8 @@ namespace
 					Gj[c] = rj[0] * jt[c] + rj[1] * jt[3 + c] + rj[2] * jt[6 + c];
 				}
 				const double dot = a * (Gi[0] * Gj[0] + Gi[1] * Gj[1] + Gi[2] * Gj[2]);
-				if (MODEL == M_LINEAR)
+				const int model = (MODEL == M_MULTI) ? (int)jt[9] : MODEL;
+				if (model == M_LINEAR)
 				{
 					// a = mu da, c1 = lambda da
 					for (int m = 0; m < 3; ++m)
@@ -348,7 +351,7 @@ namespace
 							b[3 * m + n] += a * Gi[n] * Gj[m] + c1 * Gi[m] * Gj[n] + (m == n ? dot : 0.0);
 					continue;
 				}
-				if (MODEL == M_STVK)
+				if (model == M_STVK)
 				{
 					// a = mu da, c1 = lambda da; S da = c1 tr(E) I + 2 a E from F
 					double E[6]; // xx, yy, zz, yz, xz, xy of (F^T F - I)/2
@@ -417,12 +420,14 @@ namespace
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
 #define PFX_LOCAL_NL(MODEL_)                                                                                                              \
 	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
-					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, (int)en, (int)gr, (int)he,     \
+					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, (int)en, (int)gr, (int)he,     \
 					   ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
 		if (ctx->model == PFX_NEOHOOKEAN)
 			PFX_LOCAL_NL(M_NEO);
 		else if (ctx->model == PFX_SAINT_VENANT)
 			PFX_LOCAL_NL(M_STVK);
+		else if (ctx->model == PFX_MULTI_MODEL)
+			PFX_LOCAL_NL(M_MULTI);
 		else
 			PFX_LOCAL_NL(M_LINEAR);
 #undef PFX_LOCAL_NL
@@ -435,6 +440,8 @@ namespace
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
 		else if (ctx->model == PFX_SAINT_VENANT)
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab}, false);
+		else if (ctx->model == PFX_MULTI_MODEL)
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab}, false);
 		else
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
 	}
@@ -446,6 +453,8 @@ namespace
 			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_SAINT_VENANT)
 			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
+		else if (ctx->model == PFX_MULTI_MODEL)
+			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab});
 		else
 			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
 		if (rc)
@@ -457,8 +466,10 @@ namespace
 
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess)
 {
-	if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY && ctx->model != PFX_SAINT_VENANT)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the nonlinear-assembler interface is implemented for NeoHookean, SaintVenant and LinearElasticity");
+	if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY && ctx->model != PFX_SAINT_VENANT && ctx->model != PFX_MULTI_MODEL)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the nonlinear-assembler interface is implemented for NeoHookean, SaintVenant, LinearElasticity and MultiModel");
+	if (ctx->model == PFX_MULTI_MODEL && !ctx->d_model_e)
+		PFX_FAIL(PFX_ERR_ARG, "pfx_set_element_models must follow pfx_set_material");
 	const int np = ctx->n_pts;
 	bool ok = true;
 	switch (ctx->kind)

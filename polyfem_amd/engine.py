@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpolyfem_amd.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR = 0, 1, 2, 3, 4
+LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
 PRECOND_IDENTITY, PRECOND_JACOBI = 0, 1
 MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN,
                  "SaintVenant": SAINT_VENANT}
@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
-    "pfx_inertia_enable_host", "pfx_set_elasticity_tensor",
+    "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_element_models",
 ]
 
 
@@ -119,6 +119,7 @@ def load():
         "pfx_set_material": [_vp, _i32, _i32, _dbl, _dbl],
         "pfx_set_material_per_element": [_vp, _i32, _i32, _pd, _pd, _i64],
         "pfx_set_elasticity_tensor": [_vp, _i32, _pd],
+        "pfx_set_element_models": [_vp, _pi32, _i64],
         "pfx_build_pattern": [_vp, _pi64],
         "pfx_get_pattern": [_vp, _pi64, _pi32],
         "pfx_get_values": [_vp, _pd],
@@ -245,6 +246,11 @@ class Engine:
             assert la.shape == ma.shape and la.ndim == 1
             self._ck(self.L.pfx_set_material_per_element(self.h, model, dim, _d(la), _d(ma), la.size))
         self.model = model
+
+    def set_element_models(self, models):
+        """MultiModel: one of LINEAR_ELASTICITY / NEOHOOKEAN / SAINT_VENANT (ids or names) per element, after set_material."""
+        ids = np.ascontiguousarray([MODEL_BY_NAME[m] if isinstance(m, str) else int(m) for m in models], dtype=np.int32)
+        self._ck(self.L.pfx_set_element_models(self.h, ids.ctypes.data_as(_pi32), ids.size))
 
     def set_elasticity_tensor(self, tensor, dim: int = 3):
         """HookeLinearElasticity: symmetric 6 x 6 tensor (Voigt order xx yy zz yz xz xy); linear assembly only."""

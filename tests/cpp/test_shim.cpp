@@ -184,6 +184,40 @@ int main()
 		REQUIRE(K2.values == K.values && K2.inner == K.inner);
 	}
 
+	// MultiModel with one model everywhere reproduces that model; a mixture lies between
+	{
+		assembler::NLAssembler<assembler::MultiModel> mm;
+		mm.local_assembler().set_E_nu(2e4, 0.3);
+		mm.local_assembler().init_multimodels(std::vector<std::string>(bases.size(), "NeoHookean"));
+		const double e_all_neo = mm.assemble(true, bases, gbases, cache, 0.0, x, x);
+		REQUIRE(std::fabs(e_all_neo - e0) <= 1e-13 * std::fabs(e0));
+		std::vector<std::string> mix(bases.size(), "NeoHookean");
+		for (size_t e = 0; e < mix.size(); e += 2)
+			mix[e] = "SaintVenant";
+		mm.local_assembler().init_multimodels(mix);
+		VectorXd gm;
+		const double e_mix = mm.assemble(true, bases, gbases, cache, 0.0, x, x);
+		mm.assemble_grad(true, n_basis, bases, gbases, cache, 0.0, x, x, gm);
+		REQUIRE(e_mix > 0 && e_mix != e_all_neo && (int)gm.size() == N);
+		const double fdm = (mm.assemble(true, bases, gbases, cache, 0.0, xp, xp) - mm.assemble(true, bases, gbases, cache, 0.0, xm, xm)) / (2 * h);
+		double gdm = 0;
+		for (int i = 0; i < N; ++i)
+			gdm += gm[i] * d[i];
+		REQUIRE(std::fabs(fdm - gdm) <= 1e-5 * std::fabs(gdm));
+		bool rejected = false;
+		try
+		{
+			mm.local_assembler().init_multimodels({"Ogden"});
+		}
+		catch (const std::runtime_error &)
+		{
+			rejected = true;
+		}
+		REQUIRE(rejected);
+		// back to a single model
+		REQUIRE(std::fabs(nl.assemble(true, bases, gbases, cache, 0.0, x, x) - e0) <= 1e-15 * std::fabs(e0));
+	}
+
 	// "hessian_lin" (tests/test_assembler.cpp:12-64): LinearElasticity through the nonlinear interface reproduces the
 	// stiffness matrix for any displacement
 	{

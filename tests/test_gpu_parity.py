@@ -174,6 +174,66 @@ def test_saint_venant_energy_gradient_hessian(eng, oracle, name):
 
 
 @pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
+def test_multi_model_energy_gradient_hessian(eng, oracle, name):
+    """MultiModel (assembler/MultiModel.cpp:42-96): LinearElasticity / NeoHookean / SaintVenant chosen per element,
+    with per-element Lame parameters; energy, gradient, Hessian (plain and projected) and a Newton solve."""
+    mesh = MESHES[name]()
+    n = mesh.n_nodes * 3
+    h = 1.0 / round((mesh.n_el / (6 if mesh.kind < 2 else 1)) ** (1 / 3))
+    ids = np.array([oracle.NEOHOOKEAN, oracle.SAINT_VENANT, oracle.LINEAR_ELASTICITY])[(np.arange(mesh.n_el) * 7 // 3) % 3]
+    lam, mu = oracle.lame(2e4, 0.3)
+    l2, m2 = oracle.lame(5e4, 0.2)
+    half = np.arange(mesh.n_el) % 2 == 0
+    for lam_e, mu_e in ((lam, mu), (np.where(half, lam, l2), np.where(half, mu, m2))):
+        eng.set_mesh(mesh)
+        eng.set_material(E.NEOHOOKEAN, lam_e, mu_e)
+        eng.set_element_models(ids)
+        nnz = eng.build_pattern()
+        for amp in (0.0, 2e-2 * h):
+            x = M.seeded_displacement(mesh, 3, amp, seed=8)
+            e_ref = oracle.assemble_energy(mesh, ids, lam_e, mu_e, x)
+            g_ref = oracle.assemble_gradient(mesh, ids, lam_e, mu_e, x)
+            outer, inner, vals = oracle.assemble_hessian(mesh, ids, lam_e, mu_e, x)
+            e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+            rp, ci = eng.get_pattern()
+            assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and nnz == inner.size
+            if amp == 0.0:
+                assert abs(e) <= 1e-9 and np.abs(g).max() <= 1e-9 * np.abs(vals).max()
+            else:
+                assert abs(e - e_ref) <= TOL * abs(e_ref)
+                assert rel_err(g, g_ref) <= TOL
+            assert rel_err(v, vals) <= TOL
+        vp = eng.hessian(x, project_to_psd=True)
+        ref = oracle.assemble_hessian_psd(mesh, ids, lam_e, mu_e, x)
+        assert np.abs(vp - ref[2]).max() <= 1e-10 * np.abs(ref[2]).max()
+    # a single model through the per-element interface equals that model
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    eng.set_element_models(["SaintVenant"] * mesh.n_el)
+    e_multi, g_multi = eng.energy(x), eng.gradient(x)
+    eng.set_material(E.SAINT_VENANT, lam, mu)
+    # (same formulas; the run-time model test lets the compiler contract the arithmetic differently)
+    assert abs(e_multi - eng.energy(x)) <= 1e-14 * abs(e_multi) and rel_err(g_multi, eng.gradient(x)) <= 1e-14
+    # error behaviour
+    with pytest.raises(E.PfxError):
+        eng.set_element_models(ids[:-1])
+    with pytest.raises(E.PfxError):
+        eng.set_element_models(np.full(mesh.n_el, E.LAPLACIAN))
+    if name != "q1":  # the Q1 one-point rule leaves the clamped static problem singular
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.set_element_models(ids)
+        bnd = M.boundary_dofs(mesh, 3, "x0")
+        eng.set_dirichlet(bnd)
+        rhs = np.zeros(n)
+        rhs[2::3] = -100.0 / mesh.n_nodes
+        xs, info = eng.newton_solve(np.zeros(n), rhs)
+        xr, iref = oracle.newton_solve(mesh, ids, lam, mu, rhs, bnd, np.zeros(n))
+        eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+        assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+        assert info["line_search_iterations"] == iref["line_search_iterations"]
+        assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
 def test_linear_elasticity_through_nonlinear_interface(eng, oracle, name):
     """LinearElasticity::compute_energy / assemble_grad / assemble_hessian (LinearElasticity.cpp:56-169) against the
     oracle, and the reference's own property (tests/test_assembler.cpp:12-64): Hessian == stiffness for any x."""

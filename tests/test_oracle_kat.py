@@ -519,3 +519,33 @@ def test_hooke_linear_oracle(oracle, kind):
         e6 = np.array([eps[0, 0], eps[1, 1], eps[2, 2], 2 * eps[1, 2], 2 * eps[0, 2], 2 * eps[0, 1]])
         vol = 1.0  # the unit cube
         assert abs(u @ (k @ u) - vol * e6 @ C @ e6) <= 1e-11 * abs(e6 @ C @ e6)
+
+
+@pytest.mark.parametrize("kind", ["p2", "q1"])
+def test_multi_model_oracle(oracle, kind):
+    """MultiModel (assembler/MultiModel.cpp:42-96) only dispatches on the element id: energy, gradient and Hessian are
+    the sums of the single-model results over the elements of each model (the single models are pinned above)."""
+    mesh = M.cube_tets(2, 2, jitter=0.2, seed=3) if kind == "p2" else M.cube_hexes(2, 1)
+    n = mesh.n_nodes * 3
+    lam, mu = oracle.lame(2e4, 0.3)
+    x = M.seeded_displacement(mesh, 3, 1e-2)
+    ids = np.array([oracle.NEOHOOKEAN, oracle.SAINT_VENANT, oracle.LINEAR_ELASTICITY])[np.arange(mesh.n_el) % 3]
+    e = oracle.assemble_energy(mesh, ids, lam, mu, x)
+    g = oracle.assemble_gradient(mesh, ids, lam, mu, x)
+    h = csc_to_scipy(oracle.assemble_hessian(mesh, ids, lam, mu, x), n)
+    e_sum, g_sum, h_sum = 0.0, np.zeros(n), None
+    for mid in (oracle.NEOHOOKEAN, oracle.SAINT_VENANT, oracle.LINEAR_ELASTICITY):
+        sel = ids == mid
+        sub = M.Mesh(mesh.kind, mesh.gkind, mesh.conn[sel].copy(), mesh.gconn[sel].copy(), mesh.xyz, mesh.n_nodes, mesh.node_xyz, mesh.quad_order)
+        e_sum += oracle.assemble_energy(sub, mid, lam, mu, x)
+        g_sum += oracle.assemble_gradient(sub, mid, lam, mu, x)
+        hs = csc_to_scipy(oracle.assemble_hessian(sub, mid, lam, mu, x), n)
+        h_sum = hs if h_sum is None else h_sum + hs
+    assert abs(e - e_sum) <= 1e-13 * abs(e)
+    assert np.abs(g - g_sum).max() <= 1e-13 * np.abs(g).max()
+    assert abs(h - h_sum).max() <= 1e-13 * abs(h).max()
+    # finite-difference check of the mixed gradient
+    d = np.random.default_rng(2).standard_normal(n)
+    eps = 1e-6
+    fd = (oracle.assemble_energy(mesh, ids, lam, mu, x + eps * d) - oracle.assemble_energy(mesh, ids, lam, mu, x - eps * d)) / (2 * eps)
+    assert abs(fd - g @ d) <= 1e-6 * abs(g @ d)
