@@ -259,6 +259,19 @@ pfx_status pfx_newton_solve_dev(pfx_ctx *ctx, const double *d_rhs, double *d_x_i
  *                       pfx_newton_solve; on error v and a are left untouched. */
 pfx_status pfx_inertia_set_mass(pfx_ctx *ctx, double density, const double *density_e);
 pfx_status pfx_inertia_enable(pfx_ctx *ctx, double acceleration_scaling, const double *d_x_tilde);
+/* Augmented-Lagrangian treatment of the Dirichlet conditions (solver/forms/ALForm.cpp:7-86, solver/ALSolver.cpp:22-108):
+ * while enabled, pfx_newton_solve(_dev) adds  weight/2 (x - target)^T diag(masked_lumped_mass) (x - target)  to its
+ * objective.  masked_lumped_mass is the lumped mass matrix (utils::lump_matrix: row sums; the identity for a static
+ * problem) with the entries of the free dofs set to 0; target holds the Dirichlet values (RhsAssembler::set_bc).  The
+ * caller drives ALSolver's loop: pfx_set_dirichlet with no dofs, pfx_al_enable(weight), solve, double the weight while
+ * the projected state is invalid, then pfx_al_enable(0) + pfx_set_dirichlet(dofs) and the final solve.
+ * weight <= 0 or a null pointer disables the term.  The _dev form keeps the caller's device pointers (n_dofs doubles
+ * each, valid until disabled); the _host form copies.  pfx_lumped_mass returns the row sums of the mass matrix kept by
+ * pfx_inertia_set_mass (host vector of n_dofs). */
+pfx_status pfx_al_enable(pfx_ctx *ctx, double weight, const double *d_masked_lumped_mass, const double *d_target);
+pfx_status pfx_al_enable_host(pfx_ctx *ctx, double weight, const double *masked_lumped_mass, const double *target);
+pfx_status pfx_lumped_mass(pfx_ctx *ctx, double *lumped);
+
 /* the same with x_tilde on the host: it is copied into a buffer of the context */
 pfx_status pfx_inertia_enable_host(pfx_ctx *ctx, double acceleration_scaling, const double *x_tilde);
 pfx_status pfx_implicit_euler_step(pfx_ctx *ctx, double dt, const double *rhs, double *x_inout, double *v_inout, double *a_out,

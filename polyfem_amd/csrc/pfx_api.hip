@@ -86,6 +86,10 @@ namespace
 		ctx->newton_count = 0;
 		free_dev(ctx->d_mass_blk);
 		free_dev(ctx->d_tstep);
+		free_dev(ctx->d_al_store);
+		ctx->al_count = 0;
+		ctx->al_weight = 0.0;
+		ctx->d_al_mass = ctx->d_al_target = nullptr;
 		ctx->mass_count = ctx->tstep_count = 0;
 		ctx->inertia_weight = 0.0;
 		ctx->d_x_tilde = nullptr;
@@ -788,6 +792,69 @@ extern "C"
 		PFX_HIP(hipMemcpyAsync(ctx->d_tstep + n, x_tilde, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return pfx_inertia_enable(ctx, acceleration_scaling, ctx->d_tstep + n);
+	}
+
+	pfx_status pfx_al_enable(pfx_ctx *ctx, double weight, const double *d_masked_lumped_mass, const double *d_target)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (!(weight > 0.0) || !d_masked_lumped_mass || !d_target)
+		{
+			ctx->al_weight = 0.0;
+			ctx->d_al_mass = ctx->d_al_target = nullptr;
+			return PFX_OK;
+		}
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->bs != 3)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs block size 3");
+		ctx->al_weight = weight;
+		ctx->d_al_mass = d_masked_lumped_mass;
+		ctx->d_al_target = d_target;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_al_enable_host(pfx_ctx *ctx, double weight, const double *masked_lumped_mass, const double *target)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (!(weight > 0.0) || !masked_lumped_mass || !target)
+			return pfx_al_enable(ctx, 0.0, nullptr, nullptr);
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		const int64_t n = ctx->n_dofs();
+		for (int64_t k = 0; k < n; ++k)
+			if (!(masked_lumped_mass[k] >= 0.0))
+				PFX_FAIL(PFX_ERR_ARG, "the masked lumped mass must be non-negative");
+		if (ctx->al_count < 2 * n)
+		{
+			if (pfx_alloc(ctx, &ctx->d_al_store, 2 * n))
+				return PFX_ERR_HIP;
+			ctx->al_count = 2 * n;
+		}
+		PFX_HIP(hipMemcpyAsync(ctx->d_al_store, masked_lumped_mass, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_al_store + n, target, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return pfx_al_enable(ctx, weight, ctx->d_al_store, ctx->d_al_store + n);
+	}
+
+	pfx_status pfx_lumped_mass(pfx_ctx *ctx, double *lumped)
+	{
+		if (!ctx || !lumped)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->mass_count == 0 || ctx->bs != 3)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
+		const int64_t n = ctx->n_dofs();
+		pfx_tmp<double> d;
+		PFX_HIP(d.alloc((size_t)n));
+		pfx_status rc = pfx_lumped_mass_run(ctx, d.p);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(lumped, d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
 	}
 
 	pfx_status pfx_mass_apply_dev(pfx_ctx *ctx, const double *d_v, double *d_y)

@@ -123,6 +123,11 @@ struct pfx_ctx
 	double inertia_weight = 0.0;  // acceleration_scaling of the time integrator; 0 = static problem
 	const double *d_x_tilde = nullptr;
 	double *d_tstep = nullptr;    // x_prev and x_tilde of pfx_implicit_euler_step
+	// augmented-Lagrangian penalty al_weight/2 (x - target)^T diag(al_mass) (x - target) beside the other terms (0: off)
+	double al_weight = 0.0;
+	const double *d_al_mass = nullptr, *d_al_target = nullptr; // n_dofs each: masked lumped mass, Dirichlet target
+	double *d_al_store = nullptr; // the two vectors when they came from the host (pfx_al_enable_host)
+	int64_t al_count = 0;
 	int64_t tstep_count = 0;
 
 	// solver copy of the matrix (block-SELL-64, pfx_sell.hip)
@@ -261,6 +266,7 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 pfx_status pfx_eval_all_dev(pfx_ctx *ctx, const double *d_u, double *d_energy, double *d_g);
 pfx_status pfx_hessian_from_state(pfx_ctx *ctx, bool project_to_psd);
 pfx_status pfx_capture_mass(pfx_ctx *ctx);
+pfx_status pfx_lumped_mass_run(pfx_ctx *ctx, double *d_out);
 pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y);
 pfx_status pfx_add_mass_run(pfx_ctx *ctx, double w);
 pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,

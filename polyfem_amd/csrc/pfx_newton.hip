@@ -29,7 +29,8 @@ namespace
 	// g = gradient of the objective restricted to the free dofs: (g - rhs), 0 on constrained dofs
 	__global__ __launch_bounds__(256) void k_objective_gradient(double *__restrict__ g, const double *__restrict__ rhs,
 																const uint8_t *__restrict__ fixed, int64_t n, double w,
-																const double *__restrict__ md)
+																const double *__restrict__ md, double alw, const double *__restrict__ alm,
+																const double *__restrict__ alt, const double *__restrict__ x)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
 		{
@@ -38,6 +39,8 @@ namespace
 				v -= rhs[k];
 			if (md) // transient step: weighted elastic + body forms, plus M (x - x_tilde)
 				v = w * v + md[k];
+			if (alm) // augmented-Lagrangian penalty on the Dirichlet dofs: weight * m (x - target)
+				v += alw * alm[k] * (x[k] - alt[k]);
 			if (fixed && fixed[k])
 				v = 0.0;
 			g[k] = v;
@@ -83,6 +86,54 @@ namespace
 			}
 			if (g < n_rows && sub < 3)
 				md[3 * g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
+		}
+	}
+
+	// q = sqrt(m) (x - target): the penalty is weight/2 |q|^2 (ALForm::value_unweighted, solver/forms/ALForm.cpp:50-63)
+	__global__ __launch_bounds__(256) void k_al_residual(const double *__restrict__ x, const double *__restrict__ m, const double *__restrict__ t,
+														 int64_t n, double *__restrict__ q)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			q[k] = sqrt(m[k]) * (x[k] - t[k]);
+	}
+
+	// Hessian of the penalty: weight * m on the diagonal (ALForm::second_derivative_unweighted, :70-73); one thread per node
+	__global__ __launch_bounds__(256) void k_al_add_diag(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes,
+														 double alw, const double *__restrict__ m, double *__restrict__ values)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double m0 = m[3 * g], m1 = m[3 * g + 1], m2 = m[3 * g + 2];
+			if (m0 == 0.0 && m1 == 0.0 && m2 == 0.0)
+				continue;
+			int64_t lo = node_ptr[g], hi = node_ptr[g + 1];
+			while (lo < hi)
+			{
+				const int64_t mid = (lo + hi) >> 1;
+				if (node_col[mid] < g)
+					lo = mid + 1;
+				else
+					hi = mid;
+			}
+			if (lo < node_ptr[g + 1] && node_col[lo] == g)
+			{
+				values[lo * 9] += alw * m0;
+				values[lo * 9 + 4] += alw * m1;
+				values[lo * 9 + 8] += alw * m2;
+			}
+		}
+	}
+
+	// utils::lump_matrix of the mass matrix: row sums on the diagonal; every component of a node gets the node's sum
+	__global__ __launch_bounds__(256) void k_lump_mass(const int64_t *__restrict__ node_ptr, const double *__restrict__ mass, int64_t n_nodes,
+													   double *__restrict__ out)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			double s = 0.0;
+			for (int64_t b = node_ptr[g]; b < node_ptr[g + 1]; ++b)
+				s += mass[b];
+			out[3 * g] = out[3 * g + 1] = out[3 * g + 2] = s;
 		}
 	}
 
@@ -208,6 +259,20 @@ namespace
 		double iw = 1.0;               // weight of the elastic and body forms
 		const double *mass = nullptr, *xt = nullptr;
 		double *d = nullptr, *md = nullptr; // n each: x - x_tilde and M (x - x_tilde)
+		// augmented-Lagrangian penalty on the Dirichlet dofs (null mass: none)
+		double alw = 0.0;
+		const double *alm = nullptr, *alt = nullptr;
+		double *alq = nullptr; // n
+
+		// weight/2 (x - target)^T m (x - target)
+		pfx_status al_value(const double *x, double *val)
+		{
+			hipLaunchKernelGGL(k_al_residual, dim3(NB), dim3(256), 0, ctx->stream, x, alm, alt, n, alq);
+			double r[3];
+			pfx_status rc = reduce(alq, alq, nullptr, r);
+			*val = 0.5 * alw * r[0];
+			return rc;
+		}
 
 		// d = x - x_tilde, md = M d
 		void mass_apply(const double *x)
@@ -266,7 +331,14 @@ namespace
 					return rc;
 				e = iw * e + 0.5 * r[0];
 			}
-			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, g, rhs, fixed, n, iw, (const double *)(mass ? md : nullptr));
+			if (alm && std::isfinite(e))
+			{
+				double pen = 0;
+				if ((rc = al_value(x, &pen)))
+					return rc;
+				e += pen;
+			}
+			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, g, rhs, fixed, n, iw, (const double *)(mass ? md : nullptr), alw, alm, alt, x);
 			if ((rc = reduce(g, g, nullptr, r)))
 				return rc;
 			*val = e;
@@ -309,6 +381,13 @@ namespace
 					return rc;
 				e = iw * e + 0.5 * r[0];
 			}
+			if (alm && std::isfinite(e))
+			{
+				double pen = 0;
+				if ((rc = al_value(x, &pen)))
+					return rc;
+				e += pen;
+			}
 			*val = e;
 			return PFX_OK;
 		}
@@ -322,7 +401,7 @@ namespace
 				return rc;
 			if (mass)
 				mass_apply(x);
-			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, out, rhs, fixed, n, iw, (const double *)(mass ? md : nullptr));
+			hipLaunchKernelGGL(k_objective_gradient, dim3(NB), dim3(256), 0, st, out, rhs, fixed, n, iw, (const double *)(mass ? md : nullptr), alw, alm, alt, x);
 			double r[3];
 			if ((rc = reduce(out, out, nullptr, r)))
 				return rc;
@@ -439,23 +518,29 @@ namespace
 pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
 {
 	const int64_t n = ctx->n_dofs();
-	if (ctx->newton_count < 7 * n + 3 * NB + 8)
+	if (ctx->newton_count < 8 * n + 3 * NB + 8)
 	{
-		if (pfx_alloc(ctx, &ctx->d_newton, 7 * n + 3 * NB + 8))
+		if (pfx_alloc(ctx, &ctx->d_newton, 8 * n + 3 * NB + 8))
 			return PFX_ERR_HIP;
-		ctx->newton_count = 7 * n + 3 * NB + 8;
+		ctx->newton_count = 8 * n + 3 * NB + 8;
 	}
 	newton S;
 	S.ctx = ctx, S.par = par, S.info = info, S.n = n, S.rhs = d_rhs;
 	S.fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	S.g = ctx->d_newton, S.dx = S.g + n, S.xn = S.dx + n, S.w = S.xn + n, S.gls = S.w + n;
-	S.d = S.gls + n, S.md = S.d + n;
-	S.partial = S.md + n, S.scal = S.partial + 3 * NB;
+	S.d = S.gls + n, S.md = S.d + n, S.alq = S.md + n;
+	S.partial = S.alq + n, S.scal = S.partial + 3 * NB;
 	if (ctx->inertia_weight > 0.0 && ctx->d_x_tilde && ctx->mass_count > 0)
 	{
 		if (ctx->bs != 3 || ctx->n_owned != ctx->n_nodes)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs block size 3 and an unpartitioned mesh");
 		S.iw = ctx->inertia_weight, S.mass = ctx->d_mass_blk, S.xt = ctx->d_x_tilde;
+	}
+	if (ctx->al_weight > 0.0 && ctx->d_al_mass && ctx->d_al_target)
+	{
+		if (ctx->bs != 3 || ctx->n_owned != ctx->n_nodes)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs block size 3 and an unpartitioned mesh");
+		S.alw = ctx->al_weight, S.alm = ctx->d_al_mass, S.alt = ctx->d_al_target;
 	}
 	hipStream_t st = ctx->stream;
 	*info = pfx_newton_info{};
@@ -546,6 +631,11 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 			if (S.mass)
 			{
 				hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, st, ctx->d_values, ctx->nnz, S.iw, S.mass);
+				ctx->values_gen++;
+			}
+			if (S.alm)
+			{
+				hipLaunchKernelGGL(k_al_add_diag, dim3(NB), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, S.alw, S.alm, ctx->d_values);
 				ctx->values_gen++;
 			}
 			ctx->diag_shift = reg_weight;
@@ -668,6 +758,13 @@ pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, 
 }
 
 // y[owned rows] = M v with the captured mass matrix (v needs a current halo on a partitioned mesh)
+pfx_status pfx_lumped_mass_run(pfx_ctx *ctx, double *d_out)
+{
+	hipLaunchKernelGGL(k_lump_mass, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_mass_blk, ctx->n_nodes, d_out);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
 pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y)
 {
 	hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_mass_blk, d_v, ctx->n_owned, d_y);

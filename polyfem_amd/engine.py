@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
     "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_element_models",
+    "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
 ]
 
 
@@ -120,6 +121,9 @@ def load():
         "pfx_set_material_per_element": [_vp, _i32, _i32, _pd, _pd, _i64],
         "pfx_set_elasticity_tensor": [_vp, _i32, _pd],
         "pfx_set_element_models": [_vp, _pi32, _i64],
+        "pfx_al_enable": [_vp, C.c_double, _vp, _vp],
+        "pfx_al_enable_host": [_vp, C.c_double, _pd, _pd],
+        "pfx_lumped_mass": [_vp, _pd],
         "pfx_build_pattern": [_vp, _pi64],
         "pfx_get_pattern": [_vp, _pi64, _pi32],
         "pfx_get_values": [_vp, _pd],
@@ -251,6 +255,66 @@ class Engine:
         """MultiModel: one of LINEAR_ELASTICITY / NEOHOOKEAN / SAINT_VENANT (ids or names) per element, after set_material."""
         ids = np.ascontiguousarray([MODEL_BY_NAME[m] if isinstance(m, str) else int(m) for m in models], dtype=np.int32)
         self._ck(self.L.pfx_set_element_models(self.h, ids.ctypes.data_as(_pi32), ids.size))
+
+    # ---- augmented-Lagrangian Dirichlet conditions -----------------------------------------------------------
+    def al_enable(self, weight: float, d_masked_lumped_mass: int, d_target: int):
+        """Device pointers (kept by the engine until al_disable)."""
+        self._ck(self.L.pfx_al_enable(self.h, weight, _vp(d_masked_lumped_mass), _vp(d_target)))
+
+    def al_enable_host(self, weight: float, masked_lumped_mass, target):
+        m = np.ascontiguousarray(masked_lumped_mass, dtype=np.float64)
+        t = np.ascontiguousarray(target, dtype=np.float64)
+        self._ck(self.L.pfx_al_enable_host(self.h, weight, _d(m), _d(t)))
+
+    def al_disable(self):
+        self._ck(self.L.pfx_al_enable(self.h, 0.0, None, None))
+
+    def lumped_mass(self):
+        out = np.zeros(self.info().n_dofs)
+        self._ck(self.L.pfx_lumped_mass(self.h, _d(out)))
+        return out
+
+    def al_solve(self, x0, rhs, dirichlet_dofs, dirichlet_values, lumped_mass=None, initial_weight=1e6, max_weight=1e11,
+                 force_al=False, **newton_params):
+        """ALSolver::solve (solver/ALSolver.cpp:22-84).  While the state with the Dirichlet values imposed is invalid
+        (non-finite energy) -- or once, with force_al -- solve the full-size problem with the penalty, doubling its
+        weight; then one solve with the Dirichlet dofs held at their values.  lumped_mass: vector of n_dofs (None: the
+        identity, the static problem's choice).  Returns (x, info of the final solve, list of penalty weights used)."""
+        n = self.info().n_dofs
+        dofs = np.ascontiguousarray(dirichlet_dofs, dtype=np.int32)
+        target = np.zeros(n)
+        target[dofs] = dirichlet_values
+        mass = np.ones(n) if lumped_mass is None else np.asarray(lumped_mass, dtype=np.float64)
+        masked = np.zeros(n)
+        masked[dofs] = mass[dofs]
+        x = np.array(x0, dtype=np.float64, copy=True)
+
+        def projected_valid():
+            xp = x.copy()
+            xp[dofs] = target[dofs]
+            try:
+                return bool(np.isfinite(self.energy(xp)))
+            except PfxError:
+                self.take_numeric_flag()
+                return False
+
+        weight, used = float(initial_weight), []
+        while force_al or not projected_valid():
+            force_al = False
+            self.set_dirichlet(np.zeros(0, dtype=np.int32))
+            self.al_enable_host(weight, masked, target)
+            try:
+                x, _ = self.newton_solve(x, rhs, **newton_params)
+            finally:
+                self.al_disable()
+            used.append(weight)
+            weight *= 2
+            if weight >= max_weight:
+                raise PfxError(f"Unable to solve AL problem, weight {weight} >= {max_weight}, stopping")
+        self.set_dirichlet(dofs)
+        x[dofs] = target[dofs]
+        x, info = self.newton_solve(x, rhs, **newton_params)
+        return x, info, used
 
     def set_elasticity_tensor(self, tensor, dim: int = 3):
         """HookeLinearElasticity: symmetric 6 x 6 tensor (Voigt order xx yy zz yz xz xy); linear assembly only."""

@@ -704,6 +704,60 @@ def test_inertia_form_pieces(eng, oracle, name):
     assert abs(Hm - ref).max() <= TOL * abs(ref).max()
 
 
+def test_augmented_lagrangian_dirichlet(eng, oracle):
+    """ALForm / ALSolver (solver/forms/ALForm.cpp:7-86, solver/ALSolver.cpp:22-108): the penalised full-size solve against
+    the oracle (for the static problem the penalty w/2 (x-t)^T D (x-t) is the oracle's inertia term with mass w D,
+    predictor t and weight 1), the lumped mass, and the solver loop."""
+    import scipy.sparse as sp
+    mesh = MESHES["p2_jitter_polyfem"]()
+    n = mesh.n_nodes * 3
+    lam, mu = oracle.lame(2e4, 0.3)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    target = np.zeros(n)
+    target[bnd[0::3]] = 0.02  # the clamped face is pushed along x
+    rhs = np.zeros(n)
+    rhs[2::3] = -50.0 / mesh.n_nodes
+    # lumped mass = row sums of the mass matrix
+    eng.inertia_set_mass(1000.0)
+    mo = csc_to_scipy(oracle.assemble_mass(mesh, 3, 1000.0), n)
+    lumped = eng.lumped_mass()
+    assert rel_err(lumped, np.asarray(mo.sum(axis=1)).ravel()) <= 1e-13
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    # one penalised solve, identity lumped mass (static problem), no dof held
+    w = 1e6
+    masked = np.zeros(n)
+    masked[bnd] = 1.0
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    eng.al_enable_host(w, masked, target)
+    xs, info = eng.newton_solve(np.zeros(n), rhs)
+    eng.al_disable()
+    d = sp.diags(w * masked).tocsc()
+    d.sort_indices()
+    xr, iref = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, np.zeros(0, dtype=np.int32), np.zeros(n),
+                                   mass=(d.indptr.astype(np.int32), d.indices.astype(np.int32), d.data), x_tilde=target, weight=1.0)
+    assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+    assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+    assert np.abs(xs[bnd] - target[bnd]).max() <= 1e-3 * 0.02  # the penalty holds the face near its target
+    # the loop: forced penalty pass, then the solve with the dofs held; equals the direct constrained solve
+    xa, ia, used = eng.al_solve(np.zeros(n), rhs, bnd, target[bnd], force_al=True)
+    assert used == [1e6] and np.array_equal(xa[bnd], target[bnd])
+    eng.set_dirichlet(bnd)
+    xd, _ = eng.newton_solve(target.copy(), rhs)
+    assert np.abs(xa - xd).max() <= 1e-7 * np.abs(xd).max()
+    # Dirichlet values that invert the elements next to the face when imposed at once: the penalty passes run unforced
+    big = np.zeros(n)
+    big[bnd[0::3]] = 0.45
+    xb, ib, used_b = eng.al_solve(np.zeros(n), None, bnd, big[bnd], initial_weight=1e3)
+    assert len(used_b) >= 1 and np.array_equal(xb[bnd], big[bnd]) and np.isfinite(eng.energy(xb))
+    assert ib["status"] in (2, 3, 4)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    # with the term enabled but weight 0 nothing changes; null pointers disable
+    eng.al_enable_host(0.0, masked, target)
+    with pytest.raises(E.PfxError):
+        eng.al_enable_host(1.0, -masked, target)
+
+
 def test_inertia_error_behaviour(eng, oracle):
     mesh = M.cube_tets(2, 1)
     lam, mu = oracle.lame(2e4, 0.3)
