@@ -18,7 +18,8 @@
 // the lane's own (i, j), and reading them through the vector memory path would cost more than the arithmetic.
 //
 // Value layout = node-block storage: block b of the node-block CSR (row node g, slot s = b - node_ptr[g]) holds its
-// bs*bs entries contiguously, entry (m, n) at b*bs*bs + m*bs + n.  A window's output is therefore one contiguous run.
+// bs*bs entries contiguously, entry (m, n) at b*bs*bs + m*bs + n.  The upper blocks of a row are its last ones, so a window's
+// output is one contiguous run per row it touches (plus the transposed copies in the rows of the mirror images).
 // The scalar CSR order the reference uses is produced on export only (pfx_values_to_csr).
 #pragma once
 #include "pfx_internal.h"
