@@ -35,24 +35,6 @@ namespace
 				x[k] = b[k];
 	}
 
-	inline int grid_for(int64_t n, int block = 256)
-	{
-		int64_t g = (n + block - 1) / block;
-		if (g > 256 * 16)
-			g = 256 * 16;
-		if (g < 1)
-			g = 1;
-		return (int)g;
-	}
-
-	template <typename T>
-	void free_dev(T *&p)
-	{
-		if (p)
-			(void)hipFree(p);
-		p = nullptr;
-	}
-
 	void release_pattern(pfx_ctx *ctx)
 	{
 		free_dev(ctx->d_node_ptr);

@@ -156,16 +156,6 @@ namespace
 			flag[r] = fixed[r] ? 0 : 1;
 	}
 
-	inline int grid_for(int64_t n, int block = 256)
-	{
-		int64_t g = (n + block - 1) / block;
-		if (g > 256 * 16)
-			g = 256 * 16;
-		if (g < 1)
-			g = 1;
-		return (int)g;
-	}
-
 	template <int NLOC, int BS>
 	void launch_gv(pfx_ctx *ctx, double *d_g, bool drop_tiny)
 	{

@@ -191,6 +191,26 @@ pfx_status pfx_alloc(pfx_ctx *ctx, T **p, int64_t count)
 	return PFX_OK;
 }
 
+// grid of a grid-stride kernel over n items: enough blocks to fill the device, capped at 16 per CU
+inline int grid_for(int64_t n, int block = 256)
+{
+	int64_t g = (n + block - 1) / block;
+	if (g > 256 * 16)
+		g = 256 * 16;
+	if (g < 1)
+		g = 1;
+	return (int)g;
+}
+
+// hipFree + null (pointers owned by the context)
+template <typename T>
+inline void free_dev(T *&p)
+{
+	if (p)
+		(void)hipFree(p);
+	p = nullptr;
+}
+
 // Temporary device buffer of the host-side sequencing code: released when it goes out of scope, i.e. also on the early
 // returns of PFX_HIP / PFX_FAIL.  Kernel launches take the raw pointer (.p).
 template <typename T>

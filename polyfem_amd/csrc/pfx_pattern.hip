@@ -216,15 +216,6 @@ namespace
 		return b;
 	}
 
-	inline int grid_for(int64_t n, int block = 256)
-	{
-		int64_t g = (n + block - 1) / block;
-		if (g > 256 * 16)
-			g = 256 * 16;
-		if (g < 1)
-			g = 1;
-		return (int)g;
-	}
 } // namespace
 
 pfx_status pfx_pattern_build(pfx_ctx *ctx)

@@ -304,16 +304,6 @@ namespace
 				v[k] = 0.0;
 	}
 
-	inline int grid_for(int64_t n, int block = 256)
-	{
-		int64_t g = (n + block - 1) / block;
-		if (g > 256 * 16)
-			g = 256 * 16;
-		if (g < 1)
-			g = 1;
-		return (int)g;
-	}
-
 } // namespace
 
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y)
