@@ -36,28 +36,48 @@
 // The index data of a window are loaded one window ahead.
 // MASK: also record, per entry, whether any of its contributions is non-zero (the value-dependent pattern of the
 // linear assemblers); the Hessian keeps every structural entry and skips that bookkeeping.
-template <int NLOC, int BS, int RPG, bool MASK, class Op>
-__global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr, const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_low,
+// WPB waves per workgroup, each with its own row group and its own staging area; they share only the functor's tables
+// (worth it when those are large: 19 KB for Q2 would otherwise limit a CU to six single-wave workgroups).
+template <int NLOC, int BS, int RPG, bool MASK, int WPB, class Op>
+__global__ __launch_bounds__(64 * WPB) void k_assemble_rows(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr, const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_low,
 													   const uint32_t *__restrict__ blk_src, const uint8_t *__restrict__ blk_slot, Op op, int64_t n_nodes,
 													   double *__restrict__ values, uint8_t *__restrict__ mask)
 {
 	constexpr int B2 = BS * BS;
 	constexpr uint32_t NL2 = NLOC * NLOC;
-	__shared__ double stage[64 * B2];
-	__shared__ int bp[66]; // start of block bl+s in the window, clamped to [-1, nw+1]
-	__shared__ uint32_t boff[64]; // block bl+s is block bl+s+boff[s] of the whole matrix
-	__shared__ uint32_t blow[64]; // its mirror image below the diagonal (0xFFFFFFFF: none)
-	__shared__ double carry[2][B2];
-	__shared__ uint8_t carry_any[2][B2];
+	__shared__ double stage_[WPB][64 * B2];
+	__shared__ int bp_[WPB][66];        // start of block bl+s in the window, clamped to [-1, nw+1]
+	__shared__ uint32_t boff_[WPB][64]; // block bl+s is block bl+s+boff[s] of the whole matrix
+	__shared__ uint32_t blow_[WPB][64]; // its mirror image below the diagonal (0xFFFFFFFF: none)
+	__shared__ double carry_[WPB][2][B2];
+	__shared__ uint8_t carry_any_[WPB][2][B2];
 	__shared__ double optab[Op::LDS_DOUBLES]; // the functor's constant tables (reference gradients, weights)
-	const int lane = threadIdx.x;
-	op.load_tables(optab, lane);
-	const int64_t g_first = (int64_t)blockIdx.x * RPG;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	double *const stage = stage_[wv];
+	int *const bp = bp_[wv];
+	uint32_t *const boff = boff_[wv], *const blow = blow_[wv];
+	double(*const carry)[B2] = carry_[wv];
+	uint8_t(*const carry_any)[B2] = carry_any_[wv];
+	op.load_tables(optab, lane); // every wave writes the same values
+	const int64_t g_first = ((int64_t)blockIdx.x * WPB + wv) * RPG;
+	const bool have_rows = g_first < n_nodes;
 	const int64_t g_last = (g_first + RPG <= n_nodes) ? g_first + RPG : n_nodes;
-	const int64_t b_begin = node_ptr[g_first], b_end = node_ptr[g_last];
+	const int64_t b_begin = have_rows ? node_ptr[g_first] : 0, b_end = have_rows ? node_ptr[g_last] : 0;
 	__syncthreads();
 	if (b_begin == b_end)
 		return;
+	// from here on a wave only talks to itself through its own part of the LDS: a wave-level barrier is enough
+	// (with one wave per workgroup the workgroup barrier is the same thing)
+	auto wave_sync = [] {
+		if (WPB == 1)
+			__syncthreads();
+		else
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+	};
 	const int64_t c_end = blk_ptr[b_end];
 	int64_t bl = b_begin; // first block that intersects the window
 	int cur = 0;
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 				stage[slot_now * B2 + k] = (kt != k && tr) ? out[kt] : out[k];
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		// C: consecutive lanes own consecutive entries of the blocks bl .. bl+nb-1 (contiguous in the value array row by row)
 		const int n_items = nb * B2;
 		for (int o = lane; o < n_items; o += 64)
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(64) void k_assemble_rows(const int64_t *__restrict_
 		}
 		bl = bl_next;
 		cur ^= 1;
-		__syncthreads();
+		wave_sync();
 	}
 }
 
@@ -177,11 +197,13 @@ template <int NLOC, int BS, class Op>
 inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask)
 {
 	constexpr int RPG = PFX_ROWS_PER_GROUP;
+	constexpr int WPB = (Op::LDS_DOUBLES * 8 > 12 * 1024) ? 4 : 1; // share large tables between four waves
 	const int64_t groups = (ctx->n_nodes + RPG - 1) / RPG;
+	const unsigned grid = (unsigned)((groups + WPB - 1) / WPB);
 	if (write_mask)
-		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, true, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, true, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
 						   ctx->d_ublk_off, ctx->d_ublk_low, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
 	else
-		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, false, Op>), dim3((unsigned)groups), dim3(64), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, false, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
 						   ctx->d_ublk_off, ctx->d_ublk_low, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
 }
