@@ -112,7 +112,7 @@ struct pfx_ctx
 	double *d_work = nullptr;     // 4 * n_dofs: r, p, tmp, invdiag
 	double *d_work_ext = nullptr; // caller-owned workspace of the same layout (multi-GPU driver)
 	double diag_shift = 0.0;      // the solver works with A + diag_shift * I on the free dofs (Newton regularisation)
-	double *d_partials = nullptr; // 3 x 2048 per-block partial sums of the vector kernels, then 8 scalars (first: p.Ap of the current iteration)
+	double *d_partials = nullptr; // room for 3 x 2048 per-block partial sums of the vector kernels (3 x PFX_NPART used), then 8 scalars at 3 * PFX_NPART (first: p.Ap of the current iteration)
 	double *d_part0 = nullptr;    // per-block partials of the SpMV (one per SpMV block)
 	int64_t part0_count = 0;
 	double *d_newton = nullptr;   // workspace of the Newton driver (pfx_newton.hip)
