@@ -901,3 +901,38 @@ def test_isolated_nodes_and_single_element(eng, oracle):
     u = np.random.default_rng(3).standard_normal(one.n_nodes * 3) * 1e-3
     assert rel_err(eng.hessian(u), oracle.assemble_hessian(one, oracle.NEOHOOKEAN, lam, mu, u)[2]) <= TOL
     assert rel_err(eng.gradient(u), oracle.assemble_gradient(one, oracle.NEOHOOKEAN, lam, mu, u)) <= TOL
+
+
+def test_no_device_memory_drift(oracle):
+    """Engines created, driven through every kind of call and closed again leave the free device memory unchanged."""
+    import torch
+    mesh = M.cube_tets(6, 2)
+    n = mesh.n_nodes * 3
+    bnd = M.boundary_dofs(mesh, 3, "x0")
+    rhs = np.zeros(n)
+    rhs[2::3] = -1.0 / mesh.n_nodes
+    free = []
+    for rep in range(4):
+        e = E.Engine(0)
+        e.set_mesh(mesh)
+        e.set_material(E.LINEAR_ELASTICITY, 5e4, 4e4)
+        e.build_pattern()
+        e.assemble_linear()
+        e.get_linear_csr()
+        e.set_elasticity_tensor(E.elasticity_tensor(lam=5e4, mu=4e4))
+        e.assemble_linear()
+        e.set_material(E.NEOHOOKEAN, 1e4, 8e3)
+        e.set_element_models([E.NEOHOOKEAN, E.SAINT_VENANT] * (mesh.n_el // 2))
+        e.set_dirichlet(bnd)
+        e.newton_solve(np.zeros(n), rhs)
+        e.hessian(np.zeros(n), project_to_psd=True)
+        e.inertia_set_mass(1000.0)
+        e.implicit_euler_step(1e-3, np.zeros(n), np.zeros(n), rhs)
+        e.al_solve(np.zeros(n), rhs, bnd, np.zeros(bnd.size), force_al=True)
+        e.set_mesh(M.cube_hexes(3, 2))
+        e.set_material(E.LAPLACIAN, 1, 1)
+        e.build_pattern()
+        e.assemble_linear()
+        e.close()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert free[-1] == free[1], free
