@@ -442,10 +442,9 @@ pfx_status pfx_launch_project_psd(pfx_ctx *ctx, Op op)
 {
 	constexpr int N = NLOC * 3, LD = N | 1;
 	const size_t bytes = sizeof(double) * N * LD;
-	auto kernel = k_project_psd<NLOC, Op>;
 	if (bytes > 32 * 1024)
-		PFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-	hipLaunchKernelGGL(kernel, dim3((unsigned)ctx->n_el), dim3(64), bytes, ctx->stream, op, ctx->n_el, ctx->d_kloc);
+		PFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_project_psd<NLOC, Op>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	hipLaunchKernelGGL((k_project_psd<NLOC, Op>), dim3((unsigned)ctx->n_el), dim3(64), bytes, ctx->stream, op, ctx->n_el, ctx->d_kloc);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -18,7 +18,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpolyfem_amd.so")
+# PFX_LIBRARY selects another build of the same ABI (e.g. one with host-side sanitizers)
+LIB_PATH = os.environ.get("PFX_LIBRARY") or os.path.join(_HERE, "libpolyfem_amd.so")
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
 LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
