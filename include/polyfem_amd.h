@@ -184,6 +184,13 @@ pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int pre
 pfx_status pfx_assemble_mass(pfx_ctx *ctx, double density, const double *density_e);
 pfx_status pfx_assemble_rhs(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *rhs);
 pfx_status pfx_assemble_rhs_dev(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *d_rhs);
+/* The same with a force density that varies in space: force_pts holds what problem.rhs() returns in the reference
+ * (RhsAssembler.cpp:66-75), one vector per (element, quadrature point), n_el x n_pts x d doubles.  pfx_quadrature_points
+ * gives the physical positions of those points (ElementAssemblyValues::val, ElementAssemblyValues.cpp:328-345;
+ * n_el x n_pts x 3 doubles, pts may be NULL to ask for n_pts only) for the caller to evaluate its function at. */
+pfx_status pfx_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts);
+pfx_status pfx_assemble_rhs_pointwise(pfx_ctx *ctx, const double *force_pts, double density, const double *density_e, double *rhs);
+pfx_status pfx_assemble_rhs_pointwise_dev(pfx_ctx *ctx, const double *d_force_pts, double density, const double *density_e, double *d_rhs);
 
 /* ---- Newton solve with the iterate resident on the device ------------------------------------------------------
  *

@@ -2614,6 +2614,64 @@ int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const doub
 	return rc;
 }
 
+/* Physical positions of the quadrature points (ElementAssemblyValues::val, assembler/ElementAssemblyValues.cpp:328-345):
+ * sum_j N_j^geo(xi_q) x_j; pts is n_el x n_pts x 3.  Returns n_pts (or -1). */
+int pfo_quadrature_points(const pfo_mesh *mesh, double *pts)
+{
+	const int n_g = pfo_n_loc(mesh->gkind);
+	pfo_quad quad;
+	if (pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad))
+		return -1;
+	for (int64_t e = 0; e < mesh->n_el; ++e)
+		for (int q = 0; q < quad.n_pts; ++q)
+		{
+			double p[3] = {0, 0, 0};
+			for (int j = 0; j < n_g; ++j)
+			{
+				double nv;
+				pfo_basis_value(mesh->gkind, j, quad.pts[q], &nv);
+				const double *node = mesh->xyz + 3 * (int64_t)mesh->gconn[e * n_g + j];
+				for (int c = 0; c < 3; ++c)
+					p[c] += nv * node[c];
+			}
+			for (int c = 0; c < 3; ++c)
+				pts[((int64_t)e * quad.n_pts + q) * 3 + c] = p[c];
+		}
+	return quad.n_pts;
+}
+
+/* RhsAssembler::assemble (assembler/RhsAssembler.cpp:55-98) with the force density given at every quadrature point
+ * (what problem.rhs() returns there): force_pts is n_el x n_pts x size. */
+int pfo_assemble_rhs_pointwise(const pfo_mesh *mesh, int size, const double *force_pts, double density, const double *density_e, double *rhs)
+{
+	const int n_loc = pfo_n_loc(mesh->kind);
+	pfo_quad quad;
+	if (pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad))
+		return -1;
+	pfo_vals *v = (pfo_vals *)malloc(sizeof(pfo_vals));
+	double rhs_fun[PFO_MAX_PTS][3];
+	for (int64_t k = 0; k < mesh->n_nodes * size; ++k)
+		rhs[k] = 0;
+	for (int64_t e = 0; e < mesh->n_el; ++e)
+	{
+		pfo_compute_vals(mesh, e, &quad, v);
+		const double rho = density_e ? density_e[e] : density;
+		for (int d = 0; d < size; ++d)
+			for (int q = 0; q < quad.n_pts; ++q)
+				rhs_fun[q][d] = force_pts[((int64_t)e * quad.n_pts + q) * size + d] * (v->det[q] * quad.w[q] * rho);
+		for (int i = 0; i < n_loc; ++i)
+			for (int d = 0; d < size; ++d)
+			{
+				double rhs_value = 0;
+				for (int q = 0; q < quad.n_pts; ++q)
+					rhs_value += rhs_fun[q][d] * v->val[i][q];
+				rhs[(int64_t)mesh->conn[e * n_loc + i] * size + d] += rhs_value * 1.0;
+			}
+	}
+	free(v);
+	return 0;
+}
+
 int pfo_assemble_rhs(const pfo_mesh *mesh, int size, const double *f, double density, const double *density_e, double *rhs)
 {
 	const int n_loc = pfo_n_loc(mesh->kind);

@@ -126,6 +126,10 @@ int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const doub
 /* Body-force right-hand side (assembler/RhsAssembler.cpp:55-98) for a constant force density f (size components):
  * rhs[idx*size+d] += sum_q f_d rho det w phi_i(q), stiffness quadrature, serial element loop. */
 int pfo_assemble_rhs(const pfo_mesh *mesh, int size, const double *f, double density, const double *density_e, double *rhs);
+/* the same with the force density given per quadrature point (n_el x n_pts x size), and the physical positions of those
+ * points (n_el x n_pts x 3; returns n_pts) for the caller to evaluate its force function at */
+int pfo_assemble_rhs_pointwise(const pfo_mesh *mesh, int size, const double *force_pts, double density, const double *density_e, double *rhs);
+int pfo_quadrature_points(const pfo_mesh *mesh, double *pts);
 
 /* ipc::project_to_psd (ipc-toolkit, un-vendored; call site assembler/Assembler.cpp:554-555): symmetric eigendecomposition,
  * A returned unchanged if its smallest eigenvalue is >= 0, otherwise V max(D,0) V^T.  The eigenvalues come from cyclic

@@ -447,6 +447,29 @@ def assemble_rhs(mesh, size: int, force, density=1.0):
     return rhs
 
 
+def quadrature_points(mesh):
+    """Physical positions of the stiffness-rule quadrature points, shape (n_el, n_pts, 3)."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    buf = np.zeros(om.s.n_el * 125 * 3)
+    lib().pfo_quadrature_points.restype = C.c_int
+    n_pts = lib().pfo_quadrature_points(C.byref(om.s), _dp(buf))
+    assert n_pts > 0
+    return buf[: om.s.n_el * n_pts * 3].reshape(om.s.n_el, n_pts, 3).copy()
+
+
+def assemble_rhs_pointwise(mesh, size: int, force_pts, density=1.0):
+    """RhsAssembler::assemble with the force density given per quadrature point: force_pts (n_el, n_pts, size)."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    rho_e = None if np.ndim(density) == 0 else np.ascontiguousarray(density, dtype=np.float64)
+    f = np.ascontiguousarray(force_pts, dtype=np.float64)
+    assert f.shape[0] == om.s.n_el and f.shape[2] == size
+    rhs = np.zeros(om.s.n_nodes * size)
+    rc = lib().pfo_assemble_rhs_pointwise(C.byref(om.s), int(size), _dp(f), C.c_double(float(density) if rho_e is None else float(rho_e[0])),
+                                          _dp(rho_e) if rho_e is not None else None, _dp(rhs))
+    assert rc == 0
+    return rhs
+
+
 def mass_quadrature(kind: int):
     q = Quad()
     assert lib().pfo_mass_quadrature(kind, C.byref(q)) == 0

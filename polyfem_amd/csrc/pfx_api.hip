@@ -491,7 +491,7 @@ extern "C"
 		pfx_status rc = upload_density(ctx, density_e, &d_rho);
 		if (rc)
 			return rc;
-		if ((rc = pfx_launch_local_rhs(ctx, force, density, d_rho)))
+		if ((rc = pfx_launch_local_rhs(ctx, force, nullptr, density, d_rho)))
 			return rc;
 		return pfx_launch_gather_vector(ctx, d_rhs, false);
 	}
@@ -506,6 +506,61 @@ extern "C"
 		if (rc)
 			return rc;
 		PFX_HIP(hipMemcpyAsync(rhs, ctx->d_vec, sizeof(double) * (size_t)ctx->n_dofs(), hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_assemble_rhs_pointwise_dev(pfx_ctx *ctx, const double *d_force_pts, double density, const double *density_e, double *d_rhs)
+	{
+		if (!ctx || !d_force_pts || !d_rhs)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const double *d_rho = nullptr;
+		pfx_status rc = upload_density(ctx, density_e, &d_rho);
+		if (rc)
+			return rc;
+		if ((rc = pfx_launch_local_rhs(ctx, nullptr, d_force_pts, density, d_rho)))
+			return rc;
+		return pfx_launch_gather_vector(ctx, d_rhs, false);
+	}
+
+	pfx_status pfx_assemble_rhs_pointwise(pfx_ctx *ctx, const double *force_pts, double density, const double *density_e, double *rhs)
+	{
+		if (!ctx || !force_pts || !rhs)
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		const size_t count = (size_t)(ctx->n_el * ctx->n_pts * ctx->bs);
+		pfx_tmp<double> d_f;
+		PFX_HIP(d_f.alloc(count > 0 ? count : 1));
+		PFX_HIP(hipMemcpyAsync(d_f.p, force_pts, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc = pfx_assemble_rhs_pointwise_dev(ctx, d_f.p, density, density_e, ctx->d_vec);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(rhs, ctx->d_vec, sizeof(double) * (size_t)ctx->n_dofs(), hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts)
+	{
+		if (!ctx || !n_pts)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0 || ctx->n_el <= 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_mesh must be called first");
+		*n_pts = ctx->n_pts;
+		if (!pts)
+			return PFX_OK;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const size_t count = (size_t)(ctx->n_el * ctx->n_pts * 3);
+		pfx_tmp<double> d_p;
+		PFX_HIP(d_p.alloc(count));
+		pfx_status rc = pfx_launch_quadrature_points(ctx, d_p.p);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(pts, d_p.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
 	}

@@ -23,6 +23,7 @@ struct pfx_tables
 	double grad[PFX_MAX_PTS][PFX_MAX_LOC][3];     // d(basis j)/d(ref coord) at point k
 	double ggrad[PFX_MAX_PTS][PFX_MAX_GLOC][3];   // same for the geometry bases
 	double val[PFX_MAX_PTS][PFX_MAX_LOC];         // basis j at point k
+	double gval[PFX_MAX_PTS][PFX_MAX_GLOC];       // geometry basis j at point k
 };
 
 #define PFX_ROWS_PER_GROUP 16
@@ -293,7 +294,8 @@ pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, 
 								  const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = true);
 pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e);                       // strict arithmetic
-pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, double density, const double *d_density_e); // strict arithmetic
+pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e); // strict arithmetic
+pfx_status pfx_launch_quadrature_points(pfx_ctx *ctx, double *d_pts);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
 void pfx_sell_release(pfx_ctx *ctx);

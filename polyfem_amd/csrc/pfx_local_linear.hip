@@ -297,8 +297,8 @@ namespace
 	// (element, local basis); gloc[e][i][d] = sum_q (f_d * (det w rho)) * phi_i(q)
 	template <int NLOC, int NPTS, int BS, int SP>
 	__global__ __launch_bounds__(256) void k_local_rhs(const double *__restrict__ geo, const pfx_tables *__restrict__ tab, int64_t n_el,
-													   double f0, double f1, double f2, double density, const double *__restrict__ density_e,
-													   double *__restrict__ gloc)
+													   double f0, double f1, double f2, const double *__restrict__ force_pts, double density,
+													   const double *__restrict__ density_e, double *__restrict__ gloc)
 	{
 		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 		if (t >= n_el * NLOC)
@@ -314,11 +314,35 @@ namespace
 			const double det = ge[(SP == 1 ? 0 : q) * 10 + 9];
 			const double s = det * tab->w[q] * rho;
 			const double v = tab->val[q][i];
+			// force density: one constant vector, or one value per (element, point) (what problem.rhs() returns in the reference)
+			const double *fq = force_pts ? force_pts + (e * NPTS + q) * BS : f;
 			for (int d = 0; d < BS; ++d)
-				acc[d] += (f[d] * s) * v;
+				acc[d] += (fq[d] * s) * v;
 		}
 		for (int d = 0; d < BS; ++d)
 			gloc[t * BS + d] = acc[d];
+	}
+
+	// physical position of every quadrature point: sum_j N_j^geo(xi_q) x_j  (ElementAssemblyValues.cpp:328-345)
+	template <int NGLOC, int NPTS>
+	__global__ __launch_bounds__(256) void k_quadrature_points(const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
+															   const pfx_tables *__restrict__ tab, int64_t n_el, double *__restrict__ pts)
+	{
+		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (t >= n_el * NPTS)
+			return;
+		const int64_t e = t / NPTS;
+		const int q = (int)(t - e * NPTS);
+		double p[3] = {0, 0, 0};
+		for (int j = 0; j < NGLOC; ++j)
+		{
+			const double nv = tab->gval[q][j];
+			const double *node = xyz + 3 * (int64_t)gconn[e * NGLOC + j];
+			for (int c = 0; c < 3; ++c)
+				p[c] += nv * node[c];
+		}
+		for (int c = 0; c < 3; ++c)
+			pts[t * 3 + c] = p[c];
 	}
 
 	template <int NGLOC, int NPTS>
@@ -342,17 +366,17 @@ namespace
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
-	void launch_rhs(pfx_ctx *ctx, const double *f, double density, const double *d_density_e)
+	void launch_rhs(pfx_ctx *ctx, const double *f, const double *d_force_pts, double density, const double *d_density_e)
 	{
 		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
 		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab);
 		const int64_t n = ctx->n_el * NLOC;
 		if (ctx->bs == 1)
 			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 1, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
-							   ctx->n_el, f[0], 0.0, 0.0, density, d_density_e, ctx->d_gloc);
+							   ctx->n_el, f ? f[0] : 0.0, 0.0, 0.0, d_force_pts, density, d_density_e, ctx->d_gloc);
 		else
 			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 3, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
-							   ctx->n_el, f[0], f[1], f[2], density, d_density_e, ctx->d_gloc);
+							   ctx->n_el, f ? f[0] : 0.0, f ? f[1] : 0.0, f ? f[2] : 0.0, d_force_pts, density, d_density_e, ctx->d_gloc);
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
@@ -457,25 +481,49 @@ pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density
 }
 
 // per-element body-force vectors into ctx->d_gloc (stiffness quadrature rule)
-pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, double density, const double *d_density_e)
+pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e)
 {
 	if (!supported(ctx))
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "rhs assembly: unsupported element kind / quadrature order combination");
 	switch (ctx->kind)
 	{
 	case PFX_P1TET:
-		launch_rhs<4, 4, 1>(ctx, force, density, d_density_e);
+		launch_rhs<4, 4, 1>(ctx, force, d_force_pts, density, d_density_e);
 		break;
 	case PFX_P2TET:
-		launch_rhs<10, 4, 6>(ctx, force, density, d_density_e);
+		launch_rhs<10, 4, 6>(ctx, force, d_force_pts, density, d_density_e);
 		break;
 	case PFX_Q1HEX:
-		launch_rhs<8, 8, 1>(ctx, force, density, d_density_e);
+		launch_rhs<8, 8, 1>(ctx, force, d_force_pts, density, d_density_e);
 		break;
 	default:
-		launch_rhs<27, 8, 27>(ctx, force, density, d_density_e);
+		launch_rhs<27, 8, 27>(ctx, force, d_force_pts, density, d_density_e);
 	}
 	ctx->estate_kind = PFX_ESTATE_NONE;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_launch_quadrature_points(pfx_ctx *ctx, double *d_pts)
+{
+	if (!supported(ctx))
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "quadrature points: unsupported element kind / quadrature order combination");
+	const int64_t n = ctx->n_el * ctx->n_pts;
+	const unsigned grid = (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		hipLaunchKernelGGL((k_quadrature_points<4, 1>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
+		break;
+	case PFX_P2TET:
+		hipLaunchKernelGGL((k_quadrature_points<4, 6>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
+		break;
+	case PFX_Q1HEX:
+		hipLaunchKernelGGL((k_quadrature_points<8, 1>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
+		break;
+	default:
+		hipLaunchKernelGGL((k_quadrature_points<8, 27>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
+	}
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -341,7 +341,10 @@ void fill(int kind, int real_order, pfx_tables *t)
 			t->val[k][j] = basis_value(kind, j, r.p[k]);
 		}
 		for (int j = 0; j < t->n_gloc; ++j)
+		{
 			basis_grad(gkind, j, r.p[k], t->ggrad[k][j]);
+			t->gval[k][j] = basis_value(gkind, j, r.p[k]);
+		}
 	}
 }
 } // namespace

@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
     "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_element_models",
     "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
+    "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev",
 ]
 
 
@@ -125,6 +126,9 @@ def load():
         "pfx_al_enable": [_vp, C.c_double, _vp, _vp],
         "pfx_al_enable_host": [_vp, C.c_double, _pd, _pd],
         "pfx_lumped_mass": [_vp, _pd],
+        "pfx_quadrature_points": [_vp, C.POINTER(C.c_int), _pd],
+        "pfx_assemble_rhs_pointwise": [_vp, _pd, C.c_double, _pd, _pd],
+        "pfx_assemble_rhs_pointwise_dev": [_vp, _vp, C.c_double, _pd, _vp],
         "pfx_build_pattern": [_vp, _pi64],
         "pfx_get_pattern": [_vp, _pi64, _pi32],
         "pfx_get_values": [_vp, _pd],
@@ -437,6 +441,26 @@ class Engine:
         else:
             rho = np.ascontiguousarray(density, dtype=np.float64)
             self._ck(self.L.pfx_assemble_mass(self.h, float(rho[0]), _d(rho)))
+
+    def quadrature_points(self):
+        """Physical positions of the quadrature points of the stiffness rule, shape (n_el, n_pts, 3)."""
+        n_pts = C.c_int()
+        self._ck(self.L.pfx_quadrature_points(self.h, C.byref(n_pts), None))
+        out = np.zeros((self.info().n_el, n_pts.value, 3))
+        self._ck(self.L.pfx_quadrature_points(self.h, C.byref(n_pts), _d(out)))
+        return out
+
+    def assemble_rhs_pointwise(self, force_pts, density=1.0):
+        """Body-force vector for a force density given at every quadrature point, (n_el, n_pts, d)."""
+        f = np.ascontiguousarray(force_pts, dtype=np.float64)
+        inf = self.info()
+        if f.ndim != 3 or f.shape[0] != inf.n_el or f.shape[1] != inf.n_pts:
+            raise ValueError("force_pts must have shape (n_el, n_pts, d)")
+        rho_e = None if np.ndim(density) == 0 else np.ascontiguousarray(density, dtype=np.float64)
+        out = np.zeros(inf.n_dofs)
+        self._ck(self.L.pfx_assemble_rhs_pointwise(self.h, _d(f), float(density) if rho_e is None else float(rho_e[0]),
+                                                   _d(rho_e) if rho_e is not None else None, _d(out)))
+        return out
 
     def assemble_rhs(self, force, density=1.0):
         """RhsAssembler::assemble for a constant body force (one component per dof of a node)."""

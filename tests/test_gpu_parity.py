@@ -903,6 +903,25 @@ def test_isolated_nodes_and_single_element(eng, oracle):
     assert rel_err(eng.gradient(u), oracle.assemble_gradient(one, oracle.NEOHOOKEAN, lam, mu, u)) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
+def test_space_dependent_body_force(eng, oracle, name):
+    """RhsAssembler::assemble with problem.rhs() evaluated per quadrature point (assembler/RhsAssembler.cpp:55-98)."""
+    mesh = MESHES[name]()
+    _setup(eng, mesh, E.LINEAR_ELASTICITY, 1.0, 1.0)
+    pts = eng.quadrature_points()
+    ref_pts = oracle.quadrature_points(mesh)
+    assert pts.shape == ref_pts.shape and np.abs(pts - ref_pts).max() <= 1e-15
+    f = np.stack([np.sin(3 * pts[..., 0]) * pts[..., 1], pts[..., 2] ** 2 - 0.3, np.exp(-pts[..., 0]) + pts[..., 1] * pts[..., 2]], axis=-1)
+    rho_e = 900.0 + 200.0 * (np.arange(mesh.n_el) % 3)
+    for rho in (1000.0, rho_e):
+        got = eng.assemble_rhs_pointwise(f, rho)
+        assert rel_err(got, oracle.assemble_rhs_pointwise(mesh, 3, f, rho)) <= 1e-14
+    const = np.array([0.0, -9.81, 0.5])
+    assert np.array_equal(eng.assemble_rhs_pointwise(np.broadcast_to(const, pts.shape).copy(), 1000.0), eng.assemble_rhs(const, 1000.0))
+    with pytest.raises(ValueError):
+        eng.assemble_rhs_pointwise(f[:, :-1] if f.shape[1] > 1 else f[:-1], 1.0)
+
+
 def test_no_device_memory_drift(oracle):
     """Engines created, driven through every kind of call and closed again leave the free device memory unchanged."""
     import torch

@@ -549,3 +549,17 @@ def test_multi_model_oracle(oracle, kind):
     eps = 1e-6
     fd = (oracle.assemble_energy(mesh, ids, lam, mu, x + eps * d) - oracle.assemble_energy(mesh, ids, lam, mu, x - eps * d)) / (2 * eps)
     assert abs(fd - g @ d) <= 1e-6 * abs(g @ d)
+
+
+@pytest.mark.parametrize("kind", ["p1", "p2", "q1", "q2"])
+def test_pointwise_body_force_oracle(oracle, kind):
+    """The quadrature points lie inside their elements and integrate x exactly; a constant field reproduces the
+    constant-force assembly bit for bit; a linear field f(x) = x gives sum_i rhs_i = integral of x over the unit cube."""
+    mesh = {"p1": lambda: M.cube_tets(3, 1, jitter=0.2, seed=2), "p2": lambda: M.cube_tets(2, 2, jitter=0.2, seed=3),
+            "q1": lambda: M.cube_hexes(2, 1), "q2": lambda: M.cube_hexes(2, 2)}[kind]()
+    pts = oracle.quadrature_points(mesh)
+    assert pts.shape[0] == mesh.n_el and pts.min() > 0.0 and pts.max() < 1.0
+    f = np.array([0.3, -1.0, 2.0])
+    assert np.array_equal(oracle.assemble_rhs(mesh, 3, f, 1000.0), oracle.assemble_rhs_pointwise(mesh, 3, np.broadcast_to(f, pts.shape).copy(), 1000.0))
+    lin = oracle.assemble_rhs_pointwise(mesh, 3, pts, 1.0).reshape(-1, 3).sum(axis=0)
+    assert np.abs(lin - 0.5).max() <= 1e-13
