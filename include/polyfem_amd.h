@@ -95,6 +95,10 @@ pfx_status pfx_set_material(pfx_ctx *ctx, int model, int dim, double lambda, dou
  * Call after pfx_set_mesh; a later pfx_set_mesh or pfx_set_material drops the arrays. */
 pfx_status pfx_set_material_per_element(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu,
 										int64_t n_el);
+/* The same with one (lambda, mu) per element AND quadrature point of the stiffness rule (n_el x n_pts values each, point
+ * fastest): LameParameters::lambda_mu is evaluated at every point in the reference (utils/ElasticityUtils.cpp:490-517;
+ * space-dependent materials).  pfx_quadrature_points gives the positions to evaluate them at. */
+pfx_status pfx_set_material_per_point(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu, int64_t n_el, int n_pts);
 /* HookeLinearElasticity with its `elasticity_tensor`: the symmetric 6 x 6 tensor in Voigt order xx yy zz yz xz xy,
  * row-major, as ElasticityTensor holds it after set_from_entries / set_from_lambda_mu / set_from_young_poisson
  * (utils/ElasticityUtils.cpp:298-413).  Selects the model PFX_HOOKE_LINEAR (pfx_assemble_linear only). */

@@ -1245,6 +1245,108 @@ static int trips_to_csc(int32_t n, const trip *t, int64_t nt, pfo_csc *out)
 static double mat_lambda(const pfo_material *mat, int64_t e) { return mat->lambda_e ? mat->lambda_e[e] : mat->lambda; }
 static double mat_mu(const pfo_material *mat, int64_t e) { return mat->mu_e ? mat->mu_e[e] : mat->mu; }
 
+/* Materials that vary from quadrature point to quadrature point.  Every local quantity is a sum over the points of
+ * terms weighted with da[q], so it is evaluated point by point -- all other weights set to zero, which adds exact zeros
+ * -- with that point's (lambda, mu), and the per-point results are added in point order: the additions the reference's
+ * fused loop performs with lambda_mu() called inside it. */
+static int mat_points(const pfo_material *mat) { return (mat->per_point > 0 && mat->lambda_e && mat->mu_e) ? mat->per_point : 0; }
+static void one_point(const double *da, int n, int q, double *out)
+{
+	for (int k = 0; k < n; ++k)
+		out[k] = k == q ? da[k] : 0.0;
+}
+static void local_linear_elasticity_mat(const pfo_vals *v, int i, int j, const double *da, const pfo_material *mat, int64_t e, double *res)
+{
+	const int np = mat_points(mat);
+	if (!np)
+	{
+		pfo_local_linear_elasticity(v, i, j, da, mat_lambda(mat, e), mat_mu(mat, e), res);
+		return;
+	}
+	double daq[PFO_MAX_PTS], part[9];
+	for (int c = 0; c < 9; ++c)
+		res[c] = 0;
+	for (int q = 0; q < v->n_pts; ++q)
+	{
+		one_point(da, v->n_pts, q, daq);
+		pfo_local_linear_elasticity(v, i, j, daq, mat->lambda_e[e * np + q], mat->mu_e[e * np + q], part);
+		for (int c = 0; c < 9; ++c)
+			res[c] += part[c];
+	}
+}
+static double nl_local_energy(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu);
+static double nl_local_energy_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e)
+{
+	const int np = mat_points(mat);
+	if (!np)
+		return nl_local_energy(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
+	double daq[PFO_MAX_PTS], sum = 0;
+	for (int q = 0; q < v->n_pts; ++q)
+	{
+		one_point(da, v->n_pts, q, daq);
+		sum += nl_local_energy(model, v, daq, ld, mat->lambda_e[e * np + q], mat->mu_e[e * np + q]);
+	}
+	return sum;
+}
+static void nl_local_grad(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *G)
+{
+	if (model == PFO_NEOHOOKEAN)
+		pfo_local_neohookean_grad(v, da, ld, lambda, mu, G);
+	else if (model == PFO_SAINT_VENANT)
+		pfo_local_saint_venant_grad(v, da, ld, lambda, mu, G);
+	else
+		pfo_local_linear_elasticity_grad(v, da, ld, lambda, mu, G);
+}
+static void nl_local_hessian(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *H)
+{
+	if (model == PFO_NEOHOOKEAN)
+		pfo_local_neohookean_hessian(v, da, ld, lambda, mu, H);
+	else if (model == PFO_SAINT_VENANT)
+		pfo_local_saint_venant_hessian(v, da, ld, lambda, mu, H);
+	else
+		pfo_local_linear_elasticity_hessian(v, da, lambda, mu, H);
+}
+static void nl_local_grad_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e, double *G)
+{
+	const int np = mat_points(mat), N = v->n_loc * 3;
+	if (!np)
+	{
+		nl_local_grad(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
+		return;
+	}
+	double daq[PFO_MAX_PTS], part[3 * PFO_MAX_LOC];
+	for (int c = 0; c < N; ++c)
+		G[c] = 0;
+	for (int q = 0; q < v->n_pts; ++q)
+	{
+		one_point(da, v->n_pts, q, daq);
+		nl_local_grad(model, v, daq, ld, mat->lambda_e[e * np + q], mat->mu_e[e * np + q], part);
+		for (int c = 0; c < N; ++c)
+			G[c] += part[c];
+	}
+}
+static void nl_local_hessian_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e, double *H)
+{
+	const int np = mat_points(mat), N = v->n_loc * 3;
+	if (!np)
+	{
+		nl_local_hessian(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
+		return;
+	}
+	double daq[PFO_MAX_PTS];
+	double *part = (double *)malloc(sizeof(double) * (size_t)(N * N));
+	for (int c = 0; c < N * N; ++c)
+		H[c] = 0;
+	for (int q = 0; q < v->n_pts; ++q)
+	{
+		one_point(da, v->n_pts, q, daq);
+		nl_local_hessian(model, v, daq, ld, mat->lambda_e[e * np + q], mat->mu_e[e * np + q], part);
+		for (int c = 0; c < N * N; ++c)
+			H[c] += part[c];
+	}
+	free(part);
+}
+
 static int block_size(const pfo_material *mat) { return mat->model == PFO_LAPLACIAN ? 1 : mat->dim; }
 
 typedef struct
@@ -1370,7 +1472,7 @@ static void *job_run(void *arg)
 					else if (mat->model == PFO_HOOKE_LINEAR)
 						pfo_local_hooke(v, i, j, da, mat->tensor, sv);
 					else
-						pfo_local_linear_elasticity(v, i, j, da, mat_lambda(mat, e), mat_mu(mat, e), sv);
+						local_linear_elasticity_mat(v, i, j, da, mat, e, sv);
 					for (int n = 0; n < size; ++n)
 						for (int m = 0; m < size; ++m)
 						{
@@ -1391,18 +1493,13 @@ static void *job_run(void *arg)
 			if (jb->mode == 1)
 			{
 				/* Assembler.cpp:657-668 */
-				const double val = nl_local_energy(mat_model(mat, e), v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
+				const double val = nl_local_energy_mat(mat_model(mat, e), v, da, ld, mat, e);
 				jb->scalar += val;
 			}
 			else if (jb->mode == 2)
 			{
 				/* Assembler.cpp:465-492 */
-				if (mat_model(mat, e) == PFO_NEOHOOKEAN)
-					pfo_local_neohookean_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
-				else if (mat_model(mat, e) == PFO_SAINT_VENANT)
-					pfo_local_saint_venant_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
-				else
-					pfo_local_linear_elasticity_grad(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
+				nl_local_grad_mat(mat_model(mat, e), v, da, ld, mat, e, G);
 				for (int j = 0; j < n_loc; ++j)
 					for (int m = 0; m < size; ++m)
 					{
@@ -1415,12 +1512,7 @@ static void *job_run(void *arg)
 			else
 			{
 				/* Assembler.cpp:550-616 : every entry, order (i, j, n, m) */
-				if (mat_model(mat, e) == PFO_NEOHOOKEAN)
-					pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
-				else if (mat_model(mat, e) == PFO_SAINT_VENANT)
-					pfo_local_saint_venant_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
-				else
-					pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
+				nl_local_hessian_mat(mat_model(mat, e), v, da, ld, mat, e, H);
 				const int N = n_loc * size;
 				if (jb->mode == 4) /* Assembler.cpp:554-555 */
 					pfo_project_to_psd(H, N);
@@ -1928,12 +2020,7 @@ int pfo_assemble_hessian_cached(const pfo_mesh *mesh, const pfo_material *mat, c
 		for (int k = 0; k < quad.n_pts; ++k)
 			da[k] = v->det[k] * quad.w[k];
 		gather_local_disp(mesh, e, n_loc, x, ld);
-		if (mat_model(mat, e) == PFO_NEOHOOKEAN)
-			pfo_local_neohookean_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
-		else if (mat_model(mat, e) == PFO_SAINT_VENANT)
-			pfo_local_saint_venant_hessian(v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
-		else
-			pfo_local_linear_elasticity_hessian(v, da, mat_lambda(mat, e), mat_mu(mat, e), H);
+		nl_local_hessian_mat(mat_model(mat, e), v, da, ld, mat, e, H);
 		const int32_t *idx = mesh->conn + e * n_loc;
 		for (int i = 0; i < n_loc; ++i)
 			for (int j = 0; j < n_loc; ++j)

@@ -67,6 +67,9 @@ typedef struct
 	                                  utils/ElasticityUtils.cpp:490-517); NULL = uniform */
 	const double *tensor;          /* PFO_HOOKE_LINEAR: the symmetric 6 x 6 elasticity tensor, row-major, Voigt order
 	                                  xx yy zz yz xz xy (ElasticityTensor, utils/ElasticityUtils.cpp:298-413) */
+	int per_point;                 /* > 0: lambda_e / mu_e hold one value per (element, quadrature point), per_point =
+	                                  points per element (LameParameters::lambda_mu is evaluated at every point,
+	                                  utils/ElasticityUtils.cpp:490-517); 0: one value per element */
 	const int32_t *model_e;        /* PFO_MULTI_MODEL: the model of every element (MultiModel::multi_material_models_,
 	                                  assembler/MultiModel.cpp:42-96): LINEAR_ELASTICITY, NEOHOOKEAN or SAINT_VENANT */
 } pfo_material;

@@ -43,11 +43,12 @@ class MeshS(C.Structure):
 class Material(C.Structure):
     _fields_ = [("model", C.c_int), ("dim", C.c_int), ("lambda_", C.c_double), ("mu", C.c_double),
                 ("lambda_e", C.POINTER(C.c_double)), ("mu_e", C.POINTER(C.c_double)), ("tensor", C.POINTER(C.c_double)),
-                ("model_e", C.POINTER(C.c_int32))]
+                ("per_point", C.c_int), ("model_e", C.POINTER(C.c_int32))]
 
 
 def make_material(model: int, lam, mu):
-    """Uniform Lame parameters (scalars) or one value per element (arrays); for HOOKE_LINEAR `lam` is the symmetric
+    """Uniform Lame parameters (scalars), one value per element (1-D arrays) or per quadrature point (2-D arrays, n_el x
+    n_pts); for HOOKE_LINEAR `lam` is the symmetric
     6 x 6 elasticity tensor (and `mu` is ignored).  Returns (Material, keep-alive)."""
     if np.ndim(model) == 1:  # MultiModel: one model id per element
         me = np.ascontiguousarray(model, dtype=np.int32)
@@ -58,12 +59,15 @@ def make_material(model: int, lam, mu):
     if model == HOOKE_LINEAR:
         t = np.ascontiguousarray(lam, dtype=np.float64).reshape(6, 6)
         assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
-        return Material(model, 3, 0.0, 0.0, None, None, _dp(t), None), t
+        return Material(model, 3, 0.0, 0.0, None, None, _dp(t), 0, None), t
     if np.ndim(lam) == 0:
-        return Material(model, 3, float(lam), float(mu), None, None, None, None), None
+        return Material(model, 3, float(lam), float(mu), None, None, None, 0, None), None
     la = np.ascontiguousarray(lam, dtype=np.float64)
     ma = np.ascontiguousarray(mu, dtype=np.float64)
-    return Material(model, 3, float(la[0]), float(ma[0]), _dp(la), _dp(ma), None, None), (la, ma)
+    # (n_el,) = one value per element; (n_el, n_pts) = one value per quadrature point
+    per_point = int(la.shape[1]) if la.ndim == 2 else 0
+    assert la.shape == ma.shape
+    return Material(model, 3, float(la.flat[0]), float(ma.flat[0]), _dp(la), _dp(ma), None, per_point, None), (la, ma)
 
 
 def elasticity_tensor(lam=None, mu=None, entries=None):

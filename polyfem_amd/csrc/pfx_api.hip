@@ -317,6 +317,7 @@ extern "C"
 		free_dev(ctx->d_lambda_e);
 		free_dev(ctx->d_mu_e);
 		free_dev(ctx->d_model_e);
+		ctx->mat_per_point = 0;
 		return PFX_OK;
 	}
 
@@ -367,6 +368,28 @@ extern "C"
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		ctx->model = PFX_MULTI_MODEL;
 		ctx->estate_kind = PFX_ESTATE_NONE;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_material_per_point(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu, int64_t n_el, int n_pts)
+	{
+		if (!ctx || !lambda || !mu)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0 || n_el != ctx->n_el || n_pts != ctx->n_pts)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_material_per_point: call pfx_set_mesh first and pass one value per element and quadrature point");
+		if (model == PFX_LAPLACIAN)
+			PFX_FAIL(PFX_ERR_ARG, "the Laplacian has no material parameters");
+		pfx_status rc = pfx_set_material(ctx, model, dim, n_el > 0 ? lambda[0] : 0.0, n_el > 0 ? mu[0] : 0.0);
+		if (rc)
+			return rc;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const int64_t count = n_el * n_pts;
+		if (pfx_alloc(ctx, &ctx->d_lambda_e, count) || pfx_alloc(ctx, &ctx->d_mu_e, count))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemcpyAsync(ctx->d_lambda_e, lambda, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_mu_e, mu, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		ctx->mat_per_point = 1;
 		return PFX_OK;
 	}
 

@@ -93,7 +93,8 @@ struct pfx_ctx
 	bool have_mask = false;
 
 	// scratch for the two-pass (local blocks, then per-row sums) assembly
-	double *d_lambda_e = nullptr, *d_mu_e = nullptr; // per-element Lame parameters (null: uniform ctx->lambda, ctx->mu)
+	double *d_lambda_e = nullptr, *d_mu_e = nullptr; // per-element or per-point Lame parameters (null: uniform ctx->lambda, ctx->mu)
+	int mat_per_point = 0; // 1: the two arrays hold one value per (element, quadrature point)
 	double *d_kloc = nullptr;   // projected element Hessians (project_to_psd only): n_el * n_loc(n_loc+1)/2 * 9
 	int64_t kloc_count = 0;
 	double *d_estate = nullptr; // per-element state the row assembly computes its blocks from (n_el * 22 * n_pts doubles)

@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
     "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_element_models",
     "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
-    "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev",
+    "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev", "pfx_set_material_per_point",
 ]
 
 
@@ -121,6 +121,7 @@ def load():
         "pfx_set_mesh": [_vp, _i32, _i64, _i64, _i64, _pi32, _pi32, _pd, _i32],
         "pfx_set_material": [_vp, _i32, _i32, _dbl, _dbl],
         "pfx_set_material_per_element": [_vp, _i32, _i32, _pd, _pd, _i64],
+        "pfx_set_material_per_point": [_vp, _i32, _i32, _pd, _pd, _i64, _i32],
         "pfx_set_elasticity_tensor": [_vp, _i32, _pd],
         "pfx_set_element_models": [_vp, _pi32, _i64],
         "pfx_al_enable": [_vp, C.c_double, _vp, _vp],
@@ -246,14 +247,18 @@ class Engine:
         self.mesh = mesh
 
     def set_material(self, model: int, lam=1.0, mu=1.0, dim: int = 3):
-        """Scalars: uniform Lame parameters; arrays: one value per element (multi-material bodies)."""
+        """Scalars: uniform Lame parameters; 1-D arrays: one value per element (multi-material bodies); 2-D arrays
+        (n_el, n_pts): one value per quadrature point (space-dependent materials)."""
         if np.ndim(lam) == 0:
             self._ck(self.L.pfx_set_material(self.h, model, dim, float(lam), float(mu)))
         else:
             la = np.ascontiguousarray(lam, dtype=np.float64)
             ma = np.ascontiguousarray(mu, dtype=np.float64)
-            assert la.shape == ma.shape and la.ndim == 1
-            self._ck(self.L.pfx_set_material_per_element(self.h, model, dim, _d(la), _d(ma), la.size))
+            assert la.shape == ma.shape and la.ndim in (1, 2)
+            if la.ndim == 1:
+                self._ck(self.L.pfx_set_material_per_element(self.h, model, dim, _d(la), _d(ma), la.size))
+            else:
+                self._ck(self.L.pfx_set_material_per_point(self.h, model, dim, _d(la), _d(ma), la.shape[0], la.shape[1]))
         self.model = model
 
     def set_element_models(self, models):

@@ -922,6 +922,45 @@ def test_space_dependent_body_force(eng, oracle, name):
         eng.assemble_rhs_pointwise(f[:, :-1] if f.shape[1] > 1 else f[:-1], 1.0)
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
+def test_space_dependent_materials(eng, oracle, name):
+    """LameParameters::lambda_mu evaluated at every quadrature point (utils/ElasticityUtils.cpp:490-517): linear
+    stiffness (bit-exact pattern), energy, gradient, Hessian for the three elastic models."""
+    mesh = MESHES[name]()
+    eng.set_mesh(mesh)
+    eng.set_material(E.LINEAR_ELASTICITY, 1.0, 1.0)
+    pts = eng.quadrature_points()
+    young = 1e5 * (1.0 + 0.5 * pts[..., 0] + 0.25 * np.sin(4 * pts[..., 1]))
+    nu = 0.25 + 0.1 * pts[..., 2]
+    lam = young * nu / ((1 + nu) * (1 - 2 * nu))
+    mu = young / (2 * (1 + nu))
+    eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+    eng.build_pattern()
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner)
+    assert rel_err(v, vals) <= TOL
+    h = 1.0 / round((mesh.n_el / (6 if mesh.kind < 2 else 1)) ** (1 / 3))
+    x = M.seeded_displacement(mesh, 3, 2e-2 * h, seed=11)
+    for mid in (E.NEOHOOKEAN, E.SAINT_VENANT, E.LINEAR_ELASTICITY):
+        eng.set_material(mid, lam, mu)
+        e_ref = oracle.assemble_energy(mesh, mid, lam, mu, x)
+        assert abs(eng.energy(x) - e_ref) <= TOL * abs(e_ref)
+        assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, mid, lam, mu, x)) <= TOL
+        assert rel_err(eng.hessian(x), oracle.assemble_hessian(mesh, mid, lam, mu, x)[2]) <= TOL
+    # per-point arrays that are constant inside every element reproduce the per-element interface
+    le = lam[:, 0].copy()
+    me = mu[:, 0].copy()
+    eng.set_material(E.NEOHOOKEAN, np.repeat(le[:, None], lam.shape[1], axis=1), np.repeat(me[:, None], lam.shape[1], axis=1))
+    g_pp = eng.gradient(x)
+    eng.set_material(E.NEOHOOKEAN, le, me)
+    assert np.array_equal(g_pp, eng.gradient(x))
+    with pytest.raises(E.PfxError):
+        eng.set_material(E.NEOHOOKEAN, lam[:, :-1] if lam.shape[1] > 1 else lam[:-1], mu[:, :-1] if lam.shape[1] > 1 else mu[:-1])
+    eng.set_material(E.LINEAR_ELASTICITY, 1.0, 1.0)
+
+
 def test_no_device_memory_drift(oracle):
     """Engines created, driven through every kind of call and closed again leave the free device memory unchanged."""
     import torch

@@ -563,3 +563,30 @@ def test_pointwise_body_force_oracle(oracle, kind):
     assert np.array_equal(oracle.assemble_rhs(mesh, 3, f, 1000.0), oracle.assemble_rhs_pointwise(mesh, 3, np.broadcast_to(f, pts.shape).copy(), 1000.0))
     lin = oracle.assemble_rhs_pointwise(mesh, 3, pts, 1.0).reshape(-1, 3).sum(axis=0)
     assert np.abs(lin - 0.5).max() <= 1e-13
+
+
+@pytest.mark.parametrize("kind", ["p2", "q2"])
+def test_per_point_materials_oracle(oracle, kind):
+    """Materials given per quadrature point: uniform arrays reproduce the scalar results bit for bit (the point-by-point
+    evaluation adds exact zeros only), and with varying values the gradient is the derivative of the energy."""
+    mesh = M.cube_tets(2, 2, jitter=0.2, seed=3) if kind == "p2" else M.cube_hexes(2, 2)
+    n = mesh.n_nodes * 3
+    lam, mu = oracle.lame(2e4, 0.3)
+    pts = oracle.quadrature_points(mesh)
+    L, Mu = np.full(pts.shape[:2], lam), np.full(pts.shape[:2], mu)
+    x = M.seeded_displacement(mesh, 3, 1e-2)
+    for mid in (oracle.NEOHOOKEAN, oracle.SAINT_VENANT, oracle.LINEAR_ELASTICITY):
+        assert oracle.assemble_energy(mesh, mid, lam, mu, x) == oracle.assemble_energy(mesh, mid, L, Mu, x)
+        assert np.array_equal(oracle.assemble_gradient(mesh, mid, lam, mu, x), oracle.assemble_gradient(mesh, mid, L, Mu, x))
+        assert np.array_equal(oracle.assemble_hessian(mesh, mid, lam, mu, x)[2], oracle.assemble_hessian(mesh, mid, L, Mu, x)[2])
+    a, b = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, L, Mu)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    Lv, Mv = L * (1.0 + pts[..., 0]), Mu * (1.0 + 0.5 * pts[..., 1])
+    d = np.random.default_rng(4).standard_normal(n)
+    eps = 1e-6
+    for mid in (oracle.NEOHOOKEAN, oracle.SAINT_VENANT):
+        g = oracle.assemble_gradient(mesh, mid, Lv, Mv, x)
+        fd = (oracle.assemble_energy(mesh, mid, Lv, Mv, x + eps * d) - oracle.assemble_energy(mesh, mid, Lv, Mv, x - eps * d)) / (2 * eps)
+        assert abs(fd - g @ d) <= 1e-6 * abs(g @ d)
+        # a material that is stiffer everywhere stores more energy
+        assert oracle.assemble_energy(mesh, mid, Lv, Mv, x) > oracle.assemble_energy(mesh, mid, lam, mu, x)
