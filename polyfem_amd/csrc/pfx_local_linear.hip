@@ -81,14 +81,14 @@ namespace
 
 	// block of the pair (i, j), j <= i : out[m*BS+n] = (row component m of basis i, column component n of basis j),
 	// values with |v| < 1e-30 replaced by an exact zero (they are absent from the reference's matrix)
-	template <int NLOC, int NPTS, int BS, int SP>
+	// PP: the material arrays hold one value per (element, point) instead of one per element
+	template <int NLOC, int NPTS, int BS, int SP, bool PP = false>
 	struct linear_block
 	{
 		const double *geo;
 		const pfx_tables *tab;
 		double lambda, mu;                // uniform Lame parameters, or
 		const double *lambda_e, *mu_e;    // one value per element or per (element, point) (LameParameters::lambda_mu, utils/ElasticityUtils.cpp:490-517)
-		int per_point;                    // 1: per (element, point)
 		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + NPTS; // grad[k][i][3], then w[k]
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
@@ -110,7 +110,7 @@ namespace
 					const d2 v = ge[q];
 					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 				}
-			double lambda = lambda_e ? lambda_e[per_point ? (int64_t)e * NPTS : e] : this->lambda, mu = mu_e ? mu_e[per_point ? (int64_t)e * NPTS : e] : this->mu;
+			double lambda = lambda_e ? lambda_e[PP ? (int64_t)e * NPTS : e] : this->lambda, mu = mu_e ? mu_e[PP ? (int64_t)e * NPTS : e] : this->mu;
 			double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 			for (int k = 0; k < NPTS; ++k)
 			{
@@ -121,7 +121,7 @@ namespace
 						jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 					}
 				const double dak = jt[9] * lds[NPTS * NLOC * 3 + k]; // det * weight
-				if (per_point && k > 0)
+				if (PP && k > 0)
 					lambda = lambda_e[(int64_t)e * NPTS + k], mu = mu_e[(int64_t)e * NPTS + k];
 				const double *ri = lds + (k * NLOC + i) * 3, *rj = lds + (k * NLOC + j) * 3;
 				double gi[3], gj[3];
@@ -389,9 +389,11 @@ namespace
 		if (ctx->model == PFX_HOOKE_LINEAR)
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, hooke_block<NLOC, NPTS, SP>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, write_mask);
 		else if (ctx->bs == 1)
-			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->mat_per_point}, write_mask);
+			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
+		else if (ctx->mat_per_point && ctx->d_lambda_e)
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP, true>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->mat_per_point}, write_mask);
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 	}
 
 	bool supported(const pfx_ctx *ctx)

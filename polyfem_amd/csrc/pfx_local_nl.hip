@@ -91,11 +91,12 @@ namespace
 		__host__ __device__ static constexpr int f_at(int k) { return affine ? 10 + 12 * k : 22 * k + 10; }
 	};
 
-	template <int NLOC, int NGLOC, int NPTS, int TPE, int MODEL, int BLOCK>
+	// PP: the material arrays hold one value per (element, point) instead of one per element
+	template <int NLOC, int NGLOC, int NPTS, int TPE, int MODEL, int BLOCK, bool PP>
 	__global__ __launch_bounds__(BLOCK) void k_local_nl(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
 																   const double *__restrict__ xyz, const double *__restrict__ u,
 																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u, double mu_u,
-																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e, int per_point, const uint8_t *__restrict__ model_e,
+																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e, const uint8_t *__restrict__ model_e,
 																   int want_e, int want_g, int want_h,
 																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
 																   int *__restrict__ flag)
@@ -111,7 +112,7 @@ namespace
 		nl_smem<NLOC, NGLOC, NPTS> &s = sm[grp];
 		// LameParameters::lambda_mu (utils/ElasticityUtils.cpp:490-517): one value, or one per element
 		// ... or one per (element, quadrature point)
-		const double lambda_el = (lambda_e && active) ? lambda_e[per_point ? e * NPTS : e] : lambda_u, mu_el = (mu_e && active) ? mu_e[per_point ? e * NPTS : e] : mu_u;
+		const double lambda_el = (lambda_e && active) ? lambda_e[PP ? e * NPTS : e] : lambda_u, mu_el = (mu_e && active) ? mu_e[PP ? e * NPTS : e] : mu_u;
 		const int model = (MODEL == M_MULTI) ? (active ? (int)model_e[e] : (int)M_LINEAR) : MODEL;
 
 		if (active)
@@ -167,7 +168,7 @@ namespace
 				const double *F = &s.F[9 * k];
 				double *dJ = &s.dJ[9 * k];
 				const double da = s.da[k];
-				const double lambda = per_point ? lambda_e[e * NPTS + k] : lambda_el, mu = per_point ? mu_e[e * NPTS + k] : mu_el;
+				const double lambda = PP ? lambda_e[e * NPTS + k] : lambda_el, mu = PP ? mu_e[e * NPTS + k] : mu_el;
 				if (model == M_NEO)
 				{
 					// cofactor matrix: dJ(r,c) = d det / d F(r,c)
@@ -420,10 +421,18 @@ namespace
 	{
 		constexpr int EPB = BLOCK / TPE;
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
-#define PFX_LOCAL_NL(MODEL_)                                                                                                              \
-	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
-					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->mat_per_point, ctx->d_model_e, (int)en, (int)gr, (int)he,     \
+#define PFX_LOCAL_NL_PP(MODEL_, PP_)                                                                                                              \
+	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK, PP_>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
+					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, (int)en, (int)gr, (int)he,     \
 					   ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
+#define PFX_LOCAL_NL(MODEL_)                               \
+	do                                                     \
+	{                                                      \
+		if (ctx->mat_per_point && ctx->d_lambda_e)         \
+			PFX_LOCAL_NL_PP(MODEL_, true);                 \
+		else                                               \
+			PFX_LOCAL_NL_PP(MODEL_, false);                \
+	} while (0)
 		if (ctx->model == PFX_NEOHOOKEAN)
 			PFX_LOCAL_NL(M_NEO);
 		else if (ctx->model == PFX_SAINT_VENANT)
@@ -433,6 +442,7 @@ namespace
 		else
 			PFX_LOCAL_NL(M_LINEAR);
 #undef PFX_LOCAL_NL
+#undef PFX_LOCAL_NL_PP
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
