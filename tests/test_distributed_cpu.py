@@ -31,6 +31,8 @@ def _worker(rank, world, port, case, ret):
         from tests.dist_helpers import OracleOps, csc_tuple_to_csr
         if case == "laplace_p1":
             mesh, model, bs = M.cube_tets(5, 1), O.LAPLACIAN, 1
+        elif case == "elastic_q2":
+            mesh, model, bs = M.cube_hexes(2, 2), O.LINEAR_ELASTICITY, 3
         else:
             mesh, model, bs = M.cube_tets(3, 2, jitter=0.1), O.LINEAR_ELASTICITY, 3
         lam, mu = O.lame(1e5, 0.3)
@@ -88,7 +90,7 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "laplace_p1"), (2, "elastic_p2"), (3, "elastic_p2")])
+@pytest.mark.parametrize("world,case", [(2, "laplace_p1"), (2, "elastic_p2"), (3, "elastic_p2"), (2, "elastic_q2"), (4, "laplace_p1")])
 def test_distributed_cg_gloo(world, case):
     port = _free_port()
     with mp.Manager() as mgr:
