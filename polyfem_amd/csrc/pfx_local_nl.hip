@@ -296,6 +296,105 @@ namespace
 		}
 	}
 
+	// Energy only (the line search asks for nothing else): one THREAD per element, everything in registers, the points
+	// visited in order so that the element's energy is the same sum as in k_local_nl.  No LDS, no barriers: 1 M P2 tets
+	// take a fraction of the fused kernel's time.  The reference-gradient tables are read through the constant path
+	// (every lane reads the same entry).
+	template <int NLOC, int NGLOC, int NPTS, int MODEL, bool PP>
+	__global__ __launch_bounds__(256) void k_local_energy(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
+															   const double *__restrict__ u, const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u,
+															   double mu_u, const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
+															   const uint8_t *__restrict__ model_e, double *__restrict__ eloc, int *__restrict__ flag)
+	{
+		const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (e >= n_el)
+			return;
+		const int model = (MODEL == M_MULTI) ? (int)model_e[e] : MODEL;
+		double xs[NGLOC * 3];
+		for (int j = 0; j < NGLOC; ++j)
+		{
+			const int64_t gv = gconn[e * NGLOC + j];
+			xs[3 * j] = xyz[3 * gv], xs[3 * j + 1] = xyz[3 * gv + 1], xs[3 * j + 2] = xyz[3 * gv + 2];
+		}
+		int32_t nd[NLOC];
+		for (int i = 0; i < NLOC; ++i)
+			nd[i] = conn[e * NLOC + i];
+		double en = 0.0;
+		bool bad = false;
+		double jt[9], det = 0.0;
+		for (int k = 0; k < NPTS; ++k)
+		{
+			if (k == 0 || NGLOC != 4) // affine geometry: one Jacobian per element
+			{
+				double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+				for (int j = 0; j < NGLOC; ++j)
+					for (int r = 0; r < 3; ++r)
+						for (int c = 0; c < 3; ++c)
+							tmp[3 * r + c] += tab->ggrad[NGLOC == 4 ? 0 : k][j][r] * xs[3 * j + c];
+				inv3_transposed_det(tmp, jt, &det);
+			}
+			const double da = det * tab->w[k];
+			double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			if (model != M_LINEAR)
+				F[0] = F[4] = F[8] = 1.0;
+			for (int i = 0; i < NLOC; ++i)
+			{
+				const double g0 = tab->grad[k][i][0], g1 = tab->grad[k][i][1], g2 = tab->grad[k][i][2];
+				double G[3];
+				for (int c = 0; c < 3; ++c)
+					G[c] = g0 * jt[c] + g1 * jt[3 + c] + g2 * jt[6 + c];
+				const double *ui = u + 3 * (int64_t)nd[i];
+				for (int d = 0; d < 3; ++d)
+					for (int c = 0; c < 3; ++c)
+						F[3 * d + c] += ui[d] * G[c];
+			}
+			const double lambda = lambda_e ? lambda_e[PP ? e * NPTS + k : e] : lambda_u, mu = mu_e ? mu_e[PP ? e * NPTS + k : e] : mu_u;
+			if (model == M_NEO)
+			{
+				const double J = F[0] * (F[4] * F[8] - F[5] * F[7]) + F[1] * (F[5] * F[6] - F[3] * F[8]) + F[2] * (F[3] * F[7] - F[4] * F[6]);
+				if (!(J > 0.0))
+					bad = true;
+				const double lj = log(J);
+				double tr = 0;
+				for (int q = 0; q < 9; ++q)
+					tr += F[q] * F[q];
+				en += (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+			}
+			else if (model == M_STVK)
+			{
+				double tr = 0, se = 0;
+				double E[9];
+				for (int r = 0; r < 3; ++r)
+					for (int c = 0; c < 3; ++c)
+						E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
+				tr = E[0] + E[4] + E[8];
+				for (int q = 0; q < 9; ++q)
+				{
+					double S = 2 * mu * E[q];
+					if (q == 0 || q == 4 || q == 8)
+						S += lambda * tr;
+					se += S * E[q];
+				}
+				en += se / 2 * da;
+			}
+			else
+			{
+				double ee = 0, eps[9];
+				for (int r = 0; r < 3; ++r)
+					for (int c = 0; c < 3; ++c)
+					{
+						eps[3 * r + c] = (F[3 * r + c] + F[3 * c + r]) / 2;
+						ee += eps[3 * r + c] * eps[3 * r + c];
+					}
+				const double tr = eps[0] + eps[4] + eps[8];
+				en += (mu * ee + lambda / 2 * tr * tr) * da;
+			}
+		}
+		eloc[e] = en;
+		if (bad)
+			atomicOr(flag, 1);
+	}
+
 	// H_ij for the pair (i, j), j <= i : out[m*3+n] = d2 E / d u_{i,m} d u_{j,n}
 	template <int NLOC, int NGLOC, int NPTS, int MODEL>
 	struct nl_block
@@ -421,6 +520,32 @@ namespace
 	{
 		constexpr int EPB = BLOCK / TPE;
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
+		if (en && !gr && !he && NLOC <= 10) // energy alone: the register-only kernel (the 27-node elements keep the fused one)
+		{
+			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
+#define PFX_LOCAL_E_PP(MODEL_, PP_)                                                                                                                   \
+	hipLaunchKernelGGL((k_local_energy<NLOC, NGLOC, NPTS, MODEL_, PP_>), dim3(eb), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, \
+					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_eloc, ctx->d_flag)
+#define PFX_LOCAL_E(MODEL_)                            \
+	do                                                 \
+	{                                                  \
+		if (ctx->mat_per_point && ctx->d_lambda_e)     \
+			PFX_LOCAL_E_PP(MODEL_, true);              \
+		else                                           \
+			PFX_LOCAL_E_PP(MODEL_, false);             \
+	} while (0)
+			if (ctx->model == PFX_NEOHOOKEAN)
+				PFX_LOCAL_E(M_NEO);
+			else if (ctx->model == PFX_SAINT_VENANT)
+				PFX_LOCAL_E(M_STVK);
+			else if (ctx->model == PFX_MULTI_MODEL)
+				PFX_LOCAL_E(M_MULTI);
+			else
+				PFX_LOCAL_E(M_LINEAR);
+#undef PFX_LOCAL_E
+#undef PFX_LOCAL_E_PP
+			return;
+		}
 #define PFX_LOCAL_NL_PP(MODEL_, PP_)                                                                                                              \
 	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK, PP_>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
 					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, (int)en, (int)gr, (int)he,     \
