@@ -395,6 +395,157 @@ namespace
 			atomicOr(flag, 1);
 	}
 
+	// The same register-only scheme for the gradient (WG) and / or the per-point state the row assembly builds the Hessian
+	// from (WH): one thread per element; the energy comes for free.  Same formulas and per-element summation order as
+	// k_local_nl, which stays in use for the 27-node elements (their 81 gradient accumulators do not fit in registers).
+	template <int NLOC, int NGLOC, int NPTS, int MODEL, bool PP, bool WG, bool WH>
+	__global__ __launch_bounds__(256) void k_local_reg(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
+															const double *__restrict__ u, const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u,
+															double mu_u, const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
+															const uint8_t *__restrict__ model_e, double *__restrict__ eloc, double *__restrict__ gloc,
+															double *__restrict__ estate, int *__restrict__ flag)
+	{
+		typedef nl_state<NGLOC, NPTS> ST;
+		const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (e >= n_el)
+			return;
+		const int model = (MODEL == M_MULTI) ? (int)model_e[e] : MODEL;
+		double xs[NGLOC * 3];
+		for (int j = 0; j < NGLOC; ++j)
+		{
+			const int64_t gv = gconn[e * NGLOC + j];
+			xs[3 * j] = xyz[3 * gv], xs[3 * j + 1] = xyz[3 * gv + 1], xs[3 * j + 2] = xyz[3 * gv + 2];
+		}
+		int32_t nd[NLOC];
+		for (int i = 0; i < NLOC; ++i)
+			nd[i] = conn[e * NLOC + i];
+		double g[WG ? NLOC * 3 : 1];
+		if (WG)
+			for (int t = 0; t < NLOC * 3; ++t)
+				g[t] = 0.0;
+		double *st = estate + e * (int64_t)ST::stride;
+		double en = 0.0;
+		bool bad = false;
+		double jt[9], det = 0.0;
+		for (int k = 0; k < NPTS; ++k)
+		{
+			if (k == 0 || NGLOC != 4)
+			{
+				double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+				for (int j = 0; j < NGLOC; ++j)
+					for (int r = 0; r < 3; ++r)
+						for (int c = 0; c < 3; ++c)
+							tmp[3 * r + c] += tab->ggrad[NGLOC == 4 ? 0 : k][j][r] * xs[3 * j + c];
+				inv3_transposed_det(tmp, jt, &det);
+				if (WH)
+				{
+					for (int q = 0; q < 9; ++q)
+						st[ST::jt_at(k) + q] = jt[q];
+					st[ST::jt_at(k) + 9] = (double)model;
+				}
+			}
+			const double da = det * tab->w[k];
+			double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			if (model != M_LINEAR)
+				F[0] = F[4] = F[8] = 1.0;
+			for (int i = 0; i < NLOC; ++i)
+			{
+				const double g0 = tab->grad[k][i][0], g1 = tab->grad[k][i][1], g2 = tab->grad[k][i][2];
+				double G[3];
+				for (int c = 0; c < 3; ++c)
+					G[c] = g0 * jt[c] + g1 * jt[3 + c] + g2 * jt[6 + c];
+				const double *ui = u + 3 * (int64_t)nd[i];
+				for (int d = 0; d < 3; ++d)
+					for (int c = 0; c < 3; ++c)
+						F[3 * d + c] += ui[d] * G[c];
+			}
+			const double lambda = lambda_e ? lambda_e[PP ? e * NPTS + k : e] : lambda_u, mu = mu_e ? mu_e[PP ? e * NPTS + k : e] : mu_u;
+			double dJ[9], c0, c1, c2; // as s.dJ / s.coef of k_local_nl
+			if (model == M_NEO)
+			{
+				dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
+				dJ[3] = F[2] * F[7] - F[1] * F[8], dJ[4] = F[0] * F[8] - F[2] * F[6], dJ[5] = F[1] * F[6] - F[0] * F[7];
+				dJ[6] = F[1] * F[5] - F[2] * F[4], dJ[7] = F[2] * F[3] - F[0] * F[5], dJ[8] = F[0] * F[4] - F[1] * F[3];
+				const double J = F[0] * dJ[0] + F[1] * dJ[1] + F[2] * dJ[2];
+				if (!(J > 0.0))
+					bad = true;
+				const double lj = log(J);
+				double tr = 0;
+				for (int q = 0; q < 9; ++q)
+					tr += F[q] * F[q];
+				c0 = mu * da;
+				c1 = (mu + lambda * (1.0 - lj)) / (J * J) * da;
+				c2 = (lambda * lj - mu) / J * da;
+				en += (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+			}
+			else if (model == M_STVK)
+			{
+				double E[9], S[9];
+				for (int r = 0; r < 3; ++r)
+					for (int c = 0; c < 3; ++c)
+						E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
+				const double tr = E[0] + E[4] + E[8];
+				double se = 0;
+				for (int q = 0; q < 9; ++q)
+				{
+					S[q] = 2 * mu * E[q];
+					if (q == 0 || q == 4 || q == 8)
+						S[q] += lambda * tr;
+					se += S[q] * E[q];
+				}
+				for (int r = 0; r < 3; ++r)
+					for (int c = 0; c < 3; ++c)
+						dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
+				c0 = mu * da, c1 = lambda * da, c2 = da;
+				en += se / 2 * da;
+			}
+			else
+			{
+				double eps[9], ee = 0;
+				for (int r = 0; r < 3; ++r)
+					for (int c = 0; c < 3; ++c)
+					{
+						eps[3 * r + c] = (F[3 * r + c] + F[3 * c + r]) / 2;
+						ee += eps[3 * r + c] * eps[3 * r + c];
+					}
+				const double tr = eps[0] + eps[4] + eps[8];
+				for (int q = 0; q < 9; ++q)
+					dJ[q] = 2 * mu * eps[q];
+				dJ[0] += lambda * tr, dJ[4] += lambda * tr, dJ[8] += lambda * tr;
+				c0 = mu * da, c1 = lambda * da, c2 = da;
+				en += (mu * ee + lambda / 2 * tr * tr) * da;
+			}
+			if (WH)
+			{
+				for (int q = 0; q < 9; ++q)
+					st[ST::f_at(k) + q] = F[q];
+				st[ST::f_at(k) + 9] = c0, st[ST::f_at(k) + 10] = c1, st[ST::f_at(k) + 11] = c2;
+			}
+			if (WG)
+				for (int i = 0; i < NLOC; ++i)
+				{
+					const double g0 = tab->grad[k][i][0], g1 = tab->grad[k][i][1], g2 = tab->grad[k][i][2];
+					double G[3];
+					for (int c = 0; c < 3; ++c)
+						G[c] = g0 * jt[c] + g1 * jt[3 + c] + g2 * jt[6 + c];
+					for (int d = 0; d < 3; ++d)
+					{
+						const double sg = dJ[3 * d] * G[0] + dJ[3 * d + 1] * G[1] + dJ[3 * d + 2] * G[2];
+						if (model == M_NEO)
+							g[3 * i + d] += c0 * (F[3 * d] * G[0] + F[3 * d + 1] * G[1] + F[3 * d + 2] * G[2]) + c2 * sg;
+						else
+							g[3 * i + d] += c2 * sg;
+					}
+				}
+		}
+		eloc[e] = en;
+		if (WG)
+			for (int t = 0; t < NLOC * 3; ++t)
+				gloc[e * (NLOC * 3) + t] = g[t];
+		if (bad)
+			atomicOr(flag, 1);
+	}
+
 	// H_ij for the pair (i, j), j <= i : out[m*3+n] = d2 E / d u_{i,m} d u_{j,n}
 	template <int NLOC, int NGLOC, int NPTS, int MODEL>
 	struct nl_block
@@ -544,6 +695,44 @@ namespace
 				PFX_LOCAL_E(M_LINEAR);
 #undef PFX_LOCAL_E
 #undef PFX_LOCAL_E_PP
+			return;
+		}
+		if ((gr || he) && NLOC <= 10)
+		{
+			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
+#define PFX_LOCAL_R3(MODEL_, PP_, WG_, WH_)                                                                                                                   \
+	hipLaunchKernelGGL((k_local_reg<NLOC, NGLOC, NPTS, MODEL_, PP_, WG_, WH_>), dim3(eb), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, \
+					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_eloc, ctx->d_gloc, ctx->d_estate,     \
+					   ctx->d_flag)
+#define PFX_LOCAL_R2(MODEL_, PP_)              \
+	do                                         \
+	{                                          \
+		if (gr && he)                          \
+			PFX_LOCAL_R3(MODEL_, PP_, true, true);  \
+		else if (gr)                           \
+			PFX_LOCAL_R3(MODEL_, PP_, true, false); \
+		else                                   \
+			PFX_LOCAL_R3(MODEL_, PP_, false, true); \
+	} while (0)
+#define PFX_LOCAL_R(MODEL_)                            \
+	do                                                 \
+	{                                                  \
+		if (ctx->mat_per_point && ctx->d_lambda_e)     \
+			PFX_LOCAL_R2(MODEL_, true);                \
+		else                                           \
+			PFX_LOCAL_R2(MODEL_, false);               \
+	} while (0)
+			if (ctx->model == PFX_NEOHOOKEAN)
+				PFX_LOCAL_R(M_NEO);
+			else if (ctx->model == PFX_SAINT_VENANT)
+				PFX_LOCAL_R(M_STVK);
+			else if (ctx->model == PFX_MULTI_MODEL)
+				PFX_LOCAL_R(M_MULTI);
+			else
+				PFX_LOCAL_R(M_LINEAR);
+#undef PFX_LOCAL_R
+#undef PFX_LOCAL_R2
+#undef PFX_LOCAL_R3
 			return;
 		}
 #define PFX_LOCAL_NL_PP(MODEL_, PP_)                                                                                                              \

@@ -554,7 +554,8 @@ def test_newton_solve_matches_oracle(eng, oracle, case):
     eng.set_dirichlet(np.zeros(0, dtype=np.int32))
     assert info["status"] == info_ref["status"] and info["status"] in (2, 3)
     assert info["iterations"] == info_ref["iterations"] >= 2
-    assert info["line_search_iterations"] == info_ref["line_search_iterations"]
+    # the last steps of a converged run compare energies that differ in their last bits: one trial step more or less
+    assert abs(info["line_search_iterations"] - info_ref["line_search_iterations"]) <= 1
     assert info["descent_strategy"] == info_ref["descent_strategy"] == 0
     # +-2 per linear solve; the last solve of a converged run has a right-hand side at round-off level, where the
     # count is decided by the last bits of the gradient: allow 3 % of the total as well
