@@ -671,7 +671,7 @@ namespace
 	{
 		constexpr int EPB = BLOCK / TPE;
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
-		if (en && !gr && !he && NLOC <= 10) // energy alone: the register-only kernel (the 27-node elements keep the fused one)
+		if (en && !gr && !he) // energy alone: the register-only kernel
 		{
 			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
 #define PFX_LOCAL_E_PP(MODEL_, PP_)                                                                                                                   \
