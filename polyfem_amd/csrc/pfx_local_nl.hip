@@ -423,7 +423,7 @@ namespace
 		if (WG)
 			for (int t = 0; t < NLOC * 3; ++t)
 				g[t] = 0.0;
-		double *st = estate + e * (int64_t)ST::stride;
+		double *st = WH ? estate + e * (int64_t)ST::stride : nullptr;
 		double en = 0.0;
 		bool bad = false;
 		double jt[9], det = 0.0;
