@@ -1,4 +1,4 @@
-"""Golden fixtures (tests/golden/*.npz, made by tools/make_golden.py from the oracle): the oracle must keep
+"""Golden fixtures (tests/golden/*.npz, made by tests/tools/make_golden.py from the oracle): the oracle must keep
 reproducing them (CPU), and the HIP path must match them through the C ABI (GPU)."""
 import glob
 import os

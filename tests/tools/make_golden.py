@@ -4,13 +4,13 @@
 The reference itself cannot be built or imported in this environment (C++ with un-vendored Eigen/TBB/polysolve), and
 its own test meshes live in the un-vendored polyfem-data repository, so these vectors pin the ORACLE (a regression
 guard for it, and a second, file-based target for the HIP path); the oracle in turn is pinned by the reference's
-self-contained known-answer tests (tests/test_oracle_kat.py).  Usage: python tools/make_golden.py [--force]   (without --force only missing fixtures are written)"""
+self-contained known-answer tests (tests/test_oracle_kat.py).  Usage: python tests/tools/make_golden.py [--force]   (without --force only missing fixtures are written)"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pf_oracle as O  # noqa: E402
 from polyfem_amd import mesh as M  # noqa: E402

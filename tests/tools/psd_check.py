@@ -1,6 +1,6 @@
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 import torch
 from polyfem_amd import engine as E, mesh as M
 from oracle import pf_oracle as O

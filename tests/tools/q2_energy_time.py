@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root
 from polyfem_amd import engine as E, mesh as M
 from oracle import pf_oracle as O
 mesh = M.cube_hexes(40, 2)
