@@ -313,7 +313,10 @@ pfx_status pfx_implicit_euler_step_dev(pfx_ctx *ctx, double dt, const double *d_
  * form exactly the single-GPU pfx_cg_dev.  d_work (4 * n_local_dofs doubles: r, p, tmp, invdiag in this order) is the
  * caller-owned workspace, so that the caller can address the halo part of p. */
 pfx_status pfx_set_owned(pfx_ctx *ctx, int64_t n_owned_nodes, const uint8_t *elem_owned /* n_el flags or NULL */);
-pfx_status pfx_cgs_set_workspace(pfx_ctx *ctx, double *d_work);
+/* n_doubles = size of the caller's buffer, at least 4 * n_local_dofs (rejected otherwise); d_work == NULL returns to the
+ * context's own workspace.  The pointer is dropped by pfx_set_mesh / pfx_build_pattern (its size belonged to the old
+ * pattern) and must be cleared by the caller before the buffer is released. */
+pfx_status pfx_cgs_set_workspace(pfx_ctx *ctx, double *d_work, int64_t n_doubles);
 pfx_status pfx_cgs_prepare(pfx_ctx *ctx, double *d_x, int precond);
 pfx_status pfx_cgs_residual(pfx_ctx *ctx, const double *d_b, const double *d_x, double *d_scal);
 pfx_status pfx_cgs_start(pfx_ctx *ctx, double *d_x, double tol, double *d_scal);

@@ -37,38 +37,38 @@ namespace
 
 	void release_pattern(pfx_ctx *ctx)
 	{
-		free_dev(ctx->d_node_ptr);
-		free_dev(ctx->d_node_col);
-		free_dev(ctx->d_blk_ptr);
-		free_dev(ctx->d_blk_src);
-		free_dev(ctx->d_blk_slot);
-		free_dev(ctx->d_unode_ptr);
-		free_dev(ctx->d_ublk_off);
-		free_dev(ctx->d_ublk_low);
+		free_dev(ctx, ctx->d_node_ptr);
+		free_dev(ctx, ctx->d_node_col);
+		free_dev(ctx, ctx->d_blk_ptr);
+		free_dev(ctx, ctx->d_blk_src);
+		free_dev(ctx, ctx->d_blk_slot);
+		free_dev(ctx, ctx->d_unode_ptr);
+		free_dev(ctx, ctx->d_ublk_off);
+		free_dev(ctx, ctx->d_ublk_low);
 		ctx->n_ublocks = ctx->n_upair = 0;
-		free_dev(ctx->d_ne_ptr);
-		free_dev(ctx->d_ne_src);
-		free_dev(ctx->d_values);
-		free_dev(ctx->d_mask);
-		free_dev(ctx->d_estate);
-		free_dev(ctx->d_kloc);
+		free_dev(ctx, ctx->d_ne_ptr);
+		free_dev(ctx, ctx->d_ne_src);
+		free_dev(ctx, ctx->d_values);
+		free_dev(ctx, ctx->d_mask);
+		free_dev(ctx, ctx->d_estate);
+		free_dev(ctx, ctx->d_kloc);
 		ctx->kloc_count = 0;
 		ctx->estate_count = 0;
 		ctx->estate_kind = PFX_ESTATE_NONE;
-		free_dev(ctx->d_gloc);
-		free_dev(ctx->d_eloc);
-		free_dev(ctx->d_fixed);
-		free_dev(ctx->d_dirichlet);
-		free_dev(ctx->d_work);
-		free_dev(ctx->d_u);
-		free_dev(ctx->d_vec);
-		free_dev(ctx->d_part0);
+		free_dev(ctx, ctx->d_gloc);
+		free_dev(ctx, ctx->d_eloc);
+		free_dev(ctx, ctx->d_fixed);
+		free_dev(ctx, ctx->d_dirichlet);
+		free_dev(ctx, ctx->d_work);
+		free_dev(ctx, ctx->d_u);
+		free_dev(ctx, ctx->d_vec);
+		free_dev(ctx, ctx->d_part0);
 		ctx->part0_count = 0;
-		free_dev(ctx->d_newton);
+		free_dev(ctx, ctx->d_newton);
 		ctx->newton_count = 0;
-		free_dev(ctx->d_mass_blk);
-		free_dev(ctx->d_tstep);
-		free_dev(ctx->d_al_store);
+		free_dev(ctx, ctx->d_mass_blk);
+		free_dev(ctx, ctx->d_tstep);
+		free_dev(ctx, ctx->d_al_store);
 		ctx->al_count = 0;
 		ctx->al_weight = 0.0;
 		ctx->d_al_mass = ctx->d_al_target = nullptr;
@@ -76,6 +76,7 @@ namespace
 		ctx->inertia_weight = 0.0;
 		ctx->d_x_tilde = nullptr;
 		pfx_sell_release(ctx);
+		ctx->d_work_ext = nullptr; // a caller-owned workspace was sized for the pattern that is going away
 		ctx->n_blocks = ctx->nnz = 0;
 		ctx->n_dirichlet = 0;
 		ctx->have_mask = false;
@@ -116,8 +117,12 @@ namespace
 		*d_out = nullptr;
 		if (!density_e)
 			return PFX_OK;
-		if (pfx_alloc(ctx, &ctx->d_density_e, ctx->n_el))
-			return PFX_ERR_HIP;
+		if (ctx->density_count < ctx->n_el)
+		{
+			if (pfx_alloc(ctx, &ctx->d_density_e, ctx->n_el))
+				return PFX_ERR_HIP;
+			ctx->density_count = ctx->n_el;
+		}
 		PFX_HIP(hipMemcpyAsync(ctx->d_density_e, density_e, sizeof(double) * (size_t)ctx->n_el, hipMemcpyHostToDevice, ctx->stream));
 		*d_out = ctx->d_density_e;
 		return PFX_OK;
@@ -196,20 +201,20 @@ extern "C"
 		(void)hipSetDevice(ctx->device);
 		(void)hipStreamSynchronize(ctx->stream);
 		release_pattern(ctx);
-		free_dev(ctx->d_conn);
-		free_dev(ctx->d_gconn);
-		free_dev(ctx->d_xyz);
-		free_dev(ctx->d_tab);
-		free_dev(ctx->d_tab_mass);
-		free_dev(ctx->d_density_e);
-		free_dev(ctx->d_flag);
-		free_dev(ctx->d_elem_owned);
-		free_dev(ctx->d_lambda_e);
-		free_dev(ctx->d_mu_e);
-		free_dev(ctx->d_model_e);
-		free_dev(ctx->d_tensor);
-		free_dev(ctx->d_partials);
-		free_dev(ctx->d_cgstate);
+		free_dev(ctx, ctx->d_conn);
+		free_dev(ctx, ctx->d_gconn);
+		free_dev(ctx, ctx->d_xyz);
+		free_dev(ctx, ctx->d_tab);
+		free_dev(ctx, ctx->d_tab_mass);
+		free_dev(ctx, ctx->d_density_e);
+		free_dev(ctx, ctx->d_flag);
+		free_dev(ctx, ctx->d_elem_owned);
+		free_dev(ctx, ctx->d_lambda_e);
+		free_dev(ctx, ctx->d_mu_e);
+		free_dev(ctx, ctx->d_model_e);
+		free_dev(ctx, ctx->d_tensor);
+		free_dev(ctx, ctx->d_partials);
+		free_dev(ctx, ctx->d_cgstate);
 		resolve_timers(ctx);
 		for (auto e : ctx->ev_free)
 			(void)hipEventDestroy(e);
@@ -260,11 +265,14 @@ extern "C"
 		if (n_nodes >= ((int64_t)1 << 31) / 3)
 			PFX_FAIL(PFX_ERR_SIZE, "n_nodes*dim must fit the reference's 32-bit column index");
 		PFX_HIP(hipSetDevice(ctx->device));
-		pfx_fill_tables(elem_kind, quad_order, &ctx->h_tab);
-		pfx_fill_tables_mass(elem_kind, &ctx->h_tab_mass);
-		if (ctx->h_tab.n_pts == 0)
+		// the tables go into the context only once every argument has been accepted: a rejected call leaves the
+		// previous mesh fully intact
+		static thread_local pfx_tables tab, tab_mass;
+		pfx_fill_tables(elem_kind, quad_order, &tab);
+		pfx_fill_tables_mass(elem_kind, &tab_mass);
+		if (tab.n_pts == 0)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "quadrature order not available for this element kind");
-		const int n_loc = ctx->h_tab.n_loc, n_gloc = ctx->h_tab.n_gloc;
+		const int n_loc = tab.n_loc, n_gloc = tab.n_gloc;
 		// the kernels index device arrays with these values: validate them on the host
 		for (int64_t k = 0; k < n_el * n_loc; ++k)
 			if (conn[k] < 0 || conn[k] >= n_nodes)
@@ -273,6 +281,8 @@ extern "C"
 			if (gconn[k] < 0 || gconn[k] >= n_gnodes)
 				PFX_FAIL(PFX_ERR_ARG, "gconn entry out of range");
 		release_pattern(ctx);
+		ctx->h_tab = tab;
+		ctx->h_tab_mass = tab_mass;
 		ctx->kind = elem_kind;
 		ctx->gkind = (elem_kind == PFX_Q1HEX || elem_kind == PFX_Q2HEX) ? PFX_Q1HEX : PFX_P1TET;
 		ctx->n_loc = n_loc;
@@ -282,10 +292,10 @@ extern "C"
 		ctx->n_el = n_el;
 		ctx->n_nodes = n_nodes;
 		ctx->n_owned = n_nodes;
-		free_dev(ctx->d_elem_owned);
-		free_dev(ctx->d_lambda_e);
-		free_dev(ctx->d_mu_e);
-		free_dev(ctx->d_model_e);
+		free_dev(ctx, ctx->d_elem_owned);
+		free_dev(ctx, ctx->d_lambda_e);
+		free_dev(ctx, ctx->d_mu_e);
+		free_dev(ctx, ctx->d_model_e);
 		ctx->n_gnodes = n_gnodes;
 		if (pfx_alloc(ctx, &ctx->d_conn, n_el * n_loc) || pfx_alloc(ctx, &ctx->d_gconn, n_el * n_gloc) || pfx_alloc(ctx, &ctx->d_xyz, n_gnodes * 3))
 			return PFX_ERR_HIP;
@@ -314,9 +324,9 @@ extern "C"
 		ctx->bs = bs;
 		ctx->lambda = lambda;
 		ctx->mu = mu;
-		free_dev(ctx->d_lambda_e);
-		free_dev(ctx->d_mu_e);
-		free_dev(ctx->d_model_e);
+		free_dev(ctx, ctx->d_lambda_e);
+		free_dev(ctx, ctx->d_mu_e);
+		free_dev(ctx, ctx->d_model_e);
 		ctx->mat_per_point = 0;
 		return PFX_OK;
 	}
@@ -361,7 +371,7 @@ extern "C"
 			default: PFX_FAIL(PFX_ERR_ARG, "element models are PFX_LINEAR_ELASTICITY, PFX_NEOHOOKEAN or PFX_SAINT_VENANT");
 			}
 		PFX_HIP(hipSetDevice(ctx->device));
-		free_dev(ctx->d_model_e);
+		free_dev(ctx, ctx->d_model_e);
 		if (pfx_alloc(ctx, &ctx->d_model_e, n_el))
 			return PFX_ERR_HIP;
 		PFX_HIP(hipMemcpyAsync(ctx->d_model_e, m.data(), (size_t)n_el, hipMemcpyHostToDevice, ctx->stream));
@@ -399,6 +409,8 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (ctx->kind < 0 || n_el != ctx->n_el)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_set_material_per_element: call pfx_set_mesh first and pass one value per element");
+		if (model == PFX_LAPLACIAN)
+			PFX_FAIL(PFX_ERR_ARG, "the Laplacian has no material parameters");
 		pfx_status rc = pfx_set_material(ctx, model, dim, n_el > 0 ? lambda[0] : 0.0, n_el > 0 ? mu[0] : 0.0);
 		if (rc)
 			return rc;
@@ -1128,7 +1140,7 @@ extern "C"
 		if (n_owned_nodes < 0 || n_owned_nodes > ctx->n_nodes)
 			PFX_FAIL(PFX_ERR_ARG, "n_owned_nodes out of range");
 		ctx->n_owned = n_owned_nodes;
-		free_dev(ctx->d_elem_owned);
+		free_dev(ctx, ctx->d_elem_owned);
 		if (elem_owned)
 		{
 			if (pfx_alloc(ctx, &ctx->d_elem_owned, ctx->n_el))
@@ -1139,10 +1151,19 @@ extern "C"
 		return PFX_OK;
 	}
 
-	pfx_status pfx_cgs_set_workspace(pfx_ctx *ctx, double *d_work)
+	pfx_status pfx_cgs_set_workspace(pfx_ctx *ctx, double *d_work, int64_t n_doubles)
 	{
 		if (!ctx)
 			return PFX_ERR_ARG;
+		if (!d_work)
+		{
+			ctx->d_work_ext = nullptr;
+			return PFX_OK;
+		}
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (n_doubles < 4 * ctx->n_dofs())
+			PFX_FAIL(PFX_ERR_ARG, "pfx_cgs_set_workspace: the workspace must hold 4 * n_dofs doubles");
 		ctx->d_work_ext = d_work;
 		return PFX_OK;
 	}

@@ -59,6 +59,7 @@ struct pfx_ctx
 	pfx_tables *d_tab_mass = nullptr; // same for the mass quadrature rule (order 2p+1)
 	pfx_tables h_tab_mass;
 	double *d_density_e = nullptr;    // per-element density of the last mass / rhs assembly
+	int64_t density_count = 0;        // doubles allocated in d_density_e
 
 	// material
 	int model = -1, dim = 3, bs = 0; // bs = block size (1 or dim)
@@ -143,7 +144,8 @@ struct pfx_ctx
 	int *d_cgstate = nullptr;
 	double *d_u = nullptr, *d_vec = nullptr; // staging for host-pointer entry points
 
-	int64_t bytes_device = 0;
+	int64_t bytes_device = 0;                   // device memory currently held through pfx_alloc
+	std::map<const void *, int64_t> alloc_bytes; // size of every live pfx_alloc allocation
 
 	bool timing = false;
 	int timing_stride = 1;                             // every timing_stride-th launch of a family is timed
@@ -178,18 +180,32 @@ struct pfx_ctx
 		return (code);       \
 	} while (0)
 
+// hipFree + null (pointers owned by the context); keeps pfx_info.bytes_device equal to what is currently held
+template <typename T>
+inline void free_dev(pfx_ctx *ctx, T *&p)
+{
+	if (p)
+	{
+		auto it = ctx->alloc_bytes.find((const void *)p);
+		if (it != ctx->alloc_bytes.end())
+		{
+			ctx->bytes_device -= it->second;
+			ctx->alloc_bytes.erase(it);
+		}
+		(void)hipFree(p);
+	}
+	p = nullptr;
+}
+
 template <typename T>
 pfx_status pfx_alloc(pfx_ctx *ctx, T **p, int64_t count)
 {
-	if (*p)
-	{
-		(void)hipFree(*p);
-		*p = nullptr;
-	}
+	free_dev(ctx, *p);
 	if (count <= 0)
 		count = 1;
 	PFX_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)count));
 	ctx->bytes_device += (int64_t)sizeof(T) * count;
+	ctx->alloc_bytes[(const void *)*p] = (int64_t)sizeof(T) * count;
 	return PFX_OK;
 }
 
@@ -202,15 +218,6 @@ inline int grid_for(int64_t n, int block = 256)
 	if (g < 1)
 		g = 1;
 	return (int)g;
-}
-
-// hipFree + null (pointers owned by the context)
-template <typename T>
-inline void free_dev(T *&p)
-{
-	if (p)
-		(void)hipFree(p);
-	p = nullptr;
 }
 
 // Temporary device buffer of the host-side sequencing code: released when it goes out of scope, i.e. also on the early

@@ -224,11 +224,11 @@ namespace
 
 void pfx_sell_release(pfx_ctx *ctx)
 {
-	free_dev(ctx->d_sell_perm);
-	free_dev(ctx->d_sell_base);
-	free_dev(ctx->d_sell_cols);
-	free_dev(ctx->d_sell_vals);
-	free_dev(ctx->d_sell_order);
+	free_dev(ctx, ctx->d_sell_perm);
+	free_dev(ctx, ctx->d_sell_base);
+	free_dev(ctx, ctx->d_sell_cols);
+	free_dev(ctx, ctx->d_sell_vals);
+	free_dev(ctx, ctx->d_sell_order);
 	ctx->sell_slices = 0;
 	ctx->sell_interior = 0;
 	ctx->sell_owned = -1;
@@ -287,7 +287,7 @@ static pfx_status sell_build(pfx_ctx *ctx)
 	PFX_HIP(hipGetLastError());
 	// slice list: interior slices first, then the slices that need halo entries (distributed solves overlap the halo
 	// exchange with the interior part).  A mesh without halo keeps the natural order (no list).
-	free_dev(ctx->d_sell_order);
+	free_dev(ctx, ctx->d_sell_order);
 	ctx->sell_interior = n_slices;
 	if (n_owned < ctx->n_nodes && n_slices > 0)
 	{

@@ -249,13 +249,36 @@ class HaloExchange:
 
 
 class HipOps:
-    """Adapter from tensors to the engine's device-pointer step functions (include/polyfem_amd.h, pfx_cgs_*)."""
+    """Adapter from tensors to the engine's device-pointer step functions (include/polyfem_amd.h, pfx_cgs_*).
 
-    def __init__(self, engine):
+    Stream contract: the drivers below interleave torch operations (index gathers, axpys, reductions) with the
+    engine's kernels on the same buffers, so both must be enqueued on ONE stream.  The constructor therefore puts the
+    engine on torch's current stream of the engine's device; that stream has to be a non-default one (make it current
+    with torch.cuda.set_stream / torch.cuda.stream before constructing HipOps), because the C ABI uses the null handle
+    for "the context's own stream".  check_stream() -- called at the start of every distributed solve -- raises if
+    torch's current stream is no longer the engine's."""
+
+    def __init__(self, engine, stream=None):
+        import torch
         self.e = engine
+        self.torch = torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        if int(s.cuda_stream) == 0:
+            raise RuntimeError("HipOps needs a non-default torch stream: call torch.cuda.set_stream(torch.cuda.Stream()) "
+                               "first (the engine would otherwise run on a stream of its own, unordered with torch)")
+        self.stream_handle = int(s.cuda_stream)
+        engine.set_stream(self.stream_handle)
+
+    def check_stream(self):
+        cur = int(self.torch.cuda.current_stream().cuda_stream)
+        if cur != self.stream_handle:
+            raise RuntimeError("torch's current stream is not the stream the engine was bound to by HipOps")
 
     def set_workspace(self, work):
-        self.e.cgs_set_workspace(work.data_ptr())
+        if work is None:
+            self.e.cgs_set_workspace(0, 0)
+        else:
+            self.e.cgs_set_workspace(work.data_ptr(), work.numel())
 
     def prepare(self, x, precond):
         self.e.cgs_prepare(x.data_ptr(), precond)
@@ -330,9 +353,23 @@ class DistributedCG:
         self.ops.set_workspace(self.work)
         self.p_nodes = self.work[self.n: 2 * self.n].view(self.n_local, bs)
 
+    def close(self):
+        """Hands the solver workspace back to the engine (the engine must not keep a pointer into a freed tensor)."""
+        if self.work is not None:
+            try:
+                self.ops.set_workspace(None)
+            except Exception:
+                pass
+            self.work = None
+
+    def __del__(self):
+        self.close()
+
     def solve(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 25):
         """b, x: local vectors of n_local*bs doubles (halo entries of b are ignored).  Returns (iters, rel_res)."""
         ops, scal, ar = self.ops, self.scal, self.comm.all_reduce_sum
+        if hasattr(ops, "check_stream"):
+            ops.check_stream()
         ops.prepare(x, precond)
         self.halo(x.view(self.n_local, self.bs))
         ops.residual(b, x, scal)
@@ -524,6 +561,8 @@ class DistributedNewton:
                 raise TypeError(f"unknown Newton parameter {k!r}")
         par.update(params)
         ops, t, no, bs = self.ops, self.torch, self.no, self.bs
+        if hasattr(ops, "check_stream"):
+            ops.check_stream()
         nl = self.part.n_local
         self.rhs = rhs
         info = self.info = dict(status=CONTINUE, iterations=0, line_search_iterations=0, descent_strategy=0,

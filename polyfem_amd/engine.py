@@ -24,6 +24,7 @@ LIB_PATH = os.environ.get("PFX_LIBRARY") or os.path.join(_HERE, "libpolyfem_amd.
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
 LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
 PRECOND_IDENTITY, PRECOND_JACOBI = 0, 1
+PFX_ERR_ARG, PFX_ERR_HIP, PFX_ERR_UNSUPPORTED, PFX_ERR_NUMERIC, PFX_ERR_SIZE = -1, -2, -3, -4, -5
 MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN,
                  "SaintVenant": SAINT_VENANT}
 
@@ -154,7 +155,7 @@ def load():
         "pfx_timing_get": [_vp, C.c_char_p, _pd, _pi64],
         "pfx_timing_reset": [_vp],
         "pfx_set_owned": [_vp, _i64, C.POINTER(C.c_uint8)],
-        "pfx_cgs_set_workspace": [_vp, _vp],
+        "pfx_cgs_set_workspace": [_vp, _vp, _i64],
         "pfx_cgs_prepare": [_vp, _vp, _i32],
         "pfx_cgs_residual": [_vp, _vp, _vp, _vp],
         "pfx_cgs_start": [_vp, _vp, _dbl, _vp],
@@ -320,7 +321,7 @@ class Engine:
             used.append(weight)
             weight *= 2
             if weight >= max_weight:
-                raise PfxError(f"Unable to solve AL problem, weight {weight} >= {max_weight}, stopping")
+                raise PfxError(PFX_ERR_NUMERIC, f"Unable to solve AL problem, weight {weight} >= {max_weight}, stopping")
         self.set_dirichlet(dofs)
         x[dofs] = target[dofs]
         x, info = self.newton_solve(x, rhs, **newton_params)
@@ -585,8 +586,10 @@ class Engine:
         self._ck(self.L.pfx_take_numeric_flag(self.h, C.byref(f)))
         return bool(f.value)
 
-    def cgs_set_workspace(self, d_work: int):
-        self._ck(self.L.pfx_cgs_set_workspace(self.h, _vp(d_work) if d_work else None))
+    def cgs_set_workspace(self, d_work: int, n_doubles: int = 0):
+        """Caller-owned CG workspace of n_doubles >= 4 * n_dofs doubles; d_work = 0 returns to the engine's own."""
+        if getattr(self, "h", None):
+            self._ck(self.L.pfx_cgs_set_workspace(self.h, _vp(d_work) if d_work else None, int(n_doubles)))
 
     def cgs_prepare(self, d_x: int, precond: int):
         self._ck(self.L.pfx_cgs_prepare(self.h, _vp(d_x), precond))

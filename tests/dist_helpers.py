@@ -18,6 +18,8 @@ class OracleOps:
         self.shift = 0.0
 
     def set_workspace(self, work):
+        if work is None:
+            return
         n = work.numel() // 4
         w = work.numpy()
         self.r, self.p, self.tmp, self.invdiag = w[0:n], w[n:2 * n], w[2 * n:3 * n], w[3 * n:4 * n]
