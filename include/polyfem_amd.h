@@ -146,6 +146,15 @@ pfx_status pfx_gradient_dev(pfx_ctx *ctx, const double *d_u, double *d_g);
 pfx_status pfx_hessian_dev(pfx_ctx *ctx, const double *d_u);
 pfx_status pfx_hessian_psd_dev(pfx_ctx *ctx, const double *d_u); /* project_to_psd = true */
 
+/* Energy evaluation that allocates nothing.  No counterpart in the reference: it is for callers that cannot allocate
+ * device memory at the call site -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same result as pfx_energy_dev (same kernels, same fixed summation order), but the per-element energies
+ * and the partial sums live in a static device array of the library (8 MiB per GPU, held until the process ends)
+ * instead of buffers of the context, and the call needs only pfx_set_mesh + pfx_set_material (no pattern).  Limit:
+ * n_el <= 1048576, larger meshes are rejected with PFX_ERR_SIZE.  Every call on a GPU shares that GPU's array: calls
+ * that overlap on one GPU (two contexts / streams) race; calls on one stream do not. */
+pfx_status pfx_energy_dev_noalloc(pfx_ctx *ctx, const double *d_u, double *d_energy);
+
 /* ---- Dirichlet handling --------------------------------------------------------------------------------------- */
 
 /* Sorted list of constrained dofs.  Afterwards the solver works on the reduced system of

@@ -190,6 +190,11 @@ extern "C"
 			pfx_destroy(ctx); // releases whatever was allocated so far, and the stream
 			return PFX_ERR_HIP;
 		}
+		if (pfx_noalloc_init(ctx) != PFX_OK)
+		{
+			pfx_destroy(ctx);
+			return PFX_ERR_HIP;
+		}
 		*out = ctx;
 		return PFX_OK;
 	}
@@ -625,6 +630,15 @@ extern "C"
 				return rc;
 		}
 		return pfx_launch_reduce_energy(ctx, d_energy);
+	}
+
+	pfx_status pfx_energy_dev_noalloc(pfx_ctx *ctx, const double *d_u, double *d_energy)
+	{
+		if (!ctx || !d_u || !d_energy)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0 || ctx->model < 0 || ctx->n_el <= 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_mesh and pfx_set_material must be called first");
+		return pfx_energy_noalloc_run(ctx, d_u, d_energy);
 	}
 
 	pfx_status pfx_gradient_dev(pfx_ctx *ctx, const double *d_u, double *d_g)

@@ -202,13 +202,55 @@ pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny)
 	return PFX_OK;
 }
 
-pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy)
+pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy, const double *d_eloc, double *d_partials)
 {
 	const int nb = 256;
-	hipLaunchKernelGGL(k_reduce_stage1, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_eloc, ctx->d_elem_owned, ctx->n_el, ctx->d_partials);
-	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partials, nb, d_energy);
+	if (!d_eloc)
+		d_eloc = ctx->d_eloc;
+	if (!d_partials)
+		d_partials = ctx->d_partials;
+	hipLaunchKernelGGL(k_reduce_stage1, dim3(nb), dim3(256), 0, ctx->stream, d_eloc, ctx->d_elem_owned, ctx->n_el, d_partials);
+	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, ctx->stream, d_partials, nb, d_energy);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
+}
+
+// ---- energy evaluation that allocates nothing ------------------------------------------------------------------
+// Scratch of pfx_energy_dev_noalloc: the per-element energies (PFX_NOALLOC_MAX_EL doubles) followed by the 256 partial
+// sums of the first reduction stage.  A file-scope device array: every GPU the library runs on holds its own copy
+// (8 MiB) at its own address until the process ends.  Host code never uses the array's name as an address: the
+// device address is looked up once per device (pfx_noalloc_init, called by pfx_create with that device current) and
+// passed to the kernels as an ordinary pointer argument.
+static __device__ __align__(256) double pfx_noalloc_scratch[PFX_NOALLOC_MAX_EL + 256];
+static double *g_noalloc_ptr[PFX_MAX_DEVICES] = {nullptr};
+
+pfx_status pfx_noalloc_init(pfx_ctx *ctx)
+{
+	if (ctx->device < 0 || ctx->device >= PFX_MAX_DEVICES)
+		PFX_FAIL(PFX_ERR_ARG, "device index beyond PFX_MAX_DEVICES");
+	if (g_noalloc_ptr[ctx->device])
+		return PFX_OK;
+	double *ptr = nullptr;
+	PFX_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(pfx_noalloc_scratch)));
+	if (!ptr)
+		PFX_FAIL(PFX_ERR_HIP, "hipGetSymbolAddress returned a null address for the no-allocation scratch");
+	g_noalloc_ptr[ctx->device] = ptr;
+	return PFX_OK;
+}
+
+pfx_status pfx_energy_noalloc_run(pfx_ctx *ctx, const double *d_u, double *d_energy)
+{
+	double *ptr = (ctx->device >= 0 && ctx->device < PFX_MAX_DEVICES) ? g_noalloc_ptr[ctx->device] : nullptr;
+	if (!ptr)
+		PFX_FAIL(PFX_ERR_HIP, "the no-allocation scratch of this device was not initialised");
+	if (ctx->n_el > PFX_NOALLOC_MAX_EL)
+		PFX_FAIL(PFX_ERR_SIZE, "pfx_energy_dev_noalloc: more than PFX_NOALLOC_MAX_EL (1048576) elements; use pfx_energy_dev");
+	// every slot read below is written first in this call (n_el element energies, then all 256 partials): nothing
+	// has to be cleared although the array keeps the previous call's contents
+	pfx_status rc = pfx_launch_local_nl(ctx, d_u, true, false, false, ptr);
+	if (rc)
+		return rc;
+	return pfx_launch_reduce_energy(ctx, d_energy, ptr, ptr + PFX_NOALLOC_MAX_EL);
 }
 
 // copies the matrix values to the host in the order of the scalar CSR returned by pfx_export_pattern

@@ -28,6 +28,9 @@ struct pfx_tables
 
 #define PFX_ROWS_PER_GROUP 16
 
+#define PFX_NOALLOC_MAX_EL (1 << 20) // element limit of pfx_energy_dev_noalloc (size of its static device scratch)
+#define PFX_MAX_DEVICES 64
+
 enum
 {
 	PFX_ESTATE_NONE = 0,
@@ -284,7 +287,8 @@ void pfx_fill_tables(int kind, int quad_order, pfx_tables *t);
 void pfx_fill_tables_mass(int kind, pfx_tables *t);
 pfx_status pfx_pattern_build(pfx_ctx *ctx);
 pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                                                   // strict arithmetic
-pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess); // NeoHookean
+// d_eloc_out: where the per-element energies go (null: the context's buffer)
+pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess, double *d_eloc_out = nullptr);
 pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask); // strict arithmetic
 pfx_status pfx_launch_rows_nl(pfx_ctx *ctx);
 pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx);
@@ -304,7 +308,9 @@ pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = 
 pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e);                       // strict arithmetic
 pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e); // strict arithmetic
 pfx_status pfx_launch_quadrature_points(pfx_ctx *ctx, double *d_pts);
-pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy);
+pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy, const double *d_eloc = nullptr, double *d_partials = nullptr);
+pfx_status pfx_noalloc_init(pfx_ctx *ctx);
+pfx_status pfx_energy_noalloc_run(pfx_ctx *ctx, const double *d_u, double *d_energy);
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y);
 void pfx_sell_release(pfx_ctx *ctx);
 pfx_status pfx_sell_refresh(pfx_ctx *ctx);

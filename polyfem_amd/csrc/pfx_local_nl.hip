@@ -667,7 +667,7 @@ namespace
 	};
 
 	template <int NLOC, int NGLOC, int NPTS, int TPE, int BLOCK = 256>
-	void launch(pfx_ctx *ctx, const double *d_u, bool en, bool gr, bool he)
+	void launch(pfx_ctx *ctx, const double *d_u, bool en, bool gr, bool he, double *eloc)
 	{
 		constexpr int EPB = BLOCK / TPE;
 		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
@@ -676,7 +676,7 @@ namespace
 			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
 #define PFX_LOCAL_E_PP(MODEL_, PP_)                                                                                                                   \
 	hipLaunchKernelGGL((k_local_energy<NLOC, NGLOC, NPTS, MODEL_, PP_>), dim3(eb), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, \
-					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_eloc, ctx->d_flag)
+					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, eloc, ctx->d_flag)
 #define PFX_LOCAL_E(MODEL_)                            \
 	do                                                 \
 	{                                                  \
@@ -702,7 +702,7 @@ namespace
 			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
 #define PFX_LOCAL_R3(MODEL_, PP_, WG_, WH_)                                                                                                                   \
 	hipLaunchKernelGGL((k_local_reg<NLOC, NGLOC, NPTS, MODEL_, PP_, WG_, WH_>), dim3(eb), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, \
-					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_eloc, ctx->d_gloc, ctx->d_estate,     \
+					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, eloc, ctx->d_gloc, ctx->d_estate,     \
 					   ctx->d_flag)
 #define PFX_LOCAL_R2(MODEL_, PP_)              \
 	do                                         \
@@ -738,7 +738,7 @@ namespace
 #define PFX_LOCAL_NL_PP(MODEL_, PP_)                                                                                                              \
 	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK, PP_>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
 					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, (int)en, (int)gr, (int)he,     \
-					   ctx->d_eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
+					   eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
 #define PFX_LOCAL_NL(MODEL_)                               \
 	do                                                     \
 	{                                                      \
@@ -790,8 +790,9 @@ namespace
 	}
 } // namespace
 
-pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess)
+pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess, double *d_eloc_out)
 {
+	double *const eloc = d_eloc_out ? d_eloc_out : ctx->d_eloc;
 	if (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY && ctx->model != PFX_SAINT_VENANT && ctx->model != PFX_MULTI_MODEL)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the nonlinear-assembler interface is implemented for NeoHookean, SaintVenant, LinearElasticity and MultiModel");
 	if (ctx->model == PFX_MULTI_MODEL && !ctx->d_model_e)
@@ -804,7 +805,7 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 		if (np != 1)
 			ok = false;
 		else
-			launch<4, 4, 1, 16>(ctx, d_u, energy, grad, hess);
+			launch<4, 4, 1, 16>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_P2TET:
 		if (np != 6)
@@ -813,19 +814,19 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 			// two elements per single-wave workgroup: measured best of {64, 32, 16 lanes per element} x {256, 128, 64 threads}
 			// (energy 0.70 ms, gradient 1.00 ms, Hessian state 0.82 ms per 1 M elements against 0.94 / 1.53 / 0.99 ms for a
 			// wavefront per element in 256-thread workgroups)
-			launch<10, 4, 6, 32, 64>(ctx, d_u, energy, grad, hess);
+			launch<10, 4, 6, 32, 64>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_Q1HEX:
 		if (np != 1)
 			ok = false;
 		else
-			launch<8, 8, 1, 64>(ctx, d_u, energy, grad, hess);
+			launch<8, 8, 1, 64>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_Q2HEX:
 		if (np != 27)
 			ok = false;
 		else
-			launch<27, 8, 27, 256>(ctx, d_u, energy, grad, hess);
+			launch<27, 8, 27, 256>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	default:
 		ok = false;

@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = [
     "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_element_models",
     "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
     "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev", "pfx_set_material_per_point",
+    "pfx_energy_dev_noalloc",
 ]
 
 
@@ -140,6 +141,7 @@ def load():
         "pfx_gradient": [_vp, _pd, _pd],
         "pfx_hessian": [_vp, _pd, _i32, _pd],
         "pfx_energy_dev": [_vp, _vp, _vp],
+        "pfx_energy_dev_noalloc": [_vp, _vp, _vp],
         "pfx_gradient_dev": [_vp, _vp, _vp],
         "pfx_hessian_dev": [_vp, _vp],
         "pfx_hessian_psd_dev": [_vp, _vp],
@@ -394,6 +396,10 @@ class Engine:
     # device-pointer variants (raw integer addresses, e.g. torch.Tensor.data_ptr())
     def energy_dev(self, d_u: int, d_e: int):
         self._ck(self.L.pfx_energy_dev(self.h, _vp(d_u), _vp(d_e)))
+
+    def energy_dev_noalloc(self, d_u: int, d_e: int):
+        """pfx_energy_dev without any device allocation (static scratch of the library, n_el <= 2^20)."""
+        self._ck(self.L.pfx_energy_dev_noalloc(self.h, _vp(d_u), _vp(d_e)))
 
     def gradient_dev(self, d_u: int, d_g: int):
         self._ck(self.L.pfx_gradient_dev(self.h, _vp(d_u), _vp(d_g)))
