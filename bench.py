@@ -294,7 +294,7 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
                                 f"backend '{backend}'" + (" (RCCL over xGMI)" if backend == "nccl" else " -- NOT RCCL: single-card rehearsal of the N > 1 path"))
                                if world > 1 else "single GPU",
                 "halo_bytes_per_exchange_rank0": halo_bytes,
-                "bytes_device": inf.bytes_device,
+                "bytes_device": eng.info().bytes_device,  # everything the context holds now: pattern, values, solver copy, vectors
             },
             "roofline": {"kernel": "k_sell_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic,
