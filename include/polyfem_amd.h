@@ -64,7 +64,8 @@ enum
 enum
 {
 	PFX_PRECOND_IDENTITY = 0,
-	PFX_PRECOND_JACOBI = 1 /* Eigen::DiagonalPreconditioner, polysolve's default for Eigen::ConjugateGradient */
+	PFX_PRECOND_JACOBI = 1, /* Eigen::DiagonalPreconditioner, polysolve's default for Eigen::ConjugateGradient */
+	PFX_PRECOND_AMG = 2     /* aggregation multigrid with rigid-body modes (see the AMG section below); block size 3 only */
 };
 
 /* ---- context ------------------------------------------------------------------------------------------------ */
@@ -182,6 +183,49 @@ pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x_inout, int pr
  * the constrained dofs set with pfx_set_dirichlet; solves the modified system and returns the full-size x. */
 pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol,
 							   int *iters, double *rel_res);
+
+/* ---- algebraic multigrid preconditioner -------------------------------------------------------------------------------
+ *
+ * The role of polysolve's AMG solvers ("AMGCL", "Hypre": CMakeLists.txt:101-102; options input-spec.json:1397-1558 --
+ * CG with an AMG preconditioner, Chebyshev relaxation, `ncycle`, `max_levels`, tol 1e-10), which is what a PolyFEM user
+ * selects when Jacobi-CG runs into max_iter.  Neither library is in the reference tree and this is not a restatement of
+ * either: it is this library's own plain-aggregation AMG for 3-D elasticity (aggregates by repeated pairwise matching, six
+ * rigid-body modes per aggregate, Galerkin coarse matrices in the same node-block format, Chebyshev relaxation), selected
+ * with precond = PFX_PRECOND_AMG in pfx_cg(_dev), pfx_dirichlet_solve and pfx_newton_params.cg_precond.  The iteration
+ * is still Eigen's ConjugateGradient (same stopping rule); only z = M^-1 r changes.  Single GPU (unpartitioned mesh).
+ * The hierarchy is rebuilt when the pattern or the Dirichlet set changes; coarse matrices at every new matrix. */
+typedef struct
+{
+	int aggregate_passes; /* 4: rounds of pairwise matching per level, aggregates of up to 2^passes vertices */
+	int relax_degree;     /* 1: Chebyshev degree of the relaxation before / after the coarse correction (AMGCL/precond/relax/degree) */
+	int ncycle;           /* 1: V cycle; 2: W cycle (AMGCL/precond/ncycle) */
+	int max_levels;       /* 12 (AMGCL/precond/max_levels) */
+	int coarsest_dofs;    /* 600: levels at or below this size are solved with a dense inverse */
+	int power_iters;      /* 10: power iterations for the spectral radius of D^-1 A (AMGCL/precond/relax/power_iters) */
+	double relax_lower;   /* 0.1: the relaxation targets the eigenvalues in [relax_lower * lmax, lmax] */
+} pfx_amg_params;
+
+typedef struct
+{
+	int n_levels;
+	int64_t n_vertices[16];   /* vertices per level (level 0: owned mesh nodes; coarser: aggregates of the level above) */
+	int64_t n_aggregates[16]; /* aggregates each level is cut into (0 on the coarsest) */
+	int64_t n_blocks[16];     /* 3x3 blocks of each level's matrix */
+	double lambda_max[16];    /* estimated spectral radius of D^-1 A per relaxed level */
+	double operator_complexity; /* sum of n_blocks over the levels / n_blocks[0] */
+	double symbolic_s, numeric_s; /* host wall time of the last hierarchy build / coarse-matrix refresh */
+} pfx_amg_info;
+
+void pfx_amg_default_params(pfx_amg_params *params);
+pfx_status pfx_amg_set_params(pfx_ctx *ctx, const pfx_amg_params *params);
+/* Builds / refreshes the hierarchy for the matrix the context holds now (solves with PFX_PRECOND_AMG do this themselves). */
+pfx_status pfx_amg_setup(pfx_ctx *ctx);
+pfx_status pfx_amg_get_info(pfx_ctx *ctx, pfx_amg_info *info);
+/* agg[v] = aggregate of vertex v of `level` (-1: left out: constrained node), n_vertices[level] entries. */
+pfx_status pfx_amg_get_aggregates(pfx_ctx *ctx, int level, int32_t *agg);
+/* One application of the preconditioner, d_z = M^-1 d_r (device vectors of n_dofs; entries of constrained dofs of d_r
+ * must be zero and come back zero). */
+pfx_status pfx_amg_apply_dev(pfx_ctx *ctx, const double *d_r, double *d_z);
 
 /* ---- mass matrix and body-force right-hand side -------------------------------------------------------------------
  *

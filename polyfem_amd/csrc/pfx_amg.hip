@@ -1,0 +1,1523 @@
+// pfx_amg.hip -- aggregation multigrid preconditioner for the CG solver (3-D elasticity, block size 3).
+//
+// Role in the reference: polysolve's algebraic-multigrid solvers ("AMGCL", "Hypre"; /root/reference/CMakeLists.txt:101-102,
+// options input-spec.json:1397-1558: CG with an AMG preconditioner, Chebyshev relaxation, ncycle, max_levels) are what a
+// PolyFEM user selects when Jacobi-CG does not converge in max_iter.  Neither library is part of the reference tree, and
+// this is NOT a restatement of either: it is this library's own plain-aggregation AMG, built on the node-block
+// structure the assembler already has.  Jacobi stays the default preconditioner (Eigen parity).
+//
+// Hierarchy.  Level 0 = the assembled matrix (vertices = mesh nodes, 3 dofs each).  A level is coarsened by
+// `aggregate_passes` rounds of greedy pairwise matching on the vertex graph (weights = number of fine connections), so
+// aggregates hold up to 2^passes vertices.  Every aggregate carries the six rigid-body modes of its vertices about the
+// aggregate's centre c: a translation T and a rotation W, u(x) = T + W x (x - c).  They are stored as TWO coarse nodes
+// of 3 dofs (node 2a = T, node 2a+1 = W), so every level is again a node-block matrix with 3x3 blocks and reuses the
+// assembler's SELL matrix-vector product.  Prolongation of vertex v (offset d = x_v - c from its aggregate's centre):
+//     level 0:   u_v = T + W x d                       P_v   = [ I  -[d]x ]                (3 x 6)
+//     level > 0: (T_v, W_v) = (T + W x d, W)           P_v   = [ I  -[d]x ; 0  I ]         (6 x 6)
+// Coarse matrices are Galerkin products P^T A P, computed on the device from lists (built with the hierarchy) of the
+// fine vertex pairs behind every coarse pair, in a fixed order: no atomics, bitwise reproducible.
+// Dirichlet dofs: the level-0 operator is the masked one (identity on constrained dofs); their rows of P are zero,
+// nodes with all dofs constrained are left out of the aggregation.
+//
+// Cycle (one application = the preconditioner z = M^-1 r): Chebyshev relaxation of degree `relax_degree` for
+// D^-1 A on [relax_lower * lmax, lmax] before and after the coarse correction (lmax by power iteration), V or W cycle,
+// dense inverse at the coarsest level.  Same polynomial before and after: M is symmetric positive definite.
+//
+// The symbolic part (matching, coarse patterns, Galerkin lists) runs on the host, once per pattern and Dirichlet set;
+// the numeric part (Galerkin products, diagonals, spectral radii, coarsest inverse) on the device at every new matrix.
+#include "pfx_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cfloat>
+#include <numeric>
+#include <thread>
+
+#define AMG_MAX_LEVELS 16
+#define AMG_NPART 256
+
+namespace
+{
+	// ---------------------------------------------------------------------------------------------------------
+	// host side: graphs, matching, quotient graphs
+	// ---------------------------------------------------------------------------------------------------------
+	struct hgraph
+	{
+		int64_t n = 0;
+		std::vector<int64_t> ptr;
+		std::vector<int32_t> col;
+		std::vector<int32_t> w; // empty: every edge has weight 1
+	};
+
+	struct qentry
+	{
+		int32_t b;  // coarse column
+		int32_t w;  // weight
+		uint32_t e; // fine edge index
+		int32_t i;  // fine row vertex
+	};
+
+	int host_threads()
+	{
+		unsigned h = std::thread::hardware_concurrency();
+		if (const char *e = getenv("OMP_NUM_THREADS"))
+			if (atoi(e) > 0)
+				h = (unsigned)atoi(e);
+		if (h < 1)
+			h = 1;
+		if (h > 16)
+			h = 16;
+		return (int)h;
+	}
+
+	// Quotient of the graph (n, ptr, col, w) by `map` (vertex -> coarse vertex in [0, nc), or -1 = dropped): edge (a, b)
+	// for every fine edge (i, j) with both ends kept, weight = sum of the fine weights, self loops kept, columns
+	// ascending.  With pair_ptr: also the list, per coarse edge, of the fine edges behind it (fine row ascending, then
+	// fine edge ascending) and their row vertices.
+	void quotient(int64_t n, const int64_t *ptr, const int32_t *col, const int32_t *w, const std::vector<int32_t> &map, int64_t nc, hgraph &out,
+				  std::vector<int64_t> *pair_ptr, std::vector<uint32_t> *pair_src, std::vector<int32_t> *pair_row)
+	{
+		// members of every coarse vertex, ascending
+		std::vector<int64_t> mptr((size_t)nc + 1, 0);
+		for (int64_t i = 0; i < n; ++i)
+			if (map[(size_t)i] >= 0)
+				mptr[(size_t)map[(size_t)i] + 1]++;
+		for (int64_t a = 0; a < nc; ++a)
+			mptr[(size_t)a + 1] += mptr[(size_t)a];
+		std::vector<int32_t> mlist((size_t)mptr[(size_t)nc]);
+		{
+			std::vector<int64_t> fill(mptr.begin(), mptr.end() - 1);
+			for (int64_t i = 0; i < n; ++i)
+				if (map[(size_t)i] >= 0)
+					mlist[(size_t)fill[(size_t)map[(size_t)i]]++] = (int32_t)i;
+		}
+		const int T = host_threads();
+		struct part
+		{
+			std::vector<int64_t> deg;
+			std::vector<int32_t> col, w;
+			std::vector<int64_t> plen;
+			std::vector<uint32_t> psrc;
+			std::vector<int32_t> prow;
+		};
+		std::vector<part> parts((size_t)T);
+		const bool lists = pair_ptr != nullptr;
+		auto work = [&](int t) {
+			const int64_t a0 = nc * t / T, a1 = nc * (t + 1) / T;
+			part &p = parts[(size_t)t];
+			p.deg.reserve((size_t)(a1 - a0));
+			std::vector<qentry> buf;
+			for (int64_t a = a0; a < a1; ++a)
+			{
+				buf.clear();
+				for (int64_t k = mptr[(size_t)a]; k < mptr[(size_t)a + 1]; ++k)
+				{
+					const int32_t i = mlist[(size_t)k];
+					for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e)
+					{
+						const int32_t b = map[(size_t)col[e]];
+						if (b >= 0)
+							buf.push_back({b, w ? w[e] : 1, (uint32_t)e, i});
+					}
+				}
+				std::stable_sort(buf.begin(), buf.end(), [](const qentry &x, const qentry &y) { return x.b < y.b; });
+				int64_t d = 0;
+				for (size_t k = 0; k < buf.size();)
+				{
+					size_t k2 = k;
+					int64_t ws = 0;
+					while (k2 < buf.size() && buf[k2].b == buf[k].b)
+					{
+						ws += buf[k2].w;
+						if (lists)
+						{
+							p.psrc.push_back(buf[k2].e);
+							p.prow.push_back(buf[k2].i);
+						}
+						++k2;
+					}
+					p.col.push_back(buf[k].b);
+					p.w.push_back((int32_t)(ws > INT32_MAX ? INT32_MAX : ws));
+					if (lists)
+						p.plen.push_back((int64_t)(k2 - k));
+					++d;
+					k = k2;
+				}
+				p.deg.push_back(d);
+			}
+		};
+		{
+			std::vector<std::thread> th;
+			for (int t = 1; t < T; ++t)
+				th.emplace_back(work, t);
+			work(0);
+			for (auto &x : th)
+				x.join();
+		}
+		out.n = nc;
+		out.ptr.assign((size_t)nc + 1, 0);
+		int64_t a = 0, tot = 0, ptot = 0;
+		for (auto &p : parts)
+		{
+			for (int64_t d : p.deg)
+			{
+				out.ptr[(size_t)a + 1] = out.ptr[(size_t)a] + d;
+				++a;
+			}
+			tot += (int64_t)p.col.size();
+			ptot += (int64_t)p.psrc.size();
+		}
+		out.col.resize((size_t)tot);
+		out.w.resize((size_t)tot);
+		if (lists)
+		{
+			pair_ptr->assign((size_t)tot + 1, 0);
+			pair_src->resize((size_t)ptot);
+			pair_row->resize((size_t)ptot);
+		}
+		int64_t at = 0, pat = 0;
+		for (auto &p : parts)
+		{
+			std::copy(p.col.begin(), p.col.end(), out.col.begin() + at);
+			std::copy(p.w.begin(), p.w.end(), out.w.begin() + at);
+			if (lists)
+			{
+				for (size_t k = 0; k < p.plen.size(); ++k)
+					(*pair_ptr)[(size_t)at + k + 1] = p.plen[k];
+				std::copy(p.psrc.begin(), p.psrc.end(), pair_src->begin() + pat);
+				std::copy(p.prow.begin(), p.prow.end(), pair_row->begin() + pat);
+				pat += (int64_t)p.psrc.size();
+			}
+			at += (int64_t)p.col.size();
+			p = part();
+		}
+		if (lists)
+			for (int64_t k = 0; k < tot; ++k)
+				(*pair_ptr)[(size_t)k + 1] += (*pair_ptr)[(size_t)k];
+	}
+
+	// One round of greedy pairwise matching in vertex order: an unmatched vertex takes its unmatched neighbour of the
+	// largest weight (the first of equals); without one it stays alone.  Returns the number of clusters.
+	int64_t match_pass(int64_t n, const int64_t *ptr, const int32_t *col, const int32_t *w, const uint8_t *excluded, std::vector<int32_t> &m)
+	{
+		m.assign((size_t)n, -1);
+		int64_t k = 0;
+		for (int64_t i = 0; i < n; ++i)
+		{
+			if ((excluded && excluded[i]) || m[(size_t)i] >= 0)
+				continue;
+			int32_t best = -1, bw = -1;
+			for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e)
+			{
+				const int32_t j = col[e];
+				if (j == i || (excluded && excluded[j]) || m[(size_t)j] >= 0)
+					continue;
+				const int32_t we = w ? w[e] : 1;
+				if (we > bw)
+					bw = we, best = j;
+			}
+			m[(size_t)i] = (int32_t)k;
+			if (best >= 0)
+				m[(size_t)best] = (int32_t)k;
+			++k;
+		}
+		return k;
+	}
+
+	// ---------------------------------------------------------------------------------------------------------
+	// device kernels
+	// ---------------------------------------------------------------------------------------------------------
+	struct node_ref
+	{
+		int n_loc, n_gloc;
+		double gval[PFX_MAX_LOC][PFX_MAX_GLOC];
+	};
+
+	// position of every basis node: geometry map of its first incident element evaluated at the local node's reference
+	// position
+	__global__ void k_node_positions(const int64_t *__restrict__ ne_ptr, const uint32_t *__restrict__ ne_src, const int32_t *__restrict__ gconn,
+									 const double *__restrict__ xyz, node_ref ref, int64_t n_nodes, double *__restrict__ pos)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			double p[3] = {0, 0, 0};
+			if (ne_ptr[g] < ne_ptr[g + 1])
+			{
+				const uint32_t s = ne_src[ne_ptr[g]];
+				const int64_t e = s / (uint32_t)ref.n_loc;
+				const int i = (int)(s - (uint32_t)e * (uint32_t)ref.n_loc);
+				for (int j = 0; j < ref.n_gloc; ++j)
+				{
+					const int64_t gv = gconn[e * ref.n_gloc + j];
+					const double v = ref.gval[i][j];
+					p[0] += v * xyz[3 * gv], p[1] += v * xyz[3 * gv + 1], p[2] += v * xyz[3 * gv + 2];
+				}
+			}
+			pos[3 * g] = p[0], pos[3 * g + 1] = p[1], pos[3 * g + 2] = p[2];
+		}
+	}
+
+	__device__ __forceinline__ void load9(const double *__restrict__ p, double *a)
+	{
+#pragma unroll
+		for (int q = 0; q < 9; ++q)
+			a[q] = p[q];
+	}
+
+	// out = [d]x * m  (row-major 3x3)
+	__device__ __forceinline__ void cross_left(const double *d, const double *m, double *out)
+	{
+#pragma unroll
+		for (int c = 0; c < 3; ++c)
+		{
+			out[0 + c] = d[1] * m[6 + c] - d[2] * m[3 + c];
+			out[3 + c] = d[2] * m[0 + c] - d[0] * m[6 + c];
+			out[6 + c] = d[0] * m[3 + c] - d[1] * m[0 + c];
+		}
+	}
+
+	// out = -m * [d]x : column c of m [d]x is  m (e_c-th column of [d]x);  (m [d]x)(r, .) = row_r(m) x ... written out:
+	// [d]x = [[0,-d2,d1],[d2,0,-d0],[-d1,d0,0]]
+	__device__ __forceinline__ void neg_cross_right(const double *m, const double *d, double *out)
+	{
+#pragma unroll
+		for (int r = 0; r < 3; ++r)
+		{
+			const double a = m[3 * r], b = m[3 * r + 1], c = m[3 * r + 2];
+			out[3 * r + 0] = -(b * d[2] - c * d[1]);
+			out[3 * r + 1] = -(c * d[0] - a * d[2]);
+			out[3 * r + 2] = -(a * d[1] - b * d[0]);
+		}
+	}
+
+	// Galerkin product of one level: thread = (coarse pair, column half beta); it walks the fine pairs of the coarse pair
+	// in list order and writes the two coarse 3x3 blocks (T row and W row) of its column half.
+	// LEVEL0: fine pairs are single 3x3 blocks of the assembled matrix (index = block index), constrained dofs masked;
+	// else fine pairs are 2x2 groups of 3x3 blocks of a coarse level's node-block matrix.
+	template <bool LEVEL0>
+	__global__ __launch_bounds__(256) void k_galerkin(const int64_t *__restrict__ cp_ptr, const uint32_t *__restrict__ cp_src, const int32_t *__restrict__ cp_row,
+														 const int64_t *__restrict__ fine_gptr, const int32_t *__restrict__ fine_gcol, const double *__restrict__ fine_values,
+														 const double *__restrict__ dvec, const uint8_t *__restrict__ fixed, const int64_t *__restrict__ coarse_gptr,
+														 const int32_t *__restrict__ coarse_row_of_pair, int64_t n_cpairs, double *__restrict__ coarse_values)
+	{
+		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (t >= 2 * n_cpairs)
+			return;
+		const int64_t cp = t >> 1;
+		const int beta = (int)(t & 1);
+		double ct[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (int64_t k = cp_ptr[cp]; k < cp_ptr[cp + 1]; ++k)
+		{
+			const int64_t q = cp_src[k];
+			const int64_t i = cp_row[k];
+			const int64_t j = fine_gcol[q];
+			const double di[3] = {dvec[3 * i], dvec[3 * i + 1], dvec[3 * i + 2]};
+			const double dj[3] = {dvec[3 * j], dvec[3 * j + 1], dvec[3 * j + 2]};
+			double mt[9], mr[9];
+			if (LEVEL0)
+			{
+				double a[9];
+				load9(fine_values + q * 9, a);
+				if (fixed)
+#pragma unroll
+					for (int m = 0; m < 3; ++m)
+#pragma unroll
+						for (int n = 0; n < 3; ++n)
+							if (fixed[3 * i + m] || fixed[3 * j + n])
+								a[3 * m + n] = 0.0;
+				if (beta == 0)
+				{
+#pragma unroll
+					for (int z = 0; z < 9; ++z)
+						mt[z] = a[z];
+				}
+				else
+					neg_cross_right(a, dj, mt);
+#pragma unroll
+				for (int z = 0; z < 9; ++z)
+					mr[z] = 0.0;
+			}
+			else
+			{
+				// blocks of the fine pair (I = i, slot s = q - gptr[i]): (alpha, beta') at 4 gptr[i] + alpha * 2 deg + 2 s + beta'
+				const int64_t g0 = fine_gptr[i], deg = fine_gptr[i + 1] - g0, s = q - g0;
+				const double *att = fine_values + (4 * g0 + 2 * s) * 9;
+				const double *atr = att + 9;
+				const double *art = fine_values + (4 * g0 + 2 * deg + 2 * s) * 9;
+				const double *arr = art + 9;
+				if (beta == 0)
+				{
+					load9(att, mt);
+					load9(art, mr);
+				}
+				else
+				{
+					double a[9], b[9];
+					load9(att, a);
+					neg_cross_right(a, dj, mt);
+					load9(atr, b);
+#pragma unroll
+					for (int z = 0; z < 9; ++z)
+						mt[z] += b[z];
+					load9(art, a);
+					neg_cross_right(a, dj, mr);
+					load9(arr, b);
+#pragma unroll
+					for (int z = 0; z < 9; ++z)
+						mr[z] += b[z];
+				}
+			}
+			double x[9];
+			cross_left(di, mt, x);
+#pragma unroll
+			for (int z = 0; z < 9; ++z)
+			{
+				ct[z] += mt[z];
+				cr[z] += x[z] + mr[z];
+			}
+		}
+		const int64_t a = coarse_row_of_pair[cp];
+		const int64_t g0 = coarse_gptr[a], deg = coarse_gptr[a + 1] - g0, s = cp - g0;
+		double *ot = coarse_values + (4 * g0 + 2 * s + beta) * 9;
+		double *orr = coarse_values + (4 * g0 + 2 * deg + 2 * s + beta) * 9;
+#pragma unroll
+		for (int z = 0; z < 9; ++z)
+		{
+			ot[z] = ct[z];
+			orr[z] = cr[z];
+		}
+	}
+
+	// coarse right-hand side: per aggregate, sum over its member vertices of P_v^T (b - t)
+	template <bool LEVEL0>
+	__global__ __launch_bounds__(256) void k_restrict(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ dvec,
+														 const double *__restrict__ b, const double *__restrict__ t, int64_t n_agg, double *__restrict__ bc)
+	{
+		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < n_agg; a += (int64_t)gridDim.x * blockDim.x)
+		{
+			double T[3] = {0, 0, 0}, W[3] = {0, 0, 0};
+			for (int64_t k = mptr[a]; k < mptr[a + 1]; ++k)
+			{
+				const int64_t v = mlist[k];
+				const double d[3] = {dvec[3 * v], dvec[3 * v + 1], dvec[3 * v + 2]};
+				const int64_t o = LEVEL0 ? 3 * v : 6 * v;
+				const double r[3] = {b[o] - t[o], b[o + 1] - t[o + 1], b[o + 2] - t[o + 2]};
+				T[0] += r[0], T[1] += r[1], T[2] += r[2];
+				W[0] += d[1] * r[2] - d[2] * r[1];
+				W[1] += d[2] * r[0] - d[0] * r[2];
+				W[2] += d[0] * r[1] - d[1] * r[0];
+				if (!LEVEL0)
+				{
+					W[0] += b[o + 3] - t[o + 3];
+					W[1] += b[o + 4] - t[o + 4];
+					W[2] += b[o + 5] - t[o + 5];
+				}
+			}
+			bc[6 * a] = T[0], bc[6 * a + 1] = T[1], bc[6 * a + 2] = T[2];
+			bc[6 * a + 3] = W[0], bc[6 * a + 4] = W[1], bc[6 * a + 5] = W[2];
+		}
+	}
+
+	// x += P xc
+	template <bool LEVEL0>
+	__global__ __launch_bounds__(256) void k_prolong(const int32_t *__restrict__ agg, const double *__restrict__ dvec, const double *__restrict__ xc,
+														const uint8_t *__restrict__ fixed, int64_t n_vert, double *__restrict__ x)
+	{
+		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t a = agg[v];
+			if (a < 0)
+				continue;
+			const double d[3] = {dvec[3 * v], dvec[3 * v + 1], dvec[3 * v + 2]};
+			const double T[3] = {xc[6 * a], xc[6 * a + 1], xc[6 * a + 2]}, W[3] = {xc[6 * a + 3], xc[6 * a + 4], xc[6 * a + 5]};
+			const double u[3] = {T[0] + W[1] * d[2] - W[2] * d[1], T[1] + W[2] * d[0] - W[0] * d[2], T[2] + W[0] * d[1] - W[1] * d[0]};
+			const int64_t o = LEVEL0 ? 3 * v : 6 * v;
+#pragma unroll
+			for (int m = 0; m < 3; ++m)
+				if (!(LEVEL0 && fixed && fixed[o + m]))
+					x[o + m] += u[m];
+			if (!LEVEL0)
+			{
+				x[o + 3] += W[0];
+				x[o + 4] += W[1];
+				x[o + 5] += W[2];
+			}
+		}
+	}
+
+	// relaxation pieces (Chebyshev for D^-1 A, see amg_relax)
+	__global__ void k_cheb_first(const double *__restrict__ dinv, const double *__restrict__ b, const double *__restrict__ t, double s, int zero_guess,
+								 int64_t n, double *__restrict__ r, double *__restrict__ dv, double *__restrict__ x)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double rk = zero_guess ? b[k] : b[k] - t[k];
+			const double d = s * dinv[k] * rk;
+			if (r)
+			{
+				r[k] = rk;
+				dv[k] = d;
+			}
+			x[k] = zero_guess ? d : x[k] + d;
+		}
+	}
+
+	__global__ void k_cheb_next(const double *__restrict__ dinv, const double *__restrict__ t, double c1, double c2, int64_t n, double *__restrict__ r,
+								double *__restrict__ dv, double *__restrict__ x)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double rk = r[k] - t[k];
+			const double d = c1 * dv[k] + c2 * dinv[k] * rk;
+			r[k] = rk;
+			dv[k] = d;
+			x[k] += d;
+		}
+	}
+
+	__global__ void k_vec_add(const double *__restrict__ a, int64_t n, double *__restrict__ x)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			x[k] += a[k];
+	}
+
+	__global__ void k_vec_sub(const double *__restrict__ a, const double *__restrict__ b, int64_t n, double *__restrict__ out)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			out[k] = a[k] - b[k];
+	}
+
+	// x = Ainv b (dense, row-major, n x n): one wave per row
+	__global__ __launch_bounds__(64) void k_dense_matvec(const double *__restrict__ ainv, const double *__restrict__ b, int n, double *__restrict__ x)
+	{
+		const int row = blockIdx.x;
+		double acc = 0;
+		for (int k = threadIdx.x; k < n; k += 64)
+			acc += ainv[(int64_t)row * n + k] * b[k];
+		for (int off = 32; off > 0; off >>= 1)
+			acc += __shfl_down(acc, off, 64);
+		if (threadIdx.x == 0)
+			x[row] = acc;
+	}
+
+	__device__ __forceinline__ double block_sum256(double v, double *sh)
+	{
+		sh[threadIdx.x] = v;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1)
+		{
+			if ((int)threadIdx.x < s)
+				sh[threadIdx.x] += sh[threadIdx.x + s];
+			__syncthreads();
+		}
+		const double r = sh[0];
+		__syncthreads();
+		return r;
+	}
+
+	// partial sums of a.b (AMG_NPART blocks of 256 threads), fixed order
+	__global__ __launch_bounds__(256) void k_dot_part(const double *__restrict__ a, const double *__restrict__ b, int64_t n, double *__restrict__ part)
+	{
+		__shared__ double sh[256];
+		double acc = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			acc += a[k] * b[k];
+		const double s = block_sum256(acc, sh);
+		if (threadIdx.x == 0)
+			part[blockIdx.x] = s;
+	}
+
+	__global__ __launch_bounds__(256) void k_dot_finish(const double *__restrict__ part, int count, double *__restrict__ out)
+	{
+		__shared__ double sh[256];
+		double acc = 0;
+		for (int k = threadIdx.x; k < count; k += 256)
+			acc += part[k];
+		const double s = block_sum256(acc, sh);
+		if (threadIdx.x == 0)
+			*out = s;
+	}
+
+	// power iteration step: v = dinv * t / sqrt(*nrm2)   (t = A v_old, *nrm2 = |dinv t|^2 of this step)
+	__global__ void k_scale_dinv(const double *__restrict__ dinv, const double *__restrict__ t, int64_t n, double *__restrict__ v)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			v[k] = dinv[k] * t[k];
+	}
+
+	__global__ void k_normalise(const double *__restrict__ nrm2, int64_t n, double *__restrict__ v)
+	{
+		const double s = *nrm2 > 0 ? 1.0 / sqrt(*nrm2) : 0.0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			v[k] *= s;
+	}
+
+	__global__ void k_seed_vector(int64_t n, const uint8_t *__restrict__ fixed, double *__restrict__ v)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			uint64_t z = (uint64_t)k * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+			z ^= z >> 31;
+			z *= 0xBF58476D1CE4E5B9ull;
+			z ^= z >> 29;
+			const double u = (double)(z >> 11) / 9007199254740992.0 - 0.5;
+			v[k] = (fixed && fixed[k]) ? 0.0 : u;
+		}
+	}
+
+	// ---- preconditioned CG with a general preconditioner (Eigen's operation order, z = M^-1 r as its own vector) ------
+	struct pcg_state
+	{
+		double abs_new, pap, rr, threshold, rhs_norm2, tmp0, tmp1;
+		int done, iters;
+	};
+
+	__global__ __launch_bounds__(256) void k_pcg_init(const double *__restrict__ b, const double *__restrict__ t, const uint8_t *__restrict__ fixed, int64_t n,
+													 double *__restrict__ r, double *__restrict__ part)
+	{
+		__shared__ double sh[256];
+		double bb = 0, rr = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const bool fx = fixed && fixed[k];
+			const double bk = fx ? 0.0 : b[k];
+			const double rk = fx ? 0.0 : bk - t[k];
+			r[k] = rk;
+			bb += bk * bk;
+			rr += rk * rk;
+		}
+		const double s0 = block_sum256(bb, sh);
+		const double s1 = block_sum256(rr, sh);
+		if (threadIdx.x == 0)
+		{
+			part[blockIdx.x] = s0;
+			part[AMG_NPART + blockIdx.x] = s1;
+		}
+	}
+
+	__global__ __launch_bounds__(256) void k_pcg_init2(const double *__restrict__ part, double tol, int64_t n, double *__restrict__ x, pcg_state *__restrict__ st)
+	{
+		__shared__ double sh[256];
+		double a0 = 0, a1 = 0;
+		for (int k = threadIdx.x; k < AMG_NPART; k += 256)
+			a0 += part[k], a1 += part[AMG_NPART + k];
+		const double bb = block_sum256(a0, sh);
+		const double rr = block_sum256(a1, sh);
+		double thr = tol * tol * bb;
+		if (thr < DBL_MIN)
+			thr = DBL_MIN;
+		const bool zero_rhs = bb == 0.0;
+		if (zero_rhs)
+			for (int64_t k = threadIdx.x; k < n; k += 256)
+				x[k] = 0.0;
+		if (threadIdx.x == 0)
+		{
+			st->rhs_norm2 = bb;
+			st->threshold = thr;
+			st->rr = zero_rhs ? 0.0 : rr;
+			st->done = (zero_rhs || rr < thr) ? 1 : 0;
+			st->iters = 0;
+		}
+	}
+
+	// first: p = z, abs_new = r.z ; later: beta = r.z / abs_new, p = z + beta p      (r.z partials in part[2*NPART..])
+	__global__ __launch_bounds__(256) void k_pcg_direction(const double *__restrict__ z, const double *__restrict__ part, int first, int64_t n,
+														  double *__restrict__ p, pcg_state *__restrict__ st)
+	{
+		__shared__ double sh[256];
+		if (st->done)
+			return;
+		double a = 0;
+		for (int k = threadIdx.x; k < AMG_NPART; k += 256)
+			a += part[2 * AMG_NPART + k];
+		const double rz = block_sum256(a, sh);
+		const double beta = first ? 0.0 : rz / st->abs_new;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			p[k] = first ? z[k] : z[k] + beta * p[k];
+		// every block has read abs_new before the last block can have finished?  No such guarantee: the new value goes
+		// to tmp0 and is moved by k_pcg_commit, a separate launch.
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+			st->tmp0 = rz;
+	}
+
+	__global__ void k_pcg_commit(pcg_state *__restrict__ st)
+	{
+		if (!st->done)
+			st->abs_new = st->tmp0;
+	}
+
+	// alpha = abs_new / p.Ap ; x += alpha p ; r -= alpha t ; partials of r.r
+	__global__ __launch_bounds__(256) void k_pcg_update(const double *__restrict__ p, const double *__restrict__ t, const double *__restrict__ pap, int64_t n,
+													   double *__restrict__ x, double *__restrict__ r, double *__restrict__ part, const pcg_state *__restrict__ st)
+	{
+		__shared__ double sh[256];
+		if (st->done)
+			return;
+		const double alpha = st->abs_new / *pap;
+		double rr = 0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			x[k] += alpha * p[k];
+			const double rk = r[k] - alpha * t[k];
+			r[k] = rk;
+			rr += rk * rk;
+		}
+		const double s = block_sum256(rr, sh);
+		if (threadIdx.x == 0)
+			part[AMG_NPART + blockIdx.x] = s;
+	}
+
+	// convergence test after the update of iteration `it` (Eigen breaks before counting the iteration)
+	__global__ __launch_bounds__(256) void k_pcg_test(const double *__restrict__ part, int it, pcg_state *__restrict__ st)
+	{
+		__shared__ double sh[256];
+		if (st->done)
+			return;
+		double a = 0;
+		for (int k = threadIdx.x; k < AMG_NPART; k += 256)
+			a += part[AMG_NPART + k];
+		const double rr = block_sum256(a, sh);
+		if (threadIdx.x == 0)
+		{
+			st->rr = rr;
+			if (rr < st->threshold)
+			{
+				st->done = 1;
+				st->iters = it;
+			}
+			else
+				st->iters = it + 1;
+		}
+	}
+
+	__global__ void k_mask(double *__restrict__ v, const uint8_t *__restrict__ fixed, int64_t n)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			if (fixed[k])
+				v[k] = 0.0;
+	}
+
+	double now_s()
+	{
+		return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	}
+} // namespace
+
+// One level of the hierarchy.  `m` holds the level's matrix (level 0: the context itself; coarser levels: a context of
+// their own that shares the stream and carries only pattern, values and the solver copy).
+struct pfx_amg_level
+{
+	pfx_ctx *m = nullptr;
+	bool own_m = false;
+	int64_t n_vert = 0, n_dofs = 0; // vertices of this level; dofs of its vectors
+	int64_t n_agg = 0, n_cpairs = 0;
+	// transfer to the next level (empty on the coarsest)
+	int32_t *d_agg = nullptr;  // vertex -> aggregate or -1
+	double *d_dvec = nullptr;  // vertex -> offset from its aggregate's centre
+	int64_t *d_mptr = nullptr; // aggregate -> members
+	int32_t *d_mlist = nullptr;
+	int64_t *d_cp_ptr = nullptr; // coarse pair -> fine pairs
+	uint32_t *d_cp_src = nullptr;
+	int32_t *d_cp_row = nullptr;
+	int32_t *d_cp_arow = nullptr; // coarse pair -> its aggregate row
+	int64_t *d_gptr = nullptr;    // this level's vertex graph (levels > 0: pair structure of the matrix; level 0: unused)
+	int32_t *d_gcol = nullptr;
+	std::vector<int32_t> h_agg;
+	std::vector<int64_t> h_gptr; // host copy of the level's vertex graph (levels > 0)
+	std::vector<int32_t> h_gcol;
+	// vectors
+	double *d_b = nullptr, *d_x = nullptr, *d_t = nullptr, *d_r = nullptr, *d_dv = nullptr, *d_b2 = nullptr, *d_x2 = nullptr, *d_dinv = nullptr;
+	double lmax = 0;
+};
+
+struct pfx_amg
+{
+	std::vector<pfx_amg_level> lv;
+	int64_t struct_gen = -1, values_gen = -1;
+	double shift = -1;
+	double *d_ainv = nullptr; // dense inverse of the coarsest matrix
+	int n_coarsest = 0;
+	double *d_part = nullptr; // 3 * AMG_NPART partial sums + scalars
+	double *d_scal = nullptr;
+	double *d_z = nullptr, *d_r0 = nullptr, *d_dv0 = nullptr, *d_pos = nullptr;
+	pcg_state *d_state = nullptr;
+	double symbolic_s = 0, numeric_s = 0;
+	int64_t work_blocks = 0; // sum of the levels' blocks
+};
+
+namespace
+{
+	void free_level(pfx_ctx *ctx, pfx_amg_level &L)
+	{
+		free_dev(ctx, L.d_agg);
+		free_dev(ctx, L.d_dvec);
+		free_dev(ctx, L.d_mptr);
+		free_dev(ctx, L.d_mlist);
+		free_dev(ctx, L.d_cp_ptr);
+		free_dev(ctx, L.d_cp_src);
+		free_dev(ctx, L.d_cp_row);
+		free_dev(ctx, L.d_cp_arow);
+		free_dev(ctx, L.d_gptr);
+		free_dev(ctx, L.d_gcol);
+		free_dev(ctx, L.d_b);
+		free_dev(ctx, L.d_x);
+		free_dev(ctx, L.d_t);
+		free_dev(ctx, L.d_r);
+		free_dev(ctx, L.d_dv);
+		free_dev(ctx, L.d_b2);
+		free_dev(ctx, L.d_x2);
+		if (L.own_m)
+		{
+			free_dev(ctx, L.d_dinv);
+			pfx_ctx *s = L.m;
+			pfx_sell_release(s);
+			free_dev(s, s->d_node_ptr);
+			free_dev(s, s->d_node_col);
+			free_dev(s, s->d_values);
+			free_dev(s, s->d_part0);
+			delete s;
+		}
+		L.m = nullptr;
+	}
+
+	template <typename T>
+	pfx_status upload(pfx_ctx *ctx, T **dst, const std::vector<T> &src)
+	{
+		if (pfx_alloc(ctx, dst, (int64_t)src.size()))
+			return PFX_ERR_HIP;
+		if (!src.empty())
+			PFX_HIP(hipMemcpyAsync(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice, ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status amg_symbolic(pfx_ctx *ctx)
+	{
+		const double t_begin = now_s();
+		pfx_amg_release(ctx);
+		pfx_amg *A = new pfx_amg();
+		ctx->amg = A;
+		const pfx_amg_params &par = ctx->amg_params;
+		hipStream_t st = ctx->stream;
+		const int64_t n_nodes = ctx->n_nodes, n_owned = ctx->n_owned;
+
+		// level-0 graph and node positions on the host
+		std::vector<int64_t> ptr0((size_t)n_nodes + 1);
+		std::vector<int32_t> col0((size_t)ctx->n_blocks);
+		std::vector<uint8_t> fixed((size_t)ctx->n_dofs(), 0);
+		std::vector<double> pos((size_t)n_nodes * 3);
+		if (pfx_alloc(ctx, &A->d_pos, n_nodes * 3))
+			return PFX_ERR_HIP;
+		{
+			node_ref ref;
+			double lp[PFX_MAX_LOC][3];
+			pfx_local_node_positions(ctx->kind, &ref.n_loc, &ref.n_gloc, lp, ref.gval);
+			hipLaunchKernelGGL(k_node_positions, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->d_ne_ptr, ctx->d_ne_src, ctx->d_gconn, ctx->d_xyz, ref, n_nodes, A->d_pos);
+		}
+		PFX_HIP(hipMemcpyAsync(ptr0.data(), ctx->d_node_ptr, sizeof(int64_t) * ptr0.size(), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(col0.data(), ctx->d_node_col, sizeof(int32_t) * col0.size(), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(pos.data(), A->d_pos, sizeof(double) * pos.size(), hipMemcpyDeviceToHost, st));
+		if (ctx->n_dirichlet > 0)
+			PFX_HIP(hipMemcpyAsync(fixed.data(), ctx->d_fixed, fixed.size(), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+
+		// vertices left out at level 0: halo nodes and nodes whose three dofs are all constrained
+		std::vector<uint8_t> excluded((size_t)n_nodes, 0);
+		for (int64_t g = 0; g < n_nodes; ++g)
+			excluded[(size_t)g] = (g >= n_owned) || (fixed[(size_t)(3 * g)] && fixed[(size_t)(3 * g + 1)] && fixed[(size_t)(3 * g + 2)]);
+
+		// current level as host data
+		int64_t n_vert = n_nodes;
+		const int64_t *gptr = ptr0.data();
+		const int32_t *gcol = col0.data();
+		hgraph glevel; // owns the graph of levels > 0
+		std::vector<double> vpos = pos;
+		A->work_blocks = ctx->n_blocks;
+
+		pfx_amg_level L; // the level being coarsened
+		L.m = ctx;
+		L.own_m = false;
+		L.n_vert = n_vert;
+		L.n_dofs = n_nodes * 3;
+		for (int level = 0;; ++level)
+		{
+			const bool level0 = level == 0;
+			const int64_t dofs = level0 ? 3 * n_owned : 6 * n_vert;
+			if ((!level0 && dofs <= par.coarsest_dofs) || n_vert < 2 || level + 1 >= par.max_levels || level + 1 >= AMG_MAX_LEVELS)
+			{
+				A->lv.push_back(L);
+				break;
+			}
+			// ---- aggregation by repeated pairwise matching
+			std::vector<int32_t> cur((size_t)n_vert), m;
+			hgraph gq;
+			int64_t nc = 0;
+			for (int pass = 0; pass < par.aggregate_passes; ++pass)
+			{
+				if (pass == 0)
+				{
+					nc = match_pass(n_vert, gptr, gcol, level0 ? nullptr : glevel.w.data(), level0 ? excluded.data() : nullptr, m);
+					cur = m;
+				}
+				else
+				{
+					nc = match_pass(gq.n, gq.ptr.data(), gq.col.data(), gq.w.data(), nullptr, m);
+					for (int64_t v = 0; v < n_vert; ++v)
+						if (cur[(size_t)v] >= 0)
+							cur[(size_t)v] = m[(size_t)cur[(size_t)v]];
+				}
+				hgraph next;
+				quotient(n_vert, gptr, gcol, level0 ? nullptr : glevel.w.data(), cur, nc, next, nullptr, nullptr, nullptr);
+				gq = std::move(next);
+				if (nc <= 1)
+					break;
+			}
+			// level 0: aggregates of fewer than three nodes cannot carry the rotations; merge them into their strongest
+			// neighbour
+			if (level0 && nc > 1)
+			{
+				std::vector<int64_t> size((size_t)nc, 0);
+				for (int64_t v = 0; v < n_vert; ++v)
+					if (cur[(size_t)v] >= 0)
+						size[(size_t)cur[(size_t)v]]++;
+				std::vector<int32_t> root((size_t)nc);
+				std::iota(root.begin(), root.end(), 0);
+				auto find = [&](int32_t a) {
+					while (root[(size_t)a] != a)
+						a = root[(size_t)a] = root[(size_t)root[(size_t)a]];
+					return a;
+				};
+				bool any = false;
+				for (int64_t a = 0; a < nc; ++a)
+				{
+					if (size[(size_t)find((int32_t)a)] >= 3)
+						continue;
+					const int32_t ra = find((int32_t)a);
+					int32_t best = -1, bw = -1;
+					for (int64_t e = gq.ptr[(size_t)a]; e < gq.ptr[(size_t)a + 1]; ++e)
+					{
+						const int32_t rb = find(gq.col[(size_t)e]);
+						if (rb == ra)
+							continue;
+						if (gq.w[(size_t)e] > bw)
+							bw = gq.w[(size_t)e], best = rb;
+					}
+					if (best >= 0)
+					{
+						root[(size_t)ra] = best;
+						size[(size_t)best] += size[(size_t)ra];
+						any = true;
+					}
+				}
+				if (any)
+				{
+					std::vector<int32_t> renum((size_t)nc, -1);
+					int32_t k = 0;
+					for (int64_t a = 0; a < nc; ++a)
+						if (find((int32_t)a) == a)
+							renum[(size_t)a] = k++;
+					for (int64_t v = 0; v < n_vert; ++v)
+						if (cur[(size_t)v] >= 0)
+							cur[(size_t)v] = renum[(size_t)find(cur[(size_t)v])];
+					nc = k;
+				}
+			}
+			if (nc < 1 || (!level0 && nc * 10 > n_vert * 8)) // no free vertex, or the coarsening stalls
+			{
+				A->lv.push_back(L);
+				break;
+			}
+			// ---- coarse graph with the Galerkin lists
+			hgraph gc;
+			std::vector<int64_t> pair_ptr;
+			std::vector<uint32_t> pair_src;
+			std::vector<int32_t> pair_row;
+			quotient(n_vert, gptr, gcol, level0 ? nullptr : glevel.w.data(), cur, nc, gc, &pair_ptr, &pair_src, &pair_row);
+			const int64_t n_cp = (int64_t)gc.col.size();
+			std::vector<int32_t> arow((size_t)n_cp);
+			for (int64_t a = 0; a < nc; ++a)
+				for (int64_t e = gc.ptr[(size_t)a]; e < gc.ptr[(size_t)a + 1]; ++e)
+					arow[(size_t)e] = (int32_t)a;
+			// ---- members, centres, offsets
+			std::vector<int64_t> mptr((size_t)nc + 1, 0);
+			for (int64_t v = 0; v < n_vert; ++v)
+				if (cur[(size_t)v] >= 0)
+					mptr[(size_t)cur[(size_t)v] + 1]++;
+			for (int64_t a = 0; a < nc; ++a)
+				mptr[(size_t)a + 1] += mptr[(size_t)a];
+			std::vector<int32_t> mlist((size_t)mptr[(size_t)nc]);
+			{
+				std::vector<int64_t> fill(mptr.begin(), mptr.end() - 1);
+				for (int64_t v = 0; v < n_vert; ++v)
+					if (cur[(size_t)v] >= 0)
+						mlist[(size_t)fill[(size_t)cur[(size_t)v]]++] = (int32_t)v;
+			}
+			std::vector<double> centre((size_t)nc * 3, 0.0), dvec((size_t)n_vert * 3, 0.0);
+			for (int64_t a = 0; a < nc; ++a)
+			{
+				double c[3] = {0, 0, 0};
+				const int64_t cnt = mptr[(size_t)a + 1] - mptr[(size_t)a];
+				for (int64_t k = mptr[(size_t)a]; k < mptr[(size_t)a + 1]; ++k)
+					for (int q = 0; q < 3; ++q)
+						c[q] += vpos[(size_t)mlist[(size_t)k] * 3 + q];
+				for (int q = 0; q < 3; ++q)
+					centre[(size_t)a * 3 + q] = c[q] / (double)cnt;
+			}
+			for (int64_t v = 0; v < n_vert; ++v)
+				if (cur[(size_t)v] >= 0)
+					for (int q = 0; q < 3; ++q)
+						dvec[(size_t)v * 3 + q] = vpos[(size_t)v * 3 + q] - centre[(size_t)cur[(size_t)v] * 3 + q];
+			// ---- upload the transfer data of this level
+			L.n_agg = nc;
+			L.n_cpairs = n_cp;
+			L.h_agg = cur;
+			if (upload(ctx, &L.d_agg, cur) || upload(ctx, &L.d_dvec, dvec) || upload(ctx, &L.d_mptr, mptr) || upload(ctx, &L.d_mlist, mlist) || upload(ctx, &L.d_cp_ptr, pair_ptr)
+				|| upload(ctx, &L.d_cp_src, pair_src) || upload(ctx, &L.d_cp_row, pair_row) || upload(ctx, &L.d_cp_arow, arow))
+				return PFX_ERR_HIP;
+			PFX_HIP(hipStreamSynchronize(st));
+			A->lv.push_back(L);
+
+			// ---- the next level: a matrix holder with the pattern of the coarse pairs (two nodes per aggregate)
+			pfx_amg_level C;
+			pfx_ctx *s = new pfx_ctx();
+			s->device = ctx->device;
+			s->stream = ctx->stream;
+			s->own_stream = false;
+			s->bs = 3;
+			s->dim = 3;
+			s->n_nodes = s->n_owned = 2 * nc;
+			s->n_blocks = 4 * n_cp;
+			s->nnz = s->n_blocks * 9;
+			C.m = s;
+			C.own_m = true;
+			C.n_vert = nc;
+			C.n_dofs = 6 * nc;
+			std::vector<int64_t> nptr((size_t)(2 * nc) + 1);
+			std::vector<int32_t> ncol((size_t)(4 * n_cp));
+			for (int64_t a = 0; a < nc; ++a)
+			{
+				const int64_t g0 = gc.ptr[(size_t)a], deg = gc.ptr[(size_t)a + 1] - g0;
+				nptr[(size_t)(2 * a)] = 4 * g0;
+				nptr[(size_t)(2 * a + 1)] = 4 * g0 + 2 * deg;
+				for (int64_t k = 0; k < deg; ++k)
+					for (int al = 0; al < 2; ++al)
+						for (int be = 0; be < 2; ++be)
+							ncol[(size_t)(4 * g0 + al * 2 * deg + 2 * k + be)] = 2 * gc.col[(size_t)(g0 + k)] + be;
+			}
+			nptr[(size_t)(2 * nc)] = 4 * n_cp;
+			if (upload(s, &s->d_node_ptr, nptr) || upload(s, &s->d_node_col, ncol) || pfx_alloc(s, &s->d_values, s->nnz + 2) || upload(ctx, &C.d_gptr, gc.ptr) || upload(ctx, &C.d_gcol, gc.col))
+			{
+				ctx->err = s->err;
+				A->lv.push_back(C); // released with the hierarchy
+				return PFX_ERR_HIP;
+			}
+			PFX_HIP(hipMemsetAsync(s->d_values, 0, sizeof(double) * (size_t)(s->nnz + 2), st));
+			PFX_HIP(hipStreamSynchronize(st));
+			C.h_gptr = gc.ptr;
+			C.h_gcol = gc.col;
+			L = C;
+			A->work_blocks += s->n_blocks;
+			// descend
+			glevel = std::move(gc);
+			gptr = glevel.ptr.data();
+			gcol = glevel.col.data();
+			n_vert = nc;
+			vpos = centre;
+		}
+		// vectors
+		const int64_t n0 = ctx->n_dofs();
+		if (pfx_alloc(ctx, &A->d_part, 3 * AMG_NPART + 8) || pfx_alloc(ctx, &A->d_scal, 8) || pfx_alloc(ctx, &A->d_z, n0) || pfx_alloc(ctx, &A->d_state, 1))
+			return PFX_ERR_HIP;
+		PFX_HIP(hipMemsetAsync(A->d_z, 0, sizeof(double) * (size_t)n0, st));
+		for (size_t l = 0; l < A->lv.size(); ++l)
+		{
+			pfx_amg_level &L = A->lv[l];
+			const int64_t n = L.n_dofs;
+			if (l == 0)
+			{
+				// level 0 works on the caller's vectors (b = r, x = z) and the solver's scratch; its own are the Chebyshev pair
+				if (par.relax_degree > 1 && (pfx_alloc(ctx, &L.d_r, n) || pfx_alloc(ctx, &L.d_dv, n)))
+					return PFX_ERR_HIP;
+				continue;
+			}
+			if (pfx_alloc(ctx, &L.d_b, n) || pfx_alloc(ctx, &L.d_x, n) || pfx_alloc(ctx, &L.d_t, n) || pfx_alloc(ctx, &L.d_dinv, n) || pfx_alloc(ctx, &L.d_b2, n) || pfx_alloc(ctx, &L.d_x2, n))
+				return PFX_ERR_HIP;
+			if (par.relax_degree > 1 && (pfx_alloc(ctx, &L.d_r, n) || pfx_alloc(ctx, &L.d_dv, n)))
+				return PFX_ERR_HIP;
+		}
+		PFX_HIP(hipStreamSynchronize(st));
+		A->struct_gen = ctx->struct_gen;
+		A->values_gen = -1;
+		A->symbolic_s = now_s() - t_begin;
+		return PFX_OK;
+	}
+
+	// lmax of D^-1 A by power iteration (vectors: L.d_x as v, L.d_t as A v)
+	pfx_status amg_lambda_max(pfx_ctx *ctx, pfx_amg *A, pfx_amg_level &L, double *v, double *t, const double *dinv, int64_t n_rows)
+	{
+		hipStream_t st = ctx->stream;
+		const uint8_t *fixed = (L.m == ctx && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
+		hipLaunchKernelGGL(k_seed_vector, dim3(grid_for(n_rows)), dim3(256), 0, st, n_rows, fixed, v);
+		for (int it = 0; it < ctx->amg_params.power_iters; ++it)
+		{
+			pfx_status rc = pfx_sell_spmv(L.m, v, t, nullptr, nullptr);
+			if (rc)
+			{
+				ctx->err = L.m->err;
+				return rc;
+			}
+			hipLaunchKernelGGL(k_scale_dinv, dim3(grid_for(n_rows)), dim3(256), 0, st, dinv, t, n_rows, v);
+			hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, v, v, n_rows, A->d_part);
+			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, A->d_scal);
+			hipLaunchKernelGGL(k_normalise, dim3(grid_for(n_rows)), dim3(256), 0, st, A->d_scal, n_rows, v);
+		}
+		double nrm2 = 0;
+		PFX_HIP(hipMemcpyAsync(&nrm2, A->d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		// constrained level-0 dofs carry the eigenvalue 1 of the identity rows: never report less
+		L.lmax = 1.1 * std::max(std::sqrt(nrm2), 1.0);
+		return PFX_OK;
+	}
+
+	pfx_status amg_numeric(pfx_ctx *ctx, double *dinv0, double *scratch_v, double *scratch_t)
+	{
+		const double t_begin = now_s();
+		pfx_amg *A = ctx->amg;
+		hipStream_t st = ctx->stream;
+		const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+		for (size_t l = 0; l + 1 < A->lv.size(); ++l)
+		{
+			pfx_amg_level &F = A->lv[l], &C = A->lv[l + 1];
+			const unsigned grid = (unsigned)((2 * F.n_cpairs + 255) / 256);
+			if (l == 0)
+				hipLaunchKernelGGL((k_galerkin<true>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, (const int64_t *)nullptr, ctx->d_node_col, ctx->d_values, F.d_dvec,
+								   fixed, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
+			else
+				hipLaunchKernelGGL((k_galerkin<false>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.d_gptr, F.d_gcol, F.m->d_values, F.d_dvec,
+								   (const uint8_t *)nullptr, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
+			C.m->values_gen++;
+			pfx_status rc = pfx_sell_refresh(C.m);
+			if (!rc)
+				rc = pfx_launch_invdiag(C.m, 1, C.d_dinv);
+			if (rc)
+			{
+				ctx->err = C.m->err;
+				return rc;
+			}
+		}
+		PFX_HIP(hipGetLastError());
+		// spectral radii of D^-1 A on every level that is relaxed
+		for (size_t l = 0; l + 1 < A->lv.size(); ++l)
+		{
+			pfx_amg_level &L = A->lv[l];
+			pfx_status rc = (l == 0) ? amg_lambda_max(ctx, A, L, scratch_v, scratch_t, dinv0, ctx->n_owned * 3) : amg_lambda_max(ctx, A, L, L.d_x, L.d_t, L.d_dinv, L.n_dofs);
+			if (rc)
+				return rc;
+		}
+		// dense inverse of the coarsest matrix (host: Gauss-Jordan with partial pivoting)
+		{
+			pfx_amg_level &L = A->lv.back();
+			if (A->lv.size() < 2)
+			{
+				A->n_coarsest = 0;
+			}
+			else
+			{
+				pfx_ctx *s = L.m;
+				const int n = (int)L.n_dofs;
+				std::vector<double> vals((size_t)s->nnz);
+				PFX_HIP(hipMemcpyAsync(vals.data(), s->d_values, sizeof(double) * vals.size(), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipStreamSynchronize(st));
+				std::vector<double> M((size_t)n * n, 0.0), I((size_t)n * n, 0.0);
+				const int64_t nv = L.n_vert;
+				double dmax = 0;
+				for (int64_t a = 0; a < nv; ++a)
+				{
+					const int64_t g0 = L.h_gptr[(size_t)a], deg = L.h_gptr[(size_t)a + 1] - g0;
+					for (int64_t k = 0; k < deg; ++k)
+						for (int al = 0; al < 2; ++al)
+							for (int be = 0; be < 2; ++be)
+							{
+								const double *blk = vals.data() + (4 * g0 + al * 2 * deg + 2 * k + be) * 9;
+								const int64_t r0 = (2 * a + al) * 3, c0 = (2 * (int64_t)L.h_gcol[(size_t)(g0 + k)] + be) * 3;
+								for (int m = 0; m < 3; ++m)
+									for (int q = 0; q < 3; ++q)
+										M[(size_t)((r0 + m) * n + c0 + q)] = blk[3 * m + q];
+							}
+				}
+				for (int k = 0; k < n; ++k)
+					dmax = std::max(dmax, std::fabs(M[(size_t)k * n + k]));
+				for (int k = 0; k < n; ++k)
+				{
+					// a coarse dof without any stiffness (rotation of a degenerate aggregate) is decoupled; a tiny shift
+					// keeps nearly dependent rigid-body modes from blowing up the inverse
+					if (M[(size_t)k * n + k] == 0.0)
+						M[(size_t)k * n + k] = dmax > 0 ? dmax : 1.0;
+					else
+						M[(size_t)k * n + k] += 1e-12 * dmax;
+					I[(size_t)k * n + k] = 1.0;
+				}
+				for (int c = 0; c < n; ++c)
+				{
+					int piv = c;
+					for (int r = c + 1; r < n; ++r)
+						if (std::fabs(M[(size_t)r * n + c]) > std::fabs(M[(size_t)piv * n + c]))
+							piv = r;
+					if (M[(size_t)piv * n + c] == 0.0)
+						PFX_FAIL(PFX_ERR_NUMERIC, "AMG: the coarsest matrix is singular");
+					if (piv != c)
+						for (int k = 0; k < n; ++k)
+						{
+							std::swap(M[(size_t)piv * n + k], M[(size_t)c * n + k]);
+							std::swap(I[(size_t)piv * n + k], I[(size_t)c * n + k]);
+						}
+					const double inv = 1.0 / M[(size_t)c * n + c];
+					for (int k = 0; k < n; ++k)
+					{
+						M[(size_t)c * n + k] *= inv;
+						I[(size_t)c * n + k] *= inv;
+					}
+					for (int r = 0; r < n; ++r)
+					{
+						if (r == c)
+							continue;
+						const double f = M[(size_t)r * n + c];
+						if (f == 0.0)
+							continue;
+						double *mr = &M[(size_t)r * n], *mc = &M[(size_t)c * n], *ir = &I[(size_t)r * n], *ic = &I[(size_t)c * n];
+						for (int k = 0; k < n; ++k)
+						{
+							mr[k] -= f * mc[k];
+							ir[k] -= f * ic[k];
+						}
+					}
+				}
+				if (A->n_coarsest != n)
+				{
+					if (pfx_alloc(ctx, &A->d_ainv, (int64_t)n * n))
+						return PFX_ERR_HIP;
+					A->n_coarsest = n;
+				}
+				PFX_HIP(hipMemcpyAsync(A->d_ainv, I.data(), sizeof(double) * I.size(), hipMemcpyHostToDevice, st));
+				PFX_HIP(hipStreamSynchronize(st));
+			}
+		}
+		A->values_gen = ctx->values_gen;
+		A->shift = ctx->diag_shift;
+		A->numeric_s = now_s() - t_begin;
+		return PFX_OK;
+	}
+
+	struct relax_vecs
+	{
+		const double *b;
+		double *x, *t, *r, *dv;
+		const double *dinv;
+		int64_t n;
+	};
+
+	// Chebyshev relaxation of degree `deg` for D^-1 A on [lower * lmax, lmax]; zero_guess: x is overwritten
+	pfx_status amg_relax(pfx_ctx *ctx, pfx_amg_level &L, const relax_vecs &v, bool zero_guess)
+	{
+		hipStream_t st = ctx->stream;
+		const pfx_amg_params &par = ctx->amg_params;
+		const int deg = par.relax_degree < 1 ? 1 : par.relax_degree;
+		const double lmax = L.lmax, lmin = L.lmax * par.relax_lower;
+		const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+		const double sigma = theta / delta;
+		double rho = 1.0 / sigma;
+		const int grid = grid_for(v.n);
+		if (!zero_guess)
+		{
+			pfx_status rc = pfx_sell_spmv(L.m, v.x, v.t, nullptr, nullptr);
+			if (rc)
+			{
+				ctx->err = L.m->err;
+				return rc;
+			}
+		}
+		hipLaunchKernelGGL(k_cheb_first, dim3(grid), dim3(256), 0, st, v.dinv, v.b, v.t, 1.0 / theta, zero_guess ? 1 : 0, v.n, deg > 1 ? v.r : nullptr, v.dv, v.x);
+		for (int k = 1; k < deg; ++k)
+		{
+			pfx_status rc = pfx_sell_spmv(L.m, v.dv, v.t, nullptr, nullptr);
+			if (rc)
+			{
+				ctx->err = L.m->err;
+				return rc;
+			}
+			const double rho_new = 1.0 / (2.0 * sigma - rho);
+			hipLaunchKernelGGL(k_cheb_next, dim3(grid), dim3(256), 0, st, v.dinv, v.t, rho_new * rho, 2.0 * rho_new / delta, v.n, v.r, v.dv, v.x);
+			rho = rho_new;
+		}
+		return PFX_OK;
+	}
+
+	// x = M_l^-1 b on level l (b, x: vectors of that level; level 0: the caller's)
+	pfx_status amg_cycle(pfx_ctx *ctx, pfx_amg *A, size_t l, const double *b, double *x, double *t0, const double *dinv0)
+	{
+		hipStream_t st = ctx->stream;
+		pfx_amg_level &L = A->lv[l];
+		if (l + 1 == A->lv.size())
+		{
+			hipLaunchKernelGGL(k_dense_matvec, dim3(A->n_coarsest), dim3(64), 0, st, A->d_ainv, b, A->n_coarsest, x);
+			return PFX_OK;
+		}
+		const bool level0 = l == 0;
+		const int64_t n = level0 ? ctx->n_owned * 3 : L.n_dofs;
+		relax_vecs v{b, x, level0 ? t0 : L.d_t, L.d_r, L.d_dv, level0 ? dinv0 : L.d_dinv, n};
+		pfx_status rc = amg_relax(ctx, L, v, true);
+		if (rc)
+			return rc;
+		// coarse correction
+		if ((rc = pfx_sell_spmv(L.m, x, v.t, nullptr, nullptr)))
+		{
+			ctx->err = L.m->err;
+			return rc;
+		}
+		pfx_amg_level &C = A->lv[l + 1];
+		if (level0)
+			hipLaunchKernelGGL((k_restrict<true>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
+		else
+			hipLaunchKernelGGL((k_restrict<false>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
+		if ((rc = amg_cycle(ctx, A, l + 1, C.d_b, C.d_x, nullptr, nullptr)))
+			return rc;
+		if (ctx->amg_params.ncycle > 1 && l + 2 < A->lv.size())
+		{
+			// W cycle: a second coarse cycle on the coarse residual
+			for (int rep = 1; rep < ctx->amg_params.ncycle; ++rep)
+			{
+				if ((rc = pfx_sell_spmv(C.m, C.d_x, C.d_t, nullptr, nullptr)))
+				{
+					ctx->err = C.m->err;
+					return rc;
+				}
+				hipLaunchKernelGGL(k_vec_sub, dim3(grid_for(C.n_dofs)), dim3(256), 0, st, C.d_b, C.d_t, C.n_dofs, C.d_b2);
+				if ((rc = amg_cycle(ctx, A, l + 1, C.d_b2, C.d_x2, nullptr, nullptr)))
+					return rc;
+				hipLaunchKernelGGL(k_vec_add, dim3(grid_for(C.n_dofs)), dim3(256), 0, st, C.d_x2, C.n_dofs, C.d_x);
+			}
+		}
+		const uint8_t *fixed = (level0 && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
+		if (level0)
+			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, x);
+		else
+			hipLaunchKernelGGL((k_prolong<false>), dim3(grid_for(L.n_vert)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_vert, x);
+		return amg_relax(ctx, L, v, false);
+	}
+} // namespace
+
+void pfx_amg_release(pfx_ctx *ctx)
+{
+	pfx_amg *A = ctx->amg;
+	if (!A)
+		return;
+	for (auto &L : A->lv)
+		free_level(ctx, L);
+	free_dev(ctx, A->d_ainv);
+	free_dev(ctx, A->d_part);
+	free_dev(ctx, A->d_scal);
+	free_dev(ctx, A->d_z);
+	free_dev(ctx, A->d_r0);
+	free_dev(ctx, A->d_dv0);
+	free_dev(ctx, A->d_pos);
+	free_dev(ctx, A->d_state);
+	delete A;
+	ctx->amg = nullptr;
+}
+
+// hierarchy for the current pattern / Dirichlet set (symbolic) and matrix values (numeric); dinv0 = Jacobi diagonal of
+// the level-0 operator (n_dofs doubles), scratch_v / scratch_t: two level-0 vectors that may be overwritten
+pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, double *scratch_t)
+{
+	if (ctx->bs != 3)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner is implemented for vector-valued problems (block size 3)");
+	if (ctx->n_owned != ctx->n_nodes)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner runs on an unpartitioned mesh");
+	pfx_status rc = pfx_sell_refresh(ctx);
+	if (rc)
+		return rc;
+	if (!ctx->amg || ctx->amg->struct_gen != ctx->struct_gen)
+		if ((rc = amg_symbolic(ctx)))
+			return rc;
+	// the Jacobi diagonal lives in the solver's workspace, which other solves overwrite: always rebuilt
+	if ((rc = pfx_launch_invdiag(ctx, 1, dinv0)))
+		return rc;
+	if (ctx->amg->values_gen != ctx->values_gen || ctx->amg->shift != ctx->diag_shift)
+		if ((rc = amg_numeric(ctx, dinv0, scratch_v, scratch_t)))
+			return rc;
+	return PFX_OK;
+}
+
+// z = M^-1 r (level-0 vectors; t0: scratch, dinv0: Jacobi diagonal)
+pfx_status pfx_amg_apply(pfx_ctx *ctx, const double *d_r, double *d_z, double *t0, const double *dinv0)
+{
+	pfx_scoped_timer tm(ctx, "precond");
+	pfx_amg *A = ctx->amg;
+	if (A->lv.size() < 2)
+	{
+		// nothing to coarsen (every node constrained): plain Jacobi
+		hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(ctx->n_owned * 3)), dim3(256), 0, ctx->stream, dinv0, d_r, (const double *)nullptr, 1.0, 1, ctx->n_owned * 3,
+						   (double *)nullptr, (double *)nullptr, d_z);
+		return PFX_OK;
+	}
+	pfx_status rc = amg_cycle(ctx, A, 0, d_r, d_z, t0, dinv0);
+	if (rc)
+		return rc;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res)
+{
+	hipStream_t st = ctx->stream;
+	const int64_t n = ctx->n_owned * ctx->bs;
+	const int64_t nfull = ctx->n_dofs();
+	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	if (ctx->d_work_ext)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG-preconditioned solve uses the context's own workspace (clear pfx_cgs_set_workspace first)");
+	if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * nfull))
+		return PFX_ERR_HIP;
+	double *r = ctx->d_work, *p = ctx->d_work + nfull, *t = ctx->d_work + 2 * nfull, *dinv = ctx->d_work + 3 * nfull;
+	pfx_status rc = pfx_amg_prepare(ctx, dinv, p, t);
+	if (rc)
+		return rc;
+	pfx_amg *A = ctx->amg;
+	if (ctx->part0_count < pfx_sell_grid(ctx))
+	{
+		if (pfx_alloc(ctx, &ctx->d_part0, pfx_sell_grid(ctx)))
+			return PFX_ERR_HIP;
+		ctx->part0_count = pfx_sell_grid(ctx);
+	}
+	pcg_state *state = A->d_state;
+	PFX_HIP(hipMemsetAsync(state, 0, sizeof(pcg_state), st));
+	if (fixed)
+		hipLaunchKernelGGL(k_mask, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n);
+	if ((rc = pfx_sell_spmv(ctx, d_x, t, nullptr, nullptr)))
+		return rc;
+	hipLaunchKernelGGL(k_pcg_init, dim3(AMG_NPART), dim3(256), 0, st, d_b, t, fixed, n, r, A->d_part);
+	hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(256), 0, st, A->d_part, tol, n, d_x, state);
+	// z = M^-1 r ; p = z ; abs_new = r.z
+	if ((rc = pfx_amg_apply(ctx, r, A->d_z, t, dinv)))
+		return rc;
+	hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, r, A->d_z, n, A->d_part + 2 * AMG_NPART);
+	hipLaunchKernelGGL(k_pcg_direction, dim3(AMG_NPART), dim3(256), 0, st, A->d_z, A->d_part, 1, n, p, state);
+	hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, st, state);
+	const int check_every = 8;
+	int it = 0;
+	pcg_state h;
+	memset(&h, 0, sizeof(h));
+	PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+	PFX_HIP(hipStreamSynchronize(st));
+	while (it < max_iter && !h.done)
+	{
+		const int stop = (it + check_every < max_iter) ? it + check_every : max_iter;
+		for (; it < stop; ++it)
+		{
+			if ((rc = pfx_sell_spmv(ctx, p, t, ctx->d_part0, &state->done)))
+				return rc;
+			pfx_launch_sum_partials(ctx, ctx->d_part0, pfx_sell_grid(ctx), A->d_scal);
+			hipLaunchKernelGGL(k_pcg_update, dim3(AMG_NPART), dim3(256), 0, st, p, t, A->d_scal, n, d_x, r, A->d_part, state);
+			hipLaunchKernelGGL(k_pcg_test, dim3(1), dim3(256), 0, st, A->d_part, it, state);
+			if ((rc = pfx_amg_apply(ctx, r, A->d_z, t, dinv)))
+				return rc;
+			hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, r, A->d_z, n, A->d_part + 2 * AMG_NPART);
+			hipLaunchKernelGGL(k_pcg_direction, dim3(AMG_NPART), dim3(256), 0, st, A->d_z, A->d_part, 0, n, p, state);
+			hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, st, state);
+		}
+		PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+	}
+	PFX_HIP(hipGetLastError());
+	*iters = h.iters;
+	*rel_res = (h.rhs_norm2 == 0.0) ? 0.0 : std::sqrt(h.rr / h.rhs_norm2);
+	return PFX_OK;
+}
+
+extern "C"
+{
+	void pfx_amg_default_params(pfx_amg_params *p)
+	{
+		if (!p)
+			return;
+		p->aggregate_passes = 4;
+		p->relax_degree = 1;
+		p->ncycle = 1;
+		p->max_levels = 12;
+		p->coarsest_dofs = 600;
+		p->power_iters = 10;
+		p->relax_lower = 0.1;
+	}
+
+	pfx_status pfx_amg_set_params(pfx_ctx *ctx, const pfx_amg_params *p)
+	{
+		if (!ctx || !p)
+			return PFX_ERR_ARG;
+		if (p->aggregate_passes < 1 || p->aggregate_passes > 8 || p->relax_degree < 1 || p->relax_degree > 16 || p->ncycle < 1 || p->ncycle > 4 || p->max_levels < 2
+			|| p->coarsest_dofs < 6 || p->coarsest_dofs > 3000 || p->power_iters < 1 || !(p->relax_lower > 0.0 && p->relax_lower < 1.0))
+			PFX_FAIL(PFX_ERR_ARG, "pfx_amg_set_params: parameter out of range");
+		ctx->amg_params = *p;
+		PFX_HIP(hipSetDevice(ctx->device));
+		pfx_amg_release(ctx); // the hierarchy depends on the parameters
+		return PFX_OK;
+	}
+
+	pfx_status pfx_amg_setup(pfx_ctx *ctx)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (!ctx->d_node_ptr)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_build_pattern must be called first");
+		PFX_HIP(hipSetDevice(ctx->device));
+		const int64_t nfull = ctx->n_dofs();
+		if (ctx->d_work_ext)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner uses the context's own workspace");
+		if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * nfull))
+			return PFX_ERR_HIP;
+		return pfx_amg_prepare(ctx, ctx->d_work + 3 * nfull, ctx->d_work + nfull, ctx->d_work + 2 * nfull);
+	}
+
+	pfx_status pfx_amg_get_info(pfx_ctx *ctx, pfx_amg_info *info)
+	{
+		if (!ctx || !info)
+			return PFX_ERR_ARG;
+		memset(info, 0, sizeof(*info));
+		pfx_amg *A = ctx->amg;
+		if (!A)
+			PFX_FAIL(PFX_ERR_ARG, "no AMG hierarchy: call pfx_amg_setup or solve with PFX_PRECOND_AMG first");
+		info->n_levels = (int)A->lv.size();
+		for (size_t l = 0; l < A->lv.size() && l < 16; ++l)
+		{
+			info->n_vertices[l] = l == 0 ? ctx->n_owned : A->lv[l].n_vert;
+			info->n_aggregates[l] = A->lv[l].n_agg;
+			info->n_blocks[l] = A->lv[l].m->n_blocks;
+			info->lambda_max[l] = A->lv[l].lmax;
+		}
+		info->operator_complexity = (double)A->work_blocks / (double)ctx->n_blocks;
+		info->symbolic_s = A->symbolic_s;
+		info->numeric_s = A->numeric_s;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_amg_get_aggregates(pfx_ctx *ctx, int level, int32_t *agg)
+	{
+		if (!ctx || !agg)
+			return PFX_ERR_ARG;
+		pfx_amg *A = ctx->amg;
+		if (!A || level < 0 || level + 1 >= (int)A->lv.size())
+			PFX_FAIL(PFX_ERR_ARG, "pfx_amg_get_aggregates: no such level");
+		const auto &h = A->lv[(size_t)level].h_agg;
+		std::copy(h.begin(), h.end(), agg);
+		return PFX_OK;
+	}
+
+	pfx_status pfx_amg_apply_dev(pfx_ctx *ctx, const double *d_r, double *d_z)
+	{
+		if (!ctx || !d_r || !d_z)
+			return PFX_ERR_ARG;
+		pfx_status rc = pfx_amg_setup(ctx);
+		if (rc)
+			return rc;
+		const int64_t nfull = ctx->n_dofs();
+		return pfx_amg_apply(ctx, d_r, d_z, ctx->d_work + 2 * nfull, ctx->d_work + 3 * nfull);
+	}
+}

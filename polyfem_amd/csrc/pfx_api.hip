@@ -76,6 +76,8 @@ namespace
 		ctx->inertia_weight = 0.0;
 		ctx->d_x_tilde = nullptr;
 		pfx_sell_release(ctx);
+		pfx_amg_release(ctx);
+		ctx->struct_gen++;
 		ctx->d_work_ext = nullptr; // a caller-owned workspace was sized for the pattern that is going away
 		ctx->n_blocks = ctx->nnz = 0;
 		ctx->n_dirichlet = 0;
@@ -782,6 +784,7 @@ extern "C"
 		}
 		PFX_HIP(hipMemsetAsync(ctx->d_fixed, 0, (size_t)nd, ctx->stream));
 		ctx->n_dirichlet = n;
+		ctx->struct_gen++;
 		if (n > 0)
 		{
 			if (pfx_alloc(ctx, &ctx->d_dirichlet, n))
@@ -1088,7 +1091,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_pattern(ctx))
 			return PFX_ERR_ARG;
-		if (precond != PFX_PRECOND_IDENTITY && precond != PFX_PRECOND_JACOBI)
+		if (precond != PFX_PRECOND_IDENTITY && precond != PFX_PRECOND_JACOBI && precond != PFX_PRECOND_AMG)
 			PFX_FAIL(PFX_ERR_ARG, "unknown preconditioner");
 		return pfx_cg_run(ctx, d_b, d_x, precond, max_iter, tol, iters, rel_res);
 	}
@@ -1154,6 +1157,7 @@ extern "C"
 		if (n_owned_nodes < 0 || n_owned_nodes > ctx->n_nodes)
 			PFX_FAIL(PFX_ERR_ARG, "n_owned_nodes out of range");
 		ctx->n_owned = n_owned_nodes;
+		ctx->struct_gen++;
 		free_dev(ctx, ctx->d_elem_owned);
 		if (elem_owned)
 		{

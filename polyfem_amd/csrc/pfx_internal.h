@@ -38,6 +38,8 @@ enum
 	PFX_ESTATE_NL = 2      // J^{-T}, F, coefficients per point (pfx_local_nl.hip)
 };
 
+struct pfx_amg; // hierarchy of the aggregation-AMG preconditioner (pfx_amg.hip)
+
 struct pfx_timer_family
 {
 	double total_ms = 0;
@@ -146,6 +148,12 @@ struct pfx_ctx
 	int64_t values_gen = 0, sell_gen = -1; // assembly counter / counter value the solver copy was made from
 	int *d_cgstate = nullptr;
 	double *d_u = nullptr, *d_vec = nullptr; // staging for host-pointer entry points
+
+	// AMG preconditioner: parameters, hierarchy, and a counter of everything its symbolic part depends on (pattern,
+	// Dirichlet set, owned range)
+	pfx_amg_params amg_params = {4, 1, 1, 12, 600, 10, 0.1};
+	pfx_amg *amg = nullptr;
+	int64_t struct_gen = 0;
 
 	int64_t bytes_device = 0;                   // device memory currently held through pfx_alloc
 	std::map<const void *, int64_t> alloc_bytes; // size of every live pfx_alloc allocation
@@ -322,6 +330,11 @@ enum
 	PFX_SPMV_BOUNDARY = 2
 };
 pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL);
+void pfx_amg_release(pfx_ctx *ctx);
+pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res);
+pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag);
+void pfx_launch_sum_partials(pfx_ctx *ctx, const double *part, int count, double *out);
+void pfx_local_node_positions(int kind, int *n_loc, int *n_gloc, double (*pos)[3], double (*gval)[PFX_MAX_GLOC]);
 pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res);
 pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal);
 pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond);

@@ -306,6 +306,23 @@ namespace
 
 } // namespace
 
+// Jacobi diagonal of the (masked, shifted) operator the solver works with: 1 / a_ii, 1 where a_ii == 0 or the dof is constrained
+pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag)
+{
+	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	if (ctx->bs == 1)
+		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jacobi, ctx->diag_shift, d_invdiag);
+	else
+		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jacobi, ctx->diag_shift, d_invdiag);
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+void pfx_launch_sum_partials(pfx_ctx *ctx, const double *part, int count, double *out)
+{
+	hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, part, count, out);
+}
+
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y)
 {
 	pfx_status rc = pfx_sell_refresh(ctx);
@@ -489,6 +506,8 @@ pfx_status pfx_cgs_status_impl(pfx_ctx *ctx, int *done, int *iters, double *rr, 
 pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond, int max_iter, double tol, int *iters, double *rel_res)
 {
 	pfx_status rc;
+	if (precond == PFX_PRECOND_AMG)
+		return pfx_pcg_amg_run(ctx, d_b, d_x, max_iter, tol, iters, rel_res);
 	if ((rc = pfx_cgs_prepare_impl(ctx, d_x, precond)) || (rc = pfx_cgs_residual_impl(ctx, d_b, d_x, nullptr)) || (rc = pfx_cgs_start_impl(ctx, d_x, tol, nullptr)) || (rc = pfx_cgs_start2_impl(ctx, nullptr)))
 		return rc;
 	// the kernels return at once after convergence (device flag), so a late check costs a few empty launches only

@@ -12,6 +12,7 @@
 #include "pf_quad_tables.h"
 #include "pf_q2_tables.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace
@@ -348,3 +349,34 @@ void fill(int kind, int real_order, pfx_tables *t)
 	}
 }
 } // namespace
+
+// Reference position of every local node of an element kind and the geometry-basis values there: the node of basis j
+// is the lattice point of {0, 1/2, 1}^3 where basis j equals one (the Kronecker property the reference's own tests
+// check, tests/test_bases.cpp:716-776).  Used to place the basis nodes in space (aggregation-AMG rigid-body modes).
+void pfx_local_node_positions(int kind, int *n_loc, int *n_gloc, double (*pos)[3], double (*gval)[PFX_MAX_GLOC])
+{
+	static const int nloc[4] = {4, 10, 8, 27};
+	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX);
+	const int gkind = hex ? PFX_Q1HEX : PFX_P1TET;
+	*n_loc = nloc[kind];
+	*n_gloc = nloc[gkind];
+	for (int j = 0; j < *n_loc; ++j)
+	{
+		bool found = false;
+		for (int a = 0; a < 3 && !found; ++a)
+			for (int b = 0; b < 3 && !found; ++b)
+				for (int c = 0; c < 3 && !found; ++c)
+				{
+					const double pt[3] = {0.5 * a, 0.5 * b, 0.5 * c};
+					if (!hex && pt[0] + pt[1] + pt[2] > 1.0)
+						continue;
+					if (std::fabs(basis_value(kind, j, pt) - 1.0) < 1e-12)
+					{
+						pos[j][0] = pt[0], pos[j][1] = pt[1], pos[j][2] = pt[2];
+						found = true;
+					}
+				}
+		for (int g = 0; g < *n_gloc; ++g)
+			gval[j][g] = basis_value(gkind, g, pos[j]);
+	}
+}

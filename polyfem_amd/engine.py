@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("PFX_LIBRARY") or os.path.join(_HERE, "libpolyfem_amd.
 
 P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
 LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
-PRECOND_IDENTITY, PRECOND_JACOBI = 0, 1
+PRECOND_IDENTITY, PRECOND_JACOBI, PRECOND_AMG = 0, 1, 2
 PFX_ERR_ARG, PFX_ERR_HIP, PFX_ERR_UNSUPPORTED, PFX_ERR_NUMERIC, PFX_ERR_SIZE = -1, -2, -3, -4, -5
 MODEL_BY_NAME = {"Laplacian": LAPLACIAN, "LinearElasticity": LINEAR_ELASTICITY, "NeoHookean": NEOHOOKEAN,
                  "SaintVenant": SAINT_VENANT}
@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = [
     "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
     "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev", "pfx_set_material_per_point",
     "pfx_energy_dev_noalloc",
+    "pfx_amg_default_params", "pfx_amg_set_params", "pfx_amg_setup", "pfx_amg_get_info", "pfx_amg_get_aggregates", "pfx_amg_apply_dev",
 ]
 
 
@@ -92,6 +93,18 @@ class NewtonInfo(C.Structure):
 
 
 NEWTON_STATUS = ["continue", "iteration_limit", "f_delta", "grad_norm", "not_started", "failed"]
+
+
+class AmgParams(C.Structure):
+    """pfx_amg_params (the options of polysolve's AMGCL block that have a counterpart here, input-spec.json:1397-1558)."""
+    _fields_ = [("aggregate_passes", C.c_int), ("relax_degree", C.c_int), ("ncycle", C.c_int), ("max_levels", C.c_int),
+                ("coarsest_dofs", C.c_int), ("power_iters", C.c_int), ("relax_lower", C.c_double)]
+
+
+class AmgInfo(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("n_vertices", C.c_int64 * 16), ("n_aggregates", C.c_int64 * 16),
+                ("n_blocks", C.c_int64 * 16), ("lambda_max", C.c_double * 16), ("operator_complexity", C.c_double),
+                ("symbolic_s", C.c_double), ("numeric_s", C.c_double)]
 
 
 class Info(C.Structure):
@@ -182,6 +195,11 @@ def load():
         "pfx_take_numeric_flag": [_vp, C.POINTER(C.c_int)],
         "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_newton_solve_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
+        "pfx_amg_set_params": [_vp, C.POINTER(AmgParams)],
+        "pfx_amg_setup": [_vp],
+        "pfx_amg_get_info": [_vp, C.POINTER(AmgInfo)],
+        "pfx_amg_get_aggregates": [_vp, _i32, _pi32],
+        "pfx_amg_apply_dev": [_vp, _vp, _vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -189,6 +207,8 @@ def load():
         fn.restype = None if name == "pfx_destroy" else C.c_int
     L.pfx_newton_default_params.argtypes = [C.POINTER(NewtonParams)]
     L.pfx_newton_default_params.restype = None
+    L.pfx_amg_default_params.argtypes = [C.POINTER(AmgParams)]
+    L.pfx_amg_default_params.restype = None
     L.pfx_last_error.argtypes = [_vp]
     L.pfx_last_error.restype = C.c_char_p
     _lib = L
@@ -445,6 +465,38 @@ class Engine:
         it, err = C.c_int(), C.c_double()
         self._ck(self.L.pfx_cg_dev(self.h, _vp(d_b), _vp(d_x), precond, max_iter, tol, C.byref(it), C.byref(err)))
         return it.value, err.value
+
+    # ---- AMG preconditioner (precond = PRECOND_AMG) -----------------------------------------------------------
+    def amg_set_params(self, **params):
+        """aggregate_passes, relax_degree, ncycle, max_levels, coarsest_dofs, power_iters, relax_lower (see pfx_amg_params)."""
+        p = AmgParams()
+        self.L.pfx_amg_default_params(C.byref(p))
+        for k, v in params.items():
+            if k not in dict(AmgParams._fields_):
+                raise TypeError(f"unknown AMG parameter {k!r}")
+            setattr(p, k, v)
+        self._ck(self.L.pfx_amg_set_params(self.h, C.byref(p)))
+
+    def amg_setup(self):
+        self._ck(self.L.pfx_amg_setup(self.h))
+
+    def amg_info(self) -> dict:
+        a = AmgInfo()
+        self._ck(self.L.pfx_amg_get_info(self.h, C.byref(a)))
+        n = a.n_levels
+        return dict(n_levels=n, n_vertices=list(a.n_vertices[:n]), n_aggregates=list(a.n_aggregates[:n]), n_blocks=list(a.n_blocks[:n]),
+                    lambda_max=list(a.lambda_max[:n]), operator_complexity=a.operator_complexity, symbolic_s=a.symbolic_s,
+                    numeric_s=a.numeric_s)
+
+    def amg_aggregates(self, level: int):
+        info = self.amg_info()
+        n = self.info().n_nodes if level == 0 else info["n_vertices"][level]
+        out = np.zeros(n, dtype=np.int32)
+        self._ck(self.L.pfx_amg_get_aggregates(self.h, level, _i(out)))
+        return out
+
+    def amg_apply_dev(self, d_r: int, d_z: int):
+        self._ck(self.L.pfx_amg_apply_dev(self.h, _vp(d_r), _vp(d_z)))
 
     def assemble_mass(self, density=1.0):
         """Assembler<Mass>::assemble(is_mass=True) into the resident pattern; density: scalar or one value per element."""
@@ -753,23 +805,46 @@ class LinearSolver:
     """polysolve::LinearSolver for solver "Eigen::ConjugateGradient" working on the matrix that the bound
     engine holds on the device (no copy of the matrix crosses PCIe)."""
 
-    def __init__(self, engine: Engine, precond: str):
+    def __init__(self, engine: Engine, precond: str, solver: str = "Eigen::ConjugateGradient"):
         self.engine = engine
-        self.precond = PRECOND_JACOBI if precond in ("", "Eigen::DiagonalPreconditioner", "Jacobi") else PRECOND_IDENTITY
-        self.max_iter, self.tolerance = 1000, 1e-12  # input-spec.json:1326-1336
+        self.solver = solver or "Eigen::ConjugateGradient"
+        if self.solver in ("AMGCL", "Hypre"):
+            # the slot of polysolve's AMG solvers: CG preconditioned by this library's own aggregation AMG (not AMGCL's
+            # or Hypre's algorithm); their defaults tol 1e-10, 1000 iterations (input-spec.json:1381-1396, 1423-1434)
+            self.precond = PRECOND_AMG
+            self.max_iter, self.tolerance = 1000, 1e-10
+        else:
+            self.precond = PRECOND_JACOBI if precond in ("", "Eigen::DiagonalPreconditioner", "Jacobi") else PRECOND_IDENTITY
+            self.max_iter, self.tolerance = 1000, 1e-12  # input-spec.json:1326-1336
         self._info = {}
 
     @staticmethod
     def create(solver: str, precond: str, engine: Engine) -> "LinearSolver":
-        if solver not in ("Eigen::ConjugateGradient", ""):
+        if solver not in ("Eigen::ConjugateGradient", "", "AMGCL", "Hypre"):
             raise RuntimeError(f"Unrecognized solver type: {solver}")
-        return LinearSolver(engine, precond)
+        return LinearSolver(engine, precond, solver)
 
     def name(self) -> str:
-        return "Eigen::ConjugateGradient"
+        return self.solver
 
     def set_parameters(self, params: dict):
         p = params.get(self.name(), params)
+        if self.solver == "AMGCL":
+            sp_, pp = p.get("solver", {}), p.get("precond", {})
+            self.max_iter = int(sp_.get("maxiter", self.max_iter))
+            self.tolerance = float(sp_.get("tol", self.tolerance))
+            amg = {}
+            if "ncycle" in pp:
+                amg["ncycle"] = int(pp["ncycle"])
+            if "max_levels" in pp:
+                amg["max_levels"] = int(pp["max_levels"])
+            if "degree" in pp.get("relax", {}):
+                amg["relax_degree"] = int(pp["relax"]["degree"])
+            if "power_iters" in pp.get("relax", {}):
+                amg["power_iters"] = int(pp["relax"]["power_iters"])
+            if amg:
+                self.engine.amg_set_params(**amg)
+            return
         self.max_iter = int(p.get("max_iter", self.max_iter))
         self.tolerance = float(p.get("tolerance", self.tolerance))
 
