@@ -142,6 +142,24 @@ int main()
 		rhs[i] = -g[i];
 	solver->solve(rhs, dx);
 	REQUIRE(solver->solver_error() < 1e-10 && solver->solver_iter() > 0);
+	// the AMG solver slot ("AMGCL"): same system, fewer iterations, same solution
+	{
+		auto amg = polysolve::LinearSolver::create("AMGCL", "");
+		REQUIRE(amg->name() == "AMGCL");
+		amg->setDirichlet(fixed);
+		amg->analyzePattern(H, H.rows());
+		amg->factorize(H);
+		VectorXd dx2;
+		amg->solve(rhs, dx2);
+		REQUIRE(amg->solver_error() <= 1e-10 && amg->solver_iter() > 0 && amg->solver_iter() < solver->solver_iter());
+		double dmax = 0, emax = 0;
+		for (int i = 0; i < N; ++i)
+		{
+			dmax = std::max(dmax, std::fabs(dx[i]));
+			emax = std::max(emax, std::fabs(dx[i] - dx2[i]));
+		}
+		REQUIRE(emax <= 1e-7 * dmax);
+	}
 	bool threw = false;
 	try
 	{

@@ -995,3 +995,21 @@ def test_no_device_memory_drift(oracle):
         e.close()
         free.append(torch.cuda.mem_get_info()[0])
     assert free[-1] == free[1], free
+
+
+def test_neohookean_hip_against_sympy_derivatives(eng):
+    """The HIP energy / gradient / Hessian of one element against the symbolic derivatives of the energy density
+    (tests/golden/neohookean_sympy.npz): independent of the oracle."""
+    import os
+    from tests.test_oracle_kat import _single_tet_with_gradient, neohookean_sympy_expected
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "neohookean_sympy.npz"))
+    lam, mu = float(g["lam"]), float(g["mu"])
+    for F, psi, dpsi, d2psi in zip(g["F"], g["psi"], g["dpsi"], g["d2psi"]):
+        mesh, u = _single_tet_with_gradient(F)
+        _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+        assert abs(eng.energy(u) - psi / 6.0) <= 1e-12 * max(abs(psi / 6.0), 1e-3 * mu)
+        grad_ref, hess_ref = neohookean_sympy_expected(F, dpsi, d2psi)
+        assert np.abs(eng.gradient(u) - grad_ref).max() <= 1e-12 * max(np.abs(grad_ref).max(), mu)
+        rp, ci = eng.get_pattern()
+        H = csc_to_scipy((rp, ci, eng.hessian(u)), 12).toarray()
+        assert np.abs(H - hess_ref).max() <= 1e-12 * np.abs(hess_ref).max()

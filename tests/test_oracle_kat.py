@@ -1,6 +1,8 @@
 """CPU tests: the oracle against the reference's own self-contained known-answer tests.
 
   tests/test_bases.cpp:173-343 (hand-written P1/P2 tet closed forms, margin 1e-10), :40-58 (node tables)
+  tests/test_bases.cpp:367-406 (Q1/Q2 hexahedron node tables), :473-626 (alpha / theta tensor-product closed forms of the
+                                 Q1/Q2 values and gradients, test cases Q1_3d / Q2_3d :940-1000)
   tests/test_quadrature.cpp:42-76 (weight sums, points in [0,1])
   tests/test_matrix.cpp:17-31 (determinant), :200-247 (SpareMatrixCache "cache")
 and property checks re-created on synthetic meshes:
@@ -59,6 +61,97 @@ def test_node_tables(oracle):
         nodes = oracle.basis_nodes(kind)
         K = np.array([[oracle.basis_value(kind, i, nodes[j]) for j in range(len(nodes))] for i in range(len(nodes))])
         assert np.abs(K - np.eye(len(nodes))).max() < 1e-12
+
+
+# ---- hexahedra: tests/test_bases.cpp:367-406 (node tables, Q2 in half units) and :473-544 (1-D factors) -----------------
+LINEAR_HEX_LOCAL_NODE = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+QUADR_HEX_LOCAL_NODE = [(0, 0, 0), (2, 0, 0), (2, 2, 0), (0, 2, 0), (0, 0, 2), (2, 0, 2), (2, 2, 2), (0, 2, 2),
+                        (1, 0, 0), (2, 1, 0), (1, 2, 0), (0, 1, 0), (0, 0, 1), (2, 0, 1), (2, 2, 1), (0, 2, 1),
+                        (1, 0, 2), (2, 1, 2), (1, 2, 2), (0, 1, 2),
+                        (0, 1, 1), (2, 1, 1), (1, 0, 1), (1, 2, 1), (1, 1, 0), (1, 1, 2), (1, 1, 1)]
+
+
+def _alpha(i, t):
+    return [1 - t, t][i]
+
+
+def _dalpha(i, t):
+    return [-1.0, 1.0][i]
+
+
+def _theta(i, t):
+    return [(1 - t) * (1 - 2 * t), 4 * t * (1 - t), t * (2 * t - 1)][i]
+
+
+def _dtheta(i, t):
+    return [-3 + 4 * t, 4 - 8 * t, -1 + 4 * t][i]
+
+
+def _tensor_value(f, idx, p):
+    return f(idx[0], p[0]) * f(idx[1], p[1]) * f(idx[2], p[2])
+
+
+def _tensor_grad(f, df, idx, p):
+    return np.array([df(idx[0], p[0]) * f(idx[1], p[1]) * f(idx[2], p[2]),
+                     f(idx[0], p[0]) * df(idx[1], p[1]) * f(idx[2], p[2]),
+                     f(idx[0], p[0]) * f(idx[1], p[1]) * df(idx[2], p[2])])
+
+
+def test_q1_q2_hex_bases_match_reference_closed_forms(oracle):
+    """Q1_3d / Q2_3d of tests/test_bases.cpp:940-1000: values and gradients against the tensor products of alpha / theta
+    (linear_hex_basis_value/_grad :576-599, quadr_hex_basis_value/_grad :601-626), margin 1e-10, and the node tables."""
+    x, _ = oracle.line_quadrature(4)
+    pts = [(a, b, c) for a in x for b in x for c in x] + [tuple(v) for v in np.random.default_rng(11).uniform(0, 1, (20, 3))]
+    for p in pts:
+        p = np.asarray(p, dtype=float)
+        for i in range(8):
+            idx = LINEAR_HEX_LOCAL_NODE[i]
+            assert abs(oracle.basis_value(oracle.Q1HEX, i, p) - _tensor_value(_alpha, idx, p)) < 1e-10
+            assert np.abs(oracle.basis_grad(oracle.Q1HEX, i, p) - _tensor_grad(_alpha, _dalpha, idx, p)).max() < 1e-10
+        for i in range(27):
+            idx = QUADR_HEX_LOCAL_NODE[i]
+            assert abs(oracle.basis_value(oracle.Q2HEX, i, p) - _tensor_value(_theta, idx, p)) < 1e-10
+            assert np.abs(oracle.basis_grad(oracle.Q2HEX, i, p) - _tensor_grad(_theta, _dtheta, idx, p)).max() < 1e-10
+    assert np.abs(oracle.basis_nodes(oracle.Q1HEX) - np.array(LINEAR_HEX_LOCAL_NODE, dtype=float)).max() < 1e-10
+    assert np.abs(oracle.basis_nodes(oracle.Q2HEX) - np.array(QUADR_HEX_LOCAL_NODE, dtype=float) / 2.0).max() < 1e-10
+
+
+def _single_tet_with_gradient(F):
+    """The reference tetrahedron with P1 bases and the displacement whose deformation gradient is F."""
+    xyz = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+    conn = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    mesh = M.Mesh(M.P1TET, M.P1TET, conn, conn.copy(), xyz, 4, xyz.copy())
+    u = np.zeros((4, 3))
+    u[1:] = (F - np.eye(3)).T  # F = I + sum_i u_i (x) grad phi_i with grad phi_j = e_{j-1}, grad phi_0 = -(1,1,1)
+    return mesh, u.reshape(-1)
+
+
+def neohookean_sympy_expected(F, dpsi, d2psi):
+    """Element energy gradient and Hessian of the single P1 tet (volume 1/6) from the derivatives of psi w.r.t. F."""
+    g_ref = np.array([[-1, -1, -1], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=float)
+    P = dpsi.reshape(3, 3)
+    C = d2psi.reshape(3, 3, 3, 3)
+    grad = np.einsum("dc,ic->id", P, g_ref).reshape(-1) / 6.0
+    hess = np.einsum("dcef,ic,jf->idje", C, g_ref, g_ref).reshape(12, 12) / 6.0
+    return grad, hess
+
+
+def test_neohookean_against_sympy_derivatives(oracle):
+    """Energy, gradient and Hessian of one element against derivatives obtained by symbolic differentiation of the energy
+    density (fixture tests/golden/neohookean_sympy.npz, generated by tests/tools/make_neohookean_sympy_golden.py): pins the
+    restated closed forms of NeoHookeanElasticity.cpp:364-565 independently of the oracle's own finite-difference checks."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "neohookean_sympy.npz"))
+    lam, mu = float(g["lam"]), float(g["mu"])
+    for F, psi, dpsi, d2psi in zip(g["F"], g["psi"], g["dpsi"], g["d2psi"]):
+        mesh, u = _single_tet_with_gradient(F)
+        e = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, u)
+        assert abs(e - psi / 6.0) <= 1e-12 * max(abs(psi / 6.0), 1e-3 * mu)
+        grad_ref, hess_ref = neohookean_sympy_expected(F, dpsi, d2psi)
+        grad = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, u)
+        assert np.abs(grad - grad_ref).max() <= 1e-12 * max(np.abs(grad_ref).max(), mu)
+        H = csc_to_scipy(oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, u), 12).toarray()
+        assert np.abs(H - hess_ref).max() <= 1e-12 * np.abs(hess_ref).max()
 
 
 def test_hex_bases_partition_of_unity_and_fd(oracle):
