@@ -275,7 +275,7 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     backend = (dist.get_backend() if world > 1 else None)
     out = None
     if rank == 0:
-        pname = {E.PRECOND_IDENTITY: "none", E.PRECOND_JACOBI: "Jacobi"}.get(args.precond, str(args.precond))
+        pname = {E.PRECOND_IDENTITY: "none", E.PRECOND_JACOBI: "Jacobi", E.PRECOND_AMG: "AMG"}.get(args.precond, str(args.precond))
         out = {
             "metric": "elements/s Hessian assembly + CG SpMV GB/s, P2 elasticity tets, 1-8 GPUs",
             "value": n_el_global * steps / elapsed,
@@ -324,6 +324,31 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
             out["config"]["workload"] = (f"NeoHookean Newton solve (backtracking line search, Jacobi-CG tol {args.cg_tol:g} max_iter "
                                          f"{args.cg_max_iter} per step), {shape}")
             out["newton"] = dict(newton_info)
+    # the same system solved to convergence with the AMG preconditioner (non-default option; N = 1, elastic workloads)
+    if out is not None and world == 1 and workload in ("neohookean", "linear_elasticity") and not args.no_amg:
+        eng.timing_reset()
+        eng.timing_enable(1)
+        if args.amg_ncycle != 2 or args.amg_degree != 1:
+            eng.amg_set_params(ncycle=args.amg_ncycle, relax_degree=args.amg_degree)
+        x.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.amg_setup()
+        eng.synchronize()
+        t_setup_amg = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        it_a, err_a = eng.cg_dev(rhs.data_ptr(), x.data_ptr(), E.PRECOND_AMG, args.cg_max_iter, args.amg_tol)
+        eng.synchronize()
+        t_solve = time.perf_counter() - t0
+        eng.timing_enable(False)
+        ai = eng.amg_info()
+        pre_ms, pre_n = eng.timing_get("precond")
+        out["amg_solve"] = {"preconditioner": "aggregation AMG (PFX_PRECOND_AMG), " + ("V" if args.amg_ncycle == 1 else "W") + f" cycle, Chebyshev degree {args.amg_degree}",
+                            "tolerance": args.amg_tol, "cg_iters": it_a, "cg_rel_residual": err_a, "solve_ms": 1e3 * t_solve, "setup_ms": 1e3 * t_setup_amg,
+                            "symbolic_s": ai["symbolic_s"], "numeric_s": ai["numeric_s"], "levels": ai["n_levels"], "vertices": ai["n_vertices"],
+                            "operator_complexity": ai["operator_complexity"], "precond_apply_ms": pre_ms,
+                            "elements_per_s_assembly_plus_converged_solve": n_el_global / (1e-3 * (asm_ms + lg_ms + gv_ms + conv_ms) + t_solve)}
+        log(f"AMG-PCG: {it_a} iterations, rel. residual {err_a:.2e}, solve {t_solve:.3f}s, setup {t_setup_amg:.3f}s")
     if dcg is not None:
         dcg.close()
     if dnewton is not None:
@@ -383,7 +408,11 @@ def main():
     ap.add_argument("--dt", type=float, default=1e-3, help="time step of the transient workload")
     ap.add_argument("--cg-max-iter", type=int, default=1000)
     ap.add_argument("--cg-tol", type=float, default=1e-12)
-    ap.add_argument("--precond", type=int, default=1, help="0 none, 1 Jacobi (the reference's default for Eigen::ConjugateGradient)")
+    ap.add_argument("--precond", type=int, default=1, help="0 none, 1 Jacobi (the reference's default for Eigen::ConjugateGradient), 2 aggregation AMG")
+    ap.add_argument("--no-amg", action="store_true", help="skip the converged AMG-preconditioned solve that is reported beside the default line")
+    ap.add_argument("--amg-tol", type=float, default=1e-10)
+    ap.add_argument("--amg-ncycle", type=int, default=2)
+    ap.add_argument("--amg-degree", type=int, default=1)
     ap.add_argument("--cpu-n", type=int, default=40, help="grid of the CPU baseline sample (40 -> 384 000 P2 tets, 1.6 M dofs)")
     ap.add_argument("--cpu-cg-iters", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -433,7 +462,7 @@ def main():
         if world == 1 and args.workload == "neohookean" and args.element == "p2tet" and not args.no_secondary and args.n != 55:
             log("secondary configuration: LinearElasticity stiffness + CG, 55^3 grid")
             sec = run_workload(args, "linear_elasticity", 55, "p2tet", min(args.steps, 3), 1, 1, 0, local_rank, dev, E, M, D, torch, dist)
-            out["linear_elasticity_1M"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "assembly", "cg")}
+            out["linear_elasticity_1M"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "assembly", "cg", "amg_solve") if k in sec}
         if not args.no_cpu_baseline and world == 1 and args.workload not in ("newton", "transient"):
             from oracle import pf_oracle
             pf_oracle.build()

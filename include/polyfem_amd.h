@@ -198,7 +198,7 @@ typedef struct
 {
 	int aggregate_passes; /* 4: rounds of pairwise matching per level, aggregates of up to 2^passes vertices */
 	int relax_degree;     /* 1: Chebyshev degree of the relaxation before / after the coarse correction (AMGCL/precond/relax/degree) */
-	int ncycle;           /* 1: V cycle; 2: W cycle (AMGCL/precond/ncycle) */
+	int ncycle;           /* 2: W cycle (AMGCL/precond/ncycle, the reference's default); 1: V cycle */
 	int max_levels;       /* 12 (AMGCL/precond/max_levels) */
 	int coarsest_dofs;    /* 600: levels at or below this size are solved with a dense inverse */
 	int power_iters;      /* 10: power iterations for the spectral radius of D^-1 A (AMGCL/precond/relax/power_iters) */

@@ -529,13 +529,32 @@ namespace polyfem_amd
 		public:
 			static std::unique_ptr<LinearSolver> create(const std::string &solver, const std::string &precond)
 			{
-				if (!solver.empty() && solver != "Eigen::ConjugateGradient")
+				const bool amg = solver == "AMGCL" || solver == "Hypre";
+				if (!solver.empty() && solver != "Eigen::ConjugateGradient" && !amg)
 					throw std::runtime_error("Unrecognized solver type: " + solver);
 				auto s = std::unique_ptr<LinearSolver>(new LinearSolver());
-				s->precond_ = (precond.empty() || precond == "Eigen::DiagonalPreconditioner") ? PFX_PRECOND_JACOBI : PFX_PRECOND_IDENTITY;
+				s->name_ = solver.empty() ? "Eigen::ConjugateGradient" : solver;
+				if (amg)
+				{
+					// the slot of polysolve's AMG solvers (CMakeLists.txt:101-102): CG preconditioned by this library's own
+					// aggregation AMG, with their defaults tol 1e-10 / 1000 iterations (input-spec.json:1381-1396, 1423-1434)
+					s->precond_ = PFX_PRECOND_AMG;
+					s->tolerance_ = 1e-10;
+				}
+				else
+					s->precond_ = (precond.empty() || precond == "Eigen::DiagonalPreconditioner") ? PFX_PRECOND_JACOBI : PFX_PRECOND_IDENTITY;
 				return s;
 			}
-			std::string name() const { return "Eigen::ConjugateGradient"; }
+			std::string name() const { return name_; }
+			// AMGCL/precond/{ncycle, max_levels, relax/degree} (input-spec.json:1447-1496)
+			void setAmgParameters(int ncycle, int max_levels, int relax_degree)
+			{
+				Context &c = Context::instance();
+				pfx_amg_params p;
+				pfx_amg_default_params(&p);
+				p.ncycle = ncycle, p.max_levels = max_levels, p.relax_degree = relax_degree;
+				c.check(pfx_amg_set_params(c.h, &p));
+			}
 			// setParameters(json): params[name()]["max_iter"|"tolerance"], defaults input-spec.json:1326-1336
 			void setParameters(int max_iter, double tolerance)
 			{
@@ -571,6 +590,7 @@ namespace polyfem_amd
 			LinearSolver() = default;
 			int precond_ = PFX_PRECOND_JACOBI, max_iter_ = 1000, iters_ = 0, n_ = 0;
 			double tolerance_ = 1e-12, error_ = 0;
+			std::string name_ = "Eigen::ConjugateGradient";
 		};
 	} // namespace polysolve
 

@@ -1441,7 +1441,7 @@ extern "C"
 			return;
 		p->aggregate_passes = 4;
 		p->relax_degree = 1;
-		p->ncycle = 1;
+		p->ncycle = 2;
 		p->max_levels = 12;
 		p->coarsest_dofs = 600;
 		p->power_iters = 10;

@@ -80,6 +80,40 @@ def partition(kind: int, conn: np.ndarray, gconn: np.ndarray, xyz: np.ndarray, b
     return Part(lmesh, n_owned, lo, halo_global, halo_owner, elem_owned, touch)
 
 
+def morton_numbering(node_xyz: np.ndarray, bits: int = 10) -> np.ndarray:
+    """new_id[g] for a renumbering of the nodes along a Morton (Z-order) curve through their bounding box: contiguous
+    owner ranges of the new numbering are compact blocks instead of slabs of whatever order the mesh came in, which is
+    what keeps the halo -- and the x gathers of the matrix-vector product -- local on a general mesh.  Ties keep the
+    incoming order (stable)."""
+    p = np.asarray(node_xyz, dtype=np.float64)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    span = np.where(hi > lo, hi - lo, 1.0)
+    q = np.minimum(((p - lo) / span * (1 << bits)).astype(np.uint64), np.uint64((1 << bits) - 1))
+    key = np.zeros(p.shape[0], dtype=np.uint64)
+    for b in range(bits):
+        for c in range(3):
+            key |= ((q[:, c] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + c)
+    order = np.argsort(key, kind="stable")
+    new_id = np.empty(p.shape[0], dtype=np.int64)
+    new_id[order] = np.arange(p.shape[0])
+    return new_id
+
+
+def renumber_nodes(mesh: M.Mesh, new_id: np.ndarray) -> M.Mesh:
+    """The same mesh with basis node g renamed new_id[g] (geometry nodes untouched)."""
+    node_xyz = None
+    if mesh.node_xyz is not None:
+        node_xyz = np.empty_like(mesh.node_xyz)
+        node_xyz[new_id] = mesh.node_xyz
+    return M.Mesh(mesh.kind, mesh.gkind, np.ascontiguousarray(new_id[mesh.conn].astype(np.int32)), mesh.gconn, mesh.xyz,
+                  mesh.n_nodes, node_xyz, mesh.quad_order)
+
+
+def halo_nodes_total(kind: int, conn: np.ndarray, gconn: np.ndarray, xyz: np.ndarray, bounds: np.ndarray) -> int:
+    """Sum over the ranks of their halo node counts (what one halo exchange moves, in nodes)."""
+    return int(sum(partition(kind, conn, gconn, xyz, bounds, r).halo_global.size for r in range(len(bounds) - 1)))
+
+
 def cube_tets_slab(n: int, nz: int, zc0: int, zc1: int, order: int = 2):
     """Cells z in [zc0, zc1) of the n x n x nz Kuhn grid on [0,1]^2 x [0, nz/n], P1/P2 bases, GLOBAL lattice
     numbering (x fastest).  Returns (kind, conn, gconn, xyz_of_all_vertices, n_nodes_global, lattice_dim_xy)."""

@@ -29,7 +29,20 @@ def _worker(rank, world, port, case, ret):
     try:
         from oracle import pf_oracle as O
         from tests.dist_helpers import OracleOps, csc_tuple_to_csr
-        if case == "laplace_p1":
+        slab = None
+        if case == "slab_p2":
+            # the benchmark's decomposition: n x n x (cells_per_rank * world) cells, one slab of node planes per rank
+            kind, conn, gconn, xyz, n_nodes, L = D.cube_tets_slab(2, world, 0, world, 2)
+            h = 0.5 / 2
+            g = np.arange(n_nodes)
+            mesh = M.Mesh(kind, M.GEOM_KIND[kind], conn.astype(np.int32), gconn.astype(np.int32), xyz, n_nodes,
+                          np.stack([g % L, (g // L) % L, g // (L * L)], axis=1) * h)
+            model, bs = O.LINEAR_ELASTICITY, 3
+            slab = D.slab_part(2, 1, rank, world, 2)
+        elif case == "morton_p2":
+            base = M.cube_tets(4, 2, jitter=0.1)
+            mesh, model, bs = D.renumber_nodes(base, D.morton_numbering(base.node_xyz)), O.LINEAR_ELASTICITY, 3
+        elif case == "laplace_p1":
             mesh, model, bs = M.cube_tets(5, 1), O.LAPLACIAN, 1
         elif case == "elastic_q2":
             mesh, model, bs = M.cube_hexes(2, 2), O.LINEAR_ELASTICITY, 3
@@ -38,6 +51,9 @@ def _worker(rank, world, port, case, ret):
         lam, mu = O.lame(1e5, 0.3)
         bounds = D.owner_ranges(mesh.n_nodes, world)
         part = D.partition(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds, rank, mesh.node_xyz)
+        if slab is not None:
+            part, bounds, nn = slab
+            assert nn == mesh.n_nodes
         l2g = part.local_to_global()
         nl = part.n_local
         # --- partition invariants
@@ -90,7 +106,8 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "laplace_p1"), (2, "elastic_p2"), (3, "elastic_p2"), (2, "elastic_q2"), (4, "laplace_p1")])
+@pytest.mark.parametrize("world,case", [(2, "laplace_p1"), (2, "elastic_p2"), (3, "elastic_p2"), (2, "elastic_q2"), (4, "laplace_p1"),
+                                        (8, "slab_p2"), (8, "morton_p2")])
 def test_distributed_cg_gloo(world, case):
     port = _free_port()
     with mp.Manager() as mgr:
@@ -99,6 +116,20 @@ def test_distributed_cg_gloo(world, case):
         assert all(ret.get(f"ok{r}") for r in range(world))
         assert abs(ret["iters"] - ret["it_ref"]) <= 2, (ret["iters"], ret["it_ref"])
         assert ret["err"] < 1e-11 and ret["dx"] < 1e-8 and ret["fixed_zero"]
+
+
+def test_morton_blocks_have_smaller_halos_than_index_slabs():
+    """Eight owner ranges of a Morton renumbering are compact blocks: fewer halo nodes in total than eight slabs of the
+    lattice numbering, and the renumbered mesh is the same mesh (same sorted element node sets up to the renaming)."""
+    mesh = M.cube_tets(8, 2)
+    new_id = D.morton_numbering(mesh.node_xyz)
+    assert np.array_equal(np.sort(new_id), np.arange(mesh.n_nodes))
+    mm = D.renumber_nodes(mesh, new_id)
+    assert np.array_equal(mm.conn, new_id[mesh.conn]) and np.allclose(mm.node_xyz[new_id], mesh.node_xyz)
+    bounds = D.owner_ranges(mesh.n_nodes, 8)
+    h_slab = D.halo_nodes_total(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds)
+    h_morton = D.halo_nodes_total(mm.kind, mm.conn, mm.gconn, mm.xyz, bounds)
+    assert h_morton < 0.8 * h_slab, (h_morton, h_slab)
 
 
 def test_slab_partition_matches_generic():
