@@ -249,6 +249,21 @@ pfx_status pfx_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts);
 pfx_status pfx_assemble_rhs_pointwise(pfx_ctx *ctx, const double *force_pts, double density, const double *density_e, double *rhs);
 pfx_status pfx_assemble_rhs_pointwise_dev(pfx_ctx *ctx, const double *d_force_pts, double density, const double *density_e, double *d_rhs);
 
+/* Density evaluated per quadrature point, as Density::operator() is in the reference (utils/ElasticityUtils.cpp:561-570,
+ * called per point at assembler/Mass.cpp:10 and assembler/RhsAssembler.cpp:81): the host evaluates its density function at
+ * the positions the library reports and passes one value per (element, point), point fastest.
+ *   pfx_mass_quadrature_points        positions of the points of the MASS quadrature rule (n_el x n_pts x 3; pts may be NULL)
+ *   pfx_assemble_mass_pointwise       pfx_assemble_mass with n_el x n_pts densities at those points
+ *   pfx_inertia_set_mass_pointwise    pfx_inertia_set_mass likewise
+ *   pfx_assemble_rhs_density_pointwise  the body-force vector with n_el x n_pts densities at the points of the STIFFNESS rule
+ *                                     (pfx_quadrature_points) and either a constant force (force, 3 doubles) or a force per
+ *                                     point (force_pts, n_el x n_pts x d); exactly one of the two is non-NULL */
+pfx_status pfx_mass_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts);
+pfx_status pfx_assemble_mass_pointwise(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts);
+pfx_status pfx_inertia_set_mass_pointwise(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts);
+pfx_status pfx_assemble_rhs_density_pointwise(pfx_ctx *ctx, const double *force, const double *force_pts, const double *density_pts, int64_t n_el,
+											  int n_pts, double *rhs);
+
 /* ---- Newton solve with the iterate resident on the device ------------------------------------------------------
  *
  * cppoptlib::NonlinearSolver::minimize (solver/NonlinearSolver.tpp:33-275) driving

@@ -2614,6 +2614,7 @@ typedef struct
 	int size;
 	double density;
 	const double *density_e;
+	const double *density_pts; /* one density per (element, mass quadrature point): Density::operator() is evaluated per point */
 	int64_t e0, e1;
 	tripvec tv;
 } mass_job;
@@ -2641,7 +2642,11 @@ static void *mass_job_run(void *arg)
 				/* Mass.cpp:5-20 */
 				double tmp = 0;
 				for (int q = 0; q < quad.n_pts; ++q)
-					tmp += rho * v->val[i][q] * v->val[j][q] * da[q];
+				{
+					/* utils/ElasticityUtils.cpp:561-570: rho at the point */
+					const double rho_q = jb->density_pts ? jb->density_pts[e * quad.n_pts + q] : rho;
+					tmp += rho_q * v->val[i][q] * v->val[j][q] * da[q];
+				}
 				for (int n = 0; n < size; ++n)
 					for (int m = 0; m < size; ++m)
 					{
@@ -2659,7 +2664,20 @@ static void *mass_job_run(void *arg)
 	return NULL;
 }
 
+static int assemble_mass_impl(const pfo_mesh *mesh, int size, double density, const double *density_e, const double *density_pts, int n_threads, pfo_csc *out);
+
 int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const double *density_e, int n_threads, pfo_csc *out)
+{
+	return assemble_mass_impl(mesh, size, density, density_e, NULL, n_threads, out);
+}
+
+/* the same with one density per (element, point of the mass quadrature rule), n_el x n_pts values */
+int pfo_assemble_mass_pointwise(const pfo_mesh *mesh, int size, const double *density_pts, int n_threads, pfo_csc *out)
+{
+	return assemble_mass_impl(mesh, size, 0.0, NULL, density_pts, n_threads, out);
+}
+
+static int assemble_mass_impl(const pfo_mesh *mesh, int size, double density, const double *density_e, const double *density_pts, int n_threads, pfo_csc *out)
 {
 	int nt = n_threads < 1 ? 1 : n_threads;
 	if (nt > mesh->n_el)
@@ -2669,7 +2687,7 @@ int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const doub
 	const int64_t chunk = (mesh->n_el + nt - 1) / nt;
 	for (int t = 0; t < nt; ++t)
 	{
-		jobs[t].mesh = mesh, jobs[t].size = size, jobs[t].density = density, jobs[t].density_e = density_e;
+		jobs[t].mesh = mesh, jobs[t].size = size, jobs[t].density = density, jobs[t].density_e = density_e, jobs[t].density_pts = density_pts;
 		jobs[t].e0 = t * chunk < mesh->n_el ? t * chunk : mesh->n_el;
 		jobs[t].e1 = (t + 1) * chunk < mesh->n_el ? (t + 1) * chunk : mesh->n_el;
 	}
@@ -2703,11 +2721,26 @@ int pfo_assemble_mass(const pfo_mesh *mesh, int size, double density, const doub
 
 /* Physical positions of the quadrature points (ElementAssemblyValues::val, assembler/ElementAssemblyValues.cpp:328-345):
  * sum_j N_j^geo(xi_q) x_j; pts is n_el x n_pts x 3.  Returns n_pts (or -1). */
+static int quadrature_points_impl(const pfo_mesh *mesh, int mass_rule, double *pts);
+
 int pfo_quadrature_points(const pfo_mesh *mesh, double *pts)
+{
+	return quadrature_points_impl(mesh, 0, pts);
+}
+
+/* the same for the points of the mass quadrature rule */
+int pfo_mass_quadrature_points(const pfo_mesh *mesh, double *pts)
+{
+	return quadrature_points_impl(mesh, 1, pts);
+}
+
+static int quadrature_points_impl(const pfo_mesh *mesh, int mass_rule, double *pts)
 {
 	const int n_g = pfo_n_loc(mesh->gkind);
 	pfo_quad quad;
-	if (pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad))
+	if (mass_rule)
+		pfo_mass_quadrature(mesh->kind, &quad);
+	else if (pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad))
 		return -1;
 	for (int64_t e = 0; e < mesh->n_el; ++e)
 		for (int q = 0; q < quad.n_pts; ++q)
@@ -2746,6 +2779,40 @@ int pfo_assemble_rhs_pointwise(const pfo_mesh *mesh, int size, const double *for
 		for (int d = 0; d < size; ++d)
 			for (int q = 0; q < quad.n_pts; ++q)
 				rhs_fun[q][d] = force_pts[((int64_t)e * quad.n_pts + q) * size + d] * (v->det[q] * quad.w[q] * rho);
+		for (int i = 0; i < n_loc; ++i)
+			for (int d = 0; d < size; ++d)
+			{
+				double rhs_value = 0;
+				for (int q = 0; q < quad.n_pts; ++q)
+					rhs_value += rhs_fun[q][d] * v->val[i][q];
+				rhs[(int64_t)mesh->conn[e * n_loc + i] * size + d] += rhs_value * 1.0;
+			}
+	}
+	free(v);
+	return 0;
+}
+
+/* RhsAssembler::assemble with the density evaluated at every quadrature point (n_el x n_pts values, the stiffness rule),
+ * force constant (f) or per point (force_pts); exactly one of f / force_pts is given */
+int pfo_assemble_rhs_density_pointwise(const pfo_mesh *mesh, int size, const double *f, const double *force_pts, const double *density_pts, double *rhs)
+{
+	const int n_loc = pfo_n_loc(mesh->kind);
+	pfo_quad quad;
+	if (pfo_element_quadrature(mesh->kind, mesh->quad_order, &quad))
+		return -1;
+	pfo_vals *v = (pfo_vals *)malloc(sizeof(pfo_vals));
+	double rhs_fun[PFO_MAX_PTS][3];
+	for (int64_t k = 0; k < mesh->n_nodes * size; ++k)
+		rhs[k] = 0;
+	for (int64_t e = 0; e < mesh->n_el; ++e)
+	{
+		pfo_compute_vals(mesh, e, &quad, v);
+		for (int d = 0; d < size; ++d)
+			for (int q = 0; q < quad.n_pts; ++q)
+			{
+				const double fq = force_pts ? force_pts[((int64_t)e * quad.n_pts + q) * size + d] : f[d];
+				rhs_fun[q][d] = fq * (v->det[q] * quad.w[q] * density_pts[e * quad.n_pts + q]);
+			}
 		for (int i = 0; i < n_loc; ++i)
 			for (int d = 0; d < size; ++d)
 			{

@@ -132,6 +132,12 @@ int pfo_assemble_rhs(const pfo_mesh *mesh, int size, const double *f, double den
 /* the same with the force density given per quadrature point (n_el x n_pts x size), and the physical positions of those
  * points (n_el x n_pts x 3; returns n_pts) for the caller to evaluate its force function at */
 int pfo_assemble_rhs_pointwise(const pfo_mesh *mesh, int size, const double *force_pts, double density, const double *density_e, double *rhs);
+/* Density evaluated per quadrature point (Density::operator(), utils/ElasticityUtils.cpp:561-570): mass matrix with one
+ * density per (element, point of the mass rule); right-hand side with one per (element, point of the stiffness rule) and a
+ * constant (f) or pointwise (force_pts) force; positions of the mass rule's points (returns n_pts). */
+int pfo_assemble_mass_pointwise(const pfo_mesh *mesh, int size, const double *density_pts, int n_threads, pfo_csc *out);
+int pfo_assemble_rhs_density_pointwise(const pfo_mesh *mesh, int size, const double *f, const double *force_pts, const double *density_pts, double *rhs);
+int pfo_mass_quadrature_points(const pfo_mesh *mesh, double *pts);
 int pfo_quadrature_points(const pfo_mesh *mesh, double *pts);
 
 /* ipc::project_to_psd (ipc-toolkit, un-vendored; call site assembler/Assembler.cpp:554-555): symmetric eigendecomposition,

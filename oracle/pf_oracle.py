@@ -432,6 +432,11 @@ def assemble_mass(mesh, size: int, density=1.0, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
     rho_e = None if np.ndim(density) == 0 else np.ascontiguousarray(density, dtype=np.float64)
     out = Csc()
+    if rho_e is not None and rho_e.ndim == 2:  # one density per (element, mass quadrature point)
+        assert rho_e.shape[0] == om.s.n_el
+        rc = lib().pfo_assemble_mass_pointwise(C.byref(om.s), int(size), _dp(rho_e), int(n_threads), C.byref(out))
+        assert rc == 0
+        return _csc_to_numpy(out)
     rc = lib().pfo_assemble_mass(C.byref(om.s), int(size), C.c_double(float(density) if rho_e is None else float(rho_e[0])),
                                  _dp(rho_e) if rho_e is not None else None, int(n_threads), C.byref(out))
     assert rc == 0
@@ -445,6 +450,9 @@ def assemble_rhs(mesh, size: int, force, density=1.0):
     f = np.ascontiguousarray(force, dtype=np.float64)
     assert f.size == size
     rhs = np.zeros(om.s.n_nodes * size)
+    if rho_e is not None and rho_e.ndim == 2:  # one density per (element, quadrature point)
+        assert lib().pfo_assemble_rhs_density_pointwise(C.byref(om.s), int(size), _dp(f), None, _dp(rho_e), _dp(rhs)) == 0
+        return rhs
     rc = lib().pfo_assemble_rhs(C.byref(om.s), int(size), _dp(f), C.c_double(float(density) if rho_e is None else float(rho_e[0])),
                                 _dp(rho_e) if rho_e is not None else None, _dp(rhs))
     assert rc == 0
@@ -461,6 +469,16 @@ def quadrature_points(mesh):
     return buf[: om.s.n_el * n_pts * 3].reshape(om.s.n_el, n_pts, 3).copy()
 
 
+def mass_quadrature_points(mesh):
+    """Physical positions of the points of the mass quadrature rule, shape (n_el, n_pts, 3)."""
+    om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
+    buf = np.zeros(om.s.n_el * 125 * 3)
+    lib().pfo_mass_quadrature_points.restype = C.c_int
+    n_pts = lib().pfo_mass_quadrature_points(C.byref(om.s), _dp(buf))
+    assert n_pts > 0
+    return buf[: om.s.n_el * n_pts * 3].reshape(om.s.n_el, n_pts, 3).copy()
+
+
 def assemble_rhs_pointwise(mesh, size: int, force_pts, density=1.0):
     """RhsAssembler::assemble with the force density given per quadrature point: force_pts (n_el, n_pts, size)."""
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
@@ -468,6 +486,9 @@ def assemble_rhs_pointwise(mesh, size: int, force_pts, density=1.0):
     f = np.ascontiguousarray(force_pts, dtype=np.float64)
     assert f.shape[0] == om.s.n_el and f.shape[2] == size
     rhs = np.zeros(om.s.n_nodes * size)
+    if rho_e is not None and rho_e.ndim == 2:
+        assert lib().pfo_assemble_rhs_density_pointwise(C.byref(om.s), int(size), None, _dp(f), _dp(rho_e), _dp(rhs)) == 0
+        return rhs
     rc = lib().pfo_assemble_rhs_pointwise(C.byref(om.s), int(size), _dp(f), C.c_double(float(density) if rho_e is None else float(rho_e[0])),
                                           _dp(rho_e) if rho_e is not None else None, _dp(rhs))
     assert rc == 0

@@ -522,6 +522,106 @@ extern "C"
 		return PFX_OK;
 	}
 
+	// mass matrix with the density evaluated at every point of the mass quadrature rule
+	static pfx_status assemble_mass_pointwise_impl(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts)
+	{
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (n_el != ctx->n_el || n_pts != ctx->h_tab_mass.n_pts)
+			PFX_FAIL(PFX_ERR_ARG, "one density per element and point of the mass quadrature rule expected (see pfx_mass_quadrature_points)");
+		PFX_HIP(hipSetDevice(ctx->device));
+		const bool hex = ctx->kind == PFX_Q1HEX || ctx->kind == PFX_Q2HEX;
+		if (ensure_estate(ctx, ctx->n_el * (int64_t)(hex ? 10 * ctx->h_tab_mass.n_pts : 10)))
+			return PFX_ERR_HIP;
+		pfx_tmp<double> d_rho;
+		const size_t count = (size_t)(n_el * n_pts);
+		PFX_HIP(d_rho.alloc(count));
+		PFX_HIP(hipMemcpyAsync(d_rho.p, density_pts, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+		pfx_status rc;
+		{
+			pfx_scoped_timer tm(ctx, "mass");
+			rc = pfx_launch_mass(ctx, 0.0, nullptr, d_rho.p);
+		}
+		PFX_HIP(hipStreamSynchronize(ctx->stream)); // the temporary goes away on return
+		if (rc)
+			return rc;
+		ctx->have_mask = true;
+		ctx->values_gen++;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_assemble_mass_pointwise(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts)
+	{
+		if (!ctx || !density_pts)
+			return PFX_ERR_ARG;
+		return assemble_mass_pointwise_impl(ctx, density_pts, n_el, n_pts);
+	}
+
+	pfx_status pfx_inertia_set_mass_pointwise(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts)
+	{
+		if (!ctx || !density_pts)
+			return PFX_ERR_ARG;
+		if (ctx->bs != 3)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 3)");
+		pfx_status rc = assemble_mass_pointwise_impl(ctx, density_pts, n_el, n_pts);
+		if (rc)
+			return rc;
+		return pfx_capture_mass(ctx);
+	}
+
+	pfx_status pfx_mass_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts)
+	{
+		if (!ctx || !n_pts)
+			return PFX_ERR_ARG;
+		if (ctx->kind < 0 || ctx->n_el <= 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_set_mesh must be called first");
+		*n_pts = ctx->h_tab_mass.n_pts;
+		if (!pts)
+			return PFX_OK;
+		PFX_HIP(hipSetDevice(ctx->device));
+		const size_t count = (size_t)(ctx->n_el * ctx->h_tab_mass.n_pts * 3);
+		pfx_tmp<double> d_p;
+		PFX_HIP(d_p.alloc(count));
+		pfx_status rc = pfx_launch_mass_quadrature_points(ctx, d_p.p);
+		if (rc)
+			return rc;
+		PFX_HIP(hipMemcpyAsync(pts, d_p.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
+	pfx_status pfx_assemble_rhs_density_pointwise(pfx_ctx *ctx, const double *force, const double *force_pts, const double *density_pts, int64_t n_el,
+												  int n_pts, double *rhs)
+	{
+		if (!ctx || !density_pts || !rhs || (!force == !force_pts))
+			return PFX_ERR_ARG;
+		if (need_pattern(ctx) || ensure_staging(ctx))
+			return PFX_ERR_ARG;
+		if (n_el != ctx->n_el || n_pts != ctx->n_pts)
+			PFX_FAIL(PFX_ERR_ARG, "one density per element and quadrature point of the stiffness rule expected (see pfx_quadrature_points)");
+		PFX_HIP(hipSetDevice(ctx->device));
+		pfx_tmp<double> d_rho, d_f;
+		const size_t count = (size_t)(n_el * n_pts);
+		PFX_HIP(d_rho.alloc(count));
+		PFX_HIP(hipMemcpyAsync(d_rho.p, density_pts, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+		if (force_pts)
+		{
+			PFX_HIP(d_f.alloc(count * (size_t)ctx->bs));
+			PFX_HIP(hipMemcpyAsync(d_f.p, force_pts, sizeof(double) * count * (size_t)ctx->bs, hipMemcpyHostToDevice, ctx->stream));
+		}
+		pfx_status rc = pfx_launch_local_rhs(ctx, force, force_pts ? d_f.p : nullptr, 0.0, nullptr, d_rho.p);
+		if (!rc)
+			rc = pfx_launch_gather_vector(ctx, ctx->d_vec, false);
+		if (rc)
+		{
+			(void)hipStreamSynchronize(ctx->stream);
+			return rc;
+		}
+		PFX_HIP(hipMemcpyAsync(rhs, ctx->d_vec, sizeof(double) * (size_t)ctx->n_dofs(), hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		return PFX_OK;
+	}
+
 	pfx_status pfx_assemble_rhs_dev(pfx_ctx *ctx, const double *force, double density, const double *density_e, double *d_rhs)
 	{
 		if (!ctx || !force || !d_rhs)

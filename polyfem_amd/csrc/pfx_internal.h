@@ -313,8 +313,9 @@ pfx_status pfx_add_mass_run(pfx_ctx *ctx, double w);
 pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
 								  const pfx_newton_params *params, pfx_newton_info *info);
 pfx_status pfx_launch_gather_vector(pfx_ctx *ctx, double *d_g, bool drop_tiny = true);
-pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e);                       // strict arithmetic
-pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e); // strict arithmetic
+pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e, const double *d_density_pts = nullptr);                       // strict arithmetic
+pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e, const double *d_density_pts = nullptr);
+pfx_status pfx_launch_mass_quadrature_points(pfx_ctx *ctx, double *d_pts); // strict arithmetic
 pfx_status pfx_launch_quadrature_points(pfx_ctx *ctx, double *d_pts);
 pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy, const double *d_eloc = nullptr, double *d_partials = nullptr);
 pfx_status pfx_noalloc_init(pfx_ctx *ctx);

@@ -265,6 +265,7 @@ namespace
 		const pfx_tables *tab; // tables of the mass quadrature rule
 		double density;
 		const double *density_e;
+		const double *density_pts; // one density per (element, point): Density::operator() (utils/ElasticityUtils.cpp:561-570)
 		static constexpr int LDS_DOUBLES = NPTS * NLOC + NPTS; // val[k][i], then w[k]
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
@@ -286,7 +287,8 @@ namespace
 				if (SP != 1)
 					det = ge[k * 10 + 9];
 				const double dak = det * lds[NPTS * NLOC + k];
-				tmp += rho * lds[k * NLOC + i] * lds[k * NLOC + j] * dak;
+				const double rho_k = density_pts ? density_pts[(int64_t)e * NPTS + k] : rho;
+				tmp += rho_k * lds[k * NLOC + i] * lds[k * NLOC + j] * dak;
 			}
 			if (fabs(tmp) < 1e-30)
 				tmp = 0.0;
@@ -301,7 +303,7 @@ namespace
 	template <int NLOC, int NPTS, int BS, int SP>
 	__global__ __launch_bounds__(256) void k_local_rhs(const double *__restrict__ geo, const pfx_tables *__restrict__ tab, int64_t n_el,
 													   double f0, double f1, double f2, const double *__restrict__ force_pts, double density,
-													   const double *__restrict__ density_e, double *__restrict__ gloc)
+													   const double *__restrict__ density_e, const double *__restrict__ density_pts, double *__restrict__ gloc)
 	{
 		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 		if (t >= n_el * NLOC)
@@ -315,7 +317,7 @@ namespace
 		for (int q = 0; q < NPTS; ++q)
 		{
 			const double det = ge[(SP == 1 ? 0 : q) * 10 + 9];
-			const double s = det * tab->w[q] * rho;
+			const double s = det * tab->w[q] * (density_pts ? density_pts[e * NPTS + q] : rho);
 			const double v = tab->val[q][i];
 			// force density: one constant vector, or one value per (element, point) (what problem.rhs() returns in the reference)
 			const double *fq = force_pts ? force_pts + (e * NPTS + q) * BS : f;
@@ -358,28 +360,28 @@ namespace
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
-	void launch_mass_rows(pfx_ctx *ctx, double density, const double *d_density_e)
+	void launch_mass_rows(pfx_ctx *ctx, double density, const double *d_density_e, const double *d_density_pts)
 	{
 		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
 		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab_mass);
 		if (ctx->bs == 1)
-			pfx_launch_assemble_rows<NLOC, 1>(ctx, mass_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e}, true);
+			pfx_launch_assemble_rows<NLOC, 1>(ctx, mass_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e, d_density_pts}, true);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, mass_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e}, true);
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, mass_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e, d_density_pts}, true);
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
-	void launch_rhs(pfx_ctx *ctx, const double *f, const double *d_force_pts, double density, const double *d_density_e)
+	void launch_rhs(pfx_ctx *ctx, const double *f, const double *d_force_pts, double density, const double *d_density_e, const double *d_density_pts)
 	{
 		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
 		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab);
 		const int64_t n = ctx->n_el * NLOC;
 		if (ctx->bs == 1)
 			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 1, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
-							   ctx->n_el, f ? f[0] : 0.0, 0.0, 0.0, d_force_pts, density, d_density_e, ctx->d_gloc);
+							   ctx->n_el, f ? f[0] : 0.0, 0.0, 0.0, d_force_pts, density, d_density_e, d_density_pts, ctx->d_gloc);
 		else
 			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 3, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
-							   ctx->n_el, f ? f[0] : 0.0, f ? f[1] : 0.0, f ? f[2] : 0.0, d_force_pts, density, d_density_e, ctx->d_gloc);
+							   ctx->n_el, f ? f[0] : 0.0, f ? f[1] : 0.0, f ? f[2] : 0.0, d_force_pts, density, d_density_e, d_density_pts, ctx->d_gloc);
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
@@ -461,7 +463,7 @@ pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask)
 
 // mass matrix into the value array (Assembler<Mass>::assemble with is_mass = true, Assembler.cpp:135-139): geometry at
 // the points of the mass quadrature rule, then the row assembly with mass_block
-pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e)
+pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e, const double *d_density_pts)
 {
 	static const int expect[4] = {6, 14, 27, 125}; // mass rules: tet order 3 / 5, hex order 3 / 5
 	if (ctx->kind < 0 || ctx->kind > 3 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
@@ -469,16 +471,16 @@ pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density
 	switch (ctx->kind)
 	{
 	case PFX_P1TET:
-		launch_mass_rows<4, 4, 6>(ctx, density, d_density_e);
+		launch_mass_rows<4, 4, 6>(ctx, density, d_density_e, d_density_pts);
 		break;
 	case PFX_P2TET:
-		launch_mass_rows<10, 4, 14>(ctx, density, d_density_e);
+		launch_mass_rows<10, 4, 14>(ctx, density, d_density_e, d_density_pts);
 		break;
 	case PFX_Q1HEX:
-		launch_mass_rows<8, 8, 27>(ctx, density, d_density_e);
+		launch_mass_rows<8, 8, 27>(ctx, density, d_density_e, d_density_pts);
 		break;
 	default:
-		launch_mass_rows<27, 8, 125>(ctx, density, d_density_e);
+		launch_mass_rows<27, 8, 125>(ctx, density, d_density_e, d_density_pts);
 	}
 	ctx->estate_kind = PFX_ESTATE_NONE;
 	PFX_HIP(hipGetLastError());
@@ -486,25 +488,51 @@ pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density
 }
 
 // per-element body-force vectors into ctx->d_gloc (stiffness quadrature rule)
-pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e)
+pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double *d_force_pts, double density, const double *d_density_e, const double *d_density_pts)
 {
 	if (!supported(ctx))
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "rhs assembly: unsupported element kind / quadrature order combination");
 	switch (ctx->kind)
 	{
 	case PFX_P1TET:
-		launch_rhs<4, 4, 1>(ctx, force, d_force_pts, density, d_density_e);
+		launch_rhs<4, 4, 1>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
 		break;
 	case PFX_P2TET:
-		launch_rhs<10, 4, 6>(ctx, force, d_force_pts, density, d_density_e);
+		launch_rhs<10, 4, 6>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
 		break;
 	case PFX_Q1HEX:
-		launch_rhs<8, 8, 1>(ctx, force, d_force_pts, density, d_density_e);
+		launch_rhs<8, 8, 1>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
 		break;
 	default:
-		launch_rhs<27, 8, 27>(ctx, force, d_force_pts, density, d_density_e);
+		launch_rhs<27, 8, 27>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
 	}
 	ctx->estate_kind = PFX_ESTATE_NONE;
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// positions of the points of the mass quadrature rule (n_el x n_pts_mass x 3)
+pfx_status pfx_launch_mass_quadrature_points(pfx_ctx *ctx, double *d_pts)
+{
+	static const int expect[4] = {6, 14, 27, 125};
+	if (ctx->kind < 0 || ctx->kind > 3 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "mass quadrature points: unsupported element kind");
+	const int64_t n = ctx->n_el * ctx->h_tab_mass.n_pts;
+	const unsigned grid = (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
+	switch (ctx->kind)
+	{
+	case PFX_P1TET:
+		hipLaunchKernelGGL((k_quadrature_points<4, 6>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
+		break;
+	case PFX_P2TET:
+		hipLaunchKernelGGL((k_quadrature_points<4, 14>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
+		break;
+	case PFX_Q1HEX:
+		hipLaunchKernelGGL((k_quadrature_points<8, 27>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
+		break;
+	default:
+		hipLaunchKernelGGL((k_quadrature_points<8, 125>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
+	}
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = [
     "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
     "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev", "pfx_set_material_per_point",
     "pfx_energy_dev_noalloc",
+    "pfx_mass_quadrature_points", "pfx_assemble_mass_pointwise", "pfx_inertia_set_mass_pointwise", "pfx_assemble_rhs_density_pointwise",
     "pfx_amg_default_params", "pfx_amg_set_params", "pfx_amg_setup", "pfx_amg_get_info", "pfx_amg_get_aggregates", "pfx_amg_apply_dev",
 ]
 
@@ -195,6 +196,10 @@ def load():
         "pfx_take_numeric_flag": [_vp, C.POINTER(C.c_int)],
         "pfx_newton_solve": [_vp, _pd, _pd, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_newton_solve_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
+        "pfx_mass_quadrature_points": [_vp, C.POINTER(C.c_int), _pd],
+        "pfx_assemble_mass_pointwise": [_vp, _pd, _i64, _i32],
+        "pfx_inertia_set_mass_pointwise": [_vp, _pd, _i64, _i32],
+        "pfx_assemble_rhs_density_pointwise": [_vp, _pd, _pd, _pd, _i64, _i32, _pd],
         "pfx_amg_set_params": [_vp, C.POINTER(AmgParams)],
         "pfx_amg_setup": [_vp],
         "pfx_amg_get_info": [_vp, C.POINTER(AmgInfo)],
@@ -498,8 +503,21 @@ class Engine:
     def amg_apply_dev(self, d_r: int, d_z: int):
         self._ck(self.L.pfx_amg_apply_dev(self.h, _vp(d_r), _vp(d_z)))
 
+    def mass_quadrature_points(self):
+        """Physical positions of the points of the mass quadrature rule, shape (n_el, n_pts, 3)."""
+        n_pts = C.c_int()
+        self._ck(self.L.pfx_mass_quadrature_points(self.h, C.byref(n_pts), None))
+        out = np.zeros((self.info().n_el, n_pts.value, 3))
+        self._ck(self.L.pfx_mass_quadrature_points(self.h, C.byref(n_pts), _d(out)))
+        return out
+
     def assemble_mass(self, density=1.0):
-        """Assembler<Mass>::assemble(is_mass=True) into the resident pattern; density: scalar or one value per element."""
+        """Assembler<Mass>::assemble(is_mass=True) into the resident pattern; density: scalar, one value per element, or
+        (n_el, n_pts) values at the points of the mass quadrature rule (mass_quadrature_points)."""
+        if np.ndim(density) == 2:
+            rho = np.ascontiguousarray(density, dtype=np.float64)
+            self._ck(self.L.pfx_assemble_mass_pointwise(self.h, _d(rho), rho.shape[0], rho.shape[1]))
+            return
         if np.ndim(density) == 0:
             self._ck(self.L.pfx_assemble_mass(self.h, float(density), None))
         else:
@@ -520,6 +538,11 @@ class Engine:
         inf = self.info()
         if f.ndim != 3 or f.shape[0] != inf.n_el or f.shape[1] != inf.n_pts:
             raise ValueError("force_pts must have shape (n_el, n_pts, d)")
+        if np.ndim(density) == 2:
+            rho = np.ascontiguousarray(density, dtype=np.float64)
+            out = np.zeros(inf.n_dofs)
+            self._ck(self.L.pfx_assemble_rhs_density_pointwise(self.h, None, _d(f), _d(rho), rho.shape[0], rho.shape[1], _d(out)))
+            return out
         rho_e = None if np.ndim(density) == 0 else np.ascontiguousarray(density, dtype=np.float64)
         out = np.zeros(inf.n_dofs)
         self._ck(self.L.pfx_assemble_rhs_pointwise(self.h, _d(f), float(density) if rho_e is None else float(rho_e[0]),
@@ -531,6 +554,10 @@ class Engine:
         f = np.zeros(3)
         f[:np.size(force)] = np.asarray(force, dtype=np.float64).reshape(-1)
         out = np.zeros(self.info().n_dofs)
+        if np.ndim(density) == 2:  # (n_el, n_pts) values at the stiffness rule's points (quadrature_points)
+            rho = np.ascontiguousarray(density, dtype=np.float64)
+            self._ck(self.L.pfx_assemble_rhs_density_pointwise(self.h, _d(f), None, _d(rho), rho.shape[0], rho.shape[1], _d(out)))
+            return out
         if np.ndim(density) == 0:
             self._ck(self.L.pfx_assemble_rhs(self.h, _d(f), float(density), None, _d(out)))
         else:
@@ -564,7 +591,10 @@ class Engine:
     # ---- transient steps -------------------------------------------------------------------------------------
     def inertia_set_mass(self, density=1.0):
         """Assembles the mass matrix (scalar density or one value per element) and keeps it for the inertia term."""
-        if np.ndim(density) == 0:
+        if np.ndim(density) == 2:
+            d = np.ascontiguousarray(density, dtype=np.float64)
+            self._ck(self.L.pfx_inertia_set_mass_pointwise(self.h, _d(d), d.shape[0], d.shape[1]))
+        elif np.ndim(density) == 0:
             self._ck(self.L.pfx_inertia_set_mass(self.h, float(density), None))
         else:
             d = np.ascontiguousarray(density, dtype=np.float64)

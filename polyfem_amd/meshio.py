@@ -5,13 +5,18 @@ Input side of the hot path: what the reference does between reading a mesh and c
   * `read_msh` follows `io/MshReader.cpp:29-160` (which parses with the un-vendored MshIO library): the elements of
     the highest dimension present become `cells` (first 4 nodes of every tetrahedron type, first 8 of every
     hexahedron type), node tags become 0-based vertex ids (tag - 1, or file order when tags are not dense, as the
-    reference does with a warning), and the body id of a cell is the first physical tag of its entity.  ASCII files of
-    format 2.2 and 4.1 are read; binary files are rejected.
-  * `flatten` stands in for `FEBasis3d::build_bases` + `mesh/MeshNodes.cpp:157-308` on conforming meshes: every mesh
-    vertex is a node (vertex id = node id), P2 edge nodes follow in the order in which the element loop first touches
-    them, local node order is that of the reference's basis functions (`autogen/auto_p_bases.cpp`: vertices, then the
-    edges (0,1) (1,2) (2,0) (0,3) (1,3) (2,3)), geometry map linear / trilinear on the cell's own vertices.
-    Elements with a negative Jacobian are re-oriented by swapping two vertices.
+    reference does with a warning), and the body id of a cell is the first physical tag of its entity.  ASCII and
+    binary files of format 2.2 and 4.1 are read.
+  * `flatten` stands in for `FEBasis3d::build_bases` + `mesh/MeshNodes.cpp:157-308` on conforming meshes.  Local node
+    order is that of the reference's basis functions: tetrahedra (`basis/FEBasis3d.cpp:201-395`, `autogen/auto_p_bases.cpp`)
+    vertices, then the edges (0,1) (1,2) (2,0) (0,3) (1,3) (2,3); hexahedra (`basis/FEBasis3d.cpp:397-520`,
+    `autogen/auto_q_bases.cpp:1873-1903`) vertices, the edges (0,1) (1,2) (2,3) (3,0) (0,4) (1,5) (2,6) (3,7) (4,5) (5,6)
+    (6,7) (7,4), the faces (0,3,4,7) (1,2,5,6) (0,1,5,4) (3,2,6,7) (0,1,2,3) (4,5,6,7), the cell.  Global numbering:
+    `numbering="first_touch"` is MeshNodes' rule -- a primitive (vertex, edge, face, cell) gets the next free node id the
+    first time the element loop asks for it, vertices included (`MeshNodes::node_id_from_primitive`, :157-175);
+    `numbering="vertices_first"` (default) keeps vertex id = node id and numbers the other primitives in first-touch order
+    after them.  Geometry map linear / trilinear on the cell's own vertices.  Tetrahedra with a negative Jacobian are
+    re-oriented by swapping two vertices.
 
 No reference fixture pins this numbering (the reference's meshes live in the external polyfem-data repository), so
 results on real meshes are comparable to a PolyFEM run only up to a node permutation.
@@ -31,13 +36,7 @@ _ELEMENT_TYPES = {
 }
 
 
-def _sections(path):
-    with open(path, "rb") as fh:
-        raw = fh.read()
-    try:
-        text = raw.decode("ascii")
-    except UnicodeDecodeError as exc:
-        raise ValueError(f"{path}: binary MSH files are not supported") from exc
+def _sections(text):
     out, name, buf = {}, None, []
     for line in text.splitlines():
         s = line.strip()
@@ -53,15 +52,8 @@ def _sections(path):
     return out
 
 
-def read_msh(path):
-    """Returns (vertices (n, 3) float64, cells (m, 4 | 8) int32, body_ids (m,) int32)."""
-    sec = _sections(path)
-    if "MeshFormat" not in sec:
-        raise ValueError(f"{path}: not an MSH file")
-    version, file_type = sec["MeshFormat"][0].split()[:2]
-    if int(file_type) != 0:
-        raise ValueError(f"{path}: binary MSH files are not supported")
-    major = int(float(version))
+def _read_ascii(sec, path, major):
+    """ASCII MSH 2.2 / 4.1: (node tags, coordinates, element blocks (dim, physical tag, type, node tags per element))."""
     tags, xyz, blocks = [], [], []  # blocks: (dim, physical tag, type, [node tags per element])
     if major == 2:
         lines = sec["Nodes"]
@@ -112,9 +104,131 @@ def read_msh(path):
                 raise ValueError(f"{path}: unsupported element type {etype}")
             blocks.append((edim, phys_of.get((edim, etag), 0), etype, [[int(v) for v in lines[pos + k].split()[1:]] for k in range(nb)]))
             pos += nb
-    else:
-        raise ValueError(f"{path}: MSH format {version} is not supported (2.2 and 4.1 are)")
 
+    return tags, xyz, blocks
+
+
+class _Bin:
+    """Cursor over the raw bytes of a binary MSH file."""
+
+    def __init__(self, raw, path):
+        self.raw, self.pos, self.path = raw, 0, path
+
+    def section(self, name):
+        k = self.raw.find(b"$" + name + b"\n")
+        if k < 0:
+            return False
+        self.pos = k + len(name) + 2
+        return True
+
+    def line(self):
+        e = self.raw.index(b"\n", self.pos)
+        s = self.raw[self.pos:e].decode("ascii")
+        self.pos = e + 1
+        return s
+
+    def take(self, dtype, count=1):
+        dt = np.dtype(dtype)
+        n = dt.itemsize * count
+        if self.pos + n > len(self.raw):
+            raise ValueError(f"{self.path}: truncated binary section")
+        a = np.frombuffer(self.raw, dtype=dt, count=count, offset=self.pos)
+        self.pos += n
+        return a
+
+
+def _read_binary(raw, path, major):
+    """Binary MSH 2.2 / 4.1 (little endian, 8-byte floats): same (tags, xyz, blocks) as the ASCII branch."""
+    b = _Bin(raw, path)
+    b.section(b"MeshFormat")
+    b.line()
+    if int(b.take("<i4")[0]) != 1:
+        raise ValueError(f"{path}: binary MSH file with the other byte order")
+    tags, xyz, blocks = [], [], []
+    if major == 2:
+        if not b.section(b"Nodes"):
+            raise ValueError(f"{path}: no $Nodes section")
+        n = int(b.line())
+        rec = b.take(np.dtype([("tag", "<i4"), ("p", "<f8", 3)]), n)
+        tags, xyz = rec["tag"].astype(np.int64).tolist(), rec["p"].tolist()
+        if not b.section(b"Elements"):
+            raise ValueError(f"{path}: no $Elements section")
+        n = int(b.line())
+        done = 0
+        while done < n:
+            etype, cnt, ntags = (int(v) for v in b.take("<i4", 3))
+            if etype not in _ELEMENT_TYPES:
+                raise ValueError(f"{path}: unsupported element type {etype}")
+            per = _ELEMENT_TYPES[etype][1]
+            data = b.take("<i4", cnt * (1 + ntags + per)).reshape(cnt, 1 + ntags + per)
+            for row in data:
+                blocks.append((_ELEMENT_TYPES[etype][0], int(row[1]) if ntags > 0 else 0, etype, [row[1 + ntags:].astype(np.int64).tolist()]))
+            done += cnt
+        return tags, xyz, blocks
+    phys_of = {}
+    if b.section(b"Entities"):
+        counts = [int(v) for v in b.take("<u8", 4)]
+        for dim, cnt in enumerate(counts):
+            for _ in range(cnt):
+                tag = int(b.take("<i4")[0])
+                b.take("<f8", 3 if dim == 0 else 6)
+                nphys = int(b.take("<u8")[0])
+                ph = b.take("<i4", nphys)
+                phys_of[(dim, tag)] = int(ph[0]) if nphys > 0 else 0
+                if dim > 0:
+                    nb = int(b.take("<u8")[0])
+                    b.take("<i4", nb)
+    if not b.section(b"Nodes"):
+        raise ValueError(f"{path}: no $Nodes section")
+    nblocks = int(b.take("<u8", 4)[0])
+    for _ in range(nblocks):
+        _, _, parametric = (int(v) for v in b.take("<i4", 3))
+        nb = int(b.take("<u8")[0])
+        tags.extend(b.take("<u8", nb).astype(np.int64).tolist())
+        edim_par = 0
+        if parametric:
+            raise ValueError(f"{path}: parametric node blocks are not supported")
+        xyz.extend(b.take("<f8", nb * (3 + edim_par)).reshape(nb, 3).tolist())
+    if not b.section(b"Elements"):
+        raise ValueError(f"{path}: no $Elements section")
+    nblocks = int(b.take("<u8", 4)[0])
+    for _ in range(nblocks):
+        edim, etag, etype = (int(v) for v in b.take("<i4", 3))
+        nb = int(b.take("<u8")[0])
+        if etype not in _ELEMENT_TYPES:
+            raise ValueError(f"{path}: unsupported element type {etype}")
+        per = _ELEMENT_TYPES[etype][1]
+        data = b.take("<u8", nb * (1 + per)).reshape(nb, 1 + per)
+        blocks.append((edim, phys_of.get((edim, etag), 0), etype, data[:, 1:].astype(np.int64).tolist()))
+    return tags, xyz, blocks
+
+
+def read_msh(path):
+    """Returns (vertices (n, 3) float64, cells (m, 4 | 8) int32, body_ids (m,) int32)."""
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    head = raw[:256].split(b"\n")
+    if len(head) < 2 or head[0].strip() != b"$MeshFormat":
+        raise ValueError(f"{path}: not an MSH file")
+    fmt = head[1].split()
+    if len(fmt) < 3:
+        raise ValueError(f"{path}: malformed $MeshFormat")
+    version, file_type, data_size = fmt[0].decode("ascii"), int(fmt[1]), int(fmt[2])
+    major = int(float(version))
+    if major not in (2, 4):
+        raise ValueError(f"{path}: MSH format {version} is not supported (2.2 and 4.1 are)")
+    if file_type == 1:
+        if data_size != 8:
+            raise ValueError(f"{path}: binary MSH files with {data_size}-byte floats are not supported")
+        if len(raw) < 300 and b"$Nodes" not in raw:
+            raise ValueError(f"{path}: binary MSH file without nodes")
+        tags, xyz, blocks = _read_binary(raw, path, major)
+    else:
+        try:
+            sec = _sections(raw.decode("ascii"))
+        except UnicodeDecodeError as exc:
+            raise ValueError(f"{path}: not an ASCII MSH file") from exc
+        tags, xyz, blocks = _read_ascii(sec, path, major)
     n_vertices = len(tags)
     if n_vertices == 0 or not blocks:
         raise ValueError(f"{path}: no nodes or no elements")
@@ -151,13 +265,64 @@ def read_msh(path):
     return vertices, np.ascontiguousarray(cells.astype(np.int32)), np.asarray(body, dtype=np.int32)
 
 
-def write_msh(path, vertices, cells, body_ids=None, version: str = "2.2"):
-    """ASCII MSH writer for tetrahedra (4 columns) / hexahedra (8 columns); the counterpart of read_msh for tests and
-    for exporting generated meshes."""
+def _write_msh_binary(path, vertices, cells, body, etype, version):
+    nv, ne = vertices.shape[0], cells.shape[0]
+    with open(path, "wb") as fh:
+        fh.write(("$MeshFormat\n%s 1 8\n" % version).encode())
+        fh.write(np.array([1], dtype="<i4").tobytes())
+        fh.write(b"\n$EndMeshFormat\n")
+        if version == "2.2":
+            fh.write(b"$Nodes\n%d\n" % nv)
+            rec = np.zeros(nv, dtype=np.dtype([("tag", "<i4"), ("p", "<f8", 3)]))
+            rec["tag"], rec["p"] = np.arange(1, nv + 1), vertices
+            fh.write(rec.tobytes())
+            fh.write(b"\n$EndNodes\n$Elements\n%d\n" % ne)
+            fh.write(np.array([etype, ne, 2], dtype="<i4").tobytes())
+            data = np.concatenate([np.arange(1, ne + 1)[:, None], body[:, None], body[:, None], cells + 1], axis=1).astype("<i4")
+            fh.write(data.tobytes())
+            fh.write(b"\n$EndElements\n")
+            return
+        ids = sorted(set(int(b) for b in body))
+        lo, hi = vertices.min(axis=0), vertices.max(axis=0)
+        fh.write(b"$Entities\n")
+        fh.write(np.array([0, 0, 0, len(ids)], dtype="<u8").tobytes())
+        for t, b in enumerate(ids):
+            fh.write(np.array([t + 1], dtype="<i4").tobytes())
+            fh.write(np.concatenate([lo, hi]).astype("<f8").tobytes())
+            fh.write(np.array([1 if b != 0 else 0], dtype="<u8").tobytes())
+            if b != 0:
+                fh.write(np.array([b], dtype="<i4").tobytes())
+            fh.write(np.array([0], dtype="<u8").tobytes())
+        fh.write(b"\n$EndEntities\n$Nodes\n")
+        fh.write(np.array([1, nv, 1, nv], dtype="<u8").tobytes())
+        fh.write(np.array([3, 1, 0], dtype="<i4").tobytes())
+        fh.write(np.array([nv], dtype="<u8").tobytes())
+        fh.write(np.arange(1, nv + 1, dtype="<u8").tobytes())
+        fh.write(vertices.astype("<f8").tobytes())
+        fh.write(b"\n$EndNodes\n$Elements\n")
+        fh.write(np.array([len(ids), ne, 1, ne], dtype="<u8").tobytes())
+        tag = 1
+        for t, b in enumerate(ids):
+            sel = np.nonzero(body == b)[0]
+            fh.write(np.array([3, t + 1, etype], dtype="<i4").tobytes())
+            fh.write(np.array([sel.size], dtype="<u8").tobytes())
+            data = np.concatenate([np.arange(tag, tag + sel.size)[:, None], cells[sel] + 1], axis=1).astype("<u8")
+            fh.write(data.tobytes())
+            tag += sel.size
+        fh.write(b"\n$EndElements\n")
+
+
+def write_msh(path, vertices, cells, body_ids=None, version: str = "2.2", binary: bool = False):
+    """MSH writer (ASCII or binary) for tetrahedra (4 columns) / hexahedra (8 columns); the counterpart of read_msh for
+    tests and for exporting generated meshes."""
     vertices = np.asarray(vertices, dtype=np.float64)
     cells = np.asarray(cells)
     etype = {4: 4, 8: 5}[cells.shape[1]]
     body = np.zeros(cells.shape[0], dtype=np.int64) if body_ids is None else np.asarray(body_ids, dtype=np.int64)
+    if version not in ("2.2", "4.1"):
+        raise ValueError("version must be '2.2' or '4.1'")
+    if binary:
+        return _write_msh_binary(path, vertices, cells.astype(np.int64), body, etype, version)
     with open(path, "w") as fh:
         if version == "2.2":
             fh.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % vertices.shape[0])
@@ -192,14 +357,50 @@ def write_msh(path, vertices, cells, body_ids=None, version: str = "2.2"):
             raise ValueError("version must be '2.2' or '4.1'")
 
 
-def flatten(vertices, cells, order: int = 1) -> M.Mesh:
-    """Mesh of P1 / P2 tetrahedra (cells with 4 columns) or Q1 hexahedra (8 columns, Gmsh corner order = the
+_HEX_EDGES = [(0, 1), (1, 2), (2, 3), (3, 0), (0, 4), (1, 5), (2, 6), (3, 7), (4, 5), (5, 6), (6, 7), (7, 4)]
+_HEX_FACES = [(0, 3, 4, 7), (1, 2, 5, 6), (0, 1, 5, 4), (3, 2, 6, 7), (0, 1, 2, 3), (4, 5, 6, 7)]
+
+
+def _number_primitives(cells, nv, groups, numbering):
+    """cells: (n_el, n_vert) vertex ids.  groups: list of (n_el, k_g, m_g) arrays: for every further local node the m_g
+    vertices of its primitive (edge: 2, face: 4, cell: 8).  Returns conn (n_el, n_loc) and node positions' recipe:
+    (n_nodes, list of (node ids, vertex tuples) per group)."""
+    n_el = cells.shape[0]
+    prim_cols, offset, tables = [cells.astype(np.int64)], nv, []
+    for g in groups:
+        key = np.sort(g.reshape(-1, g.shape[2]), axis=1)
+        uniq, inv = np.unique(key, axis=0, return_inverse=True)
+        prim_cols.append(offset + inv.reshape(n_el, g.shape[1]))
+        tables.append((offset, uniq))
+        offset += uniq.shape[0]
+    prims = np.concatenate(prim_cols, axis=1)  # element-major, local node order = the order the reference asks in
+    flat = prims.reshape(-1)
+    node_of = np.full(offset, -1, dtype=np.int64)
+    if numbering == "first_touch":
+        uniq, first = np.unique(flat, return_index=True)
+        node_of[uniq[np.argsort(first, kind="stable")]] = np.arange(uniq.size)
+        n_nodes = int(uniq.size)
+    elif numbering == "vertices_first":
+        node_of[:nv] = np.arange(nv)
+        rest = flat[flat >= nv]
+        uniq, first = np.unique(rest, return_index=True)
+        node_of[uniq[np.argsort(first, kind="stable")]] = nv + np.arange(uniq.size)
+        n_nodes = nv + int(uniq.size)
+    else:
+        raise ValueError("numbering must be 'vertices_first' or 'first_touch'")
+    return node_of[prims], n_nodes, node_of, tables
+
+
+def flatten(vertices, cells, order: int = 1, numbering: str = "vertices_first") -> M.Mesh:
+    """Mesh of P1 / P2 tetrahedra (cells with 4 columns) or Q1 / Q2 hexahedra (8 columns, Gmsh corner order = the
     reference's) in the engine's layout."""
     vertices = np.ascontiguousarray(vertices, dtype=np.float64)
     cells = np.array(cells, dtype=np.int64, copy=True)
     nv = vertices.shape[0]
     if cells.min() < 0 or cells.max() >= nv:
         raise ValueError("cell refers to a vertex that does not exist")
+    if order not in (1, 2):
+        raise ValueError("order 1 or 2")
     if cells.shape[1] == 4:
         p = vertices[cells]
         det = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0])
@@ -207,40 +408,34 @@ def flatten(vertices, cells, order: int = 1) -> M.Mesh:
             raise ValueError("degenerate tetrahedron")
         flip = det < 0
         cells[flip, 2], cells[flip, 3] = cells[flip, 3].copy(), cells[flip, 2].copy()
-        if order == 1:
-            return M.Mesh(M.P1TET, M.P1TET, np.ascontiguousarray(cells.astype(np.int32)), np.ascontiguousarray(cells.astype(np.int32)),
-                          vertices, nv, vertices.copy())
-        if order != 2:
-            raise ValueError("tetrahedra: order 1 or 2")
-        a = np.stack([cells[:, e[0]] for e in M._P2_EDGES], axis=1)
-        b = np.stack([cells[:, e[1]] for e in M._P2_EDGES], axis=1)
-        key = (np.minimum(a, b) * nv + np.maximum(a, b)).reshape(-1)  # element-major, local edge order
-        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
-        rank = np.empty(uniq.size, dtype=np.int64)
-        rank[np.argsort(first, kind="stable")] = np.arange(uniq.size)  # first-touch order of the edges
-        edge_node = nv + rank[inv].reshape(-1, 6)
-        conn = np.concatenate([cells, edge_node], axis=1)
-        n_nodes = nv + uniq.size
-        if n_nodes >= 2 ** 31:
-            raise ValueError("too many nodes for 32-bit indices")
-        node_xyz = np.zeros((n_nodes, 3))
-        node_xyz[:nv] = vertices
-        node_xyz[nv + rank] = 0.5 * (vertices[uniq // nv] + vertices[uniq % nv])
-        return M.Mesh(M.P2TET, M.P1TET, np.ascontiguousarray(conn.astype(np.int32)), np.ascontiguousarray(cells.astype(np.int32)),
-                      vertices, n_nodes, node_xyz)
-    if cells.shape[1] == 8:
-        if order != 1:
-            raise ValueError("hexahedra: only order 1 is flattened from files (Q2 needs edge, face and cell nodes)")
+        groups = [] if order == 1 else [np.stack([cells[:, list(e)] for e in M._P2_EDGES], axis=1)]
+        kind = M.P1TET if order == 1 else M.P2TET
+        gkind = M.P1TET
+    elif cells.shape[1] == 8:
         p = vertices[cells]
         det = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 3] - p[:, 0]), p[:, 4] - p[:, 0])
         if np.any(det <= 0):
             raise ValueError("hexahedron with non-positive orientation at its first corner")
-        c32 = np.ascontiguousarray(cells.astype(np.int32))
-        return M.Mesh(M.Q1HEX, M.Q1HEX, c32, c32.copy(), vertices, nv, vertices.copy())
-    raise ValueError("cells must have 4 (tetrahedra) or 8 (hexahedra) columns")
+        groups = [] if order == 1 else [np.stack([cells[:, list(e)] for e in _HEX_EDGES], axis=1),
+                                        np.stack([cells[:, list(f)] for f in _HEX_FACES], axis=1), cells[:, None, :]]
+        kind = M.Q1HEX if order == 1 else M.Q2HEX
+        gkind = M.Q1HEX
+    else:
+        raise ValueError("cells must have 4 (tetrahedra) or 8 (hexahedra) columns")
+    conn, n_nodes, node_of, tables = _number_primitives(cells, nv, groups, numbering)
+    if n_nodes >= 2 ** 31:
+        raise ValueError("too many nodes for 32-bit indices")
+    node_xyz = np.zeros((n_nodes, 3))
+    used_v = node_of[:nv] >= 0
+    node_xyz[node_of[:nv][used_v]] = vertices[used_v]
+    for offset, uniq in tables:  # barycentre of the primitive's vertices (MeshNodes.cpp:166-173)
+        ids = node_of[offset: offset + uniq.shape[0]]
+        node_xyz[ids] = vertices[uniq].mean(axis=1)
+    c32 = np.ascontiguousarray(cells.astype(np.int32))
+    return M.Mesh(kind, gkind, np.ascontiguousarray(conn.astype(np.int32)), c32, vertices, n_nodes, node_xyz)
 
 
-def load(path, order: int = 1):
+def load(path, order: int = 1, numbering: str = "vertices_first"):
     """read_msh + flatten; returns (Mesh, body_ids)."""
     vertices, cells, body = read_msh(path)
-    return flatten(vertices, cells, order), body
+    return flatten(vertices, cells, order, numbering), body

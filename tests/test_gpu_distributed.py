@@ -79,7 +79,7 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_engine():
+def test_two_ranks_on_one_gpu_match_single_engine(oracle):
     import torch.multiprocessing as mp
     from polyfem_amd import distributed as D
     from polyfem_amd import engine as E
@@ -109,6 +109,20 @@ def test_two_ranks_on_one_gpu_match_single_engine():
     assert np.abs(gg - g_ref).max() <= 1e-12 * np.abs(g_ref).max()
     assert abs(iters - it_ref) <= 2 and err < 1e-11
     assert np.abs(xg - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    # ... and the CPU oracle on the whole mesh (not only the library against itself): energy, gradient, and the Eigen-order
+    # CG on the explicitly reduced Hessian
+    mesh = part.mesh
+    lam, mu = 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6
+    e_o = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, u)
+    g_o = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, u)
+    assert abs(energy - e_o) <= 1e-12 * abs(e_o)
+    assert np.abs(gg - g_o).max() <= 1e-12 * np.abs(g_o).max()
+    bd = np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1))
+    red = oracle.full_to_reduced_matrix(oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, u, 8), bd)
+    keep = np.setdiff1d(np.arange(n_nodes * 3), bd)
+    x_o, it_o, _ = oracle.cg(red, b[keep], jacobi=True, max_iter=1000, tol=1e-12)
+    assert abs(iters - it_o) <= 2, (iters, it_o)
+    assert np.abs(xg[keep] - x_o).max() <= 1e-8 * np.abs(x_o).max() and not xg[bd].any()
 
 
 def _newton_case(n_nodes, node_xyz):

@@ -316,6 +316,42 @@ def test_mass_matrix_and_body_force(eng, oracle, name, size):
     assert rel_err(eng.get_linear_csr()[2], k_ref[2]) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q2"])
+def test_density_per_quadrature_point(eng, oracle, name):
+    """Density::operator() evaluated at every quadrature point (utils/ElasticityUtils.cpp:561-570; Mass.cpp:10,
+    RhsAssembler.cpp:81): mass matrix with a density given at the mass rule's points, right-hand side with one at the
+    stiffness rule's points (constant and pointwise force), positions of the mass rule's points, inertia mass."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+    rho_fun = lambda p: 1000.0 * (1.0 + 0.5 * p[..., 0] + 0.25 * p[..., 1] * p[..., 2])  # noqa: E731
+    mq = eng.mass_quadrature_points()
+    mq_ref = oracle.mass_quadrature_points(mesh)
+    assert mq.shape == mq_ref.shape and np.abs(mq - mq_ref).max() <= 1e-15 * max(np.abs(mq_ref).max(), 1.0) + 1e-16
+    rho_m = rho_fun(mq)
+    eng.assemble_mass(rho_m)
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_mass(mesh, 3, rho_m)
+    assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner)
+    assert rel_err(v, vals) <= TOL
+    # a constant given per point is the uniform density
+    eng.assemble_mass(np.full(rho_m.shape, 2.5))
+    assert rel_err(eng.get_linear_csr()[2], oracle.assemble_mass(mesh, 3, 2.5)[2]) <= TOL
+    sq = eng.quadrature_points()
+    rho_s = rho_fun(sq)
+    force = np.array([0.3, -0.2, -9.8])
+    assert rel_err(eng.assemble_rhs(force, rho_s), oracle.assemble_rhs(mesh, 3, force, rho_s)) <= TOL
+    f_pts = np.stack([np.sin(sq[..., 0]), sq[..., 1] ** 2, -9.8 + sq[..., 2]], axis=-1)
+    assert rel_err(eng.assemble_rhs_pointwise(f_pts, rho_s), oracle.assemble_rhs_pointwise(mesh, 3, f_pts, rho_s)) <= TOL
+    # inertia term from the same mass: lumped mass = row sums
+    eng.inertia_set_mass(rho_m)
+    Mref = csc_to_scipy(oracle.assemble_mass(mesh, 3, rho_m), mesh.n_nodes * 3)
+    assert rel_err(eng.lumped_mass(), np.asarray(Mref.sum(axis=1)).reshape(-1)) <= 1e-12
+    # wrong shapes are rejected
+    with pytest.raises(E.PfxError):
+        eng.assemble_mass(rho_s if rho_s.shape[1] != rho_m.shape[1] else rho_m[:, :-1])
+
+
 @pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
 def test_hessian_project_to_psd(eng, oracle, name):
     """assemble_hessian(project_to_psd = true): element Hessians projected onto the PSD cone (Assembler.cpp:554-555).

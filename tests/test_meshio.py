@@ -1,5 +1,6 @@
-"""Gmsh reader / flattening (input side of the path): round trips through both ASCII formats, the first-touch P2
-numbering against the generator that follows the same rule, body ids, re-orientation, rejected inputs.  The reference
+"""Gmsh reader / flattening (input side of the path): round trips through both formats in ASCII and binary, the
+first-touch numbering rule of MeshNodes, P2 / Q2 node sets against the generators, body ids, re-orientation, rejected
+inputs.  The reference
 parses MSH files with the un-vendored MshIO library and holds no mesh fixture: parity unpinned, checked for
 self-consistency only."""
 import numpy as np
@@ -37,7 +38,7 @@ def test_msh_hexes_sparse_tags_and_orientation(tmp_path):
     m, body = IO.load(path, 1)
     assert m.kind == M.Q1HEX and np.array_equal(m.conn, ref.conn) and not body.any()
     with pytest.raises(ValueError):
-        IO.flatten(ref.xyz, ref.gconn, 2)
+        IO.flatten(ref.xyz, ref.gconn, 3)
     # node tags with gaps are condensed in file order; lower-dimensional elements are ignored; higher-order
     # tetrahedra contribute their four vertices
     path = tmp_path / "sparse.msh"
@@ -70,3 +71,54 @@ def test_flattened_file_mesh_assembles_like_the_generated_one(tmp_path, oracle):
     a = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
     b = oracle.assemble_linear(ref, oracle.LINEAR_ELASTICITY, lam, mu)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("version", ["2.2", "4.1"])
+@pytest.mark.parametrize("hexes", [False, True])
+def test_binary_msh_round_trip(tmp_path, version, hexes):
+    ref = M.cube_hexes(2, 1) if hexes else M.cube_tets(2, 1, jitter=0.1)
+    body = (np.arange(ref.n_el) % 3 == 0).astype(np.int32) * 4 + 2
+    body = np.sort(body)  # bodies contiguous in the file (4.1 stores one entity block per body)
+    pa, pb = tmp_path / "a.msh", tmp_path / "b.msh"
+    IO.write_msh(pa, ref.xyz, ref.gconn, body, version)
+    IO.write_msh(pb, ref.xyz, ref.gconn, body, version, binary=True)
+    va, ca, ba = IO.read_msh(pa)
+    vb, cb, bb = IO.read_msh(pb)
+    assert np.array_equal(va, vb) and np.array_equal(ca, cb) and np.array_equal(ba, bb)
+    assert np.array_equal(vb, ref.xyz) and np.array_equal(cb, ref.gconn) and np.array_equal(bb, body)
+    raw = pb.read_bytes()
+    (tmp_path / "cut.msh").write_bytes(raw[: len(raw) // 2])
+    with pytest.raises(ValueError):
+        IO.read_msh(tmp_path / "cut.msh")
+
+
+def _first_occurrences_ascending(conn):
+    flat = conn.reshape(-1)
+    _, first = np.unique(flat, return_index=True)
+    return bool(np.all(np.diff(first) > 0))  # node k is first touched before node k + 1
+
+
+@pytest.mark.parametrize("kind", ["p2", "q2"])
+def test_first_touch_numbering_and_q2_flattening(kind, oracle):
+    """MeshNodes::node_id_from_primitive: ids in the order the element loop first asks for a primitive (vertices, edges,
+    faces, cell of each element in local order).  The flattened Q2 / P2 mesh is the generated one up to the node
+    renumbering: same node positions, and the oracle's stiffness matrices agree after the permutation."""
+    gen = M.cube_hexes(2, 2) if kind == "q2" else M.cube_tets(2, 2)
+    base = M.cube_hexes(2, 1) if kind == "q2" else M.cube_tets(2, 1)
+    for numbering in ("first_touch", "vertices_first"):
+        m = IO.flatten(base.xyz, base.gconn, 2, numbering)
+        assert m.kind == gen.kind and m.n_nodes == gen.n_nodes and m.conn.shape == gen.conn.shape
+        if numbering == "first_touch":
+            assert _first_occurrences_ascending(m.conn) and m.conn[0, 0] == 0 and np.array_equal(m.conn[0], np.arange(m.conn.shape[1]))
+        else:
+            assert np.array_equal(m.conn[:, : base.gconn.shape[1]], base.gconn)  # vertex id = node id
+        # node k of an element sits where the generator's node k of that element sits
+        assert np.allclose(m.node_xyz[m.conn], gen.node_xyz[gen.conn], atol=1e-14)
+        perm = np.empty(gen.n_nodes, dtype=np.int64)  # generator id -> flattened id
+        perm[gen.conn.reshape(-1)] = m.conn.reshape(-1)
+        lam, mu = oracle.lame(1e5, 0.3)
+        n = gen.n_nodes
+        from tests.helpers import csc_to_scipy
+        A = csc_to_scipy(oracle.assemble_linear(m, oracle.LAPLACIAN, lam, mu), n).toarray()
+        B = csc_to_scipy(oracle.assemble_linear(gen, oracle.LAPLACIAN, lam, mu), n).toarray()
+        assert np.abs(A[np.ix_(perm, perm)] - B).max() <= 1e-13 * np.abs(B).max()

@@ -683,3 +683,20 @@ def test_per_point_materials_oracle(oracle, kind):
         assert abs(fd - g @ d) <= 1e-6 * abs(g @ d)
         # a material that is stiffer everywhere stores more energy
         assert oracle.assemble_energy(mesh, mid, Lv, Mv, x) > oracle.assemble_energy(mesh, mid, lam, mu, x)
+
+
+@pytest.mark.parametrize("kind", ["p2", "q2"])
+def test_per_point_density_oracle(oracle, kind):
+    """Density::operator() per quadrature point (utils/ElasticityUtils.cpp:561-570): a density given per point that happens to
+    be constant reproduces the uniform result; a varying one integrates to the exact mass of a polynomial density."""
+    mesh = M.cube_tets(2, 2, jitter=0.1) if kind == "p2" else M.cube_hexes(2, 2)
+    mq = oracle.mass_quadrature_points(mesh)
+    a = oracle.assemble_mass(mesh, 3, np.full(mq.shape[:2], 2.5))
+    b = oracle.assemble_mass(mesh, 3, 2.5)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.abs(a[2] - b[2]).max() <= 1e-15 * np.abs(b[2]).max()
+    rho = 1.0 + mq[..., 0] + 2.0 * mq[..., 1] * mq[..., 2]  # integral over the unit cube: 1 + 1/2 + 2/4 = 2
+    Mm = csc_to_scipy(oracle.assemble_mass(mesh, 1, rho), mesh.n_nodes)
+    assert abs(Mm.sum() - 2.0) <= 1e-12
+    sq = oracle.quadrature_points(mesh)
+    r = oracle.assemble_rhs(mesh, 1, [1.0], 1.0 + sq[..., 0])  # the stiffness rule integrates a linear density exactly
+    assert abs(r.sum() - 1.5) <= 1e-12
