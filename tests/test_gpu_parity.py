@@ -1035,10 +1035,10 @@ def test_no_device_memory_drift(oracle):
 
 def test_neohookean_hip_against_sympy_derivatives(eng):
     """The HIP energy / gradient / Hessian of one element against the symbolic derivatives of the energy density
-    (tests/golden/neohookean_sympy.npz): independent of the oracle."""
+    (tests/golden/sympy/neohookean_sympy.npz): independent of the oracle."""
     import os
     from tests.test_oracle_kat import _single_tet_with_gradient, neohookean_sympy_expected
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "neohookean_sympy.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sympy", "neohookean_sympy.npz"))
     lam, mu = float(g["lam"]), float(g["mu"])
     for F, psi, dpsi, d2psi in zip(g["F"], g["psi"], g["dpsi"], g["d2psi"]):
         mesh, u = _single_tet_with_gradient(F)

@@ -138,10 +138,10 @@ def neohookean_sympy_expected(F, dpsi, d2psi):
 
 def test_neohookean_against_sympy_derivatives(oracle):
     """Energy, gradient and Hessian of one element against derivatives obtained by symbolic differentiation of the energy
-    density (fixture tests/golden/neohookean_sympy.npz, generated by tests/tools/make_neohookean_sympy_golden.py): pins the
+    density (fixture tests/golden/sympy/neohookean_sympy.npz, generated by tests/tools/make_neohookean_sympy_golden.py): pins the
     restated closed forms of NeoHookeanElasticity.cpp:364-565 independently of the oracle's own finite-difference checks."""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "neohookean_sympy.npz"))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sympy", "neohookean_sympy.npz"))
     lam, mu = float(g["lam"]), float(g["mu"])
     for F, psi, dpsi, d2psi in zip(g["F"], g["psi"], g["dpsi"], g["d2psi"]):
         mesh, u = _single_tet_with_gradient(F)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/neohookean_sympy.npz: energy density, first and second derivatives of the NeoHookean energy
+"""Generates tests/golden/sympy/neohookean_sympy.npz: energy density, first and second derivatives of the NeoHookean energy
 
     psi(F) = mu/2 (tr(F^T F) - 3 - 2 ln J) + lambda/2 ln^2 J ,  J = det F
 
@@ -42,7 +42,7 @@ def main():
         psis.append(float(f_psi(*a)))
         grads.append(np.array([float(v) for v in f_grad(*a)]))
         hesss.append(np.array([[float(v) for v in row] for row in f_hess(*a)]))
-    out = os.path.join(ROOT, "tests", "golden", "neohookean_sympy.npz")
+    out = os.path.join(ROOT, "tests", "golden", "sympy", "neohookean_sympy.npz")
     np.savez(out, F=np.array(Fs), lam=lam_v, mu=mu_v, psi=np.array(psis), dpsi=np.array(grads), d2psi=np.array(hesss))
     print("wrote", out)
 
