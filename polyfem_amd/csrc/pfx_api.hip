@@ -39,13 +39,13 @@ namespace
 	{
 		free_dev(ctx, ctx->d_node_ptr);
 		free_dev(ctx, ctx->d_node_col);
-		free_dev(ctx, ctx->d_blk_ptr);
 		free_dev(ctx, ctx->d_blk_src);
 		free_dev(ctx, ctx->d_blk_slot);
-		free_dev(ctx, ctx->d_unode_ptr);
-		free_dev(ctx, ctx->d_ublk_off);
-		free_dev(ctx, ctx->d_ublk_low);
-		ctx->n_ublocks = ctx->n_upair = 0;
+		free_dev(ctx, ctx->d_grp_c0);
+		free_dev(ctx, ctx->d_grp_win);
+		free_dev(ctx, ctx->d_win);
+		free_dev(ctx, ctx->d_desc);
+		ctx->n_ublocks = ctx->n_upair = ctx->n_groups = ctx->n_windows = 0;
 		free_dev(ctx, ctx->d_ne_ptr);
 		free_dev(ctx, ctx->d_ne_src);
 		free_dev(ctx, ctx->d_values);

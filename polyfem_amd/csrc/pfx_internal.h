@@ -26,7 +26,13 @@ struct pfx_tables
 	double gval[PFX_MAX_PTS][PFX_MAX_GLOC];       // geometry basis j at point k
 };
 
+// window descriptor (uint4): x = index of the block in the value array, y = index of its mirror image below the diagonal
+// (0xFFFFFFFF: a diagonal block), z = c0 | c1 << 8 | flags: its contributions are the window's [c0, c1)
+#define PFX_DESC_CONT_IN 0x10000u  // the block started in an earlier window: continue from the carried sums
+#define PFX_DESC_CONT_OUT 0x20000u // the block goes on in the next window: carry the sums instead of storing them
+#ifndef PFX_ROWS_PER_GROUP
 #define PFX_ROWS_PER_GROUP 16
+#endif
 
 #define PFX_NOALLOC_MAX_EL (1 << 20) // element limit of pfx_energy_dev_noalloc (size of its static device scratch)
 #define PFX_MAX_DEVICES 64
@@ -79,15 +85,17 @@ struct pfx_ctx
 	int32_t *d_node_col = nullptr; // n_blocks, ascending per node
 	// Only the blocks on and above the diagonal (column node >= row node, "upper" blocks, n_ublocks of them, numbered in
 	// block order) are assembled from contributions; the lane that finishes an entry of an upper block also writes it,
-	// transposed, into the block's mirror image below the diagonal (d_ublk_low).
+	// transposed, into the block's mirror image below the diagonal.
 	int64_t n_ublocks = 0, n_upair = 0;
-	int64_t *d_unode_ptr = nullptr; // n_nodes+1: upper blocks of the rows before each row
-	int64_t *d_blk_ptr = nullptr;   // n_ublocks+1 -> contribution list of each upper block
-	uint32_t *d_ublk_off = nullptr; // n_ublocks: (index among all blocks) - (index among the upper blocks)
-	uint32_t *d_ublk_low = nullptr; // n_ublocks: index (among all blocks) of the mirror image, 0xFFFFFFFF on the diagonal
-	// contribution lists (n_upair entries: n_loc(n_loc+1)/2 per element).  Position c of the block-ordered list belongs to the upper block ub with
-	// blk_ptr[ub] <= c < blk_ptr[ub+1] (ascending element inside a block).  The assembly kernel walks that list in windows
-	// of 64 per group of PFX_ROWS_PER_GROUP node rows; inside each window the contributions are stored reordered by
+	// contribution lists (n_upair entries: n_loc(n_loc+1)/2 per element), in block order, ascending element inside a
+	// block.  The assembly kernel walks that list in windows of 64 per group of PFX_ROWS_PER_GROUP node rows; what a
+	// window needs to know about the blocks it intersects is precomputed (pfx_pattern.hip):
+	int64_t n_groups = 0, n_windows = 0;
+	uint32_t *d_grp_c0 = nullptr;  // n_groups+1: first contribution of each group
+	uint32_t *d_grp_win = nullptr; // n_groups+1: first window of each group
+	uint2 *d_win = nullptr;        // n_windows: (first upper block bl, number of blocks nb) of the window
+	uint4 *d_desc = nullptr;       // n_ublocks + n_windows: block bl+s of window W at bl + s + W, see PFX_DESC_*
+	// Inside each window the contributions are stored reordered by
 	// element (lanes that read the same element state sit next to each other): d_blk_src[c] = e*n_loc^2 + i*n_loc + j of
 	// the contribution computed by lane c - window start, d_blk_slot[c] = its position in the window in block order.
 	uint32_t *d_blk_src = nullptr;

@@ -82,6 +82,9 @@ namespace
 	// block of the pair (i, j), j <= i : out[m*BS+n] = (row component m of basis i, column component n of basis j),
 	// values with |v| < 1e-30 replaced by an exact zero (they are absent from the reference's matrix)
 	// PP: the material arrays hold one value per (element, point) instead of one per element
+#ifndef PFX_LIN_UNROLL
+#define PFX_LIN_UNROLL 1 // quadrature points per trip of the functors' point loops
+#endif
 	template <int NLOC, int NPTS, int BS, int SP, bool PP = false>
 	struct linear_block
 	{
@@ -112,6 +115,7 @@ namespace
 				}
 			double lambda = lambda_e ? lambda_e[PP ? (int64_t)e * NPTS : e] : this->lambda, mu = mu_e ? mu_e[PP ? (int64_t)e * NPTS : e] : this->mu;
 			double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll(PFX_LIN_UNROLL)
 			for (int k = 0; k < NPTS; ++k)
 			{
 				if (SP != 1)
@@ -174,6 +178,7 @@ namespace
 		const pfx_tables *tab;
 		const double *tensor; // device, 36 doubles, symmetric 6 x 6
 		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + NPTS + 36; // grad[k][i][3], w[k], tensor
+		static constexpr int MIN_WAVES = 2; // the 6 x 6 tensor product of one point wants more registers than three waves leave
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
 		{
@@ -200,6 +205,7 @@ namespace
 			const double *C = lds + NPTS * NLOC * 3 + NPTS;
 			const double *ge = geo + (int64_t)e * (SP * 10);
 			double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll(PFX_LIN_UNROLL)
 			for (int k = 0; k < NPTS; ++k)
 			{
 				const double *jt = ge + (SP == 1 ? 0 : k * 10);
@@ -282,6 +288,7 @@ namespace
 			const double rho = density_e ? density_e[e] : density;
 			double det = ge[9];
 			double tmp = 0;
+#pragma unroll(PFX_LIN_UNROLL)
 			for (int k = 0; k < NPTS; ++k)
 			{
 				if (SP != 1)

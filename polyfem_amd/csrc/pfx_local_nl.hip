@@ -547,6 +547,9 @@ namespace
 	}
 
 	// H_ij for the pair (i, j), j <= i : out[m*3+n] = d2 E / d u_{i,m} d u_{j,n}
+#ifndef PFX_NL_UNROLL
+#define PFX_NL_UNROLL 3 // quadrature points per trip of the point loop: more keeps more state loads in flight, and more registers
+#endif
 	template <int NLOC, int NGLOC, int NPTS, int MODEL>
 	struct nl_block
 	{
@@ -573,6 +576,7 @@ namespace
 					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 				}
 			double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll(MODEL == M_MULTI ? 2 : PFX_NL_UNROLL)
 			for (int k = 0; k < NPTS; ++k)
 			{
 				if (!ST::affine)

@@ -11,7 +11,7 @@
 //      Eigen's compressed storage), and blk_ptr delimits each block's contribution list;
 //   3. only the blocks on and above the diagonal (column node >= row node) keep a contribution list: the reference
 //      evaluates the pairs j <= i only and mirrors them (Assembler.cpp:179-184), and so does the assembly here -- the
-//      blocks below the diagonal receive the transpose of their mirror image (d_ublk_low);
+//      blocks below the diagonal receive the transpose of their mirror image;
 //   4. the same grouping is done per node for (element, local index) incidences, used by the gradient.
 // The scalar CSR of a block size bs > 1 is implied: row node*bs+m owns, per neighbour slot s, the bs columns
 // node_col[s]*bs+n; it is materialised only when the caller asks for it (pfx_export_pattern).
@@ -177,6 +177,54 @@ namespace
 		}
 	}
 
+	// groups of PFX_ROWS_PER_GROUP node rows: first contribution and number of 64-wide windows of each
+	__global__ void k_group_windows(const int64_t *__restrict__ unode_ptr, const int64_t *__restrict__ blk_ptr, int64_t n_nodes, int64_t n_groups,
+									uint32_t *__restrict__ grp_c0, uint32_t *__restrict__ n_win)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g <= n_groups; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t r0 = g * PFX_ROWS_PER_GROUP < n_nodes ? g * PFX_ROWS_PER_GROUP : n_nodes;
+			const int64_t r1 = r0 + PFX_ROWS_PER_GROUP < n_nodes ? r0 + PFX_ROWS_PER_GROUP : n_nodes;
+			const int64_t c0 = blk_ptr[unode_ptr[r0]], c1 = blk_ptr[unode_ptr[r1]];
+			grp_c0[g] = (uint32_t)c0;
+			n_win[g] = (uint32_t)((c1 - c0 + 63) / 64);
+		}
+	}
+
+	// Walks the windows of every group once and writes down what the assembly kernel needs to know about each:
+	// win[W] = (first upper block, number of blocks) and one descriptor per (window, block it intersects).  A window
+	// boundary cuts at most one block, which then appears in both windows: block ub of window W sits at desc[ub + W].
+	__global__ void k_window_descriptors(const int64_t *__restrict__ unode_ptr, const int64_t *__restrict__ blk_ptr, const uint32_t *__restrict__ ublk_off,
+										 const uint32_t *__restrict__ ublk_low, const uint32_t *__restrict__ grp_win, int64_t n_nodes, int64_t n_groups,
+										 uint2 *__restrict__ win, uint4 *__restrict__ desc)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t r0 = g * PFX_ROWS_PER_GROUP;
+			const int64_t r1 = r0 + PFX_ROWS_PER_GROUP < n_nodes ? r0 + PFX_ROWS_PER_GROUP : n_nodes;
+			const int64_t b_end = unode_ptr[r1];
+			int64_t bl = unode_ptr[r0];
+			const int64_t c_end = blk_ptr[b_end];
+			int64_t W = grp_win[g];
+			for (int64_t w0 = blk_ptr[bl]; w0 < c_end; w0 += 64, ++W)
+			{
+				const int64_t nw = c_end - w0 < 64 ? c_end - w0 : 64;
+				int64_t b = bl;
+				bool cut = false;
+				while (b < b_end && blk_ptr[b] < w0 + nw)
+				{
+					const int64_t s0 = blk_ptr[b] - w0, s1 = blk_ptr[b + 1] - w0;
+					const uint32_t c0 = (uint32_t)(s0 < 0 ? 0 : s0), c1 = (uint32_t)(s1 > nw ? nw : s1);
+					cut = s1 > nw;
+					desc[b + W] = make_uint4((uint32_t)b + ublk_off[b], ublk_low[b], c0 | (c1 << 8) | (s0 < 0 ? PFX_DESC_CONT_IN : 0u) | (cut ? PFX_DESC_CONT_OUT : 0u), 0u);
+					++b;
+				}
+				win[W] = make_uint2((uint32_t)bl, (uint32_t)(b - bl));
+				bl = cut ? b - 1 : b;
+			}
+		}
+	}
+
 	__global__ void k_count_u32(const uint32_t *__restrict__ keys, int64_t n_items, int64_t *__restrict__ cnt)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_items; k += (int64_t)gridDim.x * blockDim.x)
@@ -285,8 +333,11 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	tmp.reset();
 
 	// ---- blocks on and above the diagonal: the only ones with a contribution list ------------------------------
+	// (lists of the upper blocks: needed only until the window descriptors are written)
 	int64_t n_upair = 0, n_ublocks = 0;
 	pfx_tmp<uint64_t> ukeys;
+	pfx_tmp<int64_t> unode_ptr, blk_ptr; // n_nodes+1: upper blocks before each row; n_ublocks+1: contribution range of each upper block
+	pfx_tmp<uint32_t> ublk_off, ublk_low; // (index among all blocks) - (index among the upper blocks); index of the mirror image
 	{
 		pfx_tmp<int64_t> upos, ubpos;
 		PFX_HIP(upos.alloc((size_t)(n_pair + 1)));
@@ -306,17 +357,19 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 		ctx->n_ublocks = n_ublocks;
 		ctx->n_upair = n_upair;
 		PFX_HIP(ukeys.alloc((size_t)n_upair));
-		if (pfx_alloc(ctx, &ctx->d_blk_src, n_upair) || pfx_alloc(ctx, &ctx->d_blk_ptr, n_ublocks + 1) || pfx_alloc(ctx, &ctx->d_ublk_off, n_ublocks)
-			|| pfx_alloc(ctx, &ctx->d_unode_ptr, n_nodes + 1))
+		if (pfx_alloc(ctx, &ctx->d_blk_src, n_upair))
 			return PFX_ERR_HIP;
+		PFX_HIP(blk_ptr.alloc((size_t)(n_ublocks + 1)));
+		PFX_HIP(ublk_off.alloc((size_t)n_ublocks));
+		PFX_HIP(unode_ptr.alloc((size_t)(n_nodes + 1)));
 		PFX_HIP(hipMemsetAsync(deg.p, 0, sizeof(int64_t) * (size_t)(n_nodes + 1), st));
 		hipLaunchKernelGGL(k_compact_upper, dim3(grid_for(n_pair)), dim3(256), 0, st, keys_b.p, vals_b.p, upos.p, ubpos.p, pos.p, n_pair, n_nodes, ukeys.p,
-						   ctx->d_blk_src, ctx->d_blk_ptr, ctx->d_ublk_off, deg.p);
-		hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, st, ctx->d_blk_ptr + n_ublocks, n_upair);
+						   ctx->d_blk_src, blk_ptr.p, ublk_off.p, deg.p);
+		hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, st, blk_ptr.p + n_ublocks, n_upair);
 		tmp_bytes = 0;
-		PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg.p, ctx->d_unode_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, deg.p, unode_ptr.p, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 		PFX_HIP(tmp.alloc(tmp_bytes));
-		PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_unode_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
+		PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, unode_ptr.p, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 		PFX_HIP(hipStreamSynchronize(st));
 		tmp.reset();
 	}
@@ -324,13 +377,12 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	keys_b.reset();
 	vals_b.reset();
 	{
-		if (pfx_alloc(ctx, &ctx->d_ublk_low, n_ublocks))
-			return PFX_ERR_HIP;
+		PFX_HIP(ublk_low.alloc((size_t)n_ublocks));
 		pfx_tmp<int> bad;
 		PFX_HIP(bad.alloc(1));
 		PFX_HIP(hipMemsetAsync(bad.p, 0, sizeof(int), st));
-		hipLaunchKernelGGL(k_mirror_index, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_unode_ptr, n_nodes,
-						   ctx->d_ublk_low, bad.p);
+		hipLaunchKernelGGL(k_mirror_index, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, unode_ptr.p, n_nodes,
+						   ublk_low.p, bad.p);
 		int h_bad = 0;
 		PFX_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
 		PFX_HIP(hipStreamSynchronize(st));
@@ -347,7 +399,7 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 		PFX_HIP(wv_b.alloc((size_t)n_upair));
 		if (pfx_alloc(ctx, &ctx->d_blk_slot, n_upair))
 			return PFX_ERR_HIP;
-		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_upair)), dim3(256), 0, st, ukeys.p, ctx->d_blk_src, ctx->d_unode_ptr, ctx->d_blk_ptr, n_upair,
+		hipLaunchKernelGGL(k_window_keys, dim3(grid_for(n_upair)), dim3(256), 0, st, ukeys.p, ctx->d_blk_src, unode_ptr.p, blk_ptr.p, n_upair,
 						   n_nodes, (uint32_t)(n_loc * n_loc), wk_a.p, wv_a.p);
 		const int wbits = 28 + bits_for((uint64_t)n_upair);
 		tmp_bytes = 0;
@@ -359,6 +411,35 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 		tmp.reset();
 	}
 	ukeys.reset();
+
+	// ---- what every assembly window needs to know about its blocks ------------------------------------------------
+	{
+		const int64_t n_groups = (n_nodes + PFX_ROWS_PER_GROUP - 1) / PFX_ROWS_PER_GROUP;
+		ctx->n_groups = n_groups;
+		pfx_tmp<uint32_t> n_win;
+		PFX_HIP(n_win.alloc((size_t)(n_groups + 1)));
+		if (pfx_alloc(ctx, &ctx->d_grp_c0, n_groups + 1) || pfx_alloc(ctx, &ctx->d_grp_win, n_groups + 1))
+			return PFX_ERR_HIP;
+		hipLaunchKernelGGL(k_group_windows, dim3(grid_for(n_groups + 1)), dim3(256), 0, st, unode_ptr.p, blk_ptr.p, n_nodes, n_groups, ctx->d_grp_c0, n_win.p);
+		tmp_bytes = 0;
+		PFX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, n_win.p, ctx->d_grp_win, (uint32_t)0, (size_t)(n_groups + 1), rocprim::plus<uint32_t>(), st));
+		PFX_HIP(tmp.alloc(tmp_bytes));
+		PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, n_win.p, ctx->d_grp_win, (uint32_t)0, (size_t)(n_groups + 1), rocprim::plus<uint32_t>(), st));
+		uint32_t n_windows = 0;
+		PFX_HIP(hipMemcpyAsync(&n_windows, ctx->d_grp_win + n_groups, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		tmp.reset();
+		ctx->n_windows = n_windows;
+		if (pfx_alloc(ctx, &ctx->d_win, (int64_t)n_windows) || pfx_alloc(ctx, &ctx->d_desc, n_ublocks + (int64_t)n_windows))
+			return PFX_ERR_HIP;
+		hipLaunchKernelGGL(k_window_descriptors, dim3(grid_for(n_groups)), dim3(256), 0, st, unode_ptr.p, blk_ptr.p, ublk_off.p, ublk_low.p, ctx->d_grp_win, n_nodes,
+						   n_groups, ctx->d_win, ctx->d_desc);
+		PFX_HIP(hipStreamSynchronize(st));
+	}
+	unode_ptr.reset();
+	blk_ptr.reset();
+	ublk_off.reset();
+	ublk_low.reset();
 
 	// ---- node -> (element, local index) incidences ---------------------------------------------------------
 	pfx_tmp<uint32_t> nk_a, nk_b, nv_a;

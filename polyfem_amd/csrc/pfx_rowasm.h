@@ -24,47 +24,74 @@
 #pragma once
 #include "pfx_internal.h"
 
-// One 64-lane workgroup per group of RPG consecutive node rows.  The rows' blocks are consecutive in the block list
-// and their contributions are consecutive in the contribution list, so the group is one stream of contributions,
-// walked in windows of 64:
-//   A. lane s looks at block bl+s: where its contribution range starts relative to the window;
-//   B. every lane computes one contribution of the window into LDS (the list stores them reordered by element
-//      inside each window, so that neighbouring lanes read the same element state, with the slot they belong to);
-//   C. every entry of the CSR blocks that intersect the window is owned by one lane, which adds its contributions in
-//      ascending order.  A block cut by the window boundary hands its partial sums to the next window through
-//      `carry`, so the order of the additions does not depend on where the windows fall.
-// The index data of a window are loaded one window ahead.
+// One wave per group of PFX_ROWS_PER_GROUP consecutive node rows.  The rows' upper blocks are consecutive in the block
+// list and their contributions are consecutive in the contribution list, so the group is one stream of contributions,
+// walked in windows of 64.  Everything about a window that depends only on the pattern is worked out when the pattern
+// is built (pfx_pattern.hip: k_window_descriptors) and read back here as
+//   grp_c0[g], grp_win[g]   first contribution / first window of group g (the next group's entry ends it);
+//   win[W] = (bl, nb)       the window's first upper block and how many blocks it intersects;
+//   desc[bl + s + W]        for block bl+s of window W: where its contributions sit in the window [c0, c1), whether it
+//                           continues from the previous window / into the next one, the index of the block in the value
+//                           array and of its mirror image below the diagonal (pfx_window_desc);
+// so that the kernel itself is three short phases per window:
+//   B. every lane computes one contribution into LDS (the list stores them reordered by element inside each window,
+//      so that neighbouring lanes read the same element state, with the slot they belong to);
+//   C. every entry of the blocks that intersect the window is owned by one lane, which adds its contributions in
+//      list order and stores the entry and its mirror image.  A lane keeps the same entry position (m, n) in every trip
+//      (for 3 x 3 blocks 63 lanes take 7 blocks per trip), so its addresses inside a block are loop invariants.
+//      A block cut by the window boundary hands its partial sums to the next window through `carry`, so the order of
+//      the additions does not depend on where the windows fall.
+// The index data of a window are loaded one window ahead (the window headers two ahead: they say which descriptors
+// to fetch).
 // MASK: also record, per entry, whether any of its contributions is non-zero (the value-dependent pattern of the
 // linear assemblers); the Hessian keeps every structural entry and skips that bookkeeping.
 // WPB waves per workgroup, each with its own row group and its own staging area; they share only the functor's tables
 // (worth it when those are large: 19 KB for Q2 would otherwise limit a CU to six single-wave workgroups).
-template <int NLOC, int BS, int RPG, bool MASK, int WPB, class Op>
-__global__ __launch_bounds__(64 * WPB) void k_assemble_rows(const int64_t *__restrict__ node_ptr, const int64_t *__restrict__ blk_ptr, const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_low,
-													   const uint32_t *__restrict__ blk_src, const uint8_t *__restrict__ blk_slot, Op op, int64_t n_nodes,
-													   double *__restrict__ values, uint8_t *__restrict__ mask)
+// Three waves per SIMD is what the largest functors reach without spilling; without the bound the compiler spends
+// the registers of a fourth and a third wave on keeping more of an element's state loads in flight, which pays less
+// than the extra wave does.
+// (A functor that cannot live with that many registers says so: Op::MIN_WAVES.)
+#ifndef PFX_ROWASM_MINWAVES
+#define PFX_ROWASM_MINWAVES 3
+#endif
+#include <type_traits>
+template <class Op, class = void>
+struct pfx_min_waves
+{
+	static constexpr int value = PFX_ROWASM_MINWAVES;
+};
+template <class Op>
+struct pfx_min_waves<Op, std::void_t<decltype(Op::MIN_WAVES)>>
+{
+	static constexpr int value = Op::MIN_WAVES;
+};
+template <int NLOC, int BS, bool MASK, int WPB, class Op>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(pfx_min_waves<Op>::value))) void k_assemble_rows(const uint32_t *__restrict__ grp_c0, const uint32_t *__restrict__ grp_win, const uint2 *__restrict__ win,
+															 const uint4 *__restrict__ desc, const uint32_t *__restrict__ blk_src, const uint8_t *__restrict__ blk_slot,
+															 Op op, int64_t n_groups, double *__restrict__ values, uint8_t *__restrict__ mask)
 {
 	constexpr int B2 = BS * BS;
 	constexpr uint32_t NL2 = NLOC * NLOC;
+	constexpr int BPT = 64 / B2; // blocks per trip of phase C
 	__shared__ double stage_[WPB][64 * B2];
-	__shared__ int bp_[WPB][66];        // start of block bl+s in the window, clamped to [-1, nw+1]
-	__shared__ uint32_t boff_[WPB][64]; // block bl+s is block bl+s+boff[s] of the whole matrix
-	__shared__ uint32_t blow_[WPB][64]; // its mirror image below the diagonal (0xFFFFFFFF: none)
+	__shared__ uint4 sdesc_[WPB][64];
 	__shared__ double carry_[WPB][2][B2];
 	__shared__ uint8_t carry_any_[WPB][2][B2];
 	__shared__ double optab[Op::LDS_DOUBLES]; // the functor's constant tables (reference gradients, weights)
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	double *const stage = stage_[wv];
-	int *const bp = bp_[wv];
-	uint32_t *const boff = boff_[wv], *const blow = blow_[wv];
+	uint4 *const sdesc = sdesc_[wv];
 	double(*const carry)[B2] = carry_[wv];
 	uint8_t(*const carry_any)[B2] = carry_any_[wv];
 	op.load_tables(optab, lane); // every wave writes the same values
-	const int64_t g_first = ((int64_t)blockIdx.x * WPB + wv) * RPG;
-	const bool have_rows = g_first < n_nodes;
-	const int64_t g_last = (g_first + RPG <= n_nodes) ? g_first + RPG : n_nodes;
-	const int64_t b_begin = have_rows ? node_ptr[g_first] : 0, b_end = have_rows ? node_ptr[g_last] : 0;
+	const int64_t g = (int64_t)blockIdx.x * WPB + wv;
 	__syncthreads();
-	if (b_begin == b_end)
+	if (g >= n_groups)
+		return;
+	const uint32_t c_begin = grp_c0[g], c_end = grp_c0[g + 1];
+	const uint32_t W_begin = grp_win[g], W_end = grp_win[g + 1];
+	if (W_begin == W_end)
 		return;
 	// from here on a wave only talks to itself through its own part of the LDS: a wave-level barrier is enough
 	// (with one wave per workgroup the workgroup barrier is the same thing)
@@ -78,48 +105,39 @@ __global__ __launch_bounds__(64 * WPB) void k_assemble_rows(const int64_t *__res
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
 	};
-	const int64_t c_end = blk_ptr[b_end];
-	int64_t bl = b_begin; // first block that intersects the window
+	// phase C: this lane's entry of a block, and which block of a trip it takes
+	const int mn = lane % B2, sl = lane / B2;
+	const int mn_t = (mn % BS) * BS + mn / BS;
+	const bool lane_c = sl < BPT;
+	double *const val_mn = values + mn, *const val_t = values + mn_t;
+	uint8_t *const mask_mn = mask + mn, *const mask_t = mask + mn_t;
+
+	uint2 hdr = win[W_begin];
+	uint2 hdr_next = (W_begin + 1 < W_end) ? win[W_begin + 1] : make_uint2(0u, 0u);
+	uint32_t src = (c_begin + lane < c_end) ? __builtin_nontemporal_load(blk_src + c_begin + lane) : 0u;
+	int slot = (c_begin + lane < c_end) ? __builtin_nontemporal_load(blk_slot + c_begin + lane) : 0;
+	uint4 d = make_uint4(0u, 0u, 0u, 0u);
+	if ((uint32_t)lane < hdr.y)
+		d = desc[(int64_t)hdr.x + W_begin + lane];
 	int cur = 0;
-	const int64_t w_begin = blk_ptr[b_begin];
-	uint32_t src = (w_begin + lane < c_end) ? __builtin_nontemporal_load(blk_src + w_begin + lane) : 0u;
-	int slot = (w_begin + lane < c_end) ? __builtin_nontemporal_load(blk_slot + w_begin + lane) : 0;
-	int64_t bptr = (bl + lane <= b_end) ? blk_ptr[bl + lane] : c_end + 128;
-	int64_t bptr2 = (lane < 2 && bl + 64 + lane <= b_end) ? blk_ptr[bl + 64 + lane] : c_end + 128;
-	uint32_t off = (bl + lane < b_end) ? blk_off[bl + lane] : 0u;
-	uint32_t low = (bl + lane < b_end) ? blk_low[bl + lane] : 0xFFFFFFFFu;
-	for (int64_t w0 = w_begin; w0 < c_end; w0 += 64)
+	uint32_t w0 = c_begin;
+	for (uint32_t W = W_begin; W < W_end; ++W, w0 += 64)
 	{
-		const int64_t w1 = (w0 + 64 < c_end) ? w0 + 64 : c_end;
-		const int nw = (int)(w1 - w0);
-		// A
-		const int64_t d = bptr - w0;
-		const int rel = d < 0 ? -1 : (d > nw ? nw + 1 : (int)d);
-		bp[lane] = rel;
-		boff[lane] = off;
-		blow[lane] = low;
-		if (lane < 2)
-		{
-			const int64_t d2 = bptr2 - w0;
-			bp[64 + lane] = d2 > nw ? nw + 1 : (int)d2;
-		}
-		// blocks bl .. bl+nb-1 intersect the window (every block has at least one contribution)
-		const int nb = __popcll(__ballot(rel < nw && bl + lane < b_end));
-		// the last block of the window continues into the next one iff the block after it starts beyond the window
-		const int next_start = __shfl(rel, nb < 64 ? nb : 0);
-		const int64_t d64 = __shfl(bptr2, 0) - w0;
-		const bool cont_last = (nb < 64) ? (next_start > nw) : (d64 > nw);
-		const int64_t bl_next = bl + (cont_last ? nb - 1 : nb);
+		const int nw = (c_end - w0 < 64u) ? (int)(c_end - w0) : 64;
+		const int nb = (int)hdr.y;
+		sdesc[lane] = d;
 		const uint32_t src_now = src;
 		const int slot_now = slot;
-		if (w1 < c_end)
+		if (W + 1 < W_end)
 		{
+			const uint32_t w1 = w0 + 64;
 			src = (w1 + lane < c_end) ? __builtin_nontemporal_load(blk_src + w1 + lane) : 0u;
 			slot = (w1 + lane < c_end) ? __builtin_nontemporal_load(blk_slot + w1 + lane) : 0;
-			bptr = (bl_next + lane <= b_end) ? blk_ptr[bl_next + lane] : c_end + 128;
-			bptr2 = (lane < 2 && bl_next + 64 + lane <= b_end) ? blk_ptr[bl_next + 64 + lane] : c_end + 128;
-			off = (bl_next + lane < b_end) ? blk_off[bl_next + lane] : 0u;
-			low = (bl_next + lane < b_end) ? blk_low[bl_next + lane] : 0xFFFFFFFFu;
+			hdr = hdr_next;
+			if ((uint32_t)lane < hdr.y)
+				d = desc[(int64_t)hdr.x + (W + 1) + lane];
+			if (W + 2 < W_end)
+				hdr_next = win[W + 2];
 		}
 		// B
 		if (lane < nw)
@@ -129,65 +147,71 @@ __global__ __launch_bounds__(64 * WPB) void k_assemble_rows(const int64_t *__res
 			const int i = (int)(ij / NLOC), j = (int)(ij - (ij / NLOC) * NLOC);
 			double out[B2];
 			op(optab, e, i > j ? i : j, i > j ? j : i, out);
-			const bool tr = i < j; // the functor computed the mirror image: stage its transpose
+			if (BS > 1)
+			{
+				const bool tr = i < j; // the functor computed the mirror image: stage its transpose
+#pragma unroll
+				for (int m = 0; m < BS; ++m)
+#pragma unroll
+					for (int n = m + 1; n < BS; ++n)
+					{
+						const double a = out[m * BS + n], b = out[n * BS + m];
+						out[m * BS + n] = tr ? b : a;
+						out[n * BS + m] = tr ? a : b;
+					}
+			}
 #pragma unroll
 			for (int k = 0; k < B2; ++k)
-			{
-				const int kt = (k % BS) * BS + k / BS;
-				stage[slot_now * B2 + k] = (kt != k && tr) ? out[kt] : out[k];
-			}
+				stage[slot_now * B2 + k] = out[k];
 		}
 		wave_sync();
-		// C: consecutive lanes own consecutive entries of the blocks bl .. bl+nb-1 (contiguous in the value array row by row)
-		const int n_items = nb * B2;
-		for (int o = lane; o < n_items; o += 64)
-		{
-			const int s = o / B2, mn = o - s * B2;
-			const int cb0 = bp[s], cb1 = bp[s + 1];
-			const bool cont_in = cb0 < 0, cont_out = cb1 > nw;
-			const int c0 = cont_in ? 0 : cb0, c1 = cont_out ? nw : cb1;
-			double acc = cont_in ? carry[cur][mn] : 0.0;
-			int any = (MASK && cont_in) ? carry_any[cur][mn] : 0;
-			const double *sp = stage + c0 * B2 + mn;
-			int c = c0;
-			for (; c + 1 < c1; c += 2, sp += 2 * B2) // two contributions per trip, added in list order
+		// C
+		if (lane_c)
+			for (int s = sl; s < nb; s += BPT)
 			{
-				const double v0 = sp[0], v1 = sp[B2];
-				acc += v0;
-				acc += v1;
-				if (MASK)
-					any |= (v0 != 0.0) | (v1 != 0.0);
-			}
-			if (c < c1)
-			{
-				const double v = sp[0];
-				acc += v;
-				if (MASK)
-					any |= (v != 0.0);
-			}
-			if (cont_out)
-			{
-				carry[cur ^ 1][mn] = acc;
-				if (MASK)
-					carry_any[cur ^ 1][mn] = (uint8_t)any;
-			}
-			else
-			{
-				const int64_t at = (bl + (int64_t)boff[s]) * B2 + o;
-				values[at] = acc;
-				if (MASK)
-					mask[at] = (uint8_t)any;
-				const uint32_t lw = blow[s];
-				if (lw != 0xFFFFFFFFu)
+				const uint4 dd = sdesc[s];
+				const int c0 = (int)(dd.z & 0xffu), c1 = (int)((dd.z >> 8) & 0xffu);
+				const bool cont_in = (dd.z & PFX_DESC_CONT_IN) != 0, cont_out = (dd.z & PFX_DESC_CONT_OUT) != 0;
+				double acc = cont_in ? carry[cur][mn] : 0.0;
+				int any = (MASK && cont_in) ? carry_any[cur][mn] : 0;
+				const double *sp = stage + c0 * B2 + mn;
+				int c = c0;
+				for (; c + 1 < c1; c += 2, sp += 2 * B2) // two contributions per trip, added in list order
 				{
-					const int64_t at2 = (int64_t)lw * B2 + (mn % BS) * BS + mn / BS;
-					values[at2] = acc;
+					const double v0 = sp[0], v1 = sp[B2];
+					acc += v0;
+					acc += v1;
 					if (MASK)
-						mask[at2] = (uint8_t)any;
+						any |= (v0 != 0.0) | (v1 != 0.0);
+				}
+				if (c < c1)
+				{
+					const double v = sp[0];
+					acc += v;
+					if (MASK)
+						any |= (v != 0.0);
+				}
+				if (cont_out)
+				{
+					carry[cur ^ 1][mn] = acc;
+					if (MASK)
+						carry_any[cur ^ 1][mn] = (uint8_t)any;
+				}
+				else
+				{
+					const int64_t at = (int64_t)dd.x * B2;
+					val_mn[at] = acc;
+					if (MASK)
+						mask_mn[at] = (uint8_t)any;
+					if (dd.y != 0xFFFFFFFFu)
+					{
+						const int64_t at2 = (int64_t)dd.y * B2;
+						val_t[at2] = acc;
+						if (MASK)
+							mask_t[at2] = (uint8_t)any;
+					}
 				}
 			}
-		}
-		bl = bl_next;
 		cur ^= 1;
 		wave_sync();
 	}
@@ -196,14 +220,12 @@ __global__ __launch_bounds__(64 * WPB) void k_assemble_rows(const int64_t *__res
 template <int NLOC, int BS, class Op>
 inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask)
 {
-	constexpr int RPG = PFX_ROWS_PER_GROUP;
 	constexpr int WPB = (Op::LDS_DOUBLES * 8 > 12 * 1024) ? 4 : 1; // share large tables between four waves
-	const int64_t groups = (ctx->n_nodes + RPG - 1) / RPG;
-	const unsigned grid = (unsigned)((groups + WPB - 1) / WPB);
+	const unsigned grid = (unsigned)((ctx->n_groups + WPB - 1) / WPB);
 	if (write_mask)
-		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, true, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
-						   ctx->d_ublk_off, ctx->d_ublk_low, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, true, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_grp_c0, ctx->d_grp_win, ctx->d_win,
+						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_groups, ctx->d_values, ctx->d_mask);
 	else
-		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, RPG, false, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_unode_ptr, ctx->d_blk_ptr,
-						   ctx->d_ublk_off, ctx->d_ublk_low, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_nodes, ctx->d_values, ctx->d_mask);
+		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, false, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_grp_c0, ctx->d_grp_win, ctx->d_win,
+						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_groups, ctx->d_values, ctx->d_mask);
 }
