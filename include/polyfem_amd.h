@@ -104,6 +104,12 @@ pfx_status pfx_set_material_per_point(pfx_ctx *ctx, int model, int dim, const do
  * row-major, as ElasticityTensor holds it after set_from_entries / set_from_lambda_mu / set_from_young_poisson
  * (utils/ElasticityUtils.cpp:298-413).  Selects the model PFX_HOOKE_LINEAR (pfx_assemble_linear only). */
 pfx_status pfx_set_elasticity_tensor(pfx_ctx *ctx, int dim, const double *tensor36);
+/* SaintVenantElasticity with the material's `elasticity_tensor` entries instead of (lambda, mu)
+ * (SaintVenantElasticity::add_multimaterial, assembler/SaintVenantElasticity.cpp:42-69; the stress of a point is
+ * tensor * Voigt(Green strain), :77-86, :281-307).  Same 6 x 6 layout as pfx_set_elasticity_tensor; selects
+ * PFX_SAINT_VENANT for the nonlinear interface (energy, gradient, Hessian, Newton, time steps).  A later
+ * pfx_set_material call returns to (lambda, mu). */
+pfx_status pfx_set_saint_venant_tensor(pfx_ctx *ctx, int dim, const double *tensor36);
 /* MultiModel (assembler/MultiModel.cpp:42-96, `multi_material_models_[el_id]`): after pfx_set_material(_per_element) with
  * any of the three elastic models, gives every element its own model -- PFX_LINEAR_ELASTICITY, PFX_NEOHOOKEAN or
  * PFX_SAINT_VENANT -- for the nonlinear interface (energy, gradient, Hessian, Newton, time steps).  The Lame parameters

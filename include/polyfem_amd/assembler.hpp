@@ -252,11 +252,6 @@ namespace polyfem_amd
 		{
 			static constexpr int model = PFX_NEOHOOKEAN;
 		};
-		struct SaintVenantElasticity : ElasticBase // isotropic tensor (young/nu or lambda/mu); no "elasticity_tensor" entries
-		{
-			static constexpr int model = PFX_SAINT_VENANT;
-		};
-
 		// utils/ElasticityUtils.hpp ElasticityTensor for size 3: only the upper triangle is ever written or read
 		// (operator() swaps its indices, ElasticityUtils.cpp:276-296), so full() mirrors it.
 		class ElasticityTensor
@@ -323,6 +318,23 @@ namespace polyfem_amd
 		private:
 			double upper_[36] = {};
 		};
+		// assembler/SaintVenantElasticity.hpp: (lambda, mu) / (young, nu), or the material's "elasticity_tensor" entries
+		// (add_multimaterial, SaintVenantElasticity.cpp:42-69): calling elasticity_tensor() selects the tensor form
+		struct SaintVenantElasticity : ElasticBase
+		{
+			static constexpr int model = PFX_SAINT_VENANT;
+			ElasticityTensor &elasticity_tensor()
+			{
+				has_tensor = true;
+				return tensor_;
+			}
+			const ElasticityTensor &elasticity_tensor() const { return tensor_; }
+			bool has_tensor = false;
+
+		private:
+			ElasticityTensor tensor_;
+		};
+
 		// assembler/HookeLinearElasticity.hpp: linear assembler with a general elasticity tensor ("elasticity_tensor"
 		// entries, else young/nu, else lambda/mu: HookeLinearElasticity.cpp:24-49)
 		struct HookeLinearElasticity
@@ -514,6 +526,14 @@ namespace polyfem_amd
 				}
 				else
 					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
+				if constexpr (std::is_same<LocalAssembler, SaintVenantElasticity>::value)
+					if (local_assembler_.has_tensor)
+					{
+						double t[36];
+						local_assembler_.elasticity_tensor().full(t);
+						c.check(pfx_set_saint_venant_tensor(c.h, 3, t));
+						c.bound_model = -1; // the next bind passes its own material again
+					}
 				return c;
 			}
 			LocalAssembler local_assembler_;

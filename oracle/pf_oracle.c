@@ -816,7 +816,8 @@ void pfo_local_linear_elasticity_hessian(const pfo_vals *v, const double *da, do
 		}
 }
 
-/* ---- SaintVenantElasticity (assembler/SaintVenantElasticity.cpp), isotropic elasticity tensor ---- */
+/* ---- SaintVenantElasticity (assembler/SaintVenantElasticity.cpp): isotropic tensor from (lambda, mu), or the tensor
+ * of the material's "elasticity_tensor" entries (add_multimaterial :42-69) ---- */
 
 /* ElasticityTensor::set_from_lambda_mu (utils/ElasticityUtils.cpp:372-413), 3-D: symmetric 6 x 6, Voigt order
  * xx, yy, zz, yz, xz, xy with engineering shear strains */
@@ -863,11 +864,24 @@ static void sv_strain_stress(const double *F, double C[6][6], double *E, double 
 	M(S, 2, 0) = sg[4], M(S, 2, 1) = sg[3], M(S, 2, 2) = sg[2];
 }
 
+/* the caller's symmetric 6 x 6 tensor (row-major) if there is one, the isotropic one otherwise */
+static void sv_pick_tensor(const double *tensor36, double lambda, double mu, double C[6][6])
+{
+	if (!tensor36)
+	{
+		sv_tensor(lambda, mu, C);
+		return;
+	}
+	for (int a = 0; a < 6; ++a)
+		for (int b = 0; b < 6; ++b)
+			C[a][b] = tensor36[6 * a + b];
+}
+
 /* SaintVenantElasticity::compute_energy_aux<double> (:215-312): 1/2 sum_p trace(stress * strain) da_p */
-double pfo_local_saint_venant_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu)
+double pfo_local_saint_venant_energy_t(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor36)
 {
 	double C[6][6], energy = 0;
-	sv_tensor(lambda, mu, C);
+	sv_pick_tensor(tensor36, lambda, mu, C);
 	for (int p = 0; p < v->n_pts; ++p)
 	{
 		double F[9], E[9], S[9];
@@ -893,10 +907,10 @@ static void sv_voigt_sym(const double *f, const double *g, double *e)
 
 /* SaintVenantElasticity::assemble_grad (:104-122) differentiates compute_energy_aux with forward autodiff; written
  * out: d/du_{i,d} = sum_p da_p (F S G_i)[d]  (first Piola-Kirchhoff stress F S, S = C : E symmetric) */
-void pfo_local_saint_venant_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G)
+void pfo_local_saint_venant_grad_t(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor36, double *G)
 {
 	double C[6][6];
-	sv_tensor(lambda, mu, C);
+	sv_pick_tensor(tensor36, lambda, mu, C);
 	for (int k = 0; k < 3 * v->n_loc; ++k)
 		G[k] = 0;
 	for (int p = 0; p < v->n_pts; ++p)
@@ -920,11 +934,11 @@ void pfo_local_saint_venant_grad(const pfo_vals *v, const double *da, const doub
 /* SaintVenantElasticity::assemble_hessian (:124-143, second-order autodiff in the reference), written out: the
  * variation of E along dof (j,b) is sym(f_b (x) G_j) with f_b = row b of F, so
  * d2/du_{i,a} du_{j,b} = sum_p da_p [ delta_ab G_i^T S G_j + voigt(f_a, G_i)^T C voigt(f_b, G_j) ] */
-void pfo_local_saint_venant_hessian(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H)
+void pfo_local_saint_venant_hessian_t(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor36, double *H)
 {
 	const int N = 3 * v->n_loc;
 	double C[6][6];
-	sv_tensor(lambda, mu, C);
+	sv_pick_tensor(tensor36, lambda, mu, C);
 	for (int k = 0; k < N * N; ++k)
 		H[k] = 0;
 	for (int p = 0; p < v->n_pts; ++p)
@@ -964,6 +978,19 @@ void pfo_local_saint_venant_hessian(const pfo_vals *v, const double *da, const d
 			}
 		}
 	}
+}
+
+double pfo_local_saint_venant_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu)
+{
+	return pfo_local_saint_venant_energy_t(v, da, local_disp, lambda, mu, NULL);
+}
+void pfo_local_saint_venant_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G)
+{
+	pfo_local_saint_venant_grad_t(v, da, local_disp, lambda, mu, NULL, G);
+}
+void pfo_local_saint_venant_hessian(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H)
+{
+	pfo_local_saint_venant_hessian_t(v, da, local_disp, lambda, mu, NULL, H);
 }
 
 /* the three nonlinear local assemblers behind one switch */
@@ -1277,6 +1304,8 @@ static void local_linear_elasticity_mat(const pfo_vals *v, int i, int j, const d
 static double nl_local_energy(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu);
 static double nl_local_energy_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e)
 {
+	if (model == PFO_SAINT_VENANT && mat->tensor)
+		return pfo_local_saint_venant_energy_t(v, da, ld, 0, 0, mat->tensor);
 	const int np = mat_points(mat);
 	if (!np)
 		return nl_local_energy(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
@@ -1308,6 +1337,11 @@ static void nl_local_hessian(int model, const pfo_vals *v, const double *da, con
 }
 static void nl_local_grad_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e, double *G)
 {
+	if (model == PFO_SAINT_VENANT && mat->tensor)
+	{
+		pfo_local_saint_venant_grad_t(v, da, ld, 0, 0, mat->tensor, G);
+		return;
+	}
 	const int np = mat_points(mat), N = v->n_loc * 3;
 	if (!np)
 	{
@@ -1327,6 +1361,11 @@ static void nl_local_grad_mat(int model, const pfo_vals *v, const double *da, co
 }
 static void nl_local_hessian_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e, double *H)
 {
+	if (model == PFO_SAINT_VENANT && mat->tensor)
+	{
+		pfo_local_saint_venant_hessian_t(v, da, ld, 0, 0, mat->tensor, H);
+		return;
+	}
 	const int np = mat_points(mat), N = v->n_loc * 3;
 	if (!np)
 	{

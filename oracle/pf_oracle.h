@@ -65,7 +65,7 @@ typedef struct
 	double lambda, mu; /* uniform Lame parameters */
 	const double *lambda_e, *mu_e; /* optional per-element values (LameParameters with one entry per element,
 	                                  utils/ElasticityUtils.cpp:490-517); NULL = uniform */
-	const double *tensor;          /* PFO_HOOKE_LINEAR: the symmetric 6 x 6 elasticity tensor, row-major, Voigt order
+	const double *tensor;          /* PFO_HOOKE_LINEAR, and PFO_SAINT_VENANT when not NULL (SaintVenantElasticity.cpp:64-68): the symmetric 6 x 6 elasticity tensor, row-major, Voigt order
 	                                  xx yy zz yz xz xy (ElasticityTensor, utils/ElasticityUtils.cpp:298-413) */
 	int per_point;                 /* > 0: lambda_e / mu_e hold one value per (element, quadrature point), per_point =
 	                                  points per element (LameParameters::lambda_mu is evaluated at every point,

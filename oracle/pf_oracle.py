@@ -46,10 +46,18 @@ class Material(C.Structure):
                 ("per_point", C.c_int), ("model_e", C.POINTER(C.c_int32))]
 
 
-def make_material(model: int, lam, mu):
+def make_material(model: int, lam, mu, tensor=None):
     """Uniform Lame parameters (scalars), one value per element (1-D arrays) or per quadrature point (2-D arrays, n_el x
     n_pts); for HOOKE_LINEAR `lam` is the symmetric
-    6 x 6 elasticity tensor (and `mu` is ignored).  Returns (Material, keep-alive)."""
+    6 x 6 elasticity tensor (and `mu` is ignored); SAINT_VENANT takes such a tensor as `tensor`
+    (SaintVenantElasticity::add_multimaterial, assembler/SaintVenantElasticity.cpp:42-69).  Returns (Material, keep-alive)."""
+    if tensor is None and mu is None and np.ndim(model) == 0 and model == SAINT_VENANT:
+        tensor = lam  # (SAINT_VENANT, 6 x 6 tensor, None): the positional form the assemble_* wrappers pass through
+    if tensor is not None:
+        assert model == SAINT_VENANT
+        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(6, 6)
+        assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
+        return Material(model, 3, 0.0, 0.0, None, None, _dp(t), 0, None), t
     if np.ndim(model) == 1:  # MultiModel: one model id per element
         me = np.ascontiguousarray(model, dtype=np.int32)
         assert np.isin(me, (LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT)).all()
@@ -72,10 +80,19 @@ def make_material(model: int, lam, mu):
 
 def elasticity_tensor(lam=None, mu=None, entries=None):
     """ElasticityTensor (utils/ElasticityUtils.cpp): set_from_lambda_mu (:372-413) or set_from_entries with the 21
-    upper-triangular entries row by row (:298-370); returns the full symmetric 6 x 6 matrix."""
+    upper-triangular entries row by row (:298-370), or with the 9 orthotropic constants Ex Ey Ez nuYX nuZX nuZY muYZ muZX
+    muXY, which the reference stores as the upper triangle written at :439-455; returns the full symmetric 6 x 6 matrix
+    that ElasticityTensor::operator() (:276-296) reads."""
     t = np.zeros((6, 6))
     if entries is not None:
         entries = np.asarray(entries, dtype=np.float64)
+        if entries.size == 9:
+            ex, ey, ez, nyx, nzx, nzy, myz, mzx, mxy = entries
+            t[0, :3] = 1.0 / ex, -nyx / ey, -nzx / ez
+            t[1, 1:3] = 1.0 / ey, -nzy / ez
+            t[2, 2] = 1.0 / ez
+            t[3, 3], t[4, 4], t[5, 5] = 1.0 / myz, 1.0 / mzx, 1.0 / mxy
+            return t + np.triu(t, 1).T
         assert entries.size == 21
         t[np.triu_indices(6)] = entries
         t = t + np.triu(t, 1).T

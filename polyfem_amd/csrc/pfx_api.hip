@@ -335,6 +335,19 @@ extern "C"
 		free_dev(ctx, ctx->d_mu_e);
 		free_dev(ctx, ctx->d_model_e);
 		ctx->mat_per_point = 0;
+		ctx->stvk_tensor = false;
+		return PFX_OK;
+	}
+
+	pfx_status pfx_set_saint_venant_tensor(pfx_ctx *ctx, int dim, const double *tensor36)
+	{
+		// same upload as for HookeLinearElasticity; the model stays the nonlinear one
+		pfx_status rc = pfx_set_elasticity_tensor(ctx, dim, tensor36);
+		if (rc)
+			return rc;
+		ctx->model = PFX_SAINT_VENANT;
+		ctx->stvk_tensor = true;
+		ctx->estate_kind = PFX_ESTATE_NONE;
 		return PFX_OK;
 	}
 
@@ -368,6 +381,8 @@ extern "C"
 			PFX_FAIL(PFX_ERR_ARG, "one model per element of the current mesh expected");
 		if (ctx->bs != 3)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_set_material(_per_element) with an elastic model must come first");
+		if (ctx->stvk_tensor || ctx->model == PFX_HOOKE_LINEAR)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "element models take their (lambda, mu) from pfx_set_material(_per_element), not an elasticity tensor");
 		std::vector<uint8_t> m((size_t)n_el);
 		for (int64_t e = 0; e < n_el; ++e)
 			switch (model_per_element[e])

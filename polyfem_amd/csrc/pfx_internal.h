@@ -76,7 +76,8 @@ struct pfx_ctx
 	int model = -1, dim = 3, bs = 0; // bs = block size (1 or dim)
 	double lambda = 0, mu = 0;
 	uint8_t *d_model_e = nullptr; // PFX_MULTI_MODEL: 0 LinearElasticity, 1 NeoHookean, 2 SaintVenant per element (the element kernels' numbering)
-	double *d_tensor = nullptr; // PFX_HOOKE_LINEAR: symmetric 6 x 6 elasticity tensor (36 doubles)
+	double *d_tensor = nullptr; // PFX_HOOKE_LINEAR, PFX_SAINT_VENANT with stvk_tensor: symmetric 6 x 6 elasticity tensor (36 doubles)
+	bool stvk_tensor = false;   // PFX_SAINT_VENANT reads d_tensor instead of (lambda, mu)
 
 	// pattern: node-block structure; the scalar CSR is implied (row gi*bs+m holds, for every neighbour slot s,
 	// the bs columns node_col[s]*bs+n) and the values array IS that CSR's value array.

@@ -47,7 +47,8 @@ namespace
 		M_LINEAR = 0,
 		M_NEO = 1,
 		M_STVK = 2,
-		M_MULTI = 3 // one of the three per element (MultiModel, assembler/MultiModel.cpp:42-96): the branches become run-time tests
+		M_MULTI = 3, // one of the three per element (MultiModel, assembler/MultiModel.cpp:42-96): the branches become run-time tests
+		M_STVKT = 4  // SaintVenant with the material's 6 x 6 elasticity tensor instead of (lambda, mu) (SaintVenantElasticity.cpp:64-68)
 	};
 
 	template <int NLOC, int NGLOC, int NPTS>
@@ -79,6 +80,28 @@ namespace
 		*det = d;
 	}
 
+	// SaintVenant with a general elasticity tensor: S = C : E in the Voigt order xx yy zz yz xz xy with engineering shears
+	// (SaintVenantElasticity::compute_energy_aux, assembler/SaintVenantElasticity.cpp:281-307); returns S : E
+	__device__ __forceinline__ double stvk_tensor_stress(const double *__restrict__ C, const double *E, double *S)
+	{
+		const double eps[6] = {E[0], E[4], E[8], 2 * E[5], 2 * E[2], 2 * E[1]};
+		double sg[6];
+		for (int a = 0; a < 6; ++a)
+		{
+			double r = C[6 * a] * eps[0];
+			for (int b = 1; b < 6; ++b)
+				r += C[6 * a + b] * eps[b];
+			sg[a] = r;
+		}
+		S[0] = sg[0], S[1] = sg[5], S[2] = sg[4];
+		S[3] = sg[5], S[4] = sg[1], S[5] = sg[3];
+		S[6] = sg[4], S[7] = sg[3], S[8] = sg[2];
+		double se = 0;
+		for (int q = 0; q < 9; ++q)
+			se += S[q] * E[q];
+		return se;
+	}
+
 	// doubles of Hessian state per element: affine geometric map (4-node tets): J^{-T} once, then per point F and the
 	// three coefficients (12 doubles); otherwise per point J^{-T}, F and the coefficients
 	template <int NGLOC, int NPTS>
@@ -97,7 +120,7 @@ namespace
 																   const double *__restrict__ xyz, const double *__restrict__ u,
 																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u, double mu_u,
 																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e, const uint8_t *__restrict__ model_e,
-																   int want_e, int want_g, int want_h,
+																   const double *__restrict__ tensor, int want_e, int want_g, int want_h,
 																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
 																   int *__restrict__ flag)
 	{
@@ -187,7 +210,7 @@ namespace
 					s.coef[4 * k + 2] = (lambda * lj - mu) / J * da;
 					s.coef[4 * k + 3] = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
 				}
-				else if (model == M_STVK)
+				else if (model == M_STVK || model == M_STVKT)
 				{
 					// dJ receives the first Piola-Kirchhoff stress F S
 					double E[9], S[9];
@@ -196,13 +219,16 @@ namespace
 							E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
 					const double tr = E[0] + E[4] + E[8];
 					double se = 0;
-					for (int q = 0; q < 9; ++q)
-					{
-						S[q] = 2 * mu * E[q];
-						if (q == 0 || q == 4 || q == 8)
-							S[q] += lambda * tr;
-						se += S[q] * E[q];
-					}
+					if (MODEL == M_STVKT)
+						se = stvk_tensor_stress(tensor, E, S);
+					else
+						for (int q = 0; q < 9; ++q)
+						{
+							S[q] = 2 * mu * E[q];
+							if (q == 0 || q == 4 || q == 8)
+								S[q] += lambda * tr;
+							se += S[q] * E[q];
+						}
 					for (int r = 0; r < 3; ++r)
 						for (int c = 0; c < 3; ++c)
 							dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
@@ -304,7 +330,7 @@ namespace
 	__global__ __launch_bounds__(256) void k_local_energy(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
 															   const double *__restrict__ u, const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u,
 															   double mu_u, const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
-															   const uint8_t *__restrict__ model_e, double *__restrict__ eloc, int *__restrict__ flag)
+															   const uint8_t *__restrict__ model_e, const double *__restrict__ tensor, double *__restrict__ eloc, int *__restrict__ flag)
 	{
 		const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 		if (e >= n_el)
@@ -360,7 +386,7 @@ namespace
 					tr += F[q] * F[q];
 				en += (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
 			}
-			else if (model == M_STVK)
+			else if (model == M_STVK || model == M_STVKT)
 			{
 				double tr = 0, se = 0;
 				double E[9];
@@ -368,13 +394,19 @@ namespace
 					for (int c = 0; c < 3; ++c)
 						E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
 				tr = E[0] + E[4] + E[8];
-				for (int q = 0; q < 9; ++q)
+				if (MODEL == M_STVKT)
 				{
-					double S = 2 * mu * E[q];
-					if (q == 0 || q == 4 || q == 8)
-						S += lambda * tr;
-					se += S * E[q];
+					double St[9];
+					se = stvk_tensor_stress(tensor, E, St);
 				}
+				else
+					for (int q = 0; q < 9; ++q)
+					{
+						double S = 2 * mu * E[q];
+						if (q == 0 || q == 4 || q == 8)
+							S += lambda * tr;
+						se += S * E[q];
+					}
 				en += se / 2 * da;
 			}
 			else
@@ -402,8 +434,8 @@ namespace
 	__global__ __launch_bounds__(256) void k_local_reg(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
 															const double *__restrict__ u, const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u,
 															double mu_u, const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
-															const uint8_t *__restrict__ model_e, double *__restrict__ eloc, double *__restrict__ gloc,
-															double *__restrict__ estate, int *__restrict__ flag)
+															const uint8_t *__restrict__ model_e, const double *__restrict__ tensor, double *__restrict__ eloc,
+															double *__restrict__ gloc, double *__restrict__ estate, int *__restrict__ flag)
 	{
 		typedef nl_state<NGLOC, NPTS> ST;
 		const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,7 +510,7 @@ namespace
 				c2 = (lambda * lj - mu) / J * da;
 				en += (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
 			}
-			else if (model == M_STVK)
+			else if (model == M_STVK || model == M_STVKT)
 			{
 				double E[9], S[9];
 				for (int r = 0; r < 3; ++r)
@@ -486,13 +518,16 @@ namespace
 						E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
 				const double tr = E[0] + E[4] + E[8];
 				double se = 0;
-				for (int q = 0; q < 9; ++q)
-				{
-					S[q] = 2 * mu * E[q];
-					if (q == 0 || q == 4 || q == 8)
-						S[q] += lambda * tr;
-					se += S[q] * E[q];
-				}
+				if (MODEL == M_STVKT)
+					se = stvk_tensor_stress(tensor, E, S);
+				else
+					for (int q = 0; q < 9; ++q)
+					{
+						S[q] = 2 * mu * E[q];
+						if (q == 0 || q == 4 || q == 8)
+							S[q] += lambda * tr;
+						se += S[q] * E[q];
+					}
 				for (int r = 0; r < 3; ++r)
 					for (int c = 0; c < 3; ++c)
 						dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
@@ -555,12 +590,16 @@ namespace
 	{
 		const double *estate;
 		const pfx_tables *tab;
-		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3; // grad[k][i][3]
+		const double *tensor = nullptr;                                                   // M_STVKT: the 6 x 6 elasticity tensor
+		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + (MODEL == M_STVKT ? 36 : 0); // grad[k][i][3], tensor
+		static constexpr int MIN_WAVES = MODEL == M_STVKT ? 2 : PFX_ROWASM_MINWAVES; // the tensor products want the registers of a third wave
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
 		{
 			for (int t = lane; t < NPTS * NLOC * 3; t += 64)
 				lds[t] = tab->grad[t / (NLOC * 3)][(t / 3) % NLOC][t % 3];
+			if (MODEL == M_STVKT && lane < 36)
+				lds[NPTS * NLOC * 3 + lane] = tensor[lane];
 		}
 
 		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[9]) const
@@ -576,7 +615,7 @@ namespace
 					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 				}
 			double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll(MODEL == M_MULTI ? 2 : PFX_NL_UNROLL)
+#pragma unroll(MODEL == M_STVKT ? 1 : MODEL == M_MULTI ? 2 : PFX_NL_UNROLL)
 			for (int k = 0; k < NPTS; ++k)
 			{
 				if (!ST::affine)
@@ -606,6 +645,47 @@ namespace
 					for (int m = 0; m < 3; ++m)
 						for (int n = 0; n < 3; ++n)
 							b[3 * m + n] += a * Gi[n] * Gj[m] + c1 * Gi[m] * Gj[n] + (m == n ? dot : 0.0);
+					continue;
+				}
+				if (MODEL == M_STVKT)
+				{
+					// c2 = da; block(m, n) = da [ voigt(f_m, Gi)^T C voigt(f_n, Gj) + delta_mn Gi^T S Gj ], f_m = row m of F,
+					// voigt(f, g) = the Voigt strain (engineering shears) of sym(f (x) g), S = C : E
+					const double *C = lds + NPTS * NLOC * 3;
+					double E[9], S[9];
+					for (int r = 0; r < 3; ++r)
+						for (int c = r; c < 3; ++c)
+							E[3 * r + c] = E[3 * c + r] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
+					stvk_tensor_stress(C, E, S);
+					const double sg0 = S[0] * Gj[0] + S[1] * Gj[1] + S[2] * Gj[2];
+					const double sg1 = S[3] * Gj[0] + S[4] * Gj[1] + S[5] * Gj[2];
+					const double sg2 = S[6] * Gj[0] + S[7] * Gj[1] + S[8] * Gj[2];
+					const double gsg = Gi[0] * sg0 + Gi[1] * sg1 + Gi[2] * sg2;
+					double cw[3][6];
+					for (int n = 0; n < 3; ++n)
+					{
+						const double *f = F + 3 * n;
+						const double w[6] = {f[0] * Gj[0], f[1] * Gj[1], f[2] * Gj[2], f[1] * Gj[2] + Gj[1] * f[2], f[0] * Gj[2] + Gj[0] * f[2], f[0] * Gj[1] + Gj[0] * f[1]};
+						for (int r = 0; r < 6; ++r)
+						{
+							double acc = C[6 * r] * w[0];
+							for (int c = 1; c < 6; ++c)
+								acc += C[6 * r + c] * w[c];
+							cw[n][r] = acc;
+						}
+					}
+					for (int m = 0; m < 3; ++m)
+					{
+						const double *f = F + 3 * m;
+						const double v[6] = {f[0] * Gi[0], f[1] * Gi[1], f[2] * Gi[2], f[1] * Gi[2] + Gi[1] * f[2], f[0] * Gi[2] + Gi[0] * f[2], f[0] * Gi[1] + Gi[0] * f[1]};
+						for (int n = 0; n < 3; ++n)
+						{
+							double acc = (m == n) ? gsg : 0.0;
+							for (int r = 0; r < 6; ++r)
+								acc += v[r] * cw[n][r];
+							b[3 * m + n] += acc * c2;
+						}
+					}
 					continue;
 				}
 				if (model == M_STVK)
@@ -680,7 +760,7 @@ namespace
 			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
 #define PFX_LOCAL_E_PP(MODEL_, PP_)                                                                                                                   \
 	hipLaunchKernelGGL((k_local_energy<NLOC, NGLOC, NPTS, MODEL_, PP_>), dim3(eb), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, \
-					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, eloc, ctx->d_flag)
+					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_tensor, eloc, ctx->d_flag)
 #define PFX_LOCAL_E(MODEL_)                            \
 	do                                                 \
 	{                                                  \
@@ -691,6 +771,8 @@ namespace
 	} while (0)
 			if (ctx->model == PFX_NEOHOOKEAN)
 				PFX_LOCAL_E(M_NEO);
+			else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
+				PFX_LOCAL_E(M_STVKT);
 			else if (ctx->model == PFX_SAINT_VENANT)
 				PFX_LOCAL_E(M_STVK);
 			else if (ctx->model == PFX_MULTI_MODEL)
@@ -706,7 +788,7 @@ namespace
 			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
 #define PFX_LOCAL_R3(MODEL_, PP_, WG_, WH_)                                                                                                                   \
 	hipLaunchKernelGGL((k_local_reg<NLOC, NGLOC, NPTS, MODEL_, PP_, WG_, WH_>), dim3(eb), dim3(256), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, ctx->d_xyz, d_u, \
-					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, eloc, ctx->d_gloc, ctx->d_estate,     \
+					   ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_tensor, eloc, ctx->d_gloc, ctx->d_estate,     \
 					   ctx->d_flag)
 #define PFX_LOCAL_R2(MODEL_, PP_)              \
 	do                                         \
@@ -728,6 +810,8 @@ namespace
 	} while (0)
 			if (ctx->model == PFX_NEOHOOKEAN)
 				PFX_LOCAL_R(M_NEO);
+			else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
+				PFX_LOCAL_R(M_STVKT);
 			else if (ctx->model == PFX_SAINT_VENANT)
 				PFX_LOCAL_R(M_STVK);
 			else if (ctx->model == PFX_MULTI_MODEL)
@@ -741,7 +825,7 @@ namespace
 		}
 #define PFX_LOCAL_NL_PP(MODEL_, PP_)                                                                                                              \
 	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK, PP_>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
-					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, (int)en, (int)gr, (int)he,     \
+					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_tensor, (int)en, (int)gr, (int)he,     \
 					   eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
 #define PFX_LOCAL_NL(MODEL_)                               \
 	do                                                     \
@@ -753,6 +837,8 @@ namespace
 	} while (0)
 		if (ctx->model == PFX_NEOHOOKEAN)
 			PFX_LOCAL_NL(M_NEO);
+		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
+			PFX_LOCAL_NL(M_STVKT);
 		else if (ctx->model == PFX_SAINT_VENANT)
 			PFX_LOCAL_NL(M_STVK);
 		else if (ctx->model == PFX_MULTI_MODEL)
@@ -768,6 +854,8 @@ namespace
 	{
 		if (ctx->model == PFX_NEOHOOKEAN)
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
+		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
+			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, false);
 		else if (ctx->model == PFX_SAINT_VENANT)
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab}, false);
 		else if (ctx->model == PFX_MULTI_MODEL)
@@ -781,6 +869,8 @@ namespace
 		pfx_status rc;
 		if (ctx->model == PFX_NEOHOOKEAN)
 			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
+		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
+			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor});
 		else if (ctx->model == PFX_SAINT_VENANT)
 			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_MULTI_MODEL)

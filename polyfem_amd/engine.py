@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
-    "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_element_models",
+    "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_saint_venant_tensor", "pfx_set_element_models",
     "pfx_al_enable", "pfx_al_enable_host", "pfx_lumped_mass",
     "pfx_quadrature_points", "pfx_assemble_rhs_pointwise", "pfx_assemble_rhs_pointwise_dev", "pfx_set_material_per_point",
     "pfx_energy_dev_noalloc",
@@ -56,8 +56,16 @@ def elasticity_tensor(entries=None, lam=None, mu=None, young=None, nu=None):
     t = np.zeros((6, 6))
     if entries is not None:
         entries = np.asarray(entries, dtype=np.float64).reshape(-1)
+        if entries.size == 9:
+            # the orthotropic constants Ex Ey Ez nuYX nuZX nuZY muYZ muZX muXY, stored as set_orthotropic writes them (:439-455)
+            ex, ey, ez, nyx, nzx, nzy, myz, mzx, mxy = entries
+            t[0, :3] = 1.0 / ex, -nyx / ey, -nzx / ez
+            t[1, 1:3] = 1.0 / ey, -nzy / ez
+            t[2, 2] = 1.0 / ez
+            t[3, 3], t[4, 4], t[5, 5] = 1.0 / myz, 1.0 / mzx, 1.0 / mxy
+            return np.triu(t) + np.triu(t, 1).T
         if entries.size < 21:
-            raise ValueError("21 upper-triangular entries expected")
+            raise ValueError("21 upper-triangular entries (or the 9 orthotropic constants) expected")
         t[np.triu_indices(6)] = entries[:21]
     elif young is not None:
         f = young / ((1.0 + nu) * (1.0 - 2.0 * nu))
@@ -139,6 +147,7 @@ def load():
         "pfx_set_material_per_element": [_vp, _i32, _i32, _pd, _pd, _i64],
         "pfx_set_material_per_point": [_vp, _i32, _i32, _pd, _pd, _i64, _i32],
         "pfx_set_elasticity_tensor": [_vp, _i32, _pd],
+        "pfx_set_saint_venant_tensor": [_vp, _i32, _pd],
         "pfx_set_element_models": [_vp, _pi32, _i64],
         "pfx_al_enable": [_vp, C.c_double, _vp, _vp],
         "pfx_al_enable_host": [_vp, C.c_double, _pd, _pd],
@@ -358,6 +367,11 @@ class Engine:
         """HookeLinearElasticity: symmetric 6 x 6 tensor (Voigt order xx yy zz yz xz xy); linear assembly only."""
         t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(36)
         self._ck(self.L.pfx_set_elasticity_tensor(self.h, dim, _d(t)))
+
+    def set_saint_venant_tensor(self, tensor, dim: int = 3):
+        """SaintVenantElasticity with its `elasticity_tensor` (same 6 x 6 layout) instead of (lambda, mu)."""
+        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(36)
+        self._ck(self.L.pfx_set_saint_venant_tensor(self.h, dim, _d(t)))
 
     def build_pattern(self) -> int:
         nnz = C.c_int64()

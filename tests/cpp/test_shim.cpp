@@ -202,6 +202,31 @@ int main()
 		REQUIRE(K2.values == K.values && K2.inner == K.inner);
 	}
 
+	// SaintVenant: the tensor of the same (E, nu) gives the (lambda, mu) energy; an anisotropic one is accepted and its
+	// gradient is the derivative of its energy
+	{
+		assembler::NLAssembler<assembler::SaintVenantElasticity> sv, svt;
+		sv.local_assembler().set_E_nu(2e4, 0.3);
+		svt.local_assembler().elasticity_tensor().set_from_young_poisson(2e4, 0.3);
+		const double e_sv = sv.assemble(true, bases, gbases, cache, 0.0, x, x);
+		const double e_svt = svt.assemble(true, bases, gbases, cache, 0.0, x, x);
+		REQUIRE(e_sv > 0 && std::fabs(e_sv - e_svt) <= 1e-12 * e_sv);
+		std::vector<double> entries;
+		for (int a = 0; a < 6; ++a)
+			for (int b = a; b < 6; ++b)
+				entries.push_back(a == b ? 3e4 + 1e3 * a : 2e3 / (1 + a + b));
+		svt.local_assembler().elasticity_tensor().set_from_entries(entries);
+		VectorXd gt;
+		svt.assemble_grad(true, n_basis, bases, gbases, cache, 0.0, x, x, gt);
+		const double fdt = (svt.assemble(true, bases, gbases, cache, 0.0, xp, xp) - svt.assemble(true, bases, gbases, cache, 0.0, xm, xm)) / (2 * h);
+		double gdt = 0;
+		for (int i = 0; i < N; ++i)
+			gdt += gt[i] * d[i];
+		REQUIRE(std::fabs(fdt - gdt) <= 1e-5 * std::fabs(gdt));
+		// the (lambda, mu) assembler binds its own material again
+		REQUIRE(std::fabs(sv.assemble(true, bases, gbases, cache, 0.0, x, x) - e_sv) <= 1e-15 * e_sv);
+	}
+
 	// MultiModel with one model everywhere reproduces that model; a mixture lies between
 	{
 		assembler::NLAssembler<assembler::MultiModel> mm;

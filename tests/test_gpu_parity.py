@@ -122,6 +122,59 @@ def test_neohookean_energy_gradient_hessian(eng, oracle, name):
         assert rel_err(v, vals) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
+def test_saint_venant_elasticity_tensor(eng, oracle, name):
+    """SaintVenantElasticity with the material's `elasticity_tensor` (SaintVenantElasticity.cpp:64-68, 77-86, 281-309): an
+    anisotropic symmetric tensor -- energy, gradient, Hessian (plain and project_to_psd) and a Newton solve against the
+    oracle; the isotropic tensor reproduces the (lambda, mu) model; pfx_set_material returns to (lambda, mu)."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    nnz = _setup(eng, mesh, E.SAINT_VENANT, lam, mu)
+    n = mesh.n_nodes * 3
+    h = 1.0 / round((mesh.n_el / (6 if mesh.kind < 2 else 1)) ** (1 / 3))
+    x = M.seeded_displacement(mesh, 3, 0.1 * h, seed=5)
+    e_iso, g_iso, v_iso = eng.energy(x), eng.gradient(x), eng.hessian(x)
+    eng.set_saint_venant_tensor(E.elasticity_tensor(lam=lam, mu=mu))
+    assert abs(eng.energy(x) - e_iso) <= TOL * e_iso
+    assert rel_err(eng.gradient(x), g_iso) <= TOL and rel_err(eng.hessian(x), v_iso) <= TOL
+    a = np.random.default_rng(11).standard_normal((6, 6))
+    Ct = 2e3 * (a @ a.T + 6 * np.eye(6))
+    eng.set_saint_venant_tensor(E.elasticity_tensor(entries=Ct[np.triu_indices(6)]))
+    SV = oracle.SAINT_VENANT
+    for amp in (0.0, 1e-2 * h, 0.3 * h):
+        x = M.seeded_displacement(mesh, 3, amp)
+        e_ref = oracle.assemble_energy(mesh, SV, Ct, None, x)
+        g_ref = oracle.assemble_gradient(mesh, SV, Ct, None, x)
+        outer, inner, vals = oracle.assemble_hessian(mesh, SV, Ct, None, x)
+        e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and nnz == inner.size
+        if amp == 0.0:
+            assert e == 0.0 and e_ref == 0.0 and not g.any()
+        else:
+            assert abs(e - e_ref) <= TOL * abs(e_ref)
+            assert rel_err(g, g_ref) <= TOL
+        assert rel_err(v, vals) <= TOL
+    vp = eng.hessian(x, project_to_psd=True)
+    ref = oracle.assemble_hessian_psd(mesh, SV, Ct, None, x)
+    assert np.abs(vp - ref[2]).max() <= 1e-10 * np.abs(ref[2]).max()
+    with pytest.raises(E.PfxError):
+        eng.set_element_models([E.NEOHOOKEAN] * mesh.n_el)  # element models take (lambda, mu)
+    if name != "q1":
+        bnd = M.boundary_dofs(mesh, 3, "x0")
+        eng.set_dirichlet(bnd)
+        rhs = np.zeros(n)
+        rhs[2::3] = -100.0 / mesh.n_nodes
+        xs, info = eng.newton_solve(np.zeros(n), rhs)
+        xr, iref = oracle.newton_solve(mesh, SV, Ct, None, rhs, bnd, np.zeros(n))
+        eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+        assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+        assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+    eng.set_material(E.SAINT_VENANT, lam, mu)
+    x = M.seeded_displacement(mesh, 3, 0.1 * h, seed=5)
+    assert abs(eng.energy(x) - e_iso) <= 1e-15 * e_iso
+
+
 @pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "p2_stretched", "q1", "q2"])
 def test_saint_venant_energy_gradient_hessian(eng, oracle, name):
     """SaintVenantElasticity (SaintVenantElasticity.cpp:104-143, 215-312; isotropic tensor): energy, gradient, Hessian

@@ -576,6 +576,53 @@ def test_saint_venant_oracle(oracle, kind):
         assert abs(oracle.assemble_energy(mesh, SV, lam, mu, ux) - (lam / 2 + mu) * exx * exx) <= 1e-12 * lam * exx * exx
 
 
+@pytest.mark.parametrize("kind", ["tet2", "hex2", "tet1"])
+def test_saint_venant_tensor_oracle(oracle, kind):
+    """SaintVenant with the material's `elasticity_tensor` (assembler/SaintVenantElasticity.cpp:64-68, 77-86, 281-309).
+    The reference holds no vector for it: with the isotropic tensor of set_from_lambda_mu it is the (lambda, mu) model
+    pinned above; for an anisotropic symmetric tensor the gradient and the Hessian are the derivatives of the
+    reference's energy (central differences), the Hessian is symmetric, a rigid rotation stores no energy, and a
+    uniaxial stretch has the energy C_00 E_xx^2 / 2."""
+    mesh = {"tet2": lambda: M.cube_tets(2, 2, jitter=0.1), "hex2": lambda: M.cube_hexes(2, 2), "tet1": lambda: M.cube_tets(2, 1)}[kind]()
+    lam, mu = oracle.lame(2e4, 0.3)
+    n = mesh.n_nodes * 3
+    SV = oracle.SAINT_VENANT
+    u = M.seeded_displacement(mesh, 3, 5e-2, seed=3)
+    iso = oracle.elasticity_tensor(lam, mu)
+    assert abs(oracle.assemble_energy(mesh, SV, iso, None, u) - oracle.assemble_energy(mesh, SV, lam, mu, u)) <= 1e-13 * oracle.assemble_energy(mesh, SV, lam, mu, u)
+    g_iso = oracle.assemble_gradient(mesh, SV, lam, mu, u)
+    assert np.abs(oracle.assemble_gradient(mesh, SV, iso, None, u) - g_iso).max() <= 1e-12 * np.abs(g_iso).max()
+    h_iso = oracle.assemble_hessian(mesh, SV, lam, mu, u)[2]
+    assert np.abs(oracle.assemble_hessian(mesh, SV, iso, None, u)[2] - h_iso).max() <= 1e-12 * np.abs(h_iso).max()
+
+    a = np.random.default_rng(11).standard_normal((6, 6))
+    Ct = 2e3 * (a @ a.T + 6 * np.eye(6))
+    g = oracle.assemble_gradient(mesh, SV, Ct, None, u)
+    H = csc_to_scipy(oracle.assemble_hessian(mesh, SV, Ct, None, u), n)
+    d = np.random.default_rng(0).standard_normal(n)
+    h = 1e-6
+    fd = (oracle.assemble_energy(mesh, SV, Ct, None, u + h * d) - oracle.assemble_energy(mesh, SV, Ct, None, u - h * d)) / (2 * h)
+    gfd = (oracle.assemble_gradient(mesh, SV, Ct, None, u + h * d) - oracle.assemble_gradient(mesh, SV, Ct, None, u - h * d)) / (2 * h)
+    assert abs(fd - g @ d) <= 1e-7 * abs(g @ d)
+    assert np.linalg.norm(gfd - H @ d) <= 1e-7 * np.linalg.norm(H @ d)
+    assert abs(H - H.T).max() <= 1e-13 * abs(H).max()
+    if kind != "tet2":
+        th = 0.7
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        ur = (mesh.node_xyz @ R.T - mesh.node_xyz).reshape(-1)
+        assert abs(oracle.assemble_energy(mesh, SV, Ct, None, ur)) <= 1e-20 * Ct.max()
+        assert np.abs(oracle.assemble_gradient(mesh, SV, Ct, None, ur)).max() <= 1e-10
+        s = 0.2
+        ux = np.zeros(n)
+        ux[0::3] = s * mesh.node_xyz[:, 0]
+        exx = s + s * s / 2
+        assert abs(oracle.assemble_energy(mesh, SV, Ct, None, ux) - Ct[0, 0] * exx * exx / 2) <= 1e-12 * Ct[0, 0] * exx * exx
+    # the nine orthotropic constants land where ElasticityTensor::set_orthotropic (utils/ElasticityUtils.cpp:439-455) writes them
+    t9 = oracle.elasticity_tensor(entries=[2.0, 4.0, 5.0, 0.1, 0.2, 0.3, 7.0, 8.0, 9.0])
+    assert np.array_equal(t9, t9.T) and t9[0, 1] == -0.1 / 4.0 and t9[0, 2] == -0.2 / 5.0 and t9[1, 2] == -0.3 / 5.0
+    assert np.array_equal(np.diag(t9), [1 / 2.0, 1 / 4.0, 1 / 5.0, 1 / 7.0, 1 / 8.0, 1 / 9.0])
+
+
 @pytest.mark.parametrize("kind", ["p1", "p2", "q1", "q2"])
 def test_hooke_linear_oracle(oracle, kind):
     """HookeLinearElasticity (assembler/HookeLinearElasticity.cpp:75-190).  The reference holds no self-contained
