@@ -27,12 +27,10 @@
 //   energy += da/2 S:E        grad_i += da F S G_i
 //   H_ij   += da [ (G_i^T S G_j) I + lambda (F G_i)(F G_j)^T + mu ( (G_i.G_j) F F^T + (F G_j)(F G_i)^T ) ]
 //
-// Element kernel (TPE lanes per element, BLOCK / TPE elements per workgroup, all intermediate data in LDS):
-//   1 geometry nodes, connectivity, displacements -> LDS      4 F per point (9 lanes per point)
-//   2 J^{-T}, det per quadrature point                       5 per-point scalars, cofactors, energy
-//   3 G for every (point, basis)                              6 w for every (point, basis)
-//   7 gradient rows (one lane per basis); for the Hessian the per-point state (J^{-T}, F, mu da, c1 da, c2 da) is
-//     written out instead of any local matrix.
+// Element kernels: elements with at most ten nodes take one THREAD each, everything in registers (k_local_energy,
+// k_local_reg); the 27-node hexahedra take half a wave each, a lane being a quadrature point and then a node
+// (k_local_pts).  For the Hessian the per-point state (J^{-T}, F, mu da, c1 da, c2 da) is written out instead of any
+// local matrix.
 // The Hessian blocks are then computed straight into the global matrix by k_assemble_rows (pfx_rowasm.h) with the
 // functor nl_block: one lane per contribution (element, i, j) evaluates H_ij from that state.
 #include "pfx_internal.h"
@@ -49,21 +47,6 @@ namespace
 		M_STVK = 2,
 		M_MULTI = 3, // one of the three per element (MultiModel, assembler/MultiModel.cpp:42-96): the branches become run-time tests
 		M_STVKT = 4  // SaintVenant with the material's 6 x 6 elasticity tensor instead of (lambda, mu) (SaintVenantElasticity.cpp:64-68)
-	};
-
-	template <int NLOC, int NGLOC, int NPTS>
-	struct nl_smem
-	{
-		double xs[NGLOC * 3];
-		double ul[NLOC * 3];
-		double jt[NPTS * 9];
-		double da[NPTS];
-		double G[NPTS * NLOC * 3];
-		double W[NPTS * NLOC * 3];
-		double F[NPTS * 9];
-		double dJ[NPTS * 9];
-		double coef[NPTS * 4]; // mu*da, c1*da, c2*da, energy density * da
-		int bad;
 	};
 
 	__device__ __forceinline__ void inv3_transposed_det(const double *m, double *jt, double *det)
@@ -114,217 +97,77 @@ namespace
 		__host__ __device__ static constexpr int f_at(int k) { return affine ? 10 + 12 * k : 22 * k + 10; }
 	};
 
-	// PP: the material arrays hold one value per (element, point) instead of one per element
-	template <int NLOC, int NGLOC, int NPTS, int TPE, int MODEL, int BLOCK, bool PP>
-	__global__ __launch_bounds__(BLOCK) void k_local_nl(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn,
-																   const double *__restrict__ xyz, const double *__restrict__ u,
-																   const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u, double mu_u,
-																   const double *__restrict__ lambda_e, const double *__restrict__ mu_e, const uint8_t *__restrict__ model_e,
-																   const double *__restrict__ tensor, int want_e, int want_g, int want_h,
-																   double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
-																   int *__restrict__ flag)
+	// One quadrature point of the energy density and its derivative: F the deformation gradient (the displacement gradient
+	// for M_LINEAR), da = det J * weight.  dJ receives what the gradient contracts with the physical basis gradients (NeoHookean:
+	// the cofactor matrix of F; otherwise the first Piola-Kirchhoff / Cauchy stress), c0..c2 the coefficients the gradient
+	// and the Hessian functor use; returns the point's energy.
+	template <int MODEL>
+	__device__ __forceinline__ double nl_point(int model, const double *F, double lambda, double mu, const double *__restrict__ tensor, double da, double *dJ,
+											   double &c0, double &c1, double &c2, bool &bad)
 	{
-		constexpr int EPB = BLOCK / TPE;
-		constexpr int N = NLOC * 3;
-		typedef nl_state<NGLOC, NPTS> ST;
-		__shared__ nl_smem<NLOC, NGLOC, NPTS> sm[EPB];
-
-		const int grp = threadIdx.x / TPE, lane = threadIdx.x % TPE;
-		const int64_t e = (int64_t)blockIdx.x * EPB + grp;
-		const bool active = e < n_el;
-		nl_smem<NLOC, NGLOC, NPTS> &s = sm[grp];
-		// LameParameters::lambda_mu (utils/ElasticityUtils.cpp:490-517): one value, or one per element
-		// ... or one per (element, quadrature point)
-		const double lambda_el = (lambda_e && active) ? lambda_e[PP ? e * NPTS : e] : lambda_u, mu_el = (mu_e && active) ? mu_e[PP ? e * NPTS : e] : mu_u;
-		const int model = (MODEL == M_MULTI) ? (active ? (int)model_e[e] : (int)M_LINEAR) : MODEL;
-
-		if (active)
+		double en = 0.0;
+		if (model == M_NEO)
 		{
-			for (int t = lane; t < NGLOC * 3; t += TPE)
-				s.xs[t] = xyz[3 * (int64_t)gconn[e * NGLOC + t / 3] + t % 3];
-			for (int t = lane; t < NLOC * 3; t += TPE)
-				s.ul[t] = u[3 * (int64_t)conn[e * NLOC + t / 3] + t % 3];
-			if (lane == 0)
-				s.bad = 0;
+			dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
+			dJ[3] = F[2] * F[7] - F[1] * F[8], dJ[4] = F[0] * F[8] - F[2] * F[6], dJ[5] = F[1] * F[6] - F[0] * F[7];
+			dJ[6] = F[1] * F[5] - F[2] * F[4], dJ[7] = F[2] * F[3] - F[0] * F[5], dJ[8] = F[0] * F[4] - F[1] * F[3];
+			const double J = F[0] * dJ[0] + F[1] * dJ[1] + F[2] * dJ[2];
+			if (!(J > 0.0))
+				bad = true;
+			const double lj = log(J);
+			double tr = 0;
+			for (int q = 0; q < 9; ++q)
+				tr += F[q] * F[q];
+			c0 = mu * da;
+			c1 = (mu + lambda * (1.0 - lj)) / (J * J) * da;
+			c2 = (lambda * lj - mu) / J * da;
+			en = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
 		}
-		__syncthreads();
-
-		if (active)
-			for (int k = lane; k < NPTS; k += TPE)
-			{
-				double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-				for (int j = 0; j < NGLOC; ++j)
-					for (int r = 0; r < 3; ++r)
-						for (int c = 0; c < 3; ++c)
-							tmp[3 * r + c] += tab->ggrad[k][j][r] * s.xs[3 * j + c];
-				double det;
-				inv3_transposed_det(tmp, &s.jt[9 * k], &det);
-				s.da[k] = det * tab->w[k];
-			}
-		__syncthreads();
-
-		if (active)
-			for (int t = lane; t < NPTS * NLOC; t += TPE)
-			{
-				const int k = t / NLOC, i = t % NLOC;
-				const double g0 = tab->grad[k][i][0], g1 = tab->grad[k][i][1], g2 = tab->grad[k][i][2];
-				const double *jt = &s.jt[9 * k];
+		else if (model == M_STVK || model == M_STVKT)
+		{
+			double E[9], S[9];
+			for (int r = 0; r < 3; ++r)
 				for (int c = 0; c < 3; ++c)
-					s.G[3 * t + c] = g0 * jt[c] + g1 * jt[3 + c] + g2 * jt[6 + c];
-			}
-		__syncthreads();
-
-		if (active)
-			for (int t = lane; t < NPTS * 9; t += TPE)
-			{
-				const int k = t / 9, d = (t % 9) / 3, c = t % 3;
-				double acc = (model != M_LINEAR && d == c) ? 1.0 : 0.0;
-				for (int i = 0; i < NLOC; ++i)
-					acc += s.ul[3 * i + d] * s.G[3 * (k * NLOC + i) + c];
-				s.F[t] = acc; // F(d,c) row-major
-			}
-		__syncthreads();
-
-		if (active)
-			for (int k = lane; k < NPTS; k += TPE)
-			{
-				const double *F = &s.F[9 * k];
-				double *dJ = &s.dJ[9 * k];
-				const double da = s.da[k];
-				const double lambda = PP ? lambda_e[e * NPTS + k] : lambda_el, mu = PP ? mu_e[e * NPTS + k] : mu_el;
-				if (model == M_NEO)
+					E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
+			const double tr = E[0] + E[4] + E[8];
+			double se = 0;
+			if (MODEL == M_STVKT)
+				se = stvk_tensor_stress(tensor, E, S);
+			else
+				for (int q = 0; q < 9; ++q)
 				{
-					// cofactor matrix: dJ(r,c) = d det / d F(r,c)
-					dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
-					dJ[3] = F[2] * F[7] - F[1] * F[8], dJ[4] = F[0] * F[8] - F[2] * F[6], dJ[5] = F[1] * F[6] - F[0] * F[7];
-					dJ[6] = F[1] * F[5] - F[2] * F[4], dJ[7] = F[2] * F[3] - F[0] * F[5], dJ[8] = F[0] * F[4] - F[1] * F[3];
-					const double J = F[0] * dJ[0] + F[1] * dJ[1] + F[2] * dJ[2];
-					if (!(J > 0.0))
-						s.bad = 1;
-					const double lj = log(J);
-					double tr = 0;
-					for (int q = 0; q < 9; ++q)
-						tr += F[q] * F[q];
-					s.coef[4 * k + 0] = mu * da;
-					s.coef[4 * k + 1] = (mu + lambda * (1.0 - lj)) / (J * J) * da;
-					s.coef[4 * k + 2] = (lambda * lj - mu) / J * da;
-					s.coef[4 * k + 3] = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+					S[q] = 2 * mu * E[q];
+					if (q == 0 || q == 4 || q == 8)
+						S[q] += lambda * tr;
+					se += S[q] * E[q];
 				}
-				else if (model == M_STVK || model == M_STVKT)
-				{
-					// dJ receives the first Piola-Kirchhoff stress F S
-					double E[9], S[9];
-					for (int r = 0; r < 3; ++r)
-						for (int c = 0; c < 3; ++c)
-							E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
-					const double tr = E[0] + E[4] + E[8];
-					double se = 0;
-					if (MODEL == M_STVKT)
-						se = stvk_tensor_stress(tensor, E, S);
-					else
-						for (int q = 0; q < 9; ++q)
-						{
-							S[q] = 2 * mu * E[q];
-							if (q == 0 || q == 4 || q == 8)
-								S[q] += lambda * tr;
-							se += S[q] * E[q];
-						}
-					for (int r = 0; r < 3; ++r)
-						for (int c = 0; c < 3; ++c)
-							dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
-					s.coef[4 * k + 0] = mu * da;
-					s.coef[4 * k + 1] = lambda * da;
-					s.coef[4 * k + 2] = da;
-					s.coef[4 * k + 3] = se / 2 * da;
-				}
-				else
-				{
-					// F holds the displacement gradient D; dJ receives the stress sigma
-					double eps[9], ee = 0;
-					for (int r = 0; r < 3; ++r)
-						for (int c = 0; c < 3; ++c)
-						{
-							eps[3 * r + c] = (F[3 * r + c] + F[3 * c + r]) / 2;
-							ee += eps[3 * r + c] * eps[3 * r + c];
-						}
-					const double tr = eps[0] + eps[4] + eps[8];
-					for (int q = 0; q < 9; ++q)
-						dJ[q] = 2 * mu * eps[q];
-					dJ[0] += lambda * tr, dJ[4] += lambda * tr, dJ[8] += lambda * tr;
-					s.coef[4 * k + 0] = mu * da;
-					s.coef[4 * k + 1] = lambda * da;
-					s.coef[4 * k + 2] = da;
-					s.coef[4 * k + 3] = (mu * ee + lambda / 2 * tr * tr) * da;
-				}
-			}
-		__syncthreads();
-
-		if (active && want_e && lane == 0)
-		{
-			double en = 0;
-			for (int k = 0; k < NPTS; ++k)
-				en += s.coef[4 * k + 3];
-			eloc[e] = en;
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c)
+					dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
+			c0 = mu * da, c1 = lambda * da, c2 = da;
+			en = se / 2 * da;
 		}
-		if (active && lane == 0 && s.bad)
-			atomicOr(flag, 1);
-
-		if (model == M_NEO && active && want_g)
-			for (int t = lane; t < NPTS * NLOC; t += TPE)
-			{
-				const int k = t / NLOC;
-				const double *dJ = &s.dJ[9 * k];
-				const double *g = &s.G[3 * t];
-				for (int m = 0; m < 3; ++m)
-					s.W[3 * t + m] = dJ[3 * m] * g[0] + dJ[3 * m + 1] * g[1] + dJ[3 * m + 2] * g[2];
-			}
-		__syncthreads();
-
-		if (active && want_g)
-			for (int i = lane; i < NLOC; i += TPE)
-			{
-				double g[3] = {0, 0, 0};
-				for (int k = 0; k < NPTS; ++k)
-				{
-					const double *F = &s.F[9 * k];
-					const double *Gi = &s.G[3 * (k * NLOC + i)], *Wi = &s.W[3 * (k * NLOC + i)];
-					const double a = s.coef[4 * k + 0], c2 = s.coef[4 * k + 2];
-					if (model == M_NEO)
-						for (int d = 0; d < 3; ++d)
-							g[d] += a * (F[3 * d] * Gi[0] + F[3 * d + 1] * Gi[1] + F[3 * d + 2] * Gi[2]) + c2 * Wi[d];
-					else
-					{
-						const double *sg = &s.dJ[9 * k];
-						for (int d = 0; d < 3; ++d)
-							g[d] += c2 * (sg[3 * d] * Gi[0] + sg[3 * d + 1] * Gi[1] + sg[3 * d + 2] * Gi[2]);
-					}
-				}
-				for (int d = 0; d < 3; ++d)
-					gloc[e * N + 3 * i + d] = g[d];
-			}
-
-		if (active && want_h)
+		else
 		{
-			double *st = estate + e * (int64_t)ST::stride;
-			for (int t = lane; t < NPTS * 22; t += TPE)
-			{
-				const int k = t / 22, q = t - 22 * k;
-				if (q < 10)
+			double eps[9], ee = 0;
+			for (int r = 0; r < 3; ++r)
+				for (int c = 0; c < 3; ++c)
 				{
-					if (!ST::affine || k == 0)
-						st[ST::jt_at(k) + q] = q < 9 ? s.jt[9 * k + q] : (double)model; // the tenth slot tells the row functor the element's model
+					eps[3 * r + c] = (F[3 * r + c] + F[3 * c + r]) / 2;
+					ee += eps[3 * r + c] * eps[3 * r + c];
 				}
-				else if (q < 19)
-					st[ST::f_at(k) + q - 10] = s.F[9 * k + q - 10];
-				else
-					st[ST::f_at(k) + q - 10] = s.coef[4 * k + q - 19];
-			}
+			const double tr = eps[0] + eps[4] + eps[8];
+			for (int q = 0; q < 9; ++q)
+				dJ[q] = 2 * mu * eps[q];
+			dJ[0] += lambda * tr, dJ[4] += lambda * tr, dJ[8] += lambda * tr;
+			c0 = mu * da, c1 = lambda * da, c2 = da;
+			en = (mu * ee + lambda / 2 * tr * tr) * da;
 		}
+		return en;
 	}
 
 	// Energy only (the line search asks for nothing else): one THREAD per element, everything in registers, the points
-	// visited in order so that the element's energy is the same sum as in k_local_nl.  No LDS, no barriers: 1 M P2 tets
-	// take a fraction of the fused kernel's time.  The reference-gradient tables are read through the constant path
+	// visited in order (the element's energy is the same sum in every kernel of this file).  No LDS, no barriers.  The reference-gradient tables are read through the constant path
 	// (every lane reads the same entry).
 	template <int NLOC, int NGLOC, int NPTS, int MODEL, bool PP>
 	__global__ __launch_bounds__(256) void k_local_energy(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
@@ -428,8 +271,8 @@ namespace
 	}
 
 	// The same register-only scheme for the gradient (WG) and / or the per-point state the row assembly builds the Hessian
-	// from (WH): one thread per element; the energy comes for free.  Same formulas and per-element summation order as
-	// k_local_nl, which stays in use for the 27-node elements (their 81 gradient accumulators do not fit in registers).
+	// from (WH): one thread per element; the energy comes for free.  The 27-node elements, whose 81 gradient
+	// accumulators do not fit in registers, take k_local_pts.
 	template <int NLOC, int NGLOC, int NPTS, int MODEL, bool PP, bool WG, bool WH>
 	__global__ __launch_bounds__(256) void k_local_reg(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
 															const double *__restrict__ u, const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u,
@@ -492,64 +335,8 @@ namespace
 						F[3 * d + c] += ui[d] * G[c];
 			}
 			const double lambda = lambda_e ? lambda_e[PP ? e * NPTS + k : e] : lambda_u, mu = mu_e ? mu_e[PP ? e * NPTS + k : e] : mu_u;
-			double dJ[9], c0, c1, c2; // as s.dJ / s.coef of k_local_nl
-			if (model == M_NEO)
-			{
-				dJ[0] = F[4] * F[8] - F[5] * F[7], dJ[1] = F[5] * F[6] - F[3] * F[8], dJ[2] = F[3] * F[7] - F[4] * F[6];
-				dJ[3] = F[2] * F[7] - F[1] * F[8], dJ[4] = F[0] * F[8] - F[2] * F[6], dJ[5] = F[1] * F[6] - F[0] * F[7];
-				dJ[6] = F[1] * F[5] - F[2] * F[4], dJ[7] = F[2] * F[3] - F[0] * F[5], dJ[8] = F[0] * F[4] - F[1] * F[3];
-				const double J = F[0] * dJ[0] + F[1] * dJ[1] + F[2] * dJ[2];
-				if (!(J > 0.0))
-					bad = true;
-				const double lj = log(J);
-				double tr = 0;
-				for (int q = 0; q < 9; ++q)
-					tr += F[q] * F[q];
-				c0 = mu * da;
-				c1 = (mu + lambda * (1.0 - lj)) / (J * J) * da;
-				c2 = (lambda * lj - mu) / J * da;
-				en += (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
-			}
-			else if (model == M_STVK || model == M_STVKT)
-			{
-				double E[9], S[9];
-				for (int r = 0; r < 3; ++r)
-					for (int c = 0; c < 3; ++c)
-						E[3 * r + c] = (F[r] * F[c] + F[3 + r] * F[3 + c] + F[6 + r] * F[6 + c] - (r == c ? 1.0 : 0.0)) / 2;
-				const double tr = E[0] + E[4] + E[8];
-				double se = 0;
-				if (MODEL == M_STVKT)
-					se = stvk_tensor_stress(tensor, E, S);
-				else
-					for (int q = 0; q < 9; ++q)
-					{
-						S[q] = 2 * mu * E[q];
-						if (q == 0 || q == 4 || q == 8)
-							S[q] += lambda * tr;
-						se += S[q] * E[q];
-					}
-				for (int r = 0; r < 3; ++r)
-					for (int c = 0; c < 3; ++c)
-						dJ[3 * r + c] = F[3 * r] * S[c] + F[3 * r + 1] * S[3 + c] + F[3 * r + 2] * S[6 + c];
-				c0 = mu * da, c1 = lambda * da, c2 = da;
-				en += se / 2 * da;
-			}
-			else
-			{
-				double eps[9], ee = 0;
-				for (int r = 0; r < 3; ++r)
-					for (int c = 0; c < 3; ++c)
-					{
-						eps[3 * r + c] = (F[3 * r + c] + F[3 * c + r]) / 2;
-						ee += eps[3 * r + c] * eps[3 * r + c];
-					}
-				const double tr = eps[0] + eps[4] + eps[8];
-				for (int q = 0; q < 9; ++q)
-					dJ[q] = 2 * mu * eps[q];
-				dJ[0] += lambda * tr, dJ[4] += lambda * tr, dJ[8] += lambda * tr;
-				c0 = mu * da, c1 = lambda * da, c2 = da;
-				en += (mu * ee + lambda / 2 * tr * tr) * da;
-			}
+			double dJ[9], c0, c1, c2;
+			en += nl_point<MODEL>(model, F, lambda, mu, tensor, da, dJ, c0, c1, c2, bad);
 			if (WH)
 			{
 				for (int q = 0; q < 9; ++q)
@@ -577,6 +364,139 @@ namespace
 		if (WG)
 			for (int t = 0; t < NLOC * 3; ++t)
 				gloc[e * (NLOC * 3) + t] = g[t];
+		if (bad)
+			atomicOr(flag, 1);
+	}
+
+	// Gradient and / or Hessian state of the elements with many nodes and points (27-node hexahedra, 27 points): a lane is a
+	// quadrature point while the point values are formed and a node while the gradient is summed, two elements per wave (lanes
+	// 0..31 and 32..63).  The physical basis gradients G_i = J^{-T} grad phi_i are never formed: with H = sum_i u_i (x)
+	// grad phi_i (reference gradients, one table in LDS for the whole workgroup) F = I + H J^{-1}, and the gradient
+	// sum_k X_k G_i(k) is sum_k (X_k J_k^{-1}) grad phi_i(xi_k).  Per element the energy is the sum over the points in order
+	// and the gradient the sum over the points in order.
+	// PP: the material arrays hold one value per (element, point) instead of one per element
+	template <int NLOC, int NGLOC, int NPTS, int MODEL, bool PP, int WAVES>
+	__global__ __launch_bounds__(64 * WAVES) void k_local_pts(const int32_t *__restrict__ conn, const int32_t *__restrict__ gconn, const double *__restrict__ xyz,
+																 const double *__restrict__ u, const pfx_tables *__restrict__ tab, int64_t n_el, double lambda_u,
+																 double mu_u, const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
+																 const uint8_t *__restrict__ model_e, const double *__restrict__ tensor, int want_g, int want_h,
+																 double *__restrict__ eloc, double *__restrict__ gloc, double *__restrict__ estate,
+																 int *__restrict__ flag)
+	{
+		static_assert(NLOC <= 32 && NPTS <= 32 && NGLOC <= 32, "a half wave per element");
+		typedef nl_state<NGLOC, NPTS> ST;
+		constexpr int EPB = 2 * WAVES;
+		__shared__ double s_grad[NPTS * NLOC * 3];   // grad phi_i(xi_k), [k][i][3]
+		__shared__ double s_ggrad[NPTS * NGLOC * 3]; // the same for the geometric map
+		__shared__ double s_w[NPTS];
+		__shared__ double s_u[EPB][NLOC * 3];
+		__shared__ double s_xs[EPB][NGLOC * 3];
+		__shared__ double s_q[EPB][NPTS * 9]; // X_k J_k^{-1}
+		__shared__ double s_en[EPB][NPTS];
+		for (int t = threadIdx.x; t < NPTS * NLOC * 3; t += 64 * WAVES)
+			s_grad[t] = tab->grad[t / (NLOC * 3)][(t / 3) % NLOC][t % 3];
+		for (int t = threadIdx.x; t < NPTS * NGLOC * 3; t += 64 * WAVES)
+			s_ggrad[t] = tab->ggrad[t / (NGLOC * 3)][(t / 3) % NGLOC][t % 3];
+		for (int t = threadIdx.x; t < NPTS; t += 64 * WAVES)
+			s_w[t] = tab->w[t];
+		const int l = threadIdx.x & 31;
+		const int slot = threadIdx.x >> 5; // element of the workgroup
+		const int64_t e = (int64_t)blockIdx.x * EPB + slot;
+		const bool active = e < n_el;
+		if (active)
+		{
+			if (l < NLOC)
+			{
+				const double *up = u + 3 * (int64_t)conn[e * NLOC + l];
+				s_u[slot][3 * l] = up[0], s_u[slot][3 * l + 1] = up[1], s_u[slot][3 * l + 2] = up[2];
+			}
+			if (l < NGLOC)
+			{
+				const double *xp = xyz + 3 * (int64_t)gconn[e * NGLOC + l];
+				s_xs[slot][3 * l] = xp[0], s_xs[slot][3 * l + 1] = xp[1], s_xs[slot][3 * l + 2] = xp[2];
+			}
+		}
+		__syncthreads();
+		// from here on the two elements of a wave only use their own slots
+		auto wave_sync = [] {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		};
+		const int model = (MODEL == M_MULTI) ? (active ? (int)model_e[e] : (int)M_LINEAR) : MODEL;
+		bool bad = false;
+		if (active && l < NPTS)
+		{
+			const int k = l;
+			double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+			for (int j = 0; j < NGLOC; ++j)
+				for (int r = 0; r < 3; ++r)
+					for (int c = 0; c < 3; ++c)
+						tmp[3 * r + c] += s_ggrad[(k * NGLOC + j) * 3 + r] * s_xs[slot][3 * j + c];
+			double jt[9], det;
+			inv3_transposed_det(tmp, jt, &det);
+			const double da = det * s_w[k];
+			double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 3
+			for (int i = 0; i < NLOC; ++i)
+			{
+				const double *gr = s_grad + (k * NLOC + i) * 3;
+				const double *ui = s_u[slot] + 3 * i;
+				for (int d = 0; d < 3; ++d)
+					for (int r = 0; r < 3; ++r)
+						H[3 * d + r] += ui[d] * gr[r];
+			}
+			double F[9];
+			for (int d = 0; d < 3; ++d)
+				for (int c = 0; c < 3; ++c)
+					F[3 * d + c] = ((model != M_LINEAR && d == c) ? 1.0 : 0.0) + (H[3 * d] * jt[c] + H[3 * d + 1] * jt[3 + c] + H[3 * d + 2] * jt[6 + c]);
+			const double lambda = lambda_e ? lambda_e[PP ? e * NPTS + k : e] : lambda_u, mu = mu_e ? mu_e[PP ? e * NPTS + k : e] : mu_u;
+			double dJ[9], c0, c1, c2;
+			s_en[slot][k] = nl_point<MODEL>(model, F, lambda, mu, tensor, da, dJ, c0, c1, c2, bad);
+			if (want_g)
+				for (int d = 0; d < 3; ++d)
+				{
+					double X[3];
+					for (int c = 0; c < 3; ++c)
+						X[c] = (model == M_NEO) ? c0 * F[3 * d + c] + c2 * dJ[3 * d + c] : c2 * dJ[3 * d + c];
+					for (int r = 0; r < 3; ++r)
+						s_q[slot][9 * k + 3 * d + r] = X[0] * jt[3 * r] + X[1] * jt[3 * r + 1] + X[2] * jt[3 * r + 2];
+				}
+			if (want_h)
+			{
+				double *st = estate + e * (int64_t)ST::stride;
+				for (int q = 0; q < 9; ++q)
+					st[ST::jt_at(k) + q] = jt[q];
+				st[ST::jt_at(k) + 9] = (double)model; // the tenth slot tells the row functor the element's model
+				for (int q = 0; q < 9; ++q)
+					st[ST::f_at(k) + q] = F[q];
+				st[ST::f_at(k) + 9] = c0, st[ST::f_at(k) + 10] = c1, st[ST::f_at(k) + 11] = c2;
+			}
+		}
+		wave_sync();
+		if (active && l == 0)
+		{
+			double en = 0;
+			for (int k = 0; k < NPTS; ++k)
+				en += s_en[slot][k];
+			eloc[e] = en;
+		}
+		if (active && want_g && l < NLOC)
+		{
+			const int i = l;
+			double g[3] = {0, 0, 0};
+#pragma unroll 3
+			for (int k = 0; k < NPTS; ++k)
+			{
+				const double *q = s_q[slot] + 9 * k;
+				const double *gr = s_grad + (k * NLOC + i) * 3;
+				for (int d = 0; d < 3; ++d)
+					g[d] += q[3 * d] * gr[0] + q[3 * d + 1] * gr[1] + q[3 * d + 2] * gr[2];
+			}
+			double *go = gloc + e * (NLOC * 3) + 3 * i;
+			go[0] = g[0], go[1] = g[1], go[2] = g[2];
+		}
 		if (bad)
 			atomicOr(flag, 1);
 	}
@@ -750,12 +670,10 @@ namespace
 		}
 	};
 
-	template <int NLOC, int NGLOC, int NPTS, int TPE, int BLOCK = 256>
+	template <int NLOC, int NGLOC, int NPTS>
 	void launch(pfx_ctx *ctx, const double *d_u, bool en, bool gr, bool he, double *eloc)
 	{
-		constexpr int EPB = BLOCK / TPE;
-		const int64_t blocks = (ctx->n_el + EPB - 1) / EPB;
-		if (en && !gr && !he) // energy alone: the register-only kernel
+		if (en && !gr && !he && NLOC <= 10) // energy alone: the register-only kernel
 		{
 			const unsigned eb = (unsigned)((ctx->n_el + 255) / 256);
 #define PFX_LOCAL_E_PP(MODEL_, PP_)                                                                                                                   \
@@ -824,8 +742,8 @@ namespace
 			return;
 		}
 #define PFX_LOCAL_NL_PP(MODEL_, PP_)                                                                                                              \
-	hipLaunchKernelGGL((k_local_nl<NLOC, NGLOC, NPTS, TPE, MODEL_, BLOCK, PP_>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
-					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_tensor, (int)en, (int)gr, (int)he,     \
+	hipLaunchKernelGGL((k_local_pts<NLOC, NGLOC, NPTS, MODEL_, PP_, 8>), dim3((unsigned)((ctx->n_el + 15) / 16)), dim3(512), 0, ctx->stream, ctx->d_conn, ctx->d_gconn, \
+					   ctx->d_xyz, d_u, ctx->d_tab, ctx->n_el, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e, ctx->d_model_e, ctx->d_tensor, (int)gr, (int)he,     \
 					   eloc, ctx->d_gloc, ctx->d_estate, ctx->d_flag)
 #define PFX_LOCAL_NL(MODEL_)                               \
 	do                                                     \
@@ -835,16 +753,19 @@ namespace
 		else                                               \
 			PFX_LOCAL_NL_PP(MODEL_, false);                \
 	} while (0)
-		if (ctx->model == PFX_NEOHOOKEAN)
-			PFX_LOCAL_NL(M_NEO);
-		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
-			PFX_LOCAL_NL(M_STVKT);
-		else if (ctx->model == PFX_SAINT_VENANT)
-			PFX_LOCAL_NL(M_STVK);
-		else if (ctx->model == PFX_MULTI_MODEL)
-			PFX_LOCAL_NL(M_MULTI);
-		else
-			PFX_LOCAL_NL(M_LINEAR);
+		if constexpr (NLOC > 10)
+		{
+			if (ctx->model == PFX_NEOHOOKEAN)
+				PFX_LOCAL_NL(M_NEO);
+			else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
+				PFX_LOCAL_NL(M_STVKT);
+			else if (ctx->model == PFX_SAINT_VENANT)
+				PFX_LOCAL_NL(M_STVK);
+			else if (ctx->model == PFX_MULTI_MODEL)
+				PFX_LOCAL_NL(M_MULTI);
+			else
+				PFX_LOCAL_NL(M_LINEAR);
+		}
 #undef PFX_LOCAL_NL
 #undef PFX_LOCAL_NL_PP
 	}
@@ -899,28 +820,25 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 		if (np != 1)
 			ok = false;
 		else
-			launch<4, 4, 1, 16>(ctx, d_u, energy, grad, hess, eloc);
+			launch<4, 4, 1>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_P2TET:
 		if (np != 6)
 			ok = false;
 		else
-			// two elements per single-wave workgroup: measured best of {64, 32, 16 lanes per element} x {256, 128, 64 threads}
-			// (energy 0.70 ms, gradient 1.00 ms, Hessian state 0.82 ms per 1 M elements against 0.94 / 1.53 / 0.99 ms for a
-			// wavefront per element in 256-thread workgroups)
-			launch<10, 4, 6, 32, 64>(ctx, d_u, energy, grad, hess, eloc);
+			launch<10, 4, 6>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_Q1HEX:
 		if (np != 1)
 			ok = false;
 		else
-			launch<8, 8, 1, 64>(ctx, d_u, energy, grad, hess, eloc);
+			launch<8, 8, 1>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_Q2HEX:
 		if (np != 27)
 			ok = false;
 		else
-			launch<27, 8, 27, 256>(ctx, d_u, energy, grad, hess, eloc);
+			launch<27, 8, 27>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	default:
 		ok = false;
