@@ -122,6 +122,59 @@ def test_neohookean_energy_gradient_hessian(eng, oracle, name):
         assert rel_err(v, vals) <= TOL
 
 
+def _star_mesh(n=4):
+    """P1 tetrahedra that all share the centre of a cube: one per triangle of its n x n x 6 surface grid."""
+    pts, tris = {}, []
+
+    def pid(p):
+        return pts.setdefault(tuple(p), len(pts) + 1)  # 0 is the centre
+
+    for axis in range(3):
+        for side in (0, n):
+            a, b = [d for d in range(3) if d != axis]
+            for i in range(n):
+                for j in range(n):
+                    def P(u, v):
+                        q = [0, 0, 0]
+                        q[axis], q[a], q[b] = side, u, v
+                        return pid(q)
+                    quad = [P(i, j), P(i + 1, j), P(i + 1, j + 1), P(i, j + 1)]
+                    tris += [(quad[0], quad[1], quad[2]), (quad[0], quad[2], quad[3])]
+    xyz = np.zeros((len(pts) + 1, 3))
+    xyz[0] = 0.5
+    for q, k in pts.items():
+        xyz[k] = np.array(q, dtype=np.float64) / n
+    conn = np.array([(0,) + t for t in tris], dtype=np.int32)
+    d = xyz[conn[:, 1:]] - xyz[conn[:, :1]]
+    flip = np.linalg.det(d) < 0
+    conn[flip, 2], conn[flip, 3] = conn[flip, 3].copy(), conn[flip, 2].copy()
+    return M.Mesh(kind=0, gkind=0, conn=conn, gconn=conn.copy(), xyz=xyz, n_nodes=xyz.shape[0], node_xyz=xyz.copy())
+
+
+def test_block_spanning_several_assembly_windows(eng, oracle):
+    """The row assembly walks the contributions in windows of 64 and carries the partial sums of a block that a window
+    boundary cuts.  A vertex shared by 192 tetrahedra gives a diagonal block with 192 contributions -- it starts in
+    one window, fills two and ends in a fourth: stiffness (with the value-dependent pattern), mass and the NeoHookean
+    Hessian against the oracle, and the result is the same bits on a second run."""
+    mesh = _star_mesh(4)
+    assert mesh.n_el == 192 and (mesh.conn[:, 0] == 0).all()
+    lam, mu = oracle.lame(1e5, 0.3)
+    _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner)
+    assert rel_err(v, vals) <= TOL
+    eng.assemble_linear()
+    assert np.array_equal(eng.get_linear_csr()[2], v)
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    x = M.seeded_displacement(mesh, 3, 2e-2)
+    h = eng.hessian(x)
+    assert rel_err(h, oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]) <= TOL
+    assert np.array_equal(eng.hessian(x), h)
+    assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= TOL
+
+
 @pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
 def test_saint_venant_elasticity_tensor(eng, oracle, name):
     """SaintVenantElasticity with the material's `elasticity_tensor` (SaintVenantElasticity.cpp:64-68, 77-86, 281-309): an
