@@ -50,6 +50,10 @@
 // Three waves per SIMD is what the largest functors reach without spilling; without the bound the compiler spends
 // the registers of a fourth and a third wave on keeping more of an element's state loads in flight, which pays less
 // than the extra wave does.
+#ifndef PFX_ROWASM_XCD
+#define PFX_ROWASM_XCD 1
+#endif
+#define PFX_XCDS 8
 // (A functor that cannot live with that many registers says so: Op::MIN_WAVES.)
 #ifndef PFX_ROWASM_MINWAVES
 #define PFX_ROWASM_MINWAVES 3
@@ -85,7 +89,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(pfx_mi
 	double(*const carry)[B2] = carry_[wv];
 	uint8_t(*const carry_any)[B2] = carry_any_[wv];
 	op.load_tables(optab, lane); // every wave writes the same values
-	const int64_t g = (int64_t)blockIdx.x * WPB + wv;
+	// Workgroups are handed to the eight XCDs round robin, and each XCD has its own L2.  Rows that are close in the
+	// numbering share elements, so every XCD takes one contiguous eighth of the groups: the element states its
+	// resident workgroups read are then fetched into one L2 instead of into all eight.
+	const int64_t per_xcd = gridDim.x / PFX_XCDS; // the launch rounds the grid up to a multiple of PFX_XCDS
+	const int64_t wg = PFX_ROWASM_XCD ? (int64_t)(blockIdx.x % PFX_XCDS) * per_xcd + blockIdx.x / PFX_XCDS : (int64_t)blockIdx.x;
+	const int64_t g = wg * WPB + wv;
 	__syncthreads();
 	if (g >= n_groups)
 		return;
@@ -221,7 +230,7 @@ template <int NLOC, int BS, class Op>
 inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask)
 {
 	constexpr int WPB = (Op::LDS_DOUBLES * 8 > 12 * 1024) ? 4 : 1; // share large tables between four waves
-	const unsigned grid = (unsigned)((ctx->n_groups + WPB - 1) / WPB);
+	const unsigned grid = (unsigned)(((ctx->n_groups + WPB - 1) / WPB + PFX_XCDS - 1) / PFX_XCDS * PFX_XCDS);
 	if (write_mask)
 		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, true, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_grp_c0, ctx->d_grp_win, ctx->d_win,
 						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_groups, ctx->d_values, ctx->d_mask);
