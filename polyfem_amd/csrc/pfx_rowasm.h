@@ -54,6 +54,9 @@
 #define PFX_ROWASM_XCD 1
 #endif
 #define PFX_XCDS 8
+#ifndef PFX_ROWASM_WPB_BIG
+#define PFX_ROWASM_WPB_BIG 4
+#endif
 // (A functor that cannot live with that many registers says so: Op::MIN_WAVES.)
 #ifndef PFX_ROWASM_MINWAVES
 #define PFX_ROWASM_MINWAVES 3
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(pfx_mi
 template <int NLOC, int BS, class Op>
 inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask)
 {
-	constexpr int WPB = (Op::LDS_DOUBLES * 8 > 12 * 1024) ? 4 : 1; // share large tables between four waves
+	constexpr int WPB = (Op::LDS_DOUBLES * 8 > 12 * 1024) ? PFX_ROWASM_WPB_BIG : 1; // share large tables between the waves of a workgroup
 	const unsigned grid = (unsigned)(((ctx->n_groups + WPB - 1) / WPB + PFX_XCDS - 1) / PFX_XCDS * PFX_XCDS);
 	if (write_mask)
 		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, true, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_grp_c0, ctx->d_grp_win, ctx->d_win,
