@@ -14,7 +14,12 @@ namespace
 															const double *__restrict__ gloc, int64_t n_nodes, int drop_tiny, double *__restrict__ out)
 	{
 		const int64_t n = n_nodes * BS;
-		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+		// one block per 256 rows; every XCD (blocks are dealt to the eight of them round robin, each has its own L2) takes a
+		// contiguous eighth of the rows, so that the element rows of gloc shared by neighbouring nodes are fetched into one L2
+		const int64_t per_xcd = gridDim.x / 8;
+		const int64_t vb = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+		const int64_t r = vb * blockDim.x + threadIdx.x;
+		if (r < n)
 		{
 			const int64_t g = r / BS;
 			const int d = (int)(r - g * BS);
@@ -159,7 +164,8 @@ namespace
 	template <int NLOC, int BS>
 	void launch_gv(pfx_ctx *ctx, double *d_g, bool drop_tiny)
 	{
-		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3(grid_for(ctx->n_nodes * BS)), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
+		const int64_t blocks = ((ctx->n_nodes * BS + 255) / 256 + 7) / 8 * 8; // a multiple of the number of XCDs
+		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
 						   ctx->d_gloc, ctx->n_nodes, drop_tiny ? 1 : 0, d_g);
 	}
 } // namespace
