@@ -207,7 +207,8 @@ typedef struct
 	int ncycle;           /* 2: W cycle (AMGCL/precond/ncycle, the reference's default); 1: V cycle */
 	int max_levels;       /* 12 (AMGCL/precond/max_levels) */
 	int coarsest_dofs;    /* 600: levels at or below this size are solved with a dense inverse */
-	int power_iters;      /* 10: power iterations for the spectral radius of D^-1 A (AMGCL/precond/relax/power_iters) */
+	int power_iters;      /* 15: iterations of the estimate of the spectral radius of D^-1 A (AMGCL/precond/relax/power_iters); here Lanczos
+	                         steps, whose largest Ritz value + 5 % ends the Chebyshev interval */
 	double relax_lower;   /* 0.1: the relaxation targets the eigenvalues in [relax_lower * lmax, lmax] */
 } pfx_amg_params;
 

@@ -20,7 +20,7 @@
 // nodes with all dofs constrained are left out of the aggregation.
 //
 // Cycle (one application = the preconditioner z = M^-1 r): Chebyshev relaxation of degree `relax_degree` for
-// D^-1 A on [relax_lower * lmax, lmax] before and after the coarse correction (lmax by power iteration), V or W cycle,
+// D^-1 A on [relax_lower * lmax, lmax] before and after the coarse correction (lmax by a few Lanczos steps), V or W cycle,
 // dense inverse at the coarsest level.  Same polynomial before and after: M is symmetric positive definite.
 //
 // The symbolic part (matching, coarse patterns, Galerkin lists) runs on the host, once per pattern and Dirichlet set;
@@ -539,18 +539,57 @@ namespace
 			*out = s;
 	}
 
-	// power iteration step: v = dinv * t / sqrt(*nrm2)   (t = A v_old, *nrm2 = |dinv t|^2 of this step)
-	__global__ void k_scale_dinv(const double *__restrict__ dinv, const double *__restrict__ t, int64_t n, double *__restrict__ v)
+	// Lanczos steps for S = D^-1/2 A D^-1/2 (the eigenvalues of D^-1 A): q the current vector, qp the previous one,
+	// u = D^-1/2 q the vector A is applied to, t = A u.  scal: alpha_j, beta_{j+1}^2 as they are produced.
+	// w = D^-1/2 t - beta qp; partial sums of w.q
+	__global__ __launch_bounds__(256) void k_lz_a(const double *__restrict__ dinv, const double *__restrict__ t, const double *__restrict__ qp,
+													const double *__restrict__ q, const double *__restrict__ beta2, int64_t n, double *__restrict__ w,
+													double *__restrict__ part)
 	{
+		__shared__ double sh[256];
+		const double beta = beta2 ? sqrt(*beta2) : 0.0;
+		double acc = 0;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
-			v[k] = dinv[k] * t[k];
+		{
+			const double v = sqrt(dinv[k]) * t[k] - beta * qp[k];
+			w[k] = v;
+			acc += v * q[k];
+		}
+		const double s = block_sum256(acc, sh);
+		if (threadIdx.x == 0)
+			part[blockIdx.x] = s;
 	}
 
-	__global__ void k_normalise(const double *__restrict__ nrm2, int64_t n, double *__restrict__ v)
+	// w -= alpha q; partial sums of w.w
+	__global__ __launch_bounds__(256) void k_lz_b(const double *__restrict__ q, const double *__restrict__ alpha, int64_t n, double *__restrict__ w,
+													double *__restrict__ part)
 	{
-		const double s = *nrm2 > 0 ? 1.0 / sqrt(*nrm2) : 0.0;
+		__shared__ double sh[256];
+		const double a = *alpha;
+		double acc = 0;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
-			v[k] *= s;
+		{
+			const double v = w[k] - a * q[k];
+			w[k] = v;
+			acc += v * v;
+		}
+		const double s = block_sum256(acc, sh);
+		if (threadIdx.x == 0)
+			part[blockIdx.x] = s;
+	}
+
+	// qp = q; q = w / sqrt(nrm2) (0 once the Krylov space is exhausted); u = D^-1/2 q
+	__global__ void k_lz_c(const double *__restrict__ dinv, const double *__restrict__ w, const double *__restrict__ nrm2, int64_t n, double *__restrict__ qp,
+						   double *__restrict__ q, double *__restrict__ u)
+	{
+		const double s = *nrm2 > 1e-300 ? 1.0 / sqrt(*nrm2) : 0.0;
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double v = w[k] * s;
+			qp[k] = q[k];
+			q[k] = v;
+			u[k] = sqrt(dinv[k]) * v;
+		}
 	}
 
 	__global__ void k_seed_vector(int64_t n, const uint8_t *__restrict__ fixed, double *__restrict__ v)
@@ -1052,13 +1091,62 @@ namespace
 		return PFX_OK;
 	}
 
-	// lmax of D^-1 A by power iteration (vectors: L.d_x as v, L.d_t as A v)
+	// largest eigenvalue of the symmetric tridiagonal matrix (a_1..a_m; b_2..b_m): bisection on the Sturm count
+	double tridiagonal_lambda_max(const std::vector<double> &a, const std::vector<double> &b2)
+	{
+		const int m = (int)a.size();
+		double lo = a[0], hi = a[0];
+		for (int i = 0; i < m; ++i)
+		{
+			const double r = (i > 0 ? std::sqrt(b2[i - 1]) : 0.0) + (i + 1 < m ? std::sqrt(b2[i]) : 0.0);
+			lo = std::min(lo, a[i] - r), hi = std::max(hi, a[i] + r);
+		}
+		auto below = [&](double x) { // number of eigenvalues < x
+			int c = 0;
+			double d = a[0] - x;
+			c += d < 0;
+			for (int i = 1; i < m; ++i)
+			{
+				if (d == 0)
+					d = 1e-300;
+				d = a[i] - x - b2[i - 1] / d;
+				c += d < 0;
+			}
+			return c;
+		};
+		for (int it = 0; it < 100 && hi - lo > 1e-12 * std::max(std::fabs(hi), 1.0); ++it)
+		{
+			const double mid = 0.5 * (lo + hi);
+			if (below(mid) >= m)
+				hi = mid;
+			else
+				lo = mid;
+		}
+		return hi;
+	}
+
+	// lmax of D^-1 A: `eig_iters` Lanczos steps on D^-1/2 A D^-1/2 from a fixed pseudo-random vector, largest Ritz value
+	// plus 5 % (Ritz values approach the spectrum's end from inside; a Chebyshev interval that ends below lmax would
+	// amplify the top modes).  Vectors: v (the one A is applied to) and t (A v) from the caller, three more allocated here.
 	pfx_status amg_lambda_max(pfx_ctx *ctx, pfx_amg *A, pfx_amg_level &L, double *v, double *t, const double *dinv, int64_t n_rows)
 	{
 		hipStream_t st = ctx->stream;
 		const uint8_t *fixed = (L.m == ctx && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
-		hipLaunchKernelGGL(k_seed_vector, dim3(grid_for(n_rows)), dim3(256), 0, st, n_rows, fixed, v);
-		for (int it = 0; it < ctx->amg_params.power_iters; ++it)
+		int steps = ctx->amg_params.power_iters;
+		if ((int64_t)steps > n_rows)
+			steps = (int)n_rows;
+		pfx_tmp<double> q, qp, w, scal;
+		PFX_HIP(q.alloc((size_t)n_rows));
+		PFX_HIP(qp.alloc((size_t)n_rows));
+		PFX_HIP(w.alloc((size_t)n_rows));
+		PFX_HIP(scal.alloc((size_t)(2 * steps + 1)));
+		const int grid = grid_for(n_rows);
+		PFX_HIP(hipMemsetAsync(q.p, 0, sizeof(double) * (size_t)n_rows, st));
+		hipLaunchKernelGGL(k_seed_vector, dim3(grid), dim3(256), 0, st, n_rows, fixed, w.p);
+		hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, w.p, w.p, n_rows, A->d_part);
+		hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, scal.p);
+		hipLaunchKernelGGL(k_lz_c, dim3(grid), dim3(256), 0, st, dinv, w.p, scal.p, n_rows, qp.p, q.p, v);
+		for (int j = 0; j < steps; ++j)
 		{
 			pfx_status rc = pfx_sell_spmv(L.m, v, t, nullptr, nullptr);
 			if (rc)
@@ -1066,16 +1154,30 @@ namespace
 				ctx->err = L.m->err;
 				return rc;
 			}
-			hipLaunchKernelGGL(k_scale_dinv, dim3(grid_for(n_rows)), dim3(256), 0, st, dinv, t, n_rows, v);
-			hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, v, v, n_rows, A->d_part);
-			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, A->d_scal);
-			hipLaunchKernelGGL(k_normalise, dim3(grid_for(n_rows)), dim3(256), 0, st, A->d_scal, n_rows, v);
+			double *alpha = scal.p + 1 + 2 * j, *beta2 = alpha + 1;
+			hipLaunchKernelGGL(k_lz_a, dim3(AMG_NPART), dim3(256), 0, st, dinv, t, qp.p, q.p, j > 0 ? (const double *)(alpha - 1) : (const double *)nullptr, n_rows, w.p,
+							   A->d_part);
+			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, alpha);
+			hipLaunchKernelGGL(k_lz_b, dim3(AMG_NPART), dim3(256), 0, st, q.p, alpha, n_rows, w.p, A->d_part);
+			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, beta2);
+			hipLaunchKernelGGL(k_lz_c, dim3(grid), dim3(256), 0, st, dinv, w.p, beta2, n_rows, qp.p, q.p, v);
 		}
-		double nrm2 = 0;
-		PFX_HIP(hipMemcpyAsync(&nrm2, A->d_scal, sizeof(double), hipMemcpyDeviceToHost, st));
+		std::vector<double> h((size_t)(2 * steps + 1));
+		PFX_HIP(hipMemcpyAsync(h.data(), scal.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
 		PFX_HIP(hipStreamSynchronize(st));
+		std::vector<double> a, b2;
+		for (int j = 0; j < steps; ++j)
+		{
+			a.push_back(h[1 + 2 * j]);
+			if (!(h[2 + 2 * j] > 1e-300) || j + 1 == steps)
+				break;
+			b2.push_back(h[2 + 2 * j]);
+		}
+		double ritz = 1.0;
+		if (!a.empty() && std::isfinite(a[0]))
+			ritz = tridiagonal_lambda_max(a, b2);
 		// constrained level-0 dofs carry the eigenvalue 1 of the identity rows: never report less
-		L.lmax = 1.1 * std::max(std::sqrt(nrm2), 1.0);
+		L.lmax = 1.05 * std::max(ritz, 1.0);
 		return PFX_OK;
 	}
 
@@ -1444,7 +1546,7 @@ extern "C"
 		p->ncycle = 2;
 		p->max_levels = 12;
 		p->coarsest_dofs = 600;
-		p->power_iters = 10;
+		p->power_iters = 15;
 		p->relax_lower = 0.1;
 	}
 

@@ -202,3 +202,32 @@ def test_amg_converges_at_one_million_elements():
         assert float(res) <= 1.01e-10
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("kind", ["tet2", "hex2"])
+def test_relaxation_interval_covers_the_spectrum(oracle, kind):
+    """The Chebyshev interval must end at or above the largest eigenvalue of D^-1 A (an end below it amplifies the top
+    modes: on 64^3 Q2 hexahedra an estimate 27 % short left the solve at 6e-2 after 300 iterations).  The Lanczos
+    estimate of level 0 against scipy's eigsh on the oracle's matrix: never below, at most 10 % above; and the Q2 solve
+    converges."""
+    import scipy.sparse.linalg as spla
+    eng = E.Engine(0)
+    try:
+        mesh = M.cube_tets(5, 2, jitter=0.1) if kind == "tet2" else M.cube_hexes(5, 2)
+        Am, fixed = _problem(eng, oracle, mesh, "le")
+        eng.amg_set_params(coarsest_dofs=120)
+        eng.amg_setup()
+        info = eng.amg_info()
+        ds = 1.0 / np.sqrt(Am.diagonal())
+        S = sp.diags(ds) @ Am @ sp.diags(ds)
+        lam_true = float(spla.eigsh(S, k=1, which="LA", return_eigenvectors=False, tol=1e-10)[0])
+        assert lam_true <= info["lambda_max"][0] <= 1.10 * lam_true, (lam_true, info["lambda_max"])
+        n = Am.shape[0]
+        b = np.zeros(n)
+        b[2::3] = -1.0 / mesh.n_nodes
+        b[fixed] = 0
+        x, it, err = eng.cg(b, precond=E.PRECOND_AMG, max_iter=200, tol=1e-10)
+        assert it < 60 and err <= 1e-10
+        assert np.linalg.norm(Am @ x - b) <= 1e-9 * np.linalg.norm(b)
+    finally:
+        eng.close()

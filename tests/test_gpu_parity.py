@@ -894,6 +894,10 @@ def test_augmented_lagrangian_dirichlet(eng, oracle):
     xb, ib, used_b = eng.al_solve(np.zeros(n), None, bnd, big[bnd], initial_weight=1e3)
     assert len(used_b) >= 1 and np.array_equal(xb[bnd], big[bnd]) and np.isfinite(eng.energy(xb))
     assert ib["status"] in (2, 3, 4)
+    # the weight limit: the reference's ALSolver throws "Unable to solve AL problem" (solver/ALSolver.cpp:63-69)
+    with pytest.raises(E.PfxError) as ex:
+        eng.al_solve(np.zeros(n), rhs, bnd, target[bnd], force_al=True, initial_weight=1e6, max_weight=1.5e6)
+    assert ex.value.code == E.PFX_ERR_NUMERIC and "Unable to solve AL problem" in str(ex.value)
     eng.set_dirichlet(np.zeros(0, dtype=np.int32))
     # with the term enabled but weight 0 nothing changes; null pointers disable
     eng.al_enable_host(0.0, masked, target)
