@@ -46,6 +46,7 @@ namespace
 		free_dev(ctx, ctx->d_win);
 		free_dev(ctx, ctx->d_desc);
 		ctx->n_ublocks = ctx->n_upair = ctx->n_groups = ctx->n_windows = 0;
+		ctx->h_grp_win.clear();
 		free_dev(ctx, ctx->d_ne_ptr);
 		free_dev(ctx, ctx->d_ne_src);
 		free_dev(ctx, ctx->d_values);

@@ -26,6 +26,45 @@ struct pfx_tables
 	double gval[PFX_MAX_PTS][PFX_MAX_GLOC];       // geometry basis j at point k
 };
 
+// Work split over the XCDs.  Workgroups are dealt to the eight XCDs round robin (workgroup b runs on XCD b % 8) and every
+// XCD has its own L2: kernels whose neighbouring work units share data give each XCD one CONTIGUOUS range of units,
+// units first[x] .. first[x+1]-1 to XCD x, cut so that the ranges carry equal work (rows differ in length: with vertex
+// nodes numbered before edge nodes, equal COUNTS would hand one XCD all the long rows).
+#define PFX_XCDS 8
+struct pfx_xcd_split
+{
+	int32_t first[PFX_XCDS + 1];
+	int32_t widest; // largest range: the launch has PFX_XCDS * widest workgroups
+};
+// prefix(k) = work of the units before unit k (non-decreasing, prefix(0) = 0), k = 0 .. n
+template <class Prefix>
+inline pfx_xcd_split pfx_make_xcd_split(int64_t n, Prefix prefix)
+{
+	pfx_xcd_split sp;
+	const double total = (double)prefix(n);
+	sp.first[0] = 0;
+	for (int x = 1; x < PFX_XCDS; ++x)
+	{
+		const double target = total * x / PFX_XCDS;
+		int64_t lo = sp.first[x - 1], hi = n; // smallest k with prefix(k) >= target
+		while (lo < hi)
+		{
+			const int64_t mid = (lo + hi) >> 1;
+			if ((double)prefix(mid) < target)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		sp.first[x] = (int32_t)lo;
+	}
+	sp.first[PFX_XCDS] = (int32_t)n;
+	sp.widest = 1;
+	for (int x = 0; x < PFX_XCDS; ++x)
+		if (sp.first[x + 1] - sp.first[x] > sp.widest)
+			sp.widest = sp.first[x + 1] - sp.first[x];
+	return sp;
+}
+
 // window descriptor (uint4): x = index of the block in the value array, y = index of its mirror image below the diagonal
 // (0xFFFFFFFF: a diagonal block), z = c0 | c1 << 8 | flags: its contributions are the window's [c0, c1)
 #define PFX_DESC_CONT_IN 0x10000u  // the block started in an earlier window: continue from the carried sums
@@ -96,6 +135,7 @@ struct pfx_ctx
 	uint32_t *d_grp_win = nullptr; // n_groups+1: first window of each group
 	uint2 *d_win = nullptr;        // n_windows: (first upper block bl, number of blocks nb) of the window
 	uint4 *d_desc = nullptr;       // n_ublocks + n_windows: block bl+s of window W at bl + s + W, see PFX_DESC_*
+	std::vector<uint32_t> h_grp_win; // host copy of d_grp_win (the XCD split of the row assembly is cut by windows)
 	// Inside each window the contributions are stored reordered by
 	// element (lanes that read the same element state sit next to each other): d_blk_src[c] = e*n_loc^2 + i*n_loc + j of
 	// the contribution computed by lane c - window start, d_blk_slot[c] = its position in the window in block order.
@@ -151,6 +191,7 @@ struct pfx_ctx
 	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
 	int32_t *d_sell_order = nullptr; // slice list, interior slices first (null: natural order, no halo)
 	int64_t sell_interior = 0;       // number of slices that read owned entries of x only
+	pfx_xcd_split sell_split[3];     // positions of the slice list per XCD for PFX_SPMV_ALL / _INTERIOR / _BOUNDARY, cut by stored slots
 	int64_t *d_sell_base = nullptr;
 	double *d_sell_vals = nullptr;
 	int64_t sell_slices = 0, sell_rows = 0, sell_owned = -1;

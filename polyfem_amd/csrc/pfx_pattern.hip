@@ -430,6 +430,9 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 		PFX_HIP(hipStreamSynchronize(st));
 		tmp.reset();
 		ctx->n_windows = n_windows;
+		ctx->h_grp_win.resize((size_t)(n_groups + 1));
+		PFX_HIP(hipMemcpyAsync(ctx->h_grp_win.data(), ctx->d_grp_win, sizeof(uint32_t) * (size_t)(n_groups + 1), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
 		if (pfx_alloc(ctx, &ctx->d_win, (int64_t)n_windows) || pfx_alloc(ctx, &ctx->d_desc, n_ublocks + (int64_t)n_windows))
 			return PFX_ERR_HIP;
 		hipLaunchKernelGGL(k_window_descriptors, dim3(grid_for(n_groups)), dim3(256), 0, st, unode_ptr.p, blk_ptr.p, ublk_off.p, ublk_low.p, ctx->d_grp_win, n_nodes,

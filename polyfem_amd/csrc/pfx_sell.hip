@@ -142,11 +142,12 @@ namespace
 	}
 
 	// y = (A + shift I) x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per single-wave block (measured
-	// faster than four waves per block); blocks b and b+8 run on the same XCD, so each XCD walks one contiguous eighth of the slices (x gathers stay in its L2).
+	// faster than four waves per block); blocks b and b+8 run on the same XCD, so each XCD walks one contiguous range of the slice list (x gathers stay
+	// in its L2), the ranges cut so that they hold equal numbers of stored slots (pfx_xcd_split).
 	template <int BS, bool DOT>
 	__global__ __launch_bounds__(64) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
 														const int32_t *__restrict__ cols, const double *__restrict__ values,
-														const int32_t *__restrict__ order, int first, int count,
+														const int32_t *__restrict__ order, int first, pfx_xcd_split split,
 														const uint8_t *__restrict__ fixed, double shift, const double *__restrict__ x,
 														double *__restrict__ y, double *__restrict__ part, const int *__restrict__ done)
 	{
@@ -154,10 +155,10 @@ namespace
 			return;
 		constexpr int B2 = BS * BS;
 		const int lane = threadIdx.x;
-		const int nblk = gridDim.x;
-		const int per = (nblk + 7) / 8;
-		const int vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
-		if (vb >= count)
+		// XCD x walks the positions split.first[x] .. split.first[x+1]-1 of the slice list (equal numbers of stored slots)
+		const int xcd = blockIdx.x % PFX_XCDS;
+		const int vb = split.first[xcd] + (int)(blockIdx.x / PFX_XCDS);
+		if (vb >= split.first[xcd + 1])
 			return;
 		// position first+vb of the slice list (interior slices first, then those that read halo entries of x)
 		const int64_t s = order ? order[first + vb] : first + vb;
@@ -313,6 +314,28 @@ static pfx_status sell_build(pfx_ctx *ctx)
 		PFX_HIP(hipMemcpyAsync(ctx->d_sell_order, order.data(), sizeof(int32_t) * (size_t)n_slices, hipMemcpyHostToDevice, st));
 		PFX_HIP(hipStreamSynchronize(st));
 	}
+	// XCD ranges of the slice list for the three phases, cut by the slices' lengths (+1 per slice for its fixed cost)
+	{
+		std::vector<int64_t> base((size_t)n_slices + 1);
+		PFX_HIP(hipMemcpyAsync(base.data(), ctx->d_sell_base, sizeof(int64_t) * base.size(), hipMemcpyDeviceToHost, st));
+		std::vector<int32_t> order;
+		if (ctx->d_sell_order)
+		{
+			order.resize((size_t)n_slices);
+			PFX_HIP(hipMemcpyAsync(order.data(), ctx->d_sell_order, sizeof(int32_t) * order.size(), hipMemcpyDeviceToHost, st));
+		}
+		PFX_HIP(hipStreamSynchronize(st));
+		std::vector<double> pre((size_t)n_slices + 1, 0.0); // work of the positions before each position of the list
+		for (int64_t k = 0; k < n_slices; ++k)
+		{
+			const int64_t sl = order.empty() ? k : order[(size_t)k];
+			pre[(size_t)k + 1] = pre[(size_t)k] + (double)(base[(size_t)sl + 1] - base[(size_t)sl]) + 1.0;
+		}
+		const int64_t ni = ctx->sell_interior;
+		ctx->sell_split[PFX_SPMV_ALL] = pfx_make_xcd_split(n_slices, [&](int64_t k) { return pre[(size_t)k]; });
+		ctx->sell_split[PFX_SPMV_INTERIOR] = pfx_make_xcd_split(ni, [&](int64_t k) { return pre[(size_t)k]; });
+		ctx->sell_split[PFX_SPMV_BOUNDARY] = pfx_make_xcd_split(n_slices - ni, [&](int64_t k) { return pre[(size_t)(ni + k)] - pre[(size_t)ni]; });
+	}
 	ctx->sell_owned = n_owned;
 	ctx->sell_gen = -1;
 	return PFX_OK;
@@ -366,10 +389,11 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 		first = (int)ctx->sell_interior, count = (int)(ctx->sell_slices - ctx->sell_interior);
 	if (count <= 0)
 		return PFX_OK;
-	const int grid = (count + 7) / 8 * 8; // one slice (one wave) per block
+	const pfx_xcd_split &split = ctx->sell_split[phase];
+	const int grid = PFX_XCDS * split.widest; // one slice (one wave) per block
 	const int32_t *order = ctx->d_sell_order;
 	pfx_scoped_timer tm(ctx, phase == PFX_SPMV_BOUNDARY ? "spmv_boundary" : "spmv");
-#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, order, first, count, fixed, ctx->diag_shift, d_x, d_y, part, done)
+#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, d_y, part, done)
 	if (ctx->bs == 1)
 	{
 		if (part)

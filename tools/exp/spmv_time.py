@@ -7,7 +7,7 @@ from polyfem_amd import mesh as M
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 55
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-mesh = M.cube_tets(n, 2)
+mesh = M.cube_tets(n, 2, numbering=(sys.argv[3] if len(sys.argv) > 3 else "lattice"))
 eng = E.Engine(0)
 eng.set_mesh(mesh)
 eng.set_material(E.LINEAR_ELASTICITY, 1e5 * 0.3 / (1.3 * 0.4), 1e5 / 2.6)
