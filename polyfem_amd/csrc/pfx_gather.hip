@@ -11,15 +11,17 @@ namespace
 {
 	template <int NLOC, int BS>
 	__global__ __launch_bounds__(256) void k_gather_vector(const int64_t *__restrict__ ne_ptr, const uint32_t *__restrict__ ne_src,
-															const double *__restrict__ gloc, int64_t n_nodes, int drop_tiny, double *__restrict__ out)
+															const double *__restrict__ gloc, int64_t n_nodes, int drop_tiny, pfx_xcd_split split,
+															double *__restrict__ out)
 	{
 		const int64_t n = n_nodes * BS;
 		// one block per 256 rows; every XCD (blocks are dealt to the eight of them round robin, each has its own L2) takes a
-		// contiguous eighth of the rows, so that the element rows of gloc shared by neighbouring nodes are fetched into one L2
-		const int64_t per_xcd = gridDim.x / 8;
-		const int64_t vb = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+		// contiguous range of the rows, so that the element rows of gloc shared by neighbouring nodes are fetched into one
+		// L2; the ranges hold equal numbers of incidences
+		const int xcd = blockIdx.x % PFX_XCDS;
+		const int64_t vb = split.first[xcd] + (int64_t)(blockIdx.x / PFX_XCDS);
 		const int64_t r = vb * blockDim.x + threadIdx.x;
-		if (r < n)
+		if (vb < split.first[xcd + 1] && r < n)
 		{
 			const int64_t g = r / BS;
 			const int d = (int)(r - g * BS);
@@ -164,9 +166,8 @@ namespace
 	template <int NLOC, int BS>
 	void launch_gv(pfx_ctx *ctx, double *d_g, bool drop_tiny)
 	{
-		const int64_t blocks = ((ctx->n_nodes * BS + 255) / 256 + 7) / 8 * 8; // a multiple of the number of XCDs
-		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
-						   ctx->d_gloc, ctx->n_nodes, drop_tiny ? 1 : 0, d_g);
+		hipLaunchKernelGGL((k_gather_vector<NLOC, BS>), dim3((unsigned)(PFX_XCDS * ctx->gv_split.widest)), dim3(256), 0, ctx->stream, ctx->d_ne_ptr, ctx->d_ne_src,
+						   ctx->d_gloc, ctx->n_nodes, drop_tiny ? 1 : 0, ctx->gv_split, d_g);
 	}
 } // namespace
 

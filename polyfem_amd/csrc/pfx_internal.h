@@ -136,6 +136,7 @@ struct pfx_ctx
 	uint2 *d_win = nullptr;        // n_windows: (first upper block bl, number of blocks nb) of the window
 	uint4 *d_desc = nullptr;       // n_ublocks + n_windows: block bl+s of window W at bl + s + W, see PFX_DESC_*
 	std::vector<uint32_t> h_grp_win; // host copy of d_grp_win (the XCD split of the row assembly is cut by windows)
+	pfx_xcd_split gv_split;          // XCD ranges of the vector gather's blocks (256 scalar rows each), cut by incidences
 	// Inside each window the contributions are stored reordered by
 	// element (lanes that read the same element state sit next to each other): d_blk_src[c] = e*n_loc^2 + i*n_loc + j of
 	// the contribution computed by lane c - window start, d_blk_slot[c] = its position in the window in block order.

@@ -18,6 +18,8 @@
 #include "pfx_internal.h"
 
 #include <rocprim/rocprim.hpp>
+#include <map>
+#include <algorithm>
 
 namespace
 {
@@ -467,6 +469,29 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 	PFX_HIP(hipStreamSynchronize(st));
 	PFX_HIP(hipGetLastError());
+	// XCD ranges of the vector gather (one block per 256 scalar rows), cut by the number of incidences the rows sum: the
+	// few entries of ne_ptr the bisection looks at are read from the device one by one
+	{
+		const int64_t bs = ctx->bs, n_rows = n_nodes * bs, n_blk = (n_rows + 255) / 256;
+		std::map<int64_t, int64_t> seen;
+		hipError_t err = hipSuccess;
+		auto ne_at = [&](int64_t node) {
+			auto it = seen.find(node);
+			if (it != seen.end())
+				return it->second;
+			int64_t v = 0;
+			const hipError_t e = hipMemcpy(&v, ctx->d_ne_ptr + node, sizeof(int64_t), hipMemcpyDeviceToHost);
+			if (e != hipSuccess)
+				err = e;
+			seen[node] = v;
+			return v;
+		};
+		ctx->gv_split = pfx_make_xcd_split(n_blk, [&](int64_t k) {
+			const int64_t node = std::min(n_nodes, (k * 256) / bs);
+			return (double)ne_at(node) * (double)bs + 8.0 * (double)k;
+		});
+		PFX_HIP(err);
+	}
 	return PFX_OK;
 }
 
