@@ -181,7 +181,7 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
         if workload == "transient":
             # consecutive time steps of one simulation: x and vel carry over
             newton_info.update(eng.implicit_euler_step_dev(args.dt, x.data_ptr(), vel.data_ptr(), acc.data_ptr(), gravity.data_ptr(),
-                                                           cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol))
+                                                           cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol, cg_precond=args.precond))
             return newton_info["cg_iterations"], newton_info["grad_norm"]
         if dnewton is not None:
             x.zero_()
@@ -189,7 +189,8 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
             return newton_info["cg_iterations"], newton_info["grad_norm"]
         if workload == "newton":
             x.zero_()
-            newton_info.update(eng.newton_solve_dev(x.data_ptr(), load.data_ptr(), cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol))
+            newton_info.update(eng.newton_solve_dev(x.data_ptr(), load.data_ptr(), cg_max_iter=args.cg_max_iter, cg_tol=args.cg_tol,
+                                                    cg_precond=args.precond))
             return newton_info["cg_iterations"], newton_info["grad_norm"]
         if nonlinear:
             eng.hessian_dev(u.data_ptr())
@@ -317,11 +318,11 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
             "pattern_build_s": t_pattern,
         }
         if workload == "transient":
-            out["config"]["workload"] = (f"NeoHookean implicit Euler time step (dt {args.dt:g}, Newton + backtracking, Jacobi-CG tol {args.cg_tol:g} "
+            out["config"]["workload"] = (f"NeoHookean implicit Euler time step (dt {args.dt:g}, Newton + backtracking, {pname}-CG tol {args.cg_tol:g} "
                                          f"max_iter {args.cg_max_iter}), {shape}")
             out["newton"] = dict(newton_info)
         if workload == "newton":
-            out["config"]["workload"] = (f"NeoHookean Newton solve (backtracking line search, Jacobi-CG tol {args.cg_tol:g} max_iter "
+            out["config"]["workload"] = (f"NeoHookean Newton solve (backtracking line search, {pname}-CG tol {args.cg_tol:g} max_iter "
                                          f"{args.cg_max_iter} per step), {shape}")
             out["newton"] = dict(newton_info)
     # the same system solved to convergence with the AMG preconditioner (non-default option; N = 1, elastic workloads)
