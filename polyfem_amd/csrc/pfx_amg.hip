@@ -1075,8 +1075,13 @@ namespace
 			if (l == 0)
 			{
 				// level 0 works on the caller's vectors (b = r, x = z) and the solver's scratch; its own are the Chebyshev pair
-				if (par.relax_degree > 1 && (pfx_alloc(ctx, &L.d_r, n) || pfx_alloc(ctx, &L.d_dv, n)))
-					return PFX_ERR_HIP;
+				if (par.relax_degree > 1)
+				{
+					if (pfx_alloc(ctx, &L.d_r, n) || pfx_alloc(ctx, &L.d_dv, n))
+						return PFX_ERR_HIP;
+					// entries of halo nodes are read by the level-0 product and never written: they stay zero
+					PFX_HIP(hipMemsetAsync(L.d_dv, 0, sizeof(double) * (size_t)n, st));
+				}
 				continue;
 			}
 			if (pfx_alloc(ctx, &L.d_b, n) || pfx_alloc(ctx, &L.d_x, n) || pfx_alloc(ctx, &L.d_t, n) || pfx_alloc(ctx, &L.d_dinv, n) || pfx_alloc(ctx, &L.d_b2, n) || pfx_alloc(ctx, &L.d_x2, n))
@@ -1212,6 +1217,8 @@ namespace
 		for (size_t l = 0; l + 1 < A->lv.size(); ++l)
 		{
 			pfx_amg_level &L = A->lv[l];
+			if (l == 0 && ctx->n_owned < ctx->n_nodes) // the level-0 operator is the owned-owned block: halo entries of the vector it is applied to are zero
+				PFX_HIP(hipMemsetAsync(scratch_v + ctx->n_owned * 3, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * 3), st));
 			pfx_status rc = (l == 0) ? amg_lambda_max(ctx, A, L, scratch_v, scratch_t, dinv0, ctx->n_owned * 3) : amg_lambda_max(ctx, A, L, L.d_x, L.d_t, L.d_dinv, L.n_dofs);
 			if (rc)
 				return rc;
@@ -1433,8 +1440,6 @@ pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, doubl
 {
 	if (ctx->bs != 3)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner is implemented for vector-valued problems (block size 3)");
-	if (ctx->n_owned != ctx->n_nodes)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner runs on an unpartitioned mesh");
 	pfx_status rc = pfx_sell_refresh(ctx);
 	if (rc)
 		return rc;
@@ -1475,6 +1480,8 @@ pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max
 	const int64_t n = ctx->n_owned * ctx->bs;
 	const int64_t nfull = ctx->n_dofs();
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+	if (ctx->n_owned != ctx->n_nodes)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "this loop has no halo exchange: on a partitioned mesh the caller drives the iteration and applies the preconditioner with pfx_amg_apply_dev");
 	if (ctx->d_work_ext)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG-preconditioned solve uses the context's own workspace (clear pfx_cgs_set_workspace first)");
 	if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * nfull))
@@ -1535,6 +1542,19 @@ pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max
 	return PFX_OK;
 }
 
+namespace
+{
+	// the solver's four vectors [r | p | t | 1/diag]: the caller's workspace (pfx_cgs_set_workspace) or the context's own
+	double *amg_workspace(pfx_ctx *ctx)
+	{
+		if (ctx->d_work_ext)
+			return ctx->d_work_ext;
+		if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * ctx->n_dofs()))
+			return nullptr;
+		return ctx->d_work;
+	}
+} // namespace
+
 extern "C"
 {
 	void pfx_amg_default_params(pfx_amg_params *p)
@@ -1571,11 +1591,10 @@ extern "C"
 			PFX_FAIL(PFX_ERR_ARG, "pfx_build_pattern must be called first");
 		PFX_HIP(hipSetDevice(ctx->device));
 		const int64_t nfull = ctx->n_dofs();
-		if (ctx->d_work_ext)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner uses the context's own workspace");
-		if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * nfull))
+		double *base = amg_workspace(ctx);
+		if (!base)
 			return PFX_ERR_HIP;
-		return pfx_amg_prepare(ctx, ctx->d_work + 3 * nfull, ctx->d_work + nfull, ctx->d_work + 2 * nfull);
+		return pfx_amg_prepare(ctx, base + 3 * nfull, base + nfull, base + 2 * nfull);
 	}
 
 	pfx_status pfx_amg_get_info(pfx_ctx *ctx, pfx_amg_info *info)
@@ -1620,6 +1639,11 @@ extern "C"
 		if (rc)
 			return rc;
 		const int64_t nfull = ctx->n_dofs();
-		return pfx_amg_apply(ctx, d_r, d_z, ctx->d_work + 2 * nfull, ctx->d_work + 3 * nfull);
+		double *base = amg_workspace(ctx);
+		// the preconditioner is that of the owned-owned block: the entries of halo nodes of z take part in the level-0
+		// products as zeros
+		if (ctx->n_owned < ctx->n_nodes)
+			PFX_HIP(hipMemsetAsync(d_z + ctx->n_owned * 3, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * 3), ctx->stream));
+		return pfx_amg_apply(ctx, d_r, d_z, base + 2 * nfull, base + 3 * nfull);
 	}
 }

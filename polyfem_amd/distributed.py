@@ -344,6 +344,14 @@ class HipOps:
     def status(self):
         return self.e.cgs_status()
 
+    # ---- block-Jacobi AMG preconditioner (one hierarchy per rank, on the rows and columns the rank owns) ----
+    def amg_setup(self):
+        self.e.amg_setup()
+
+    def amg_apply(self, r, z):
+        """z[owned rows] = M^-1 r, M = this rank's AMG cycle for its owned-owned block; r, z: local vectors."""
+        self.e.amg_apply_dev(r.data_ptr(), z.data_ptr())
+
     # ---- nonlinear pieces (DistributedNewton) ----
     def energy(self, x, out):
         """out[0] = energy of the elements this rank sums (pfx_set_owned's flags)."""
@@ -374,7 +382,12 @@ class HipOps:
 
 
 class DistributedCG:
-    """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition."""
+    """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition.
+
+    precond = 2 (PFX_PRECOND_AMG) preconditions with one AMG hierarchy per rank, built on the block of the matrix whose
+    rows and columns the rank owns (block-Jacobi over the ranks: couplings across a partition boundary are left to the
+    Krylov iteration, so the iteration count grows slowly with the number of ranks; no communication inside the
+    preconditioner)."""
 
     def __init__(self, ops, part: Part, bs: int, comm: Comm, device):
         import torch
@@ -404,6 +417,8 @@ class DistributedCG:
         ops, scal, ar = self.ops, self.scal, self.comm.all_reduce_sum
         if hasattr(ops, "check_stream"):
             ops.check_stream()
+        if precond == 2:
+            return self._solve_amg(b, x, max_iter, tol)
         ops.prepare(x, precond)
         self.halo(x.view(self.n_local, self.bs))
         ops.residual(b, x, scal)
@@ -429,6 +444,62 @@ class DistributedCG:
         if max_iter <= 0:
             done, iters, rr, bb = ops.status()
         return iters, (0.0 if bb == 0.0 else float(np.sqrt(rr / bb)))
+
+
+    def _solve_amg(self, b, x, max_iter, tol):
+        """Preconditioned CG with z = M^-1 r from ops.amg_apply; same stopping rule and iteration count convention as
+        the Jacobi loop (|r|^2 < tol^2 |b|^2 tested before the direction update).  The scalars of an iteration are read
+        on the host (one synchronisation per iteration, small against the cost of a cycle)."""
+        t, ops, ar = self.torch, self.ops, self.comm.all_reduce_sum
+        if not hasattr(ops, "amg_apply"):
+            raise NotImplementedError("this back end has no AMG preconditioner")
+        n, no = self.n, self.part.n_owned * self.bs
+        scal = self.scal
+        ops.prepare(x, 1)  # constrained dofs of the guess zeroed, solver copy of the matrix current
+        ops.amg_setup()    # may use the direction vector as scratch: before p is first written
+        self.halo(x.view(self.n_local, self.bs))
+        ops.residual(b, x, scal)
+        ar(scal[0:2])
+        bb, rr = (float(v) for v in scal[0:2].tolist())
+        if bb == 0.0:
+            x.zero_()
+            return 0, 0.0
+        thr = max(tol * tol * bb, np.finfo(np.float64).tiny)
+        if rr < thr:
+            return 0, float(np.sqrt(rr / bb))
+        r_full = self.work[0:n]
+        r, p, ap = self.work[0:no], self.work[n:n + no], self.work[2 * n:2 * n + no]
+        if getattr(self, "z", None) is None:
+            self.z = t.zeros(n, dtype=t.float64, device=self.work.device)
+        z_full, z = self.z, self.z[0:no]
+        xo = x[0:no]
+        ops.amg_apply(r_full, z_full)
+        p.copy_(z)
+        scal[2] = t.dot(r, z)
+        ar(scal[2:3])
+        rz = float(scal[2].item())
+        iters = 0
+        for it in range(max_iter):
+            pending = self.halo.start(self.p_nodes)
+            ops.spmv_interior()
+            self.halo.finish(pending)
+            ops.spmv_boundary(scal)  # scal[0] = local p.Ap
+            ar(scal[0:1])
+            alpha = rz / scal[0]     # device scalar
+            xo.addcmul_(p, alpha)
+            r.addcmul_(ap, alpha, value=-1.0)
+            ops.amg_apply(r_full, z_full)
+            scal[1] = t.dot(r, r)
+            scal[2] = t.dot(r, z)
+            ar(scal[1:3])
+            rr, rz_new = (float(v) for v in scal[1:3].tolist())
+            if rr < thr:
+                iters = it
+                break
+            p.mul_(rz_new / rz).add_(z)
+            rz = rz_new
+            iters = it + 1
+        return iters, float(np.sqrt(rr / bb))
 
 
 # ------------------------------------------------------------------------------------------------------------
