@@ -7,7 +7,8 @@
 // structure the assembler already has.  Jacobi stays the default preconditioner (Eigen parity).
 //
 // Hierarchy.  Level 0 = the assembled matrix (vertices = mesh nodes, 3 dofs each).  A level is coarsened by
-// `aggregate_passes` rounds of greedy pairwise matching on the vertex graph (weights = number of fine connections), so
+// `aggregate_passes` rounds of pairwise matching on the vertex graph (weights = number of fine connections; the first
+// round of a level, where all weights are equal, pairs nearest neighbours; pfx_amg_graph.hip), so
 // aggregates hold up to 2^passes vertices.  Every aggregate carries the six rigid-body modes of its vertices about the
 // aggregate's centre c: a translation T and a rotation W, u(x) = T + W x (x - c).  They are stored as TWO coarse nodes
 // of 3 dofs (node 2a = T, node 2a+1 = W), so every level is again a node-block matrix with 3x3 blocks and reuses the
@@ -23,208 +24,22 @@
 // D^-1 A on [relax_lower * lmax, lmax] before and after the coarse correction (lmax by a few Lanczos steps), V or W cycle,
 // dense inverse at the coarsest level.  Same polynomial before and after: M is symmetric positive definite.
 //
-// The symbolic part (matching, coarse patterns, Galerkin lists) runs on the host, once per pattern and Dirichlet set;
-// the numeric part (Galerkin products, diagonals, spectral radii, coarsest inverse) on the device at every new matrix.
+// The symbolic part (matching, coarse patterns, Galerkin lists) runs once per pattern and Dirichlet set, the numeric
+// part (Galerkin products, diagonals, spectral radii, coarsest inverse) at every new matrix; both on the device, except
+// for the dense inverse of the coarsest matrix (a few hundred dofs).
 #include "pfx_internal.h"
+#include "pfx_amg_graph.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cfloat>
-#include <numeric>
-#include <thread>
 
 #define AMG_MAX_LEVELS 16
 #define AMG_NPART 256
 
 namespace
 {
-	// ---------------------------------------------------------------------------------------------------------
-	// host side: graphs, matching, quotient graphs
-	// ---------------------------------------------------------------------------------------------------------
-	struct hgraph
-	{
-		int64_t n = 0;
-		std::vector<int64_t> ptr;
-		std::vector<int32_t> col;
-		std::vector<int32_t> w; // empty: every edge has weight 1
-	};
-
-	struct qentry
-	{
-		int32_t b;  // coarse column
-		int32_t w;  // weight
-		uint32_t e; // fine edge index
-		int32_t i;  // fine row vertex
-	};
-
-	int host_threads()
-	{
-		unsigned h = std::thread::hardware_concurrency();
-		if (const char *e = getenv("OMP_NUM_THREADS"))
-			if (atoi(e) > 0)
-				h = (unsigned)atoi(e);
-		if (h < 1)
-			h = 1;
-		if (h > 16)
-			h = 16;
-		return (int)h;
-	}
-
-	// Quotient of the graph (n, ptr, col, w) by `map` (vertex -> coarse vertex in [0, nc), or -1 = dropped): edge (a, b)
-	// for every fine edge (i, j) with both ends kept, weight = sum of the fine weights, self loops kept, columns
-	// ascending.  With pair_ptr: also the list, per coarse edge, of the fine edges behind it (fine row ascending, then
-	// fine edge ascending) and their row vertices.
-	void quotient(int64_t n, const int64_t *ptr, const int32_t *col, const int32_t *w, const std::vector<int32_t> &map, int64_t nc, hgraph &out,
-				  std::vector<int64_t> *pair_ptr, std::vector<uint32_t> *pair_src, std::vector<int32_t> *pair_row)
-	{
-		// members of every coarse vertex, ascending
-		std::vector<int64_t> mptr((size_t)nc + 1, 0);
-		for (int64_t i = 0; i < n; ++i)
-			if (map[(size_t)i] >= 0)
-				mptr[(size_t)map[(size_t)i] + 1]++;
-		for (int64_t a = 0; a < nc; ++a)
-			mptr[(size_t)a + 1] += mptr[(size_t)a];
-		std::vector<int32_t> mlist((size_t)mptr[(size_t)nc]);
-		{
-			std::vector<int64_t> fill(mptr.begin(), mptr.end() - 1);
-			for (int64_t i = 0; i < n; ++i)
-				if (map[(size_t)i] >= 0)
-					mlist[(size_t)fill[(size_t)map[(size_t)i]]++] = (int32_t)i;
-		}
-		const int T = host_threads();
-		struct part
-		{
-			std::vector<int64_t> deg;
-			std::vector<int32_t> col, w;
-			std::vector<int64_t> plen;
-			std::vector<uint32_t> psrc;
-			std::vector<int32_t> prow;
-		};
-		std::vector<part> parts((size_t)T);
-		const bool lists = pair_ptr != nullptr;
-		auto work = [&](int t) {
-			const int64_t a0 = nc * t / T, a1 = nc * (t + 1) / T;
-			part &p = parts[(size_t)t];
-			p.deg.reserve((size_t)(a1 - a0));
-			std::vector<qentry> buf;
-			for (int64_t a = a0; a < a1; ++a)
-			{
-				buf.clear();
-				for (int64_t k = mptr[(size_t)a]; k < mptr[(size_t)a + 1]; ++k)
-				{
-					const int32_t i = mlist[(size_t)k];
-					for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e)
-					{
-						const int32_t b = map[(size_t)col[e]];
-						if (b >= 0)
-							buf.push_back({b, w ? w[e] : 1, (uint32_t)e, i});
-					}
-				}
-				std::stable_sort(buf.begin(), buf.end(), [](const qentry &x, const qentry &y) { return x.b < y.b; });
-				int64_t d = 0;
-				for (size_t k = 0; k < buf.size();)
-				{
-					size_t k2 = k;
-					int64_t ws = 0;
-					while (k2 < buf.size() && buf[k2].b == buf[k].b)
-					{
-						ws += buf[k2].w;
-						if (lists)
-						{
-							p.psrc.push_back(buf[k2].e);
-							p.prow.push_back(buf[k2].i);
-						}
-						++k2;
-					}
-					p.col.push_back(buf[k].b);
-					p.w.push_back((int32_t)(ws > INT32_MAX ? INT32_MAX : ws));
-					if (lists)
-						p.plen.push_back((int64_t)(k2 - k));
-					++d;
-					k = k2;
-				}
-				p.deg.push_back(d);
-			}
-		};
-		{
-			std::vector<std::thread> th;
-			for (int t = 1; t < T; ++t)
-				th.emplace_back(work, t);
-			work(0);
-			for (auto &x : th)
-				x.join();
-		}
-		out.n = nc;
-		out.ptr.assign((size_t)nc + 1, 0);
-		int64_t a = 0, tot = 0, ptot = 0;
-		for (auto &p : parts)
-		{
-			for (int64_t d : p.deg)
-			{
-				out.ptr[(size_t)a + 1] = out.ptr[(size_t)a] + d;
-				++a;
-			}
-			tot += (int64_t)p.col.size();
-			ptot += (int64_t)p.psrc.size();
-		}
-		out.col.resize((size_t)tot);
-		out.w.resize((size_t)tot);
-		if (lists)
-		{
-			pair_ptr->assign((size_t)tot + 1, 0);
-			pair_src->resize((size_t)ptot);
-			pair_row->resize((size_t)ptot);
-		}
-		int64_t at = 0, pat = 0;
-		for (auto &p : parts)
-		{
-			std::copy(p.col.begin(), p.col.end(), out.col.begin() + at);
-			std::copy(p.w.begin(), p.w.end(), out.w.begin() + at);
-			if (lists)
-			{
-				for (size_t k = 0; k < p.plen.size(); ++k)
-					(*pair_ptr)[(size_t)at + k + 1] = p.plen[k];
-				std::copy(p.psrc.begin(), p.psrc.end(), pair_src->begin() + pat);
-				std::copy(p.prow.begin(), p.prow.end(), pair_row->begin() + pat);
-				pat += (int64_t)p.psrc.size();
-			}
-			at += (int64_t)p.col.size();
-			p = part();
-		}
-		if (lists)
-			for (int64_t k = 0; k < tot; ++k)
-				(*pair_ptr)[(size_t)k + 1] += (*pair_ptr)[(size_t)k];
-	}
-
-	// One round of greedy pairwise matching in vertex order: an unmatched vertex takes its unmatched neighbour of the
-	// largest weight (the first of equals); without one it stays alone.  Returns the number of clusters.
-	int64_t match_pass(int64_t n, const int64_t *ptr, const int32_t *col, const int32_t *w, const uint8_t *excluded, std::vector<int32_t> &m)
-	{
-		m.assign((size_t)n, -1);
-		int64_t k = 0;
-		for (int64_t i = 0; i < n; ++i)
-		{
-			if ((excluded && excluded[i]) || m[(size_t)i] >= 0)
-				continue;
-			int32_t best = -1, bw = -1;
-			for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e)
-			{
-				const int32_t j = col[e];
-				if (j == i || (excluded && excluded[j]) || m[(size_t)j] >= 0)
-					continue;
-				const int32_t we = w ? w[e] : 1;
-				if (we > bw)
-					bw = we, best = j;
-			}
-			m[(size_t)i] = (int32_t)k;
-			if (best >= 0)
-				m[(size_t)best] = (int32_t)k;
-			++k;
-		}
-		return k;
-	}
-
 	// ---------------------------------------------------------------------------------------------------------
 	// device kernels
 	// ---------------------------------------------------------------------------------------------------------
@@ -762,9 +577,6 @@ struct pfx_amg_level
 	int32_t *d_cp_arow = nullptr; // coarse pair -> its aggregate row
 	int64_t *d_gptr = nullptr;    // this level's vertex graph (levels > 0: pair structure of the matrix; level 0: unused)
 	int32_t *d_gcol = nullptr;
-	std::vector<int32_t> h_agg;
-	std::vector<int64_t> h_gptr; // host copy of the level's vertex graph (levels > 0)
-	std::vector<int32_t> h_gcol;
 	// vectors
 	double *d_b = nullptr, *d_x = nullptr, *d_t = nullptr, *d_r = nullptr, *d_dv = nullptr, *d_b2 = nullptr, *d_x2 = nullptr, *d_dinv = nullptr;
 	double lmax = 0;
@@ -830,6 +642,79 @@ namespace
 		return PFX_OK;
 	}
 
+	// ---- kernels of the symbolic phase -----------------------------------------------------------------------
+	// vertices left out of the aggregation at level 0: halo nodes and nodes whose three dofs are all constrained
+	__global__ void k_excluded(const uint8_t *__restrict__ fixed, int64_t n_nodes, int64_t n_owned, uint8_t *__restrict__ excl)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
+			excl[g] = (g >= n_owned) || (fixed && fixed[3 * g] && fixed[3 * g + 1] && fixed[3 * g + 2]);
+	}
+
+	// centre of every aggregate: mean of its members' positions, summed in member order
+	__global__ void k_centres(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ vpos, int64_t n_agg,
+							  double *__restrict__ centre)
+	{
+		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < n_agg; a += (int64_t)gridDim.x * blockDim.x)
+		{
+			double c[3] = {0, 0, 0};
+			const int64_t k0 = mptr[a], k1 = mptr[a + 1];
+			for (int64_t k = k0; k < k1; ++k)
+			{
+				const int64_t v = mlist[k];
+				c[0] += vpos[3 * v], c[1] += vpos[3 * v + 1], c[2] += vpos[3 * v + 2];
+			}
+			const double cnt = (double)(k1 - k0);
+			centre[3 * a] = c[0] / cnt, centre[3 * a + 1] = c[1] / cnt, centre[3 * a + 2] = c[2] / cnt;
+		}
+	}
+
+	__global__ void k_offsets(const int32_t *__restrict__ agg, const double *__restrict__ vpos, const double *__restrict__ centre, int64_t n_vert,
+							  double *__restrict__ dvec)
+	{
+		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t a = agg[v];
+			for (int q = 0; q < 3; ++q)
+				dvec[3 * v + q] = a >= 0 ? vpos[3 * v + q] - centre[3 * a + q] : 0.0;
+		}
+	}
+
+	// node-block pattern of a coarse level: two nodes (translation, rotation) per aggregate; the blocks of coarse edge k
+	// of aggregate a (slot s = k - gptr[a], deg = its number of edges) sit at 4 gptr[a] + alpha * 2 deg + 2 s + beta
+	__global__ void k_coarse_pattern(const int64_t *__restrict__ gptr, const int32_t *__restrict__ gcol, int64_t n_agg, int64_t *__restrict__ nptr,
+									 int32_t *__restrict__ ncol)
+	{
+		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a <= n_agg; a += (int64_t)gridDim.x * blockDim.x)
+		{
+			if (a == n_agg)
+			{
+				nptr[2 * n_agg] = 4 * gptr[n_agg];
+				continue;
+			}
+			const int64_t g0 = gptr[a], deg = gptr[a + 1] - g0;
+			nptr[2 * a] = 4 * g0;
+			nptr[2 * a + 1] = 4 * g0 + 2 * deg;
+			for (int64_t k = 0; k < deg; ++k)
+			{
+				const int32_t c = gcol[g0 + k];
+				for (int al = 0; al < 2; ++al)
+					for (int be = 0; be < 2; ++be)
+						ncol[4 * g0 + al * 2 * deg + 2 * k + be] = 2 * c + be;
+			}
+		}
+	}
+
+	// moves a temporary buffer into an allocation the context accounts for (device-to-device copy of `count` entries)
+	template <typename T>
+	pfx_status keep(pfx_ctx *ctx, T **dst, const T *src, int64_t count)
+	{
+		if (pfx_alloc(ctx, dst, count))
+			return PFX_ERR_HIP;
+		if (count > 0)
+			PFX_HIP(hipMemcpyAsync(*dst, src, sizeof(T) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
+		return PFX_OK;
+	}
+
 	pfx_status amg_symbolic(pfx_ctx *ctx)
 	{
 		const double t_begin = now_s();
@@ -839,12 +724,9 @@ namespace
 		const pfx_amg_params &par = ctx->amg_params;
 		hipStream_t st = ctx->stream;
 		const int64_t n_nodes = ctx->n_nodes, n_owned = ctx->n_owned;
+		pfx_status rc;
 
-		// level-0 graph and node positions on the host
-		std::vector<int64_t> ptr0((size_t)n_nodes + 1);
-		std::vector<int32_t> col0((size_t)ctx->n_blocks);
-		std::vector<uint8_t> fixed((size_t)ctx->n_dofs(), 0);
-		std::vector<double> pos((size_t)n_nodes * 3);
+		// level-0 node positions and the vertices left out of the aggregation
 		if (pfx_alloc(ctx, &A->d_pos, n_nodes * 3))
 			return PFX_ERR_HIP;
 		{
@@ -853,27 +735,21 @@ namespace
 			pfx_local_node_positions(ctx->kind, &ref.n_loc, &ref.n_gloc, lp, ref.gval);
 			hipLaunchKernelGGL(k_node_positions, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->d_ne_ptr, ctx->d_ne_src, ctx->d_gconn, ctx->d_xyz, ref, n_nodes, A->d_pos);
 		}
-		PFX_HIP(hipMemcpyAsync(ptr0.data(), ctx->d_node_ptr, sizeof(int64_t) * ptr0.size(), hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipMemcpyAsync(col0.data(), ctx->d_node_col, sizeof(int32_t) * col0.size(), hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipMemcpyAsync(pos.data(), A->d_pos, sizeof(double) * pos.size(), hipMemcpyDeviceToHost, st));
-		if (ctx->n_dirichlet > 0)
-			PFX_HIP(hipMemcpyAsync(fixed.data(), ctx->d_fixed, fixed.size(), hipMemcpyDeviceToHost, st));
-		PFX_HIP(hipStreamSynchronize(st));
+		pfx_tmp<uint8_t> excluded;
+		PFX_HIP(excluded.alloc((size_t)n_nodes));
+		hipLaunchKernelGGL(k_excluded, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->n_dirichlet > 0 ? (const uint8_t *)ctx->d_fixed : (const uint8_t *)nullptr, n_nodes, n_owned,
+						   excluded.p);
 
-		// vertices left out at level 0: halo nodes and nodes whose three dofs are all constrained
-		std::vector<uint8_t> excluded((size_t)n_nodes, 0);
-		for (int64_t g = 0; g < n_nodes; ++g)
-			excluded[(size_t)g] = (g >= n_owned) || (fixed[(size_t)(3 * g)] && fixed[(size_t)(3 * g + 1)] && fixed[(size_t)(3 * g + 2)]);
-
-		// current level as host data
+		// the level being coarsened: its vertex graph (level 0: the node-block pattern itself) and vertex positions
+		pfx_dgraph g;
+		g.n = n_nodes, g.ne = ctx->n_blocks, g.ptr = ctx->d_node_ptr, g.col = ctx->d_node_col, g.w = nullptr;
+		pfx_dgraph_own glevel; // owns the graph of levels > 0 while they are coarsened
+		pfx_tmp<double> centre_prev;
+		const double *vpos = A->d_pos;
 		int64_t n_vert = n_nodes;
-		const int64_t *gptr = ptr0.data();
-		const int32_t *gcol = col0.data();
-		hgraph glevel; // owns the graph of levels > 0
-		std::vector<double> vpos = pos;
 		A->work_blocks = ctx->n_blocks;
 
-		pfx_amg_level L; // the level being coarsened
+		pfx_amg_level L;
 		L.m = ctx;
 		L.own_m = false;
 		L.n_vert = n_vert;
@@ -887,133 +763,82 @@ namespace
 				A->lv.push_back(L);
 				break;
 			}
-			// ---- aggregation by repeated pairwise matching
-			std::vector<int32_t> cur((size_t)n_vert), m;
-			hgraph gq;
+			// ---- aggregation by repeated pairwise matching: every round matches the clusters of the round before
+			pfx_tmp<int32_t> cur, m, csize;
+			pfx_tmp<double> ppos, ppos_next; // positions of the clusters of the last round
+			PFX_HIP(cur.alloc((size_t)n_vert));
+			pfx_dgraph_own gq;
 			int64_t nc = 0;
 			for (int pass = 0; pass < par.aggregate_passes; ++pass)
 			{
+				const uint64_t seed = (uint64_t)level * 16 + (uint64_t)pass + 1;
 				if (pass == 0)
 				{
-					nc = match_pass(n_vert, gptr, gcol, level0 ? nullptr : glevel.w.data(), level0 ? excluded.data() : nullptr, m);
-					cur = m;
+					if ((rc = pfx_graph_match(ctx, g, level0 ? excluded.p : nullptr, vpos, nullptr, seed, cur.p, &nc, &ppos)))
+						return rc;
 				}
 				else
 				{
-					nc = match_pass(gq.n, gq.ptr.data(), gq.col.data(), gq.w.data(), nullptr, m);
-					for (int64_t v = 0; v < n_vert; ++v)
-						if (cur[(size_t)v] >= 0)
-							cur[(size_t)v] = m[(size_t)cur[(size_t)v]];
+					PFX_HIP(m.alloc((size_t)gq.n));
+					PFX_HIP(csize.alloc((size_t)gq.n));
+					if ((rc = pfx_graph_cluster_sizes(ctx, n_vert, cur.p, gq.n, csize.p)) || (rc = pfx_graph_match(ctx, gq.view(), nullptr, ppos.p, csize.p, seed, m.p, &nc, &ppos_next))
+						|| (rc = pfx_graph_compose(ctx, n_vert, cur.p, m.p)))
+						return rc;
+					ppos.reset();
+					ppos.p = ppos_next.p, ppos_next.p = nullptr;
 				}
-				hgraph next;
-				quotient(n_vert, gptr, gcol, level0 ? nullptr : glevel.w.data(), cur, nc, next, nullptr, nullptr, nullptr);
-				gq = std::move(next);
+				// the clusters' graph: quotient of the previous round's (same graph as the quotient of the level's graph by `cur`)
+				pfx_dgraph_own next;
+				if (pass == 0)
+					rc = pfx_graph_quotient(ctx, g, cur.p, nc, next, nullptr);
+				else
+					rc = pfx_graph_quotient(ctx, gq.view(), m.p, nc, next, nullptr);
+				if (rc)
+					return rc;
+				gq.take(next);
 				if (nc <= 1)
 					break;
 			}
-			// level 0: aggregates of fewer than three nodes cannot carry the rotations; merge them into their strongest
-			// neighbour
+			// level 0: aggregates of fewer than three nodes cannot carry the rotations; they join their strongest neighbour
 			if (level0 && nc > 1)
-			{
-				std::vector<int64_t> size((size_t)nc, 0);
-				for (int64_t v = 0; v < n_vert; ++v)
-					if (cur[(size_t)v] >= 0)
-						size[(size_t)cur[(size_t)v]]++;
-				std::vector<int32_t> root((size_t)nc);
-				std::iota(root.begin(), root.end(), 0);
-				auto find = [&](int32_t a) {
-					while (root[(size_t)a] != a)
-						a = root[(size_t)a] = root[(size_t)root[(size_t)a]];
-					return a;
-				};
-				bool any = false;
-				for (int64_t a = 0; a < nc; ++a)
-				{
-					if (size[(size_t)find((int32_t)a)] >= 3)
-						continue;
-					const int32_t ra = find((int32_t)a);
-					int32_t best = -1, bw = -1;
-					for (int64_t e = gq.ptr[(size_t)a]; e < gq.ptr[(size_t)a + 1]; ++e)
-					{
-						const int32_t rb = find(gq.col[(size_t)e]);
-						if (rb == ra)
-							continue;
-						if (gq.w[(size_t)e] > bw)
-							bw = gq.w[(size_t)e], best = rb;
-					}
-					if (best >= 0)
-					{
-						root[(size_t)ra] = best;
-						size[(size_t)best] += size[(size_t)ra];
-						any = true;
-					}
-				}
-				if (any)
-				{
-					std::vector<int32_t> renum((size_t)nc, -1);
-					int32_t k = 0;
-					for (int64_t a = 0; a < nc; ++a)
-						if (find((int32_t)a) == a)
-							renum[(size_t)a] = k++;
-					for (int64_t v = 0; v < n_vert; ++v)
-						if (cur[(size_t)v] >= 0)
-							cur[(size_t)v] = renum[(size_t)find(cur[(size_t)v])];
-					nc = k;
-				}
-			}
+				if ((rc = pfx_graph_merge_small(ctx, n_vert, cur.p, &nc, gq.view(), 3)))
+					return rc;
+			gq.ptr.reset(), gq.col.reset(), gq.w.reset();
+			m.reset();
+			csize.reset();
+			ppos.reset();
 			if (nc < 1 || (!level0 && nc * 10 > n_vert * 8)) // no free vertex, or the coarsening stalls
 			{
 				A->lv.push_back(L);
 				break;
 			}
 			// ---- coarse graph with the Galerkin lists
-			hgraph gc;
-			std::vector<int64_t> pair_ptr;
-			std::vector<uint32_t> pair_src;
-			std::vector<int32_t> pair_row;
-			quotient(n_vert, gptr, gcol, level0 ? nullptr : glevel.w.data(), cur, nc, gc, &pair_ptr, &pair_src, &pair_row);
-			const int64_t n_cp = (int64_t)gc.col.size();
-			std::vector<int32_t> arow((size_t)n_cp);
-			for (int64_t a = 0; a < nc; ++a)
-				for (int64_t e = gc.ptr[(size_t)a]; e < gc.ptr[(size_t)a + 1]; ++e)
-					arow[(size_t)e] = (int32_t)a;
+			pfx_dgraph_own gc;
+			pfx_quot_lists lists;
+			if ((rc = pfx_graph_quotient(ctx, g, cur.p, nc, gc, &lists)))
+				return rc;
+			const int64_t n_cp = gc.ne;
+			if (getenv("PFX_AMG_VERBOSE"))
+				fprintf(stderr, "[pfx amg] level %d: %lld vertices, %lld edges -> %lld aggregates, %lld coarse edges, %lld pairs (%.3f s)\n", level, (long long)n_vert,
+						(long long)g.ne, (long long)nc, (long long)n_cp, (long long)lists.n_pairs, now_s() - t_begin);
 			// ---- members, centres, offsets
-			std::vector<int64_t> mptr((size_t)nc + 1, 0);
-			for (int64_t v = 0; v < n_vert; ++v)
-				if (cur[(size_t)v] >= 0)
-					mptr[(size_t)cur[(size_t)v] + 1]++;
-			for (int64_t a = 0; a < nc; ++a)
-				mptr[(size_t)a + 1] += mptr[(size_t)a];
-			std::vector<int32_t> mlist((size_t)mptr[(size_t)nc]);
-			{
-				std::vector<int64_t> fill(mptr.begin(), mptr.end() - 1);
-				for (int64_t v = 0; v < n_vert; ++v)
-					if (cur[(size_t)v] >= 0)
-						mlist[(size_t)fill[(size_t)cur[(size_t)v]]++] = (int32_t)v;
-			}
-			std::vector<double> centre((size_t)nc * 3, 0.0), dvec((size_t)n_vert * 3, 0.0);
-			for (int64_t a = 0; a < nc; ++a)
-			{
-				double c[3] = {0, 0, 0};
-				const int64_t cnt = mptr[(size_t)a + 1] - mptr[(size_t)a];
-				for (int64_t k = mptr[(size_t)a]; k < mptr[(size_t)a + 1]; ++k)
-					for (int q = 0; q < 3; ++q)
-						c[q] += vpos[(size_t)mlist[(size_t)k] * 3 + q];
-				for (int q = 0; q < 3; ++q)
-					centre[(size_t)a * 3 + q] = c[q] / (double)cnt;
-			}
-			for (int64_t v = 0; v < n_vert; ++v)
-				if (cur[(size_t)v] >= 0)
-					for (int q = 0; q < 3; ++q)
-						dvec[(size_t)v * 3 + q] = vpos[(size_t)v * 3 + q] - centre[(size_t)cur[(size_t)v] * 3 + q];
-			// ---- upload the transfer data of this level
+			pfx_tmp<double> centre;
+			PFX_HIP(centre.alloc((size_t)nc * 3));
+			if (pfx_alloc(ctx, &L.d_mptr, nc + 1) || pfx_alloc(ctx, &L.d_mlist, n_vert) || pfx_alloc(ctx, &L.d_dvec, n_vert * 3))
+				return PFX_ERR_HIP;
+			if ((rc = pfx_graph_members(ctx, n_vert, cur.p, nc, L.d_mptr, L.d_mlist)))
+				return rc;
+			hipLaunchKernelGGL(k_centres, dim3(grid_for(nc)), dim3(256), 0, st, L.d_mptr, L.d_mlist, vpos, nc, centre.p);
+			hipLaunchKernelGGL(k_offsets, dim3(grid_for(n_vert)), dim3(256), 0, st, cur.p, vpos, centre.p, n_vert, L.d_dvec);
+			// ---- the transfer data of this level
 			L.n_agg = nc;
 			L.n_cpairs = n_cp;
-			L.h_agg = cur;
-			if (upload(ctx, &L.d_agg, cur) || upload(ctx, &L.d_dvec, dvec) || upload(ctx, &L.d_mptr, mptr) || upload(ctx, &L.d_mlist, mlist) || upload(ctx, &L.d_cp_ptr, pair_ptr)
-				|| upload(ctx, &L.d_cp_src, pair_src) || upload(ctx, &L.d_cp_row, pair_row) || upload(ctx, &L.d_cp_arow, arow))
+			if (keep(ctx, &L.d_agg, cur.p, n_vert) || keep(ctx, &L.d_cp_ptr, lists.pair_ptr.p, n_cp + 1) || keep(ctx, &L.d_cp_src, lists.pair_src.p, lists.n_pairs)
+				|| keep(ctx, &L.d_cp_row, lists.pair_row.p, lists.n_pairs) || keep(ctx, &L.d_cp_arow, lists.arow.p, n_cp))
 				return PFX_ERR_HIP;
 			PFX_HIP(hipStreamSynchronize(st));
+			lists.pair_ptr.reset(), lists.pair_src.reset(), lists.pair_row.reset(), lists.arow.reset();
+			cur.reset();
 			A->lv.push_back(L);
 
 			// ---- the next level: a matrix holder with the pattern of the coarse pairs (two nodes per aggregate)
@@ -1031,37 +856,27 @@ namespace
 			C.own_m = true;
 			C.n_vert = nc;
 			C.n_dofs = 6 * nc;
-			std::vector<int64_t> nptr((size_t)(2 * nc) + 1);
-			std::vector<int32_t> ncol((size_t)(4 * n_cp));
-			for (int64_t a = 0; a < nc; ++a)
+			if (pfx_alloc(s, &s->d_node_ptr, 2 * nc + 1) || pfx_alloc(s, &s->d_node_col, 4 * n_cp) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nc + 1)
+				|| keep(ctx, &C.d_gcol, gc.col.p, n_cp))
 			{
-				const int64_t g0 = gc.ptr[(size_t)a], deg = gc.ptr[(size_t)a + 1] - g0;
-				nptr[(size_t)(2 * a)] = 4 * g0;
-				nptr[(size_t)(2 * a + 1)] = 4 * g0 + 2 * deg;
-				for (int64_t k = 0; k < deg; ++k)
-					for (int al = 0; al < 2; ++al)
-						for (int be = 0; be < 2; ++be)
-							ncol[(size_t)(4 * g0 + al * 2 * deg + 2 * k + be)] = 2 * gc.col[(size_t)(g0 + k)] + be;
-			}
-			nptr[(size_t)(2 * nc)] = 4 * n_cp;
-			if (upload(s, &s->d_node_ptr, nptr) || upload(s, &s->d_node_col, ncol) || pfx_alloc(s, &s->d_values, s->nnz + 2) || upload(ctx, &C.d_gptr, gc.ptr) || upload(ctx, &C.d_gcol, gc.col))
-			{
-				ctx->err = s->err;
+				if (ctx->err.empty())
+					ctx->err = s->err;
 				A->lv.push_back(C); // released with the hierarchy
 				return PFX_ERR_HIP;
 			}
+			hipLaunchKernelGGL(k_coarse_pattern, dim3(grid_for(nc + 1)), dim3(256), 0, st, C.d_gptr, C.d_gcol, nc, s->d_node_ptr, s->d_node_col);
 			PFX_HIP(hipMemsetAsync(s->d_values, 0, sizeof(double) * (size_t)(s->nnz + 2), st));
 			PFX_HIP(hipStreamSynchronize(st));
-			C.h_gptr = gc.ptr;
-			C.h_gcol = gc.col;
+			PFX_HIP(hipGetLastError());
 			L = C;
 			A->work_blocks += s->n_blocks;
-			// descend
-			glevel = std::move(gc);
-			gptr = glevel.ptr.data();
-			gcol = glevel.col.data();
+			// descend: the coarse graph (with its weights) is the next level's vertex graph, the centres its positions
+			glevel.take(gc);
+			g = glevel.view();
 			n_vert = nc;
-			vpos = centre;
+			centre_prev.reset();
+			centre_prev.p = centre.p, centre.p = nullptr;
+			vpos = centre_prev.p;
 		}
 		// vectors
 		const int64_t n0 = ctx->n_dofs();
@@ -1239,16 +1054,24 @@ namespace
 				PFX_HIP(hipStreamSynchronize(st));
 				std::vector<double> M((size_t)n * n, 0.0), I((size_t)n * n, 0.0);
 				const int64_t nv = L.n_vert;
+				// the coarsest level's vertex graph, read back for the dense matrix
+				std::vector<int64_t> h_gptr((size_t)nv + 1);
+				PFX_HIP(hipMemcpyAsync(h_gptr.data(), L.d_gptr, sizeof(int64_t) * h_gptr.size(), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipStreamSynchronize(st));
+				std::vector<int32_t> h_gcol((size_t)h_gptr[(size_t)nv]);
+				if (!h_gcol.empty())
+					PFX_HIP(hipMemcpyAsync(h_gcol.data(), L.d_gcol, sizeof(int32_t) * h_gcol.size(), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipStreamSynchronize(st));
 				double dmax = 0;
 				for (int64_t a = 0; a < nv; ++a)
 				{
-					const int64_t g0 = L.h_gptr[(size_t)a], deg = L.h_gptr[(size_t)a + 1] - g0;
+					const int64_t g0 = h_gptr[(size_t)a], deg = h_gptr[(size_t)a + 1] - g0;
 					for (int64_t k = 0; k < deg; ++k)
 						for (int al = 0; al < 2; ++al)
 							for (int be = 0; be < 2; ++be)
 							{
 								const double *blk = vals.data() + (4 * g0 + al * 2 * deg + 2 * k + be) * 9;
-								const int64_t r0 = (2 * a + al) * 3, c0 = (2 * (int64_t)L.h_gcol[(size_t)(g0 + k)] + be) * 3;
+								const int64_t r0 = (2 * a + al) * 3, c0 = (2 * (int64_t)h_gcol[(size_t)(g0 + k)] + be) * 3;
 								for (int m = 0; m < 3; ++m)
 									for (int q = 0; q < 3; ++q)
 										M[(size_t)((r0 + m) * n + c0 + q)] = blk[3 * m + q];
@@ -1626,8 +1449,10 @@ extern "C"
 		pfx_amg *A = ctx->amg;
 		if (!A || level < 0 || level + 1 >= (int)A->lv.size())
 			PFX_FAIL(PFX_ERR_ARG, "pfx_amg_get_aggregates: no such level");
-		const auto &h = A->lv[(size_t)level].h_agg;
-		std::copy(h.begin(), h.end(), agg);
+		PFX_HIP(hipSetDevice(ctx->device));
+		const int64_t n = level == 0 ? ctx->n_nodes : A->lv[(size_t)level].n_vert;
+		PFX_HIP(hipMemcpyAsync(agg, A->lv[(size_t)level].d_agg, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;
 	}
 
