@@ -210,6 +210,10 @@ typedef struct
 	int power_iters;      /* 15: iterations of the estimate of the spectral radius of D^-1 A (AMGCL/precond/relax/power_iters); here Lanczos
 	                         steps, whose largest Ritz value + 5 % ends the Chebyshev interval */
 	double relax_lower;   /* 0.1: the relaxation targets the eigenvalues in [relax_lower * lmax, lmax] */
+	double coarse_scale;  /* 1.6: factor on every coarse-grid correction, in [1, 2).  Piecewise rigid-body interpolation
+	                         underestimates the smooth error it corrects; over-correcting makes up for most of it
+	                         (1 M quadratic tetrahedra: 44 iterations at 1.7, 67 at 1) and keeps the preconditioner
+	                         symmetric positive definite below 2 */
 } pfx_amg_params;
 
 typedef struct

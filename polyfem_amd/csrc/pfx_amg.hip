@@ -22,7 +22,9 @@
 //
 // Cycle (one application = the preconditioner z = M^-1 r): Chebyshev relaxation of degree `relax_degree` for
 // D^-1 A on [relax_lower * lmax, lmax] before and after the coarse correction (lmax by a few Lanczos steps), V or W cycle,
-// dense inverse at the coarsest level.  Same polynomial before and after: M is symmetric positive definite.
+// dense inverse at the coarsest level.  Same polynomial before and after: M is symmetric positive definite.  Every
+// coarse-grid correction is scaled by `coarse_scale` in [1, 2) (the piecewise rigid-body interpolation of plain
+// aggregation underestimates the smooth error; the factor makes up for it and leaves M positive definite).
 //
 // The symbolic part (matching, coarse patterns, Galerkin lists) runs once per pattern and Dirichlet set, the numeric
 // part (Galerkin products, diagonals, spectral radii, coarsest inverse) at every new matrix; both on the device, except
@@ -237,7 +239,7 @@ namespace
 	// x += P xc
 	template <bool LEVEL0>
 	__global__ __launch_bounds__(256) void k_prolong(const int32_t *__restrict__ agg, const double *__restrict__ dvec, const double *__restrict__ xc,
-														const uint8_t *__restrict__ fixed, int64_t n_vert, double *__restrict__ x)
+														const uint8_t *__restrict__ fixed, int64_t n_vert, double omega, double *__restrict__ x)
 	{
 		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
 		{
@@ -245,7 +247,7 @@ namespace
 			if (a < 0)
 				continue;
 			const double d[3] = {dvec[3 * v], dvec[3 * v + 1], dvec[3 * v + 2]};
-			const double T[3] = {xc[6 * a], xc[6 * a + 1], xc[6 * a + 2]}, W[3] = {xc[6 * a + 3], xc[6 * a + 4], xc[6 * a + 5]};
+			const double T[3] = {omega * xc[6 * a], omega * xc[6 * a + 1], omega * xc[6 * a + 2]}, W[3] = {omega * xc[6 * a + 3], omega * xc[6 * a + 4], omega * xc[6 * a + 5]};
 			const double u[3] = {T[0] + W[1] * d[2] - W[2] * d[1], T[1] + W[2] * d[0] - W[0] * d[2], T[2] + W[0] * d[1] - W[1] * d[0]};
 			const int64_t o = LEVEL0 ? 3 * v : 6 * v;
 #pragma unroll
@@ -1230,10 +1232,11 @@ namespace
 			}
 		}
 		const uint8_t *fixed = (level0 && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
+		const double omega = ctx->amg_params.coarse_scale;
 		if (level0)
-			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, x);
+			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, omega, x);
 		else
-			hipLaunchKernelGGL((k_prolong<false>), dim3(grid_for(L.n_vert)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_vert, x);
+			hipLaunchKernelGGL((k_prolong<false>), dim3(grid_for(L.n_vert)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_vert, omega, x);
 		return amg_relax(ctx, L, v, false);
 	}
 } // namespace
@@ -1391,6 +1394,7 @@ extern "C"
 		p->coarsest_dofs = 600;
 		p->power_iters = 15;
 		p->relax_lower = 0.1;
+		p->coarse_scale = 1.6;
 	}
 
 	pfx_status pfx_amg_set_params(pfx_ctx *ctx, const pfx_amg_params *p)
@@ -1398,7 +1402,7 @@ extern "C"
 		if (!ctx || !p)
 			return PFX_ERR_ARG;
 		if (p->aggregate_passes < 1 || p->aggregate_passes > 8 || p->relax_degree < 1 || p->relax_degree > 16 || p->ncycle < 1 || p->ncycle > 4 || p->max_levels < 2
-			|| p->coarsest_dofs < 6 || p->coarsest_dofs > 3000 || p->power_iters < 1 || !(p->relax_lower > 0.0 && p->relax_lower < 1.0))
+			|| p->coarsest_dofs < 6 || p->coarsest_dofs > 3000 || p->power_iters < 1 || !(p->relax_lower > 0.0 && p->relax_lower < 1.0) || !(p->coarse_scale >= 1.0 && p->coarse_scale < 2.0))
 			PFX_FAIL(PFX_ERR_ARG, "pfx_amg_set_params: parameter out of range");
 		ctx->amg_params = *p;
 		PFX_HIP(hipSetDevice(ctx->device));

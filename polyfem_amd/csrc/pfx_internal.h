@@ -202,7 +202,7 @@ struct pfx_ctx
 
 	// AMG preconditioner: parameters, hierarchy, and a counter of everything its symbolic part depends on (pattern,
 	// Dirichlet set, owned range)
-	pfx_amg_params amg_params = {4, 1, 2, 12, 600, 10, 0.1};
+	pfx_amg_params amg_params = {4, 1, 2, 12, 600, 15, 0.1, 1.6};
 	pfx_amg *amg = nullptr;
 	int64_t struct_gen = 0;
 

@@ -57,7 +57,7 @@ class Level:
     pass
 
 
-def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, relax_lower=0.1, ncycle=1):
+def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, relax_lower=0.1, ncycle=1, coarse_scale=1.6):
     """A_masked: level-0 operator with identity rows/columns on the constrained dofs; aggregates[l]: vertex -> aggregate."""
     levels, A, pos = [], A_masked.tocsr(), np.asarray(node_xyz, dtype=float)
     for l, agg in enumerate(aggregates):
@@ -83,7 +83,7 @@ def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, rel
     C.A = A
     levels.append(C)
     for L in levels:
-        L.deg, L.lower, L.ncycle = relax_degree, relax_lower, ncycle
+        L.deg, L.lower, L.ncycle, L.omega = relax_degree, relax_lower, ncycle, coarse_scale
     return levels
 
 
@@ -114,7 +114,7 @@ def cycle(levels, l, b):
     if L.ncycle > 1 and l + 2 < len(levels):
         for _ in range(1, L.ncycle):
             xc = xc + cycle(levels, l + 1, rc - levels[l + 1].A @ xc)
-    x = x + L.P @ xc
+    x = x + L.omega * (L.P @ xc)
     return relax(L, b, x)
 
 

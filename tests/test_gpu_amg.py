@@ -104,7 +104,8 @@ def test_amg_matches_scipy_mirror(oracle, model):
         eng.close()
 
 
-@pytest.mark.parametrize("params", [dict(ncycle=1), dict(relax_degree=2, ncycle=1), dict(relax_degree=3, ncycle=2, aggregate_passes=3)])
+@pytest.mark.parametrize("params", [dict(ncycle=1), dict(relax_degree=2, ncycle=1), dict(relax_degree=3, ncycle=2, aggregate_passes=3), dict(coarse_scale=1.0),
+                                    dict(ncycle=1, coarse_scale=1.9)])
 def test_amg_variants_match_mirror(oracle, params):
     eng = E.Engine(0)
     try:
@@ -112,7 +113,7 @@ def test_amg_variants_match_mirror(oracle, params):
         Am, fixed = _problem(eng, oracle, mesh)
         eng.amg_set_params(coarsest_dofs=100, **params)
         eng.amg_setup()
-        mk = {k: v for k, v in params.items() if k in ("ncycle", "relax_degree")}
+        mk = {k: v for k, v in params.items() if k in ("ncycle", "relax_degree", "coarse_scale")}
         mk.setdefault("ncycle", 2)
         levels, info, _ = _mirror(eng, Am, fixed, mesh, **mk)
         b = np.random.default_rng(5).standard_normal(Am.shape[0])

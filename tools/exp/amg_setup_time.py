@@ -15,6 +15,11 @@ eng.assemble_linear()
 n = mesh.n_nodes * 3
 b = torch.from_numpy(np.random.default_rng(1).standard_normal(n)).cuda()
 x = torch.zeros(n, dtype=torch.float64, device="cuda")
+import os
+kw = {}
+if os.environ.get('AMG_NCYCLE'): kw['ncycle'] = int(os.environ['AMG_NCYCLE'])
+if os.environ.get('AMG_DEGREE'): kw['relax_degree'] = int(os.environ['AMG_DEGREE'])
+if kw: eng.amg_set_params(**kw)
 t0 = time.time(); eng.amg_setup(); eng.synchronize(); t1 = time.time()
 info = eng.amg_info()
 print("setup wall", t1 - t0, "symbolic", info["symbolic_s"], "numeric", info["numeric_s"], "levels", info["n_levels"], "cx", info["operator_complexity"])
