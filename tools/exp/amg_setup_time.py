@@ -19,6 +19,8 @@ import os
 kw = {}
 if os.environ.get('AMG_NCYCLE'): kw['ncycle'] = int(os.environ['AMG_NCYCLE'])
 if os.environ.get('AMG_DEGREE'): kw['relax_degree'] = int(os.environ['AMG_DEGREE'])
+if os.environ.get('AMG_PASSES'): kw['aggregate_passes'] = int(os.environ['AMG_PASSES'])
+if os.environ.get('AMG_OMEGA'): kw['coarse_scale'] = float(os.environ['AMG_OMEGA'])
 if kw: eng.amg_set_params(**kw)
 t0 = time.time(); eng.amg_setup(); eng.synchronize(); t1 = time.time()
 info = eng.amg_info()
