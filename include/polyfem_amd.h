@@ -195,8 +195,9 @@ pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int pre
  * The role of polysolve's AMG solvers ("AMGCL", "Hypre": CMakeLists.txt:101-102; options input-spec.json:1397-1558 --
  * CG with an AMG preconditioner, Chebyshev relaxation, `ncycle`, `max_levels`, tol 1e-10), which is what a PolyFEM user
  * selects when Jacobi-CG runs into max_iter.  Neither library is in the reference tree and this is not a restatement of
- * either: it is this library's own plain-aggregation AMG for 3-D elasticity (aggregates by repeated pairwise matching, six
- * rigid-body modes per aggregate, Galerkin coarse matrices in the same node-block format, Chebyshev relaxation), selected
+ * either: it is this library's own plain-aggregation AMG (aggregates by repeated pairwise matching; 3-D elasticity: six
+ * rigid-body modes per aggregate; scalar problems: one constant per aggregate; Galerkin coarse matrices in the same
+ * node-block format, Chebyshev relaxation), selected
  * with precond = PFX_PRECOND_AMG in pfx_cg(_dev), pfx_dirichlet_solve and pfx_newton_params.cg_precond.  The iteration
  * is still Eigen's ConjugateGradient (same stopping rule); only z = M^-1 r changes.  Single GPU (unpartitioned mesh).
  * The hierarchy is rebuilt when the pattern or the Dirichlet set changes; coarse matrices at every new matrix. */

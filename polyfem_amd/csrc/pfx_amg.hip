@@ -1,4 +1,5 @@
-// pfx_amg.hip -- aggregation multigrid preconditioner for the CG solver (3-D elasticity, block size 3).
+// pfx_amg.hip -- aggregation multigrid preconditioner for the CG solver (3-D elasticity, block size 3; scalar problems,
+// block size 1).
 //
 // Role in the reference: polysolve's algebraic-multigrid solvers ("AMGCL", "Hypre"; /root/reference/CMakeLists.txt:101-102,
 // options input-spec.json:1397-1558: CG with an AMG preconditioner, Chebyshev relaxation, ncycle, max_levels) are what a
@@ -17,6 +18,8 @@
 //     level > 0: (T_v, W_v) = (T + W x d, W)           P_v   = [ I  -[d]x ; 0  I ]         (6 x 6)
 // Coarse matrices are Galerkin products P^T A P, computed on the device from lists (built with the hierarchy) of the
 // fine vertex pairs behind every coarse pair, in a fixed order: no atomics, bitwise reproducible.
+// Scalar problems (the Laplacian): one coarse dof per aggregate, piecewise constant interpolation, the same aggregation,
+// cycle and scaling; every level is a block-size-1 matrix.
 // Dirichlet dofs: the level-0 operator is the masked one (identity on constrained dofs); their rows of P are zero,
 // nodes with all dofs constrained are left out of the aggregation.
 //
@@ -260,6 +263,46 @@ namespace
 				x[o + 4] += W[1];
 				x[o + 5] += W[2];
 			}
+		}
+	}
+
+	// ---- scalar problems (block size 1, the Laplacian): one coarse dof per aggregate, piecewise constant interpolation.
+	// Constrained nodes are in no aggregate, so neither lists nor transfers ever see them.
+	__global__ __launch_bounds__(256) void k_galerkin_scalar(const int64_t *__restrict__ cp_ptr, const uint32_t *__restrict__ cp_src, const double *__restrict__ fine_values,
+															  int64_t n_cpairs, double *__restrict__ coarse_values)
+	{
+		const int64_t cp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (cp >= n_cpairs)
+			return;
+		double acc = 0;
+		for (int64_t k = cp_ptr[cp]; k < cp_ptr[cp + 1]; ++k)
+			acc += fine_values[cp_src[k]];
+		coarse_values[cp] = acc;
+	}
+
+	__global__ __launch_bounds__(256) void k_restrict_scalar(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ b,
+															  const double *__restrict__ t, int64_t n_agg, double *__restrict__ bc)
+	{
+		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < n_agg; a += (int64_t)gridDim.x * blockDim.x)
+		{
+			double acc = 0;
+			for (int64_t k = mptr[a]; k < mptr[a + 1]; ++k)
+			{
+				const int64_t v = mlist[k];
+				acc += b[v] - t[v];
+			}
+			bc[a] = acc;
+		}
+	}
+
+	__global__ __launch_bounds__(256) void k_prolong_scalar(const int32_t *__restrict__ agg, const double *__restrict__ xc, int64_t n_vert, double omega,
+															 double *__restrict__ x)
+	{
+		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t a = agg[v];
+			if (a >= 0)
+				x[v] += omega * xc[a];
 		}
 	}
 
@@ -646,10 +689,22 @@ namespace
 
 	// ---- kernels of the symbolic phase -----------------------------------------------------------------------
 	// vertices left out of the aggregation at level 0: halo nodes and nodes whose three dofs are all constrained
-	__global__ void k_excluded(const uint8_t *__restrict__ fixed, int64_t n_nodes, int64_t n_owned, uint8_t *__restrict__ excl)
+	__global__ void k_excluded(const uint8_t *__restrict__ fixed, int64_t n_nodes, int64_t n_owned, int bs, uint8_t *__restrict__ excl)
 	{
 		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
-			excl[g] = (g >= n_owned) || (fixed && fixed[3 * g] && fixed[3 * g + 1] && fixed[3 * g + 2]);
+		{
+			bool all = fixed != nullptr;
+			for (int m = 0; all && m < bs; ++m)
+				all = fixed[bs * g + m] != 0;
+			excl[g] = (g >= n_owned) || all;
+		}
+	}
+
+	// scalar levels: the coarse matrix has one entry per coarse edge, its pattern is the coarse graph itself
+	__global__ void k_copy_i64(const int64_t *__restrict__ src, int64_t n, int64_t *__restrict__ dst)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+			dst[k] = src[k];
 	}
 
 	// centre of every aggregate: mean of its members' positions, summed in member order
@@ -726,6 +781,8 @@ namespace
 		const pfx_amg_params &par = ctx->amg_params;
 		hipStream_t st = ctx->stream;
 		const int64_t n_nodes = ctx->n_nodes, n_owned = ctx->n_owned;
+		const int bs = ctx->bs;
+		const bool scalar = bs == 1; // one dof per vertex on every level; else 3 on level 0 and 6 (rigid-body modes) below
 		pfx_status rc;
 
 		// level-0 node positions and the vertices left out of the aggregation
@@ -740,7 +797,7 @@ namespace
 		pfx_tmp<uint8_t> excluded;
 		PFX_HIP(excluded.alloc((size_t)n_nodes));
 		hipLaunchKernelGGL(k_excluded, dim3(grid_for(n_nodes)), dim3(256), 0, st, ctx->n_dirichlet > 0 ? (const uint8_t *)ctx->d_fixed : (const uint8_t *)nullptr, n_nodes, n_owned,
-						   excluded.p);
+						   ctx->bs, excluded.p);
 
 		// the level being coarsened: its vertex graph (level 0: the node-block pattern itself) and vertex positions
 		pfx_dgraph g;
@@ -755,11 +812,11 @@ namespace
 		L.m = ctx;
 		L.own_m = false;
 		L.n_vert = n_vert;
-		L.n_dofs = n_nodes * 3;
+		L.n_dofs = n_nodes * bs;
 		for (int level = 0;; ++level)
 		{
 			const bool level0 = level == 0;
-			const int64_t dofs = level0 ? 3 * n_owned : 6 * n_vert;
+			const int64_t dofs = level0 ? bs * n_owned : (scalar ? n_vert : 6 * n_vert);
 			if ((!level0 && dofs <= par.coarsest_dofs) || n_vert < 2 || level + 1 >= par.max_levels || level + 1 >= AMG_MAX_LEVELS)
 			{
 				A->lv.push_back(L);
@@ -802,7 +859,7 @@ namespace
 					break;
 			}
 			// level 0: aggregates of fewer than three nodes cannot carry the rotations; they join their strongest neighbour
-			if (level0 && nc > 1)
+			if (level0 && nc > 1 && !scalar)
 				if ((rc = pfx_graph_merge_small(ctx, n_vert, cur.p, &nc, gq.view(), 3)))
 					return rc;
 			gq.ptr.reset(), gq.col.reset(), gq.w.reset();
@@ -826,12 +883,13 @@ namespace
 			// ---- members, centres, offsets
 			pfx_tmp<double> centre;
 			PFX_HIP(centre.alloc((size_t)nc * 3));
-			if (pfx_alloc(ctx, &L.d_mptr, nc + 1) || pfx_alloc(ctx, &L.d_mlist, n_vert) || pfx_alloc(ctx, &L.d_dvec, n_vert * 3))
+			if (pfx_alloc(ctx, &L.d_mptr, nc + 1) || pfx_alloc(ctx, &L.d_mlist, n_vert) || pfx_alloc(ctx, &L.d_dvec, scalar ? 1 : n_vert * 3))
 				return PFX_ERR_HIP;
 			if ((rc = pfx_graph_members(ctx, n_vert, cur.p, nc, L.d_mptr, L.d_mlist)))
 				return rc;
 			hipLaunchKernelGGL(k_centres, dim3(grid_for(nc)), dim3(256), 0, st, L.d_mptr, L.d_mlist, vpos, nc, centre.p);
-			hipLaunchKernelGGL(k_offsets, dim3(grid_for(n_vert)), dim3(256), 0, st, cur.p, vpos, centre.p, n_vert, L.d_dvec);
+			if (!scalar)
+				hipLaunchKernelGGL(k_offsets, dim3(grid_for(n_vert)), dim3(256), 0, st, cur.p, vpos, centre.p, n_vert, L.d_dvec);
 			// ---- the transfer data of this level
 			L.n_agg = nc;
 			L.n_cpairs = n_cp;
@@ -849,16 +907,16 @@ namespace
 			s->device = ctx->device;
 			s->stream = ctx->stream;
 			s->own_stream = false;
-			s->bs = 3;
+			s->bs = scalar ? 1 : 3;
 			s->dim = 3;
-			s->n_nodes = s->n_owned = 2 * nc;
-			s->n_blocks = 4 * n_cp;
-			s->nnz = s->n_blocks * 9;
+			s->n_nodes = s->n_owned = scalar ? nc : 2 * nc;
+			s->n_blocks = scalar ? n_cp : 4 * n_cp;
+			s->nnz = s->n_blocks * s->bs * s->bs;
 			C.m = s;
 			C.own_m = true;
 			C.n_vert = nc;
-			C.n_dofs = 6 * nc;
-			if (pfx_alloc(s, &s->d_node_ptr, 2 * nc + 1) || pfx_alloc(s, &s->d_node_col, 4 * n_cp) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nc + 1)
+			C.n_dofs = scalar ? nc : 6 * nc;
+			if (pfx_alloc(s, &s->d_node_ptr, s->n_nodes + 1) || pfx_alloc(s, &s->d_node_col, s->n_blocks) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nc + 1)
 				|| keep(ctx, &C.d_gcol, gc.col.p, n_cp))
 			{
 				if (ctx->err.empty())
@@ -866,7 +924,13 @@ namespace
 				A->lv.push_back(C); // released with the hierarchy
 				return PFX_ERR_HIP;
 			}
-			hipLaunchKernelGGL(k_coarse_pattern, dim3(grid_for(nc + 1)), dim3(256), 0, st, C.d_gptr, C.d_gcol, nc, s->d_node_ptr, s->d_node_col);
+			if (scalar)
+			{
+				hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(nc + 1)), dim3(256), 0, st, C.d_gptr, nc + 1, s->d_node_ptr);
+				PFX_HIP(hipMemcpyAsync(s->d_node_col, C.d_gcol, sizeof(int32_t) * (size_t)n_cp, hipMemcpyDeviceToDevice, st));
+			}
+			else
+				hipLaunchKernelGGL(k_coarse_pattern, dim3(grid_for(nc + 1)), dim3(256), 0, st, C.d_gptr, C.d_gcol, nc, s->d_node_ptr, s->d_node_col);
 			PFX_HIP(hipMemsetAsync(s->d_values, 0, sizeof(double) * (size_t)(s->nnz + 2), st));
 			PFX_HIP(hipStreamSynchronize(st));
 			PFX_HIP(hipGetLastError());
@@ -1013,7 +1077,9 @@ namespace
 		{
 			pfx_amg_level &F = A->lv[l], &C = A->lv[l + 1];
 			const unsigned grid = (unsigned)((2 * F.n_cpairs + 255) / 256);
-			if (l == 0)
+			if (ctx->bs == 1)
+				hipLaunchKernelGGL(k_galerkin_scalar, dim3((unsigned)((F.n_cpairs + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.m->d_values, F.n_cpairs, C.m->d_values);
+			else if (l == 0)
 				hipLaunchKernelGGL((k_galerkin<true>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, (const int64_t *)nullptr, ctx->d_node_col, ctx->d_values, F.d_dvec,
 								   fixed, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
 			else
@@ -1035,8 +1101,8 @@ namespace
 		{
 			pfx_amg_level &L = A->lv[l];
 			if (l == 0 && ctx->n_owned < ctx->n_nodes) // the level-0 operator is the owned-owned block: halo entries of the vector it is applied to are zero
-				PFX_HIP(hipMemsetAsync(scratch_v + ctx->n_owned * 3, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * 3), st));
-			pfx_status rc = (l == 0) ? amg_lambda_max(ctx, A, L, scratch_v, scratch_t, dinv0, ctx->n_owned * 3) : amg_lambda_max(ctx, A, L, L.d_x, L.d_t, L.d_dinv, L.n_dofs);
+				PFX_HIP(hipMemsetAsync(scratch_v + ctx->n_owned * ctx->bs, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * ctx->bs), st));
+			pfx_status rc = (l == 0) ? amg_lambda_max(ctx, A, L, scratch_v, scratch_t, dinv0, ctx->n_owned * ctx->bs) : amg_lambda_max(ctx, A, L, L.d_x, L.d_t, L.d_dinv, L.n_dofs);
 			if (rc)
 				return rc;
 		}
@@ -1068,6 +1134,12 @@ namespace
 				for (int64_t a = 0; a < nv; ++a)
 				{
 					const int64_t g0 = h_gptr[(size_t)a], deg = h_gptr[(size_t)a + 1] - g0;
+					if (ctx->bs == 1)
+					{
+						for (int64_t k = 0; k < deg; ++k)
+							M[(size_t)(a * n + h_gcol[(size_t)(g0 + k)])] = vals[(size_t)(g0 + k)];
+						continue;
+					}
 					for (int64_t k = 0; k < deg; ++k)
 						for (int al = 0; al < 2; ++al)
 							for (int be = 0; be < 2; ++be)
@@ -1197,7 +1269,8 @@ namespace
 			return PFX_OK;
 		}
 		const bool level0 = l == 0;
-		const int64_t n = level0 ? ctx->n_owned * 3 : L.n_dofs;
+		const int64_t n = level0 ? ctx->n_owned * ctx->bs : L.n_dofs;
+		const bool scalar = ctx->bs == 1;
 		relax_vecs v{b, x, level0 ? t0 : L.d_t, L.d_r, L.d_dv, level0 ? dinv0 : L.d_dinv, n};
 		pfx_status rc = amg_relax(ctx, L, v, true);
 		if (rc)
@@ -1209,7 +1282,9 @@ namespace
 			return rc;
 		}
 		pfx_amg_level &C = A->lv[l + 1];
-		if (level0)
+		if (scalar)
+			hipLaunchKernelGGL(k_restrict_scalar, dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, L.n_agg, C.d_b);
+		else if (level0)
 			hipLaunchKernelGGL((k_restrict<true>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
 		else
 			hipLaunchKernelGGL((k_restrict<false>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
@@ -1233,7 +1308,9 @@ namespace
 		}
 		const uint8_t *fixed = (level0 && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
 		const double omega = ctx->amg_params.coarse_scale;
-		if (level0)
+		if (scalar)
+			hipLaunchKernelGGL(k_prolong_scalar, dim3(grid_for(level0 ? ctx->n_owned : L.n_vert)), dim3(256), 0, st, L.d_agg, C.d_x, level0 ? ctx->n_owned : L.n_vert, omega, x);
+		else if (level0)
 			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, omega, x);
 		else
 			hipLaunchKernelGGL((k_prolong<false>), dim3(grid_for(L.n_vert)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_vert, omega, x);
@@ -1264,8 +1341,8 @@ void pfx_amg_release(pfx_ctx *ctx)
 // the level-0 operator (n_dofs doubles), scratch_v / scratch_t: two level-0 vectors that may be overwritten
 pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, double *scratch_t)
 {
-	if (ctx->bs != 3)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner is implemented for vector-valued problems (block size 3)");
+	if (ctx->bs != 3 && ctx->bs != 1)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner is implemented for block sizes 1 and 3");
 	pfx_status rc = pfx_sell_refresh(ctx);
 	if (rc)
 		return rc;
@@ -1289,7 +1366,7 @@ pfx_status pfx_amg_apply(pfx_ctx *ctx, const double *d_r, double *d_z, double *t
 	if (A->lv.size() < 2)
 	{
 		// nothing to coarsen (every node constrained): plain Jacobi
-		hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(ctx->n_owned * 3)), dim3(256), 0, ctx->stream, dinv0, d_r, (const double *)nullptr, 1.0, 1, ctx->n_owned * 3,
+		hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(ctx->n_owned * ctx->bs)), dim3(256), 0, ctx->stream, dinv0, d_r, (const double *)nullptr, 1.0, 1, ctx->n_owned * ctx->bs,
 						   (double *)nullptr, (double *)nullptr, d_z);
 		return PFX_OK;
 	}
@@ -1472,7 +1549,7 @@ extern "C"
 		// the preconditioner is that of the owned-owned block: the entries of halo nodes of z take part in the level-0
 		// products as zeros
 		if (ctx->n_owned < ctx->n_nodes)
-			PFX_HIP(hipMemsetAsync(d_z + ctx->n_owned * 3, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * 3), ctx->stream));
+			PFX_HIP(hipMemsetAsync(d_z + ctx->n_owned * ctx->bs, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * ctx->bs), ctx->stream));
 		return pfx_amg_apply(ctx, d_r, d_z, base + 2 * nfull, base + 3 * nfull);
 	}
 }

@@ -28,12 +28,16 @@ def skew(d):
     return np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
 
 
-def prolongation(agg, na, pos, level0, fixed=None):
-    """Rows: 3 dofs per vertex (level 0) or 6 (translation, rotation); columns: 6 per aggregate.  Returns P, centres."""
+def prolongation(agg, na, pos, level0, fixed=None, scalar=False):
+    """Rows: 3 dofs per vertex (level 0) or 6 (translation, rotation); columns: 6 per aggregate.  Scalar problems: one dof
+    per vertex and per aggregate, piecewise constant.  Returns P, centres."""
     nv = agg.size
     ok = agg >= 0
     cnt = np.bincount(agg[ok], minlength=na).astype(float)
     c = np.stack([np.bincount(agg[ok], weights=pos[ok, k], minlength=na) / cnt for k in range(3)], axis=1)
+    if scalar:
+        v = np.nonzero(ok)[0]
+        return sp.csr_matrix((np.ones(v.size), (v, agg[v])), shape=(nv, na)), c
     rows, cols, vals = [], [], []
     per = 3 if level0 else 6
     for v in np.nonzero(ok)[0]:
@@ -57,7 +61,7 @@ class Level:
     pass
 
 
-def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, relax_lower=0.1, ncycle=1, coarse_scale=1.6):
+def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, relax_lower=0.1, ncycle=1, coarse_scale=1.6, scalar=False):
     """A_masked: level-0 operator with identity rows/columns on the constrained dofs; aggregates[l]: vertex -> aggregate."""
     levels, A, pos = [], A_masked.tocsr(), np.asarray(node_xyz, dtype=float)
     for l, agg in enumerate(aggregates):
@@ -67,7 +71,7 @@ def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, rel
         L.dinv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1.0), 1.0)
         L.lmax = lambda_max[l]
         na = int(agg.max()) + 1
-        L.P, centres = prolongation(np.asarray(agg), na, pos, l == 0, fixed if l == 0 else None)
+        L.P, centres = prolongation(np.asarray(agg), na, pos, l == 0, fixed if l == 0 else None, scalar)
         levels.append(L)
         A = (L.P.T @ A @ L.P).tocsr()
         pos = centres
