@@ -352,6 +352,10 @@ class HipOps:
         """z[owned rows] = M^-1 r, M = this rank's AMG cycle for its owned-owned block; r, z: local vectors."""
         self.e.amg_apply_dev(r.data_ptr(), z.data_ptr())
 
+    def apply_matrix(self, v, y):
+        """y[owned rows] = A v with the (masked) matrix the engine holds; v, y: local vectors, v with its halo entries."""
+        self.e.spmv_dev(v.data_ptr(), y.data_ptr())
+
     # ---- nonlinear pieces (DistributedNewton) ----
     def energy(self, x, out):
         """out[0] = energy of the elements this rank sums (pfx_set_owned's flags)."""
@@ -386,8 +390,10 @@ class DistributedCG:
 
     precond = 2 (PFX_PRECOND_AMG) preconditions with one AMG hierarchy per rank, built on the block of the matrix whose
     rows and columns the rank owns (block-Jacobi over the ranks: couplings across a partition boundary are left to the
-    Krylov iteration, so the iteration count grows slowly with the number of ranks; no communication inside the
-    preconditioner)."""
+    Krylov iteration; no communication inside the hierarchy).  enable_coarse_space() adds what block-Jacobi lacks, a
+    coarse problem that spans the ranks: the rigid-body modes of every rank's block (six per rank for bs = 3, the
+    constant for bs = 1), z = M_bj^-1 r + Z (Z^T A Z)^-1 Z^T r -- additive, hence symmetric positive definite; one more
+    all-reduce of 6 N doubles per iteration, the 6 N x 6 N coarse matrix is inverted redundantly on every rank."""
 
     def __init__(self, ops, part: Part, bs: int, comm: Comm, device):
         import torch
@@ -399,6 +405,91 @@ class DistributedCG:
         self.scal = torch.zeros(4, dtype=torch.float64, device=device)
         self.ops.set_workspace(self.work)
         self.p_nodes = self.work[self.n: 2 * self.n].view(self.n_local, bs)
+        self.cs = None  # coarse space over the ranks (enable_coarse_space)
+
+    # ---- coarse space over the ranks for the AMG-preconditioned solve ------------------------------------------
+    def enable_coarse_space(self, node_pos, fixed_dofs=None):
+        """node_pos: (n_local, 3) positions of this rank's nodes (owned, then halo); fixed_dofs: local indices of the
+        constrained dofs (the list given to the engine).  The coarse matrix is rebuilt by every AMG-preconditioned
+        solve (6 (1 + neighbours) products with the current matrix)."""
+        t, dev = self.torch, self.work.device
+        bs, nl, no = self.bs, self.n_local, self.part.n_owned
+        free = np.ones(nl * bs, dtype=np.float64)
+        if fixed_dofs is not None and len(fixed_dofs):
+            free[np.asarray(fixed_dofs, dtype=np.int64)] = 0.0
+        owner = np.full(nl, self.comm.rank, dtype=np.int64)
+        owner[no:] = np.asarray(self.part.halo_owner, dtype=np.int64)
+        pos = t.from_numpy(np.ascontiguousarray(node_pos, dtype=np.float64)).to(dev)
+        # centre of every rank's owned nodes (any point would do; the centre keeps the rotations well scaled)
+        cen = t.zeros((self.comm.world, 3), dtype=t.float64, device=dev)
+        cen[self.comm.rank] = pos[:no].mean(dim=0)
+        self.comm.all_reduce_sum(cen)
+        self.cs = dict(pos=pos, free=t.from_numpy(free).to(dev).view(nl, bs), owner=t.from_numpy(owner).to(dev), centres=cen,
+                       modes=6 if bs == 3 else 1, einv=None, sources=sorted(set(int(o) for o in owner)))
+
+    def _cs_modes(self, s, k):
+        """Local part (n_local, bs) of mode k of rank s: non-zero on the free dofs of the nodes rank s owns."""
+        t, c = self.torch, self.cs
+        sel = (c["owner"] == s).to(t.float64)[:, None]
+        if self.bs == 1:
+            return sel * c["free"]
+        if k < 3:
+            v = t.zeros((self.n_local, 3), dtype=t.float64, device=c["pos"].device)
+            v[:, k] = 1.0
+        else:
+            axis = t.zeros(3, dtype=t.float64, device=c["pos"].device)
+            axis[k - 3] = 1.0
+            v = t.cross(axis.expand(self.n_local, 3), c["pos"] - c["centres"][s], dim=1)
+        return v * sel * c["free"]
+
+    def _cs_restrict(self, y_owned):
+        """Z_r^T y for this rank's own modes: y_owned (n_owned * bs)."""
+        t, c, no = self.torch, self.cs, self.part.n_owned
+        yn = y_owned.view(no, self.bs) * c["free"][:no]
+        if self.bs == 1:
+            return yn.sum().reshape(1)
+        d = c["pos"][:no] - c["centres"][self.comm.rank]
+        return t.cat([yn.sum(dim=0), t.cross(d, yn, dim=1).sum(dim=0)])
+
+    def _cs_setup(self):
+        """E = Z^T A Z with the matrix the engine holds now; rank r computes its block row (products of A with the modes
+        of itself and of the ranks that own its halo nodes), the rows are summed over the ranks."""
+        t, c, no, bs = self.torch, self.cs, self.part.n_owned, self.bs
+        m, N, r = c["modes"], self.comm.world, self.comm.rank
+        E = t.zeros((m * N, m * N), dtype=t.float64, device=c["pos"].device)
+        y = t.zeros(self.n, dtype=t.float64, device=c["pos"].device)
+        for s in c["sources"]:
+            for k in range(m):
+                v = self._cs_modes(s, k).reshape(-1).contiguous()
+                self.ops.apply_matrix(v, y)
+                E[m * r: m * r + m, m * s + k] = self._cs_restrict(y[:no * bs])
+        self.comm.all_reduce_sum(E)
+        E = 0.5 * (E + E.T)
+        # a rank without free dofs, or a mode its constraints remove, leaves a zero row: decouple it
+        dg = t.diagonal(E)
+        dmax = float(dg.abs().max().item())
+        dead = dg.abs() <= 1e-14 * (dmax if dmax > 0 else 1.0)
+        E[dead, :] = 0.0
+        E[:, dead] = 0.0
+        E[dead, dead] = 1.0
+        c["einv"] = t.linalg.inv(E)
+        c["einv"][dead, :] = 0.0
+        c["einv"][:, dead] = 0.0
+
+    def _cs_apply(self, r_owned, z_owned):
+        """z += Z E^-1 Z^T r"""
+        t, c, no = self.torch, self.cs, self.part.n_owned
+        m, N, r = c["modes"], self.comm.world, self.comm.rank
+        w = t.zeros(m * N, dtype=t.float64, device=c["pos"].device)
+        w[m * r: m * r + m] = self._cs_restrict(r_owned)
+        self.comm.all_reduce_sum(w)
+        a = (c["einv"] @ w)[m * r: m * r + m]
+        zn = z_owned.view(no, self.bs)
+        if self.bs == 1:
+            zn += a[0] * c["free"][:no]
+            return
+        d = c["pos"][:no] - c["centres"][r]
+        zn += (a[0:3] + t.cross(a[3:6].expand(no, 3), d, dim=1)) * c["free"][:no]
 
     def close(self):
         """Hands the solver workspace back to the engine (the engine must not keep a pointer into a freed tensor)."""
@@ -473,7 +564,11 @@ class DistributedCG:
             self.z = t.zeros(n, dtype=t.float64, device=self.work.device)
         z_full, z = self.z, self.z[0:no]
         xo = x[0:no]
+        if self.cs is not None:
+            self._cs_setup()
         ops.amg_apply(r_full, z_full)
+        if self.cs is not None:
+            self._cs_apply(r, z)
         p.copy_(z)
         scal[2] = t.dot(r, z)
         ar(scal[2:3])
@@ -489,6 +584,8 @@ class DistributedCG:
             xo.addcmul_(p, alpha)
             r.addcmul_(ap, alpha, value=-1.0)
             ops.amg_apply(r_full, z_full)
+            if self.cs is not None:
+                self._cs_apply(r, z)
             scal[1] = t.dot(r, r)
             scal[2] = t.dot(r, z)
             ar(scal[1:3])
@@ -542,6 +639,10 @@ class DistributedNewton:
         import torch
         self.torch, self.ops, self.part, self.bs, self.comm, self.device = torch, ops, part, bs, comm, device
         self.cg = DistributedCG(ops, part, bs, comm, device)
+        if comm.on and hasattr(ops, "apply_matrix"):
+            # the AMG-preconditioned solves (cg_precond = 2) get the coarse space over the ranks
+            from .mesh import node_positions
+            self.cg.enable_coarse_space(node_positions(part.mesh), fixed_dofs_local)
         self.n = part.n_local * bs
         self.no = part.n_owned * bs
         fixed = np.zeros(self.n, dtype=bool)

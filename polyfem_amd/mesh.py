@@ -175,6 +175,21 @@ def cube_hexes(n: int, order: int = 1, numbering: str = "lattice", scale=(1.0, 1
     return m
 
 
+def node_positions(mesh: Mesh) -> np.ndarray:
+    """Physical position of every basis node (the geometry map at the node's reference position); on tetrahedra with
+    moved vertices these differ from the lattice positions kept in mesh.node_xyz."""
+    if mesh.kind not in (P1TET, P2TET):
+        return np.asarray(mesh.node_xyz, dtype=float)
+    v = mesh.xyz[mesh.gconn]
+    pos = np.zeros((mesh.n_nodes, 3))
+    for k in range(4):
+        pos[mesh.conn[:, k]] = v[:, k]
+    if mesh.kind == P2TET:
+        for e, (a, b) in enumerate(_P2_EDGES):
+            pos[mesh.conn[:, 4 + e]] = 0.5 * (v[:, a] + v[:, b])
+    return pos
+
+
 def boundary_dofs(mesh: Mesh, dim: int, face: str = "all") -> np.ndarray:
     """Sorted dof indices (node*dim + c) of the basis nodes on the cube boundary ('all') or on the x=0 face
     ('x0'); the analogue of the reference's `boundary_nodes` list (`state/StateSolveLinear.cpp:27-29`)."""

@@ -9,19 +9,9 @@ import scipy.sparse as sp
 
 
 def node_positions(mesh):
-    """Physical position of every basis node (the geometry map at the node's reference position); tetrahedra with
-    moved vertices differ from the lattice positions kept in mesh.node_xyz."""
+    """Physical position of every basis node (polyfem_amd.mesh.node_positions)."""
     from polyfem_amd import mesh as M
-    if mesh.kind not in (M.P1TET, M.P2TET):
-        return np.asarray(mesh.node_xyz, dtype=float)
-    v = mesh.xyz[mesh.gconn]
-    pos = np.zeros((mesh.n_nodes, 3))
-    for k in range(4):
-        pos[mesh.conn[:, k]] = v[:, k]
-    if mesh.kind == M.P2TET:
-        for e, (a, b) in enumerate(M._P2_EDGES):
-            pos[mesh.conn[:, 4 + e]] = 0.5 * (v[:, a] + v[:, b])
-    return pos
+    return M.node_positions(mesh)
 
 
 def skew(d):

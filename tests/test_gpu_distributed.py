@@ -394,3 +394,73 @@ def test_block_jacobi_amg_two_ranks_converges_to_the_single_engine_solution():
     assert np.abs(xg - x_ref).max() <= 1e-7 * scale
     assert np.abs(xg2 - x_ref).max() <= 1e-7 * scale
     assert not xg[bd].any()
+
+
+def _coarse_space_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        from polyfem_amd import mesh as M
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        n, cpr = 6, 6  # a bar of 6 x 6 x (6 * world) cells, clamped at one small face: the longer, the worse block-Jacobi
+        part, bounds, n_nodes = D.slab_part(n, cpr, rank, world, 2)
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.LINEAR_ELASTICITY, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        eng.assemble_linear()
+        l2g = part.local_to_global()
+        bs = 3
+        dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
+        fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 2]) < 1e-12)[0]  # z = 0: the first rank's outer face
+        fixed_dofs = np.sort((fixed[:, None] * bs + np.arange(bs)[None]).reshape(-1)).astype(np.int32)
+        eng.set_dirichlet(fixed_dofs)
+        b_g = np.random.default_rng(21).standard_normal(n_nodes * bs)
+        comm = D.Comm()
+        cg = D.DistributedCG(D.HipOps(eng), part, bs, comm, dev)
+        b = torch.from_numpy(b_g[dof_l2g]).to(dev)
+        x0 = torch.zeros(part.n_local * bs, dtype=torch.float64, device=dev)
+        it0, err0 = cg.solve(b, x0, E.PRECOND_AMG, 1000, 1e-10)
+        cg.enable_coarse_space(M.node_positions(part.mesh), fixed_dofs)
+        x1 = torch.zeros_like(x0)
+        it1, err1 = cg.solve(b, x1, E.PRECOND_AMG, 1000, 1e-10)
+        torch.cuda.synchronize()
+        no = part.n_owned * bs
+        diff = torch.tensor([float((x1[:no] - x0[:no]).abs().max()), float(x0[:no].abs().max())], dtype=torch.float64)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ret["it0"], ret["err0"], ret["it1"], ret["err1"], ret["diff"], ret["scale"] = it0, err0, it1, err1, float(diff[0]), float(diff[1])
+        cg.close()
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_coarse_space_over_the_ranks_cuts_the_iterations(world):
+    """The rigid-body modes of every rank's block as a coarse space beside the per-rank AMG hierarchies: the same
+    solution, fewer iterations, and the more ranks the larger the gain (a bar cut into slabs and clamped at one end is the
+    hard case for block-Jacobi: the far slabs float)."""
+    import torch.multiprocessing as mp
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_coarse_space_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        it0, err0, it1, err1, diff, scale = (ret[k] for k in ("it0", "err0", "it1", "err1", "diff", "scale"))
+    print(f"world {world}: block-Jacobi AMG {it0} iterations, with the coarse space {it1}")
+    assert err0 < 1e-10 and err1 < 1e-10
+    assert diff <= 1e-6 * scale
+    assert it1 < it0
+    if world >= 4:
+        assert it1 <= 0.8 * it0
