@@ -437,7 +437,7 @@ def main():
     ap.add_argument("--amg-ncycle", type=int, default=2)
     ap.add_argument("--amg-degree", type=int, default=1)
     ap.add_argument("--cpu-n", type=int, default=40, help="grid of the CPU baseline sample (40 -> 384 000 P2 tets, 1.6 M dofs)")
-    ap.add_argument("--cpu-cg-iters", type=int, default=40)
+    ap.add_argument("--cpu-cg-iters", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the LinearElasticity 55^3 measurement that rides along at N = 1")
     ap.add_argument("--spawn-check", action="store_true", help="every rank reports its rank/world and exits (no GPU work): checks the launcher")
