@@ -249,6 +249,85 @@ def test_amg_scalar_converges_on_a_large_laplacian():
             eng.close()
 
 
+def test_amg_setup_is_deterministic_and_does_not_depend_on_the_numbering(oracle):
+    """Two set-ups of the same problem give the same aggregates and bit-identical solves; a randomly renumbered mesh
+    gives aggregates of the same sizes and a solve within a few iterations (ties of the matching are broken by a hash
+    of the edge, not by the order of the vertices)."""
+    from polyfem_amd import distributed as D
+    rng = np.random.default_rng(17)
+    mesh = M.cube_tets(7, 2, jitter=0.1)
+    n = mesh.n_nodes * 3
+    b = rng.standard_normal(n)
+    runs = []
+    for rep in range(2):
+        eng = E.Engine(0)
+        try:
+            _problem(eng, oracle, mesh)
+            eng.amg_set_params(coarsest_dofs=120)
+            x, it, err = eng.cg(b, None, E.PRECOND_AMG, 500, 1e-10)
+            info = eng.amg_info()
+            runs.append((x, it, [eng.amg_aggregates(l) for l in range(info["n_levels"] - 1)]))
+        finally:
+            eng.close()
+    assert runs[0][1] == runs[1][1] and np.array_equal(runs[0][0], runs[1][0])
+    assert all(np.array_equal(a, c) for a, c in zip(runs[0][2], runs[1][2]))
+    perm = rng.permutation(mesh.n_nodes)
+    mesh2 = D.renumber_nodes(mesh, perm)
+    eng = E.Engine(0)
+    try:
+        _problem(eng, oracle, mesh2)
+        eng.amg_set_params(coarsest_dofs=120)
+        b2 = np.zeros(n)
+        b2.reshape(-1, 3)[perm] = b.reshape(-1, 3)
+        x2, it2, err2 = eng.cg(b2, None, E.PRECOND_AMG, 500, 1e-10)
+        a0 = eng.amg_aggregates(0)
+    finally:
+        eng.close()
+    sizes, sizes2 = np.bincount(runs[0][2][0][runs[0][2][0] >= 0]), np.bincount(a0[a0 >= 0])
+    assert sizes2.min() >= 3 and sizes2.max() <= 20 and abs(sizes2.mean() - sizes.mean()) < 1.5
+    assert err2 <= 1e-10 and abs(it2 - runs[0][1]) <= 8, (it2, runs[0][1])
+    assert np.abs(x2.reshape(-1, 3)[perm] - runs[0][0].reshape(-1, 3)).max() <= 1e-7 * np.abs(runs[0][0]).max()
+
+
+def test_amg_aggregates_stay_inside_connected_bodies(oracle):
+    """Two cubes that touch nowhere in one mesh: no aggregate on any level joins nodes of both (the matching only pairs
+    graph neighbours), and the solve converges as for one body."""
+    m1 = M.cube_tets(4, 2, jitter=0.1)
+    n1 = m1.n_nodes
+    conn = np.vstack([m1.conn, m1.conn + n1]).astype(np.int32)
+    gconn = np.vstack([m1.gconn, m1.gconn + m1.xyz.shape[0]]).astype(np.int32)
+    shift = np.array([1.0 + 1e-3, 0.0, 0.0])  # the second cube right beside the first: close in space, not connected
+    mesh = M.Mesh(m1.kind, m1.gkind, conn, gconn, np.vstack([m1.xyz, m1.xyz + shift]), 2 * n1, np.vstack([m1.node_xyz, m1.node_xyz + shift]), m1.quad_order)
+    eng = E.Engine(0)
+    try:
+        lam, mu = oracle.lame(1e5, 0.3)
+        eng.set_mesh(mesh)
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        eng.build_pattern()
+        # each cube clamped on its own x-min face
+        fixed_nodes = np.nonzero((np.abs(mesh.node_xyz[:, 0]) < 1e-12) | (np.abs(mesh.node_xyz[:, 0] - shift[0]) < 1e-12))[0]
+        eng.set_dirichlet(np.sort((fixed_nodes[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+        eng.assemble_linear()
+        eng.amg_set_params(coarsest_dofs=60)
+        b = np.random.default_rng(4).standard_normal(mesh.n_nodes * 3)
+        x, it, err = eng.cg(b, None, E.PRECOND_AMG, 500, 1e-10)
+        info = eng.amg_info()
+        assert err <= 1e-10 and it < 60
+        body = (np.arange(mesh.n_nodes) >= n1).astype(int)
+        for l in range(info["n_levels"] - 1):
+            agg = eng.amg_aggregates(l)
+            na = int(agg.max()) + 1
+            ok = agg >= 0
+            lo = np.full(na, 2)
+            hi = np.full(na, -1)
+            np.minimum.at(lo, agg[ok], body[ok])
+            np.maximum.at(hi, agg[ok], body[ok])
+            assert np.array_equal(lo, hi), f"level {l}: an aggregate spans both bodies"
+            body = lo  # the aggregates are the next level's vertices
+    finally:
+        eng.close()
+
+
 def test_amg_converges_at_one_million_elements():
     """Config-2 size (LinearElasticity, 998 250 P2 tets, 4.1 M dofs, clamped x = 0 face): 1e-10 in fewer than 300 iterations
     (Jacobi-CG is at 1.3e-3 after 1000)."""
