@@ -318,3 +318,78 @@ def test_hex_slab_partition_covers_the_global_mesh():
     assert np.unique(allc, axis=0).shape[0] == allc.shape[0]
     if world == 1:
         assert ref.n_el == owned_total
+
+
+def _coarse_worker(rank, world, port, bs, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pf_oracle as O
+        from tests.dist_helpers import OracleOps, csc_tuple_to_csr
+        model = O.LINEAR_ELASTICITY if bs == 3 else O.LAPLACIAN
+        lam, mu = O.lame(1e5, 0.3)
+        part, bounds, n_nodes = D.slab_part(2, 2, rank, world, 2)  # a bar of 2 x 2 x (2 * world) cells, P2 tets
+        nl, no = part.n_local, part.n_owned * bs
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
+        Kl = csc_tuple_to_csr(O.assemble_linear(part.mesh, model, lam, mu), nl * bs)
+        fixed_nodes = np.nonzero(np.abs(part.mesh.node_xyz[:, 2]) < 1e-12)[0]  # clamped at the first rank's outer face
+        fixed_dofs = np.sort((fixed_nodes[:, None] * bs + np.arange(bs)[None]).reshape(-1))
+        fixed_l = np.zeros(nl * bs, dtype=bool)
+        fixed_l[fixed_dofs] = True
+        b_g = np.random.default_rng(9).standard_normal(n_nodes * bs)
+        comm = D.Comm()
+        cg = D.DistributedCG(OracleOps(Kl, no, fixed_l), part, bs, comm, torch.device("cpu"))
+        b = torch.from_numpy(b_g[dof_l2g].copy())
+        x0 = torch.zeros(nl * bs, dtype=torch.float64)
+        it0, err0 = cg.solve(b, x0, 2, 500, 1e-10)
+        cg.enable_coarse_space(M.node_positions(part.mesh), fixed_dofs)
+        x1 = torch.zeros(nl * bs, dtype=torch.float64)
+        it1, err1 = cg.solve(b, x1, 2, 500, 1e-10)
+        # the coarse matrix is symmetric and the coarse correction reproduces a rigid-body mode of a floating rank
+        c = cg.cs
+        m = c["modes"]
+        Einv = c["einv"]
+        assert float((Einv - Einv.T).abs().max()) <= 1e-9 * float(Einv.abs().max())
+        rows = [None] * world
+        dist.all_gather_object(rows, (int(part.lo), x0.numpy()[:no].copy(), x1.numpy()[:no].copy(), Kl[:no], dof_l2g, fixed_l[:no]))
+        if rank == 0:
+            n = n_nodes * bs
+            xg0, xg1, fx = np.zeros(n), np.zeros(n), np.zeros(n, dtype=bool)
+            A = None
+            import scipy.sparse as sp
+            blocks = []
+            for lo, v0, v1, K, l2g_r, f in rows:
+                xg0[lo * bs: lo * bs + v0.size] = v0
+                xg1[lo * bs: lo * bs + v1.size] = v1
+                fx[lo * bs: lo * bs + f.size] = f
+                coo = K.tocoo()
+                blocks.append(sp.csr_matrix((coo.data, (coo.row + lo * bs, l2g_r[coo.col])), shape=(n, n)))
+            A = sum(blocks[1:], blocks[0]).tocsr()
+            Dm = sp.diags((~fx).astype(float))
+            Am = (Dm @ A @ Dm + sp.diags(fx.astype(float))).tocsr()
+            bm = np.where(fx, 0.0, b_g)
+            import scipy.sparse.linalg as spla
+            xr = spla.spsolve(Am.tocsc(), bm)
+            ret["it0"], ret["it1"], ret["err0"], ret["err1"] = it0, it1, err0, err1
+            ret["d0"] = float(np.abs(xg0 - xr).max() / np.abs(xr).max())
+            ret["d1"] = float(np.abs(xg1 - xr).max() / np.abs(xr).max())
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bs", [(4, 3), (6, 3), (4, 1)])
+def test_coarse_space_over_the_ranks(world, bs):
+    """DistributedCG's preconditioned loop (precond = 2) with exact subdomain solves standing in for the per-rank AMG:
+    block-Jacobi alone and with the coarse space of the ranks' rigid-body modes (constants for a scalar problem) both
+    reach the direct solution of the whole system; the coarse space needs fewer iterations on a bar of slabs clamped at
+    one end (the slabs away from the clamp float)."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_coarse_worker, args=(world, _free_port(), bs, ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        it0, it1, err0, err1, d0, d1 = (ret[k] for k in ("it0", "it1", "err0", "err1", "d0", "d1"))
+    assert err0 <= 1e-10 and err1 <= 1e-10 and d0 <= 1e-7 and d1 <= 1e-7, (err0, err1, d0, d1)
+    assert it1 < it0, (it0, it1)
