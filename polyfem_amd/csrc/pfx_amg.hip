@@ -42,6 +42,7 @@
 
 #define AMG_MAX_LEVELS 16
 #define AMG_NPART 256
+#define AMG_SMALL_NODES 32768 // levels of at most this many node rows multiply through k_rowwave_spmv
 
 namespace
 {
@@ -303,6 +304,51 @@ namespace
 			const int64_t a = agg[v];
 			if (a >= 0)
 				x[v] += omega * xc[a];
+		}
+	}
+
+	// y = A x for a SMALL level straight from its node-block arrays: one wave per node row, the lanes over the row's
+	// blocks, a fixed-order butterfly over the wave.  The slice format gives every slice to one wave, which walks its
+	// longest row slot by slot: right for the large levels, but a level of a few thousand rows of 50 - 130 blocks is then a
+	// few dozen waves in a latency chain (32 - 39 us per product on levels of 1 - 13 k rows; 5 - 10 us with this kernel).
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_rowwave_spmv(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, const double *__restrict__ values,
+														  const double *__restrict__ x, int64_t n_nodes, double *__restrict__ y)
+	{
+		const int lane = threadIdx.x & 63;
+		const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		if (g >= n_nodes)
+			return;
+		double acc[BS];
+#pragma unroll
+		for (int m = 0; m < BS; ++m)
+			acc[m] = 0.0;
+		for (int64_t b = node_ptr[g] + lane; b < node_ptr[g + 1]; b += 64)
+		{
+			const int64_t c = node_col[b];
+			double xv[BS];
+#pragma unroll
+			for (int n = 0; n < BS; ++n)
+				xv[n] = x[c * BS + n];
+			const double *a = values + b * (BS * BS);
+#pragma unroll
+			for (int m = 0; m < BS; ++m)
+#pragma unroll
+				for (int n = 0; n < BS; ++n)
+					acc[m] += a[m * BS + n] * xv[n];
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+			for (int m = 0; m < BS; ++m)
+				acc[m] += __shfl_xor(acc[m], off, 64);
+		if (lane < BS)
+		{
+			double v = acc[0];
+#pragma unroll
+			for (int m = 1; m < BS; ++m)
+				v = lane == m ? acc[m] : v;
+			y[g * BS + lane] = v;
 		}
 	}
 
@@ -625,6 +671,7 @@ struct pfx_amg_level
 	// vectors
 	double *d_b = nullptr, *d_x = nullptr, *d_t = nullptr, *d_r = nullptr, *d_dv = nullptr, *d_b2 = nullptr, *d_x2 = nullptr, *d_dinv = nullptr;
 	double lmax = 0;
+	bool small = false; // products through k_rowwave_spmv on the node-block arrays; no solver copy of the matrix
 };
 
 struct pfx_amg
@@ -916,6 +963,7 @@ namespace
 			C.own_m = true;
 			C.n_vert = nc;
 			C.n_dofs = scalar ? nc : 6 * nc;
+			C.small = s->n_nodes <= AMG_SMALL_NODES;
 			if (pfx_alloc(s, &s->d_node_ptr, s->n_nodes + 1) || pfx_alloc(s, &s->d_node_col, s->n_blocks) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nc + 1)
 				|| keep(ctx, &C.d_gcol, gc.col.p, n_cp))
 			{
@@ -1011,6 +1059,25 @@ namespace
 		return hi;
 	}
 
+	// y = A_l x on level l (no Dirichlet mask or shift below level 0; level 0 always takes the slice format)
+	pfx_status amg_matvec(pfx_ctx *ctx, pfx_amg_level &L, const double *x, double *y)
+	{
+		if (!L.small)
+		{
+			pfx_status rc = pfx_sell_spmv(L.m, x, y, nullptr, nullptr);
+			if (rc)
+				ctx->err = L.m->err;
+			return rc;
+		}
+		pfx_ctx *s = L.m;
+		const unsigned grid = (unsigned)((s->n_nodes * 64 + 255) / 256);
+		if (s->bs == 1)
+			hipLaunchKernelGGL((k_rowwave_spmv<1>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_nodes, y);
+		else
+			hipLaunchKernelGGL((k_rowwave_spmv<3>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_nodes, y);
+		return PFX_OK;
+	}
+
 	// lmax of D^-1 A: `eig_iters` Lanczos steps on D^-1/2 A D^-1/2 from a fixed pseudo-random vector, largest Ritz value
 	// plus 5 % (Ritz values approach the spectrum's end from inside; a Chebyshev interval that ends below lmax would
 	// amplify the top modes).  Vectors: v (the one A is applied to) and t (A v) from the caller, three more allocated here.
@@ -1034,12 +1101,9 @@ namespace
 		hipLaunchKernelGGL(k_lz_c, dim3(grid), dim3(256), 0, st, dinv, w.p, scal.p, n_rows, qp.p, q.p, v);
 		for (int j = 0; j < steps; ++j)
 		{
-			pfx_status rc = pfx_sell_spmv(L.m, v, t, nullptr, nullptr);
+			pfx_status rc = amg_matvec(ctx, L, v, t);
 			if (rc)
-			{
-				ctx->err = L.m->err;
 				return rc;
-			}
 			double *alpha = scal.p + 1 + 2 * j, *beta2 = alpha + 1;
 			hipLaunchKernelGGL(k_lz_a, dim3(AMG_NPART), dim3(256), 0, st, dinv, t, qp.p, q.p, j > 0 ? (const double *)(alpha - 1) : (const double *)nullptr, n_rows, w.p,
 							   A->d_part);
@@ -1086,7 +1150,7 @@ namespace
 				hipLaunchKernelGGL((k_galerkin<false>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.d_gptr, F.d_gcol, F.m->d_values, F.d_dvec,
 								   (const uint8_t *)nullptr, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
 			C.m->values_gen++;
-			pfx_status rc = pfx_sell_refresh(C.m);
+			pfx_status rc = C.small ? PFX_OK : pfx_sell_refresh(C.m);
 			if (!rc)
 				rc = pfx_launch_invdiag(C.m, 1, C.d_dinv);
 			if (rc)
@@ -1235,22 +1299,16 @@ namespace
 		const int grid = grid_for(v.n);
 		if (!zero_guess)
 		{
-			pfx_status rc = pfx_sell_spmv(L.m, v.x, v.t, nullptr, nullptr);
+			pfx_status rc = amg_matvec(ctx, L, v.x, v.t);
 			if (rc)
-			{
-				ctx->err = L.m->err;
 				return rc;
-			}
 		}
 		hipLaunchKernelGGL(k_cheb_first, dim3(grid), dim3(256), 0, st, v.dinv, v.b, v.t, 1.0 / theta, zero_guess ? 1 : 0, v.n, deg > 1 ? v.r : nullptr, v.dv, v.x);
 		for (int k = 1; k < deg; ++k)
 		{
-			pfx_status rc = pfx_sell_spmv(L.m, v.dv, v.t, nullptr, nullptr);
+			pfx_status rc = amg_matvec(ctx, L, v.dv, v.t);
 			if (rc)
-			{
-				ctx->err = L.m->err;
 				return rc;
-			}
 			const double rho_new = 1.0 / (2.0 * sigma - rho);
 			hipLaunchKernelGGL(k_cheb_next, dim3(grid), dim3(256), 0, st, v.dinv, v.t, rho_new * rho, 2.0 * rho_new / delta, v.n, v.r, v.dv, v.x);
 			rho = rho_new;
@@ -1276,11 +1334,8 @@ namespace
 		if (rc)
 			return rc;
 		// coarse correction
-		if ((rc = pfx_sell_spmv(L.m, x, v.t, nullptr, nullptr)))
-		{
-			ctx->err = L.m->err;
+		if ((rc = amg_matvec(ctx, L, x, v.t)))
 			return rc;
-		}
 		pfx_amg_level &C = A->lv[l + 1];
 		if (scalar)
 			hipLaunchKernelGGL(k_restrict_scalar, dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, L.n_agg, C.d_b);
@@ -1295,11 +1350,8 @@ namespace
 			// W cycle: a second coarse cycle on the coarse residual
 			for (int rep = 1; rep < ctx->amg_params.ncycle; ++rep)
 			{
-				if ((rc = pfx_sell_spmv(C.m, C.d_x, C.d_t, nullptr, nullptr)))
-				{
-					ctx->err = C.m->err;
+				if ((rc = amg_matvec(ctx, C, C.d_x, C.d_t)))
 					return rc;
-				}
 				hipLaunchKernelGGL(k_vec_sub, dim3(grid_for(C.n_dofs)), dim3(256), 0, st, C.d_b, C.d_t, C.n_dofs, C.d_b2);
 				if ((rc = amg_cycle(ctx, A, l + 1, C.d_b2, C.d_x2, nullptr, nullptr)))
 					return rc;
