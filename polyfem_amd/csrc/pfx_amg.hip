@@ -210,33 +210,48 @@ namespace
 		}
 	}
 
-	// coarse right-hand side: per aggregate, sum over its member vertices of P_v^T (b - t)
+	// coarse right-hand side: per aggregate, sum over its member vertices of P_v^T (b - t).  Sixteen lanes per aggregate
+	// (an aggregate has 8 - 20 members): lane m takes the members m, m + 16, ..., then a fixed-order butterfly.
 	template <bool LEVEL0>
 	__global__ __launch_bounds__(256) void k_restrict(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ dvec,
 														 const double *__restrict__ b, const double *__restrict__ t, int64_t n_agg, double *__restrict__ bc)
 	{
-		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < n_agg; a += (int64_t)gridDim.x * blockDim.x)
+		const int sub = threadIdx.x & 15;
+		for (int64_t a = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; a < ((n_agg + 3) & ~(int64_t)3); a += ((int64_t)gridDim.x * blockDim.x) >> 4)
 		{
+			// (the loop bound is rounded up to whole waves of four aggregates so that every lane reaches the shuffles)
 			double T[3] = {0, 0, 0}, W[3] = {0, 0, 0};
-			for (int64_t k = mptr[a]; k < mptr[a + 1]; ++k)
-			{
-				const int64_t v = mlist[k];
-				const double d[3] = {dvec[3 * v], dvec[3 * v + 1], dvec[3 * v + 2]};
-				const int64_t o = LEVEL0 ? 3 * v : 6 * v;
-				const double r[3] = {b[o] - t[o], b[o + 1] - t[o + 1], b[o + 2] - t[o + 2]};
-				T[0] += r[0], T[1] += r[1], T[2] += r[2];
-				W[0] += d[1] * r[2] - d[2] * r[1];
-				W[1] += d[2] * r[0] - d[0] * r[2];
-				W[2] += d[0] * r[1] - d[1] * r[0];
-				if (!LEVEL0)
+			if (a < n_agg)
+				for (int64_t k = mptr[a] + sub; k < mptr[a + 1]; k += 16)
 				{
-					W[0] += b[o + 3] - t[o + 3];
-					W[1] += b[o + 4] - t[o + 4];
-					W[2] += b[o + 5] - t[o + 5];
+					const int64_t v = mlist[k];
+					const double d[3] = {dvec[3 * v], dvec[3 * v + 1], dvec[3 * v + 2]};
+					const int64_t o = LEVEL0 ? 3 * v : 6 * v;
+					const double r[3] = {b[o] - t[o], b[o + 1] - t[o + 1], b[o + 2] - t[o + 2]};
+					T[0] += r[0], T[1] += r[1], T[2] += r[2];
+					W[0] += d[1] * r[2] - d[2] * r[1];
+					W[1] += d[2] * r[0] - d[0] * r[2];
+					W[2] += d[0] * r[1] - d[1] * r[0];
+					if (!LEVEL0)
+					{
+						W[0] += b[o + 3] - t[o + 3];
+						W[1] += b[o + 4] - t[o + 4];
+						W[2] += b[o + 5] - t[o + 5];
+					}
 				}
+#pragma unroll
+			for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+				for (int q = 0; q < 3; ++q)
+				{
+					T[q] += __shfl_xor(T[q], off, 64);
+					W[q] += __shfl_xor(W[q], off, 64);
+				}
+			if (a < n_agg && sub == 0)
+			{
+				bc[6 * a] = T[0], bc[6 * a + 1] = T[1], bc[6 * a + 2] = T[2];
+				bc[6 * a + 3] = W[0], bc[6 * a + 4] = W[1], bc[6 * a + 5] = W[2];
 			}
-			bc[6 * a] = T[0], bc[6 * a + 1] = T[1], bc[6 * a + 2] = T[2];
-			bc[6 * a + 3] = W[0], bc[6 * a + 4] = W[1], bc[6 * a + 5] = W[2];
 		}
 	}
 
@@ -1340,9 +1355,9 @@ namespace
 		if (scalar)
 			hipLaunchKernelGGL(k_restrict_scalar, dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, L.n_agg, C.d_b);
 		else if (level0)
-			hipLaunchKernelGGL((k_restrict<true>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
+			hipLaunchKernelGGL((k_restrict<true>), dim3(grid_for(L.n_agg * 16)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
 		else
-			hipLaunchKernelGGL((k_restrict<false>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
+			hipLaunchKernelGGL((k_restrict<false>), dim3(grid_for(L.n_agg * 16)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
 		if ((rc = amg_cycle(ctx, A, l + 1, C.d_b, C.d_x, nullptr, nullptr)))
 			return rc;
 		if (ctx->amg_params.ncycle > 1 && l + 2 < A->lv.size())

@@ -3,7 +3,8 @@ import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(f)):
-    name = r["Kernel_Name"].split("(")[0][-40:]
+    import re
+    name = re.sub(r"^void |\(anonymous namespace\)::|rocprim::ROCPRIM_\d+_NS::detail::", "", r["Kernel_Name"]).split("(")[0][:44]
     key = (name, int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0)))
     acc[key][0] += 1
     acc[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
