@@ -190,6 +190,8 @@ struct pfx_ctx
 
 	// solver copy of the matrix (block-SELL-64, pfx_sell.hip)
 	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
+	int32_t *d_sell_pos = nullptr;   // row -> position (slice * 64 + lane) in the slice order
+	double *d_sell_ys = nullptr;     // product in slice order, before k_sell_unpermute
 	int32_t *d_sell_order = nullptr; // slice list, interior slices first (null: natural order, no halo)
 	int64_t sell_interior = 0;       // number of slices that read owned entries of x only
 	pfx_xcd_split sell_split[3];     // positions of the slice list per XCD for PFX_SPMV_ALL / _INTERIOR / _BOUNDARY, cut by stored slots

@@ -144,7 +144,11 @@ namespace
 	// y = (A + shift I) x on owned rows (constrained rows: y = x); optional per-block partial of x.y.  One slice per single-wave block (measured
 	// faster than four waves per block); blocks b and b+8 run on the same XCD, so each XCD walks one contiguous range of the slice list (x gathers stay
 	// in its L2), the ranges cut so that they hold equal numbers of stored slots (pfx_xcd_split).
-	template <int BS, bool DOT>
+	// SLICEOUT: the results go to `y` in slice order, y[(s * BS + m) * 64 + lane] -- one full-width store per row component --
+	// and k_sell_unpermute brings them into row order afterwards.  Stored directly, a lane's rows sit 24 bytes each in a
+	// cache line of their own (the rows of a slice are sorted by degree, not neighbours): every line is fetched to be
+	// merged and written back, ten times the useful bytes, 16 % of the kernel.
+	template <int BS, bool DOT, bool SLICEOUT>
 	__global__ __launch_bounds__(64) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
 														const int32_t *__restrict__ cols, const double *__restrict__ values,
 														const int32_t *__restrict__ order, int first, pfx_xcd_split split,
@@ -169,26 +173,96 @@ namespace
 			const double *v = values + base * (SL * B2);
 			const int32_t *c = cols + base * SL + lane;
 			double a0 = 0, a1 = 0, a2 = 0;
+			// what the end of the slice needs -- the row this lane owns, its entries of x and its constraint flags -- is
+			// requested now: asked for after the last slot, the chain row -> x -> store is two memory latencies during
+			// which the wave holds its place and streams nothing (16 % of the kernel)
+			const int g = perm[s * SL + lane];
+			double xr[BS];
+			bool fx[BS];
+#pragma unroll
+			for (int m = 0; m < BS; ++m)
+			{
+				xr[m] = g >= 0 ? x[(int64_t)g * BS + m] : 0.0;
+				fx[m] = (g >= 0 && fixed) ? fixed[(int64_t)g * BS + m] != 0 : false;
+			}
 			if (BS == 3)
 			{
 				// matrix values and column ids are read once per product: non-temporal loads keep them from evicting
 				// the gathered x entries out of the L2
 				typedef double d2 __attribute__((ext_vector_type(2)));
-#pragma unroll 12
-				for (int j = 0; j < len; ++j)
+#ifndef PFX_SPMV_BATCH
+#define PFX_SPMV_BATCH 6
+#endif
+				// Batches of U slots: all loads of a batch are issued back to back -- the values, the x entries (their
+				// columns were fetched one batch ahead, so their addresses are known) and the next batch's columns -- and
+				// only then waited for.  (Left to the compiler, a loop over single slots was scheduled with full waits in
+				// the middle of the unrolled body: 5.6 TB/s on the value stream alone where a plain read reaches 7.)
+				constexpr int U = PFX_SPMV_BATCH;
+				int cn[U];
+#pragma unroll
+				for (int u = 0; u < U; ++u)
+					cn[u] = u < len ? __builtin_nontemporal_load(c + u * SL) : 0;
+				int j = 0;
+				for (; j + U <= len; j += U)
 				{
-					const int64_t cc = (int64_t)__builtin_nontemporal_load(c + j * SL) * 3;
-					const double x0 = x[cc], x1 = x[cc + 1], x2 = x[cc + 2];
-					const double *vj = v + (int64_t)j * (SL * 9);
-					const d2 *vp = reinterpret_cast<const d2 *>(vj) + lane;
-					const d2 p0 = __builtin_nontemporal_load(vp);
-					const d2 p1 = __builtin_nontemporal_load(vp + 64);
-					const d2 p2 = __builtin_nontemporal_load(vp + 128);
-					const d2 p3 = __builtin_nontemporal_load(vp + 192);
-					const double p4 = __builtin_nontemporal_load(vj + 512 + lane);
-					a0 += p0.x * x0 + p0.y * x1 + p1.x * x2;
-					a1 += p1.y * x0 + p2.x * x1 + p2.y * x2;
-					a2 += p3.x * x0 + p3.y * x1 + p4 * x2;
+					d2 p0[U], p1[U], p2[U], p3[U];
+					double p4[U], x0[U], x1[U], x2[U];
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+					{
+						const double *vj = v + (int64_t)(j + u) * (SL * 9);
+						const d2 *vp = reinterpret_cast<const d2 *>(vj) + lane;
+						p0[u] = __builtin_nontemporal_load(vp);
+						p1[u] = __builtin_nontemporal_load(vp + 64);
+						p2[u] = __builtin_nontemporal_load(vp + 128);
+						p3[u] = __builtin_nontemporal_load(vp + 192);
+						p4[u] = __builtin_nontemporal_load(vj + 512 + lane);
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+					{
+						const int64_t cc = (int64_t)cn[u] * 3;
+						x0[u] = x[cc], x1[u] = x[cc + 1], x2[u] = x[cc + 2];
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+						cn[u] = j + U + u < len ? __builtin_nontemporal_load(c + (j + U + u) * SL) : 0;
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+					{
+						a0 += p0[u].x * x0[u] + p0[u].y * x1[u] + p1[u].x * x2[u];
+						a1 += p1[u].y * x0[u] + p2[u].x * x1[u] + p2[u].y * x2[u];
+						a2 += p3[u].x * x0[u] + p3[u].y * x1[u] + p4[u] * x2[u];
+					}
+				}
+				// the last len % U slots (their columns are in cn): one more batch, loads first, every slot guarded by the
+				// (wave-uniform) bound -- slot by slot they would each wait out a full memory latency
+				if (j < len)
+				{
+					d2 p0[U], p1[U], p2[U], p3[U];
+					double p4[U], x0[U], x1[U], x2[U];
+#pragma unroll
+					for (int u = 0; u < U - 1; ++u)
+						if (j + u < len)
+						{
+							const double *vj = v + (int64_t)(j + u) * (SL * 9);
+							const d2 *vp = reinterpret_cast<const d2 *>(vj) + lane;
+							p0[u] = __builtin_nontemporal_load(vp);
+							p1[u] = __builtin_nontemporal_load(vp + 64);
+							p2[u] = __builtin_nontemporal_load(vp + 128);
+							p3[u] = __builtin_nontemporal_load(vp + 192);
+							p4[u] = __builtin_nontemporal_load(vj + 512 + lane);
+							const int64_t cc = (int64_t)cn[u] * 3;
+							x0[u] = x[cc], x1[u] = x[cc + 1], x2[u] = x[cc + 2];
+						}
+#pragma unroll
+					for (int u = 0; u < U - 1; ++u)
+						if (j + u < len)
+						{
+							a0 += p0[u].x * x0[u] + p0[u].y * x1[u] + p1[u].x * x2[u];
+							a1 += p1[u].y * x0[u] + p2[u].x * x1[u] + p2[u].y * x2[u];
+							a2 += p3[u].x * x0[u] + p3[u].y * x1[u] + p4[u] * x2[u];
+						}
 				}
 			}
 			else
@@ -197,19 +271,18 @@ namespace
 				for (int j = 0; j < len; ++j)
 					a0 += __builtin_nontemporal_load(v + (int64_t)j * SL + lane) * x[__builtin_nontemporal_load(c + j * SL)];
 			}
-			const int g = perm[s * SL + lane];
-			if (g >= 0)
 			{
 				const double acc[3] = {a0, a1, a2};
 #pragma unroll
 				for (int m = 0; m < BS; ++m)
 				{
-					const int64_t r = (int64_t)g * BS + m;
-					const double xr = x[r];
-					const double yr = (fixed && fixed[r]) ? xr : acc[m] + shift * xr;
-					y[r] = yr;
+					const double yr = g < 0 ? 0.0 : fx[m] ? xr[m] : acc[m] + shift * xr[m];
+					if (SLICEOUT)
+						y[(s * BS + m) * SL + lane] = yr;
+					else if (g >= 0)
+						y[(int64_t)g * BS + m] = yr;
 					if (DOT)
-						dot += xr * yr;
+						dot += xr[m] * yr;
 				}
 			}
 		}
@@ -221,10 +294,37 @@ namespace
 		}
 	}
 
+	// pos[g] = position (slice * 64 + lane) of row g in the slice order
+	__global__ void k_sell_pos(const int32_t *__restrict__ perm, int64_t n_pad, int32_t *__restrict__ pos)
+	{
+		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_pad; k += (int64_t)gridDim.x * blockDim.x)
+			if (perm[k] >= 0)
+				pos[perm[k]] = (int32_t)k;
+	}
+
+	// y[g * BS + m] = ys[(slice * BS + m) * 64 + lane]: consecutive threads write consecutive rows; the reads stay inside
+	// the window of rows the slices were sorted in (L2)
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_sell_unpermute(const int32_t *__restrict__ pos, const double *__restrict__ ys, int64_t n_rows, double *__restrict__ y,
+															const int *__restrict__ done)
+	{
+		if (done && *done) // the product was skipped (the solve has converged): nothing new to bring over
+			return;
+		for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t g = r / BS;
+			const int m = (int)(r - g * BS);
+			const int64_t k = pos[g];
+			y[r] = ys[((k >> 6) * BS + m) * SL + (k & 63)];
+		}
+	}
+
 } // namespace
 
 void pfx_sell_release(pfx_ctx *ctx)
 {
+	free_dev(ctx, ctx->d_sell_pos);
+	free_dev(ctx, ctx->d_sell_ys);
 	free_dev(ctx, ctx->d_sell_perm);
 	free_dev(ctx, ctx->d_sell_base);
 	free_dev(ctx, ctx->d_sell_cols);
@@ -265,6 +365,9 @@ static pfx_status sell_build(pfx_ctx *ctx)
 	if (pfx_alloc(ctx, &ctx->d_sell_perm, n_pad) || pfx_alloc(ctx, &ctx->d_sell_base, n_slices + 1))
 		return PFX_ERR_HIP;
 	hipLaunchKernelGGL(k_sell_perm, dim3(grid_for(n_pad)), dim3(256), 0, st, vb.p, n_owned, n_pad, ctx->d_node_ptr, ctx->d_sell_perm, len.p);
+	if (pfx_alloc(ctx, &ctx->d_sell_pos, n_owned) || pfx_alloc(ctx, &ctx->d_sell_ys, n_pad * ctx->bs))
+		return PFX_ERR_HIP;
+	hipLaunchKernelGGL(k_sell_pos, dim3(grid_for(n_pad)), dim3(256), 0, st, ctx->d_sell_perm, n_pad, ctx->d_sell_pos);
 	PFX_HIP(hipStreamSynchronize(st));
 	tb = 0;
 	PFX_HIP(rocprim::exclusive_scan(nullptr, tb, len.p, ctx->d_sell_base, (int64_t)0, (size_t)(n_slices + 1), rocprim::plus<int64_t>(), st));
@@ -393,7 +496,23 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	const int grid = PFX_XCDS * split.widest; // one slice (one wave) per block
 	const int32_t *order = ctx->d_sell_order;
 	pfx_scoped_timer tm(ctx, phase == PFX_SPMV_BOUNDARY ? "spmv_boundary" : "spmv");
-#define PFX_GO(BS_, DOT_) hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols, ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, d_y, part, done)
+	// a whole product goes through the slice-ordered buffer and the un-permute pass; the two halves of a distributed
+	// product (and small matrices, where the second launch costs more than it saves) store their rows directly
+	const bool sliceout = phase == PFX_SPMV_ALL && !order && ctx->n_owned >= 65536;
+#define PFX_GO(BS_, DOT_)                                                                                                                                          \
+	do                                                                                                                                                             \
+	{                                                                                                                                                              \
+		if (sliceout)                                                                                                                                              \
+		{                                                                                                                                                          \
+			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, true>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,        \
+							   ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, ctx->d_sell_ys, part, done);                                      \
+			hipLaunchKernelGGL((k_sell_unpermute<BS_>), dim3(grid_for(ctx->n_owned * BS_)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys,            \
+							   ctx->n_owned * BS_, d_y, done);                                                                                                       \
+		}                                                                                                                                                          \
+		else                                                                                                                                                       \
+			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, false>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,       \
+							   ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, d_y, part, done);                                                 \
+	} while (0)
 	if (ctx->bs == 1)
 	{
 		if (part)
