@@ -192,6 +192,7 @@ struct pfx_ctx
 	int32_t *d_sell_perm = nullptr, *d_sell_cols = nullptr;
 	int32_t *d_sell_pos = nullptr;   // row -> position (slice * 64 + lane) in the slice order
 	double *d_sell_ys = nullptr;     // product in slice order, before k_sell_unpermute
+	bool cg_tmp_sliced = false;      // the CG's last A p sits in d_sell_ys (slice order), not in the work vector
 	int32_t *d_sell_order = nullptr; // slice list, interior slices first (null: natural order, no halo)
 	int64_t sell_interior = 0;       // number of slices that read owned entries of x only
 	pfx_xcd_split sell_split[3];     // positions of the slice list per XCD for PFX_SPMV_ALL / _INTERIOR / _BOUNDARY, cut by stored slots
@@ -383,7 +384,9 @@ enum
 	PFX_SPMV_INTERIOR = 1,
 	PFX_SPMV_BOUNDARY = 2
 };
-pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL);
+// sliced: where given, a product that went through the slice-ordered buffer is LEFT there (*sliced = true; d_y untouched):
+// the caller reads entry r of the product as ys[((pos[r / bs] >> 6) * bs + r % bs) * 64 + (pos[r / bs] & 63)]
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL, bool *sliced = nullptr);
 void pfx_amg_release(pfx_ctx *ctx);
 pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res);
 pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag);

@@ -482,7 +482,7 @@ int pfx_sell_grid(const pfx_ctx *ctx)
 
 // phase: PFX_SPMV_ALL, or the two halves of a distributed product: PFX_SPMV_INTERIOR (slices that read owned entries of
 // x only) and PFX_SPMV_BOUNDARY (the rest, after the halo entries have arrived)
-pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase)
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase, bool *sliced)
 {
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	int first = 0, count = (int)ctx->sell_slices;
@@ -499,6 +499,8 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	// a whole product goes through the slice-ordered buffer and the un-permute pass; the two halves of a distributed
 	// product (and small matrices, where the second launch costs more than it saves) store their rows directly
 	const bool sliceout = phase == PFX_SPMV_ALL && !order && ctx->n_owned >= 65536;
+	if (sliced)
+		*sliced = sliceout;
 #define PFX_GO(BS_, DOT_)                                                                                                                                          \
 	do                                                                                                                                                             \
 	{                                                                                                                                                              \
@@ -506,8 +508,9 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 		{                                                                                                                                                          \
 			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, true>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,        \
 							   ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, ctx->d_sell_ys, part, done);                                      \
-			hipLaunchKernelGGL((k_sell_unpermute<BS_>), dim3(grid_for(ctx->n_owned * BS_)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys,            \
-							   ctx->n_owned * BS_, d_y, done);                                                                                                       \
+			if (!sliced)                                                                                                                                           \
+				hipLaunchKernelGGL((k_sell_unpermute<BS_>), dim3(grid_for(ctx->n_owned * BS_)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys,        \
+								   ctx->n_owned * BS_, d_y, done);                                                                                                       \
 		}                                                                                                                                                          \
 		else                                                                                                                                                       \
 			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, false>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,       \

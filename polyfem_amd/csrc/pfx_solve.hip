@@ -239,9 +239,11 @@ namespace
 	}
 
 	// alpha = abs_new / p.tmp ; x += alpha p ; r -= alpha tmp ; partials [1], [2] of r.r and r.(M^-1 r)
-	__global__ __launch_bounds__(256) void k_cg_update(const double *__restrict__ p, const double *__restrict__ tmp, const double *__restrict__ invdiag,
-														int64_t n, int it, double *__restrict__ x, double *__restrict__ r, double *__restrict__ part,
-														const double *__restrict__ pap, const pfx_cg_state *__restrict__ state)
+	// BS > 0: tmp holds A p in the slice order of the solver's matrix copy (see pfx_sell_spmv), pos the rows' positions in it
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_cg_update(const double *__restrict__ p, const double *__restrict__ tmp, const int32_t *__restrict__ pos,
+														const double *__restrict__ invdiag, int64_t n, int it, double *__restrict__ x, double *__restrict__ r,
+														double *__restrict__ part, const double *__restrict__ pap, const pfx_cg_state *__restrict__ state)
 	{
 		__shared__ double sh[256];
 		if (state->done)
@@ -252,7 +254,16 @@ namespace
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
 		{
 			x[k] += alpha * p[k];
-			const double rk = r[k] - alpha * tmp[k];
+			double tk;
+			if (BS > 0)
+			{
+				const int64_t g = k / BS;
+				const int64_t q = pos[g];
+				tk = tmp[((q >> 6) * BS + (k - g * BS)) * 64 + (q & 63)];
+			}
+			else
+				tk = tmp[k];
+			const double rk = r[k] - alpha * tk;
 			r[k] = rk;
 			rr += rk * rk;
 			rz += rk * (invdiag[k] * rk);
@@ -455,7 +466,10 @@ pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal)
 	cg_vecs w;
 	if (cg_workspace(ctx, &w))
 		return PFX_ERR_HIP;
-	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done, phase);
+	// a whole product may stay in the solver copy's slice order: only the update kernel reads it
+	bool sliced = false;
+	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done, phase, phase == PFX_SPMV_ALL ? &sliced : nullptr);
+	ctx->cg_tmp_sliced = sliced;
 	if (rc)
 		return rc;
 	// one partial per slice: summed once here rather than by every block of the update kernel
@@ -472,7 +486,13 @@ pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal)
 	const int64_t n = ctx->n_owned * ctx->bs;
 	{
 		pfx_scoped_timer tm(ctx, "cg_update");
-		hipLaunchKernelGGL(k_cg_update, dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, w.invdiag, n, it, d_x, w.r, ctx->d_partials, gscal ? gscal : ctx->d_partials + 3 * PFX_NPART, (pfx_cg_state *)ctx->d_cgstate);
+		const double *pap = gscal ? gscal : ctx->d_partials + 3 * PFX_NPART;
+		if (ctx->cg_tmp_sliced && ctx->bs == 3)
+			hipLaunchKernelGGL((k_cg_update<3>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, ctx->d_sell_ys, ctx->d_sell_pos, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
+		else if (ctx->cg_tmp_sliced && ctx->bs == 1)
+			hipLaunchKernelGGL((k_cg_update<1>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, ctx->d_sell_ys, ctx->d_sell_pos, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
+		else
+			hipLaunchKernelGGL((k_cg_update<0>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, (const int32_t *)nullptr, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
 	}
 	finish(ctx, 1, 2, gscal);
 	return PFX_OK;
