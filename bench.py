@@ -265,7 +265,8 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
         for name in (f"r2_pmc_traffic_{workload}_{element}_grid{grid}.json", f"r1_pmc_traffic_grid{grid}.json" if workload == "linear_elasticity" and not hexes else ""):
             tpath = os.path.join(ROOT, "profiles", name)
             if name and os.path.exists(tpath):
-                rec = json.load(open(tpath)).get("k_sell_spmv<3, true>")
+                recs = json.load(open(tpath))
+                rec = next((v for k, v in recs.items() if k.startswith("k_sell_spmv<3, true")), None)  # the CG's product (with the p.Ap partials)
                 if rec:
                     traffic, traffic_src = rec["hbm_bytes"], os.path.relpath(tpath, ROOT)
                     break
