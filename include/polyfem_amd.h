@@ -394,6 +394,9 @@ pfx_status pfx_implicit_euler_step_dev(pfx_ctx *ctx, double dt, const double *d_
  *                     pfx_cgs_direction: convergence test, p = M^-1 r + beta p
  *   pfx_cgs_status    synchronises and reports (done, iterations, ||r||^2, ||b||^2)
  *
+ * tmp = A p may stay in the solver copy's own row order between pfx_cgs_spmv* and pfx_cgs_update (which reads it there);
+ * a caller that reads tmp in d_work itself calls pfx_cgs_fetch_product first.
+ *
  * d_scal is a device array of >= 4 doubles owned by the caller.  With d_scal == NULL the steps reduce locally and
  * form exactly the single-GPU pfx_cg_dev.  d_work (4 * n_local_dofs doubles: r, p, tmp, invdiag in this order) is the
  * caller-owned workspace, so that the caller can address the halo part of p. */
@@ -409,6 +412,7 @@ pfx_status pfx_cgs_start2(pfx_ctx *ctx, const double *d_scal);
 pfx_status pfx_cgs_spmv(pfx_ctx *ctx, double *d_scal);
 pfx_status pfx_cgs_spmv_interior(pfx_ctx *ctx);
 pfx_status pfx_cgs_spmv_boundary(pfx_ctx *ctx, double *d_scal);
+pfx_status pfx_cgs_fetch_product(pfx_ctx *ctx);
 pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal);
 pfx_status pfx_cgs_direction(pfx_ctx *ctx, int it, const double *d_scal);
 pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);

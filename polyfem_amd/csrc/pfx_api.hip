@@ -1343,6 +1343,11 @@ extern "C"
 		PFX_NEED(true);
 		return pfx_cgs_spmv_phase_impl(ctx, PFX_SPMV_BOUNDARY, d_scal);
 	}
+	pfx_status pfx_cgs_fetch_product(pfx_ctx *ctx)
+	{
+		PFX_NEED(true);
+		return pfx_cgs_fetch_product_impl(ctx);
+	}
 	pfx_status pfx_cgs_update(pfx_ctx *ctx, int it, double *d_x, double *d_scal)
 	{
 		PFX_NEED(d_x);

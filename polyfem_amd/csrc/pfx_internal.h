@@ -387,6 +387,8 @@ enum
 // sliced: where given, a product that went through the slice-ordered buffer is LEFT there (*sliced = true; d_y untouched):
 // the caller reads entry r of the product as ys[((pos[r / bs] >> 6) * bs + r % bs) * 64 + (pos[r / bs] & 63)]
 pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL, bool *sliced = nullptr);
+pfx_status pfx_sell_unpermute(pfx_ctx *ctx, double *d_y);
+pfx_status pfx_cgs_fetch_product_impl(pfx_ctx *ctx);
 void pfx_amg_release(pfx_ctx *ctx);
 pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res);
 pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag);

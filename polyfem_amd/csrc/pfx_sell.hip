@@ -475,6 +475,20 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 }
 
 // number of per-slice partial sums the SpMV writes
+// the product left in slice order by pfx_sell_spmv(..., &sliced) -> row order in d_y
+pfx_status pfx_sell_unpermute(pfx_ctx *ctx, double *d_y)
+{
+	const int64_t n = ctx->n_owned * ctx->bs;
+	if (ctx->bs == 3)
+		hipLaunchKernelGGL((k_sell_unpermute<3>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys, n, d_y, (const int *)nullptr);
+	else if (ctx->bs == 1)
+		hipLaunchKernelGGL((k_sell_unpermute<1>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys, n, d_y, (const int *)nullptr);
+	else
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
 int pfx_sell_grid(const pfx_ctx *ctx)
 {
 	return (int)ctx->sell_slices;
@@ -496,9 +510,10 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	const int grid = PFX_XCDS * split.widest; // one slice (one wave) per block
 	const int32_t *order = ctx->d_sell_order;
 	pfx_scoped_timer tm(ctx, phase == PFX_SPMV_BOUNDARY ? "spmv_boundary" : "spmv");
-	// a whole product goes through the slice-ordered buffer and the un-permute pass; the two halves of a distributed
-	// product (and small matrices, where the second launch costs more than it saves) store their rows directly
-	const bool sliceout = phase == PFX_SPMV_ALL && !order && ctx->n_owned >= 65536;
+	// a product goes through the slice-ordered buffer and, unless the caller reads it from there, the un-permute pass; small
+	// matrices, where the second launch costs more than it saves, store their rows directly
+	// (a half product can only stay in slice order: the un-permute pass covers all rows)
+	const bool sliceout = ctx->n_owned >= 65536 && (phase == PFX_SPMV_ALL || sliced);
 	if (sliced)
 		*sliced = sliceout;
 #define PFX_GO(BS_, DOT_)                                                                                                                                          \

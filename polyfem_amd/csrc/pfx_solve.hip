@@ -468,7 +468,7 @@ pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal)
 		return PFX_ERR_HIP;
 	// a whole product may stay in the solver copy's slice order: only the update kernel reads it
 	bool sliced = false;
-	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done, phase, phase == PFX_SPMV_ALL ? &sliced : nullptr);
+	pfx_status rc = pfx_sell_spmv(ctx, w.p, w.tmp, ctx->d_part0, &((pfx_cg_state *)ctx->d_cgstate)->done, phase, &sliced);
 	ctx->cg_tmp_sliced = sliced;
 	if (rc)
 		return rc;
@@ -476,6 +476,20 @@ pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal)
 	if (phase != PFX_SPMV_INTERIOR)
 		hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal ? gscal : ctx->d_partials + 3 * PFX_NPART);
 	return PFX_OK;
+}
+
+// tmp = A p in row order in the workspace, for a caller that reads it there
+pfx_status pfx_cgs_fetch_product_impl(pfx_ctx *ctx)
+{
+	if (!ctx->cg_tmp_sliced)
+		return PFX_OK;
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	pfx_status rc = pfx_sell_unpermute(ctx, w.tmp);
+	if (!rc)
+		ctx->cg_tmp_sliced = false;
+	return rc;
 }
 
 pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal)

@@ -335,6 +335,10 @@ class HipOps:
     def spmv_boundary(self, scal):
         self.e.cgs_spmv_boundary(scal.data_ptr())
 
+    def fetch_product(self):
+        """A p in row order in the workspace's third quarter (the engine may have left it in its matrix copy's order)."""
+        self.e.cgs_fetch_product()
+
     def update(self, it, x, scal):
         self.e.cgs_update(it, x.data_ptr(), scal.data_ptr())
 
@@ -579,6 +583,7 @@ class DistributedCG:
             ops.spmv_interior()
             self.halo.finish(pending)
             ops.spmv_boundary(scal)  # scal[0] = local p.Ap
+            ops.fetch_product()      # this loop reads A p in the workspace itself
             ar(scal[0:1])
             alpha = rz / scal[0]     # device scalar
             xo.addcmul_(p, alpha)

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "pfx_set_owned", "pfx_cgs_set_workspace", "pfx_cgs_prepare", "pfx_cgs_residual", "pfx_cgs_start", "pfx_cgs_start2",
     "pfx_cgs_spmv", "pfx_cgs_update", "pfx_cgs_direction", "pfx_cgs_status",
     "pfx_newton_default_params", "pfx_newton_solve", "pfx_newton_solve_dev", "pfx_set_material_per_element",
-    "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary",
+    "pfx_assemble_mass", "pfx_assemble_rhs", "pfx_assemble_rhs_dev", "pfx_cgs_spmv_interior", "pfx_cgs_spmv_boundary", "pfx_cgs_fetch_product",
     "pfx_hessian_psd_dev", "pfx_set_diag_shift", "pfx_take_numeric_flag", "pfx_inertia_set_mass", "pfx_inertia_enable",
     "pfx_implicit_euler_step", "pfx_implicit_euler_step_dev", "pfx_mass_apply_dev", "pfx_hessian_add_mass_dev",
     "pfx_inertia_enable_host", "pfx_set_elasticity_tensor", "pfx_set_saint_venant_tensor", "pfx_set_element_models",
@@ -188,6 +188,7 @@ def load():
         "pfx_cgs_spmv": [_vp, _vp],
         "pfx_cgs_spmv_interior": [_vp],
         "pfx_cgs_spmv_boundary": [_vp, _vp],
+        "pfx_cgs_fetch_product": [_vp],
         "pfx_cgs_update": [_vp, _i32, _vp, _vp],
         "pfx_cgs_direction": [_vp, _i32, _vp],
         "pfx_cgs_status": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pd, _pd],
@@ -713,6 +714,10 @@ class Engine:
 
     def cgs_spmv_boundary(self, d_scal: int):
         self._ck(self.L.pfx_cgs_spmv_boundary(self.h, _vp(d_scal) if d_scal else None))
+
+    def cgs_fetch_product(self):
+        """tmp = A p in row order in the workspace (the update step reads it wherever it is; a caller that reads it does this first)."""
+        self._ck(self.L.pfx_cgs_fetch_product(self.h))
 
     def cgs_update(self, it: int, d_x: int, d_scal: int):
         self._ck(self.L.pfx_cgs_update(self.h, it, _vp(d_x), _vp(d_scal) if d_scal else None))
