@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from polyfem_amd import engine as E, distributed as D
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 55
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+pre = float(os.environ.get("PRE_GB", "0"))
+if pre > 0:  # touch and release a large range first (does the history of the allocator change the product's speed?)
+    big = torch.empty(int(pre * 1e9), dtype=torch.uint8, device="cuda"); big.fill_(1); torch.cuda.synchronize(); del big; torch.cuda.empty_cache()
 part, _, _ = D.slab_part(n, n, 0, 1, 2, "tet")
 eng = E.Engine(0); eng.set_mesh(part.mesh); eng.set_material(E.LINEAR_ELASTICITY, 57692.3, 38461.5); eng.build_pattern(); eng.assemble_linear()
 inf = eng.info()
