@@ -318,7 +318,11 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
                                            "frac": af / (asm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if asm_ms > 0 else 0.0,
                                            "flops": af}},
             "cg": {"update_ms": upd_ms, "direction_ms": dir_ms, "spmv_ms": spmv_ms, "precond_ms": pre_ms,
-                   "ms_per_iter": spmv_ms + upd_ms + dir_ms + pre_ms},
+                   "ms_per_iter": spmv_ms + upd_ms + dir_ms + pre_ms,
+                   # fused vector kernels on their compulsory bytes: update reads p, A p, 1/diag, x, r and writes x, r
+                   # (56 B per dof); direction reads r, 1/diag, p and writes p (32 B per dof)
+                   "update_gbs": 56.0 * n / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0,
+                   "direction_gbs": 32.0 * n / (dir_ms * 1e-3) / 1e9 if dir_ms > 0 else 0.0},
             "pattern_build_s": t_pattern,
         }
         if workload == "transient":
