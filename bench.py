@@ -336,6 +336,23 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     # the same system solved to convergence with the AMG preconditioner (non-default option; elastic workloads); with
     # several ranks: one hierarchy per rank on its owned block (block-Jacobi over the ranks)
     if workload in ("neohookean", "linear_elasticity") and not args.no_amg:
+        watchdog = None
+        if world > 1:
+            # A rank that fails inside this optional leg would leave the others waiting in a collective, and the line
+            # measured above would never be printed: past the limit every rank gives up, rank 0 reports what it has.
+            import threading
+            limit = float(os.environ.get("PFX_BENCH_AMG_LIMIT_S", "300"))
+
+            def give_up():
+                log(f"AMG leg: no result within {limit:g} s, reporting the line without it")
+                if out is not None:
+                    out["amg_solve"] = {"error": f"no result within {limit:g} s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(limit, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             eng.timing_reset()
             eng.timing_enable(1)
@@ -380,6 +397,9 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
             log(f"AMG leg failed: {exc!r}")
             if out is not None:
                 out["amg_solve"] = {"error": repr(exc)}
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
     if dcg is not None:
         dcg.close()
     if dnewton is not None:
