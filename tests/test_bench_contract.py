@@ -84,3 +84,12 @@ def test_bench_two_ranks_on_one_card_over_gloo():
     # the converged leg: per-rank AMG hierarchies + the coarse space over the ranks
     a = d["amg_solve"]
     assert "error" not in a and a["cg_rel_residual"] <= 1e-10 and "coarse space" in a["preconditioner"]
+
+
+@pytest.mark.gpu
+def test_bench_reports_its_line_when_the_optional_leg_of_a_multi_rank_run_does_not_finish():
+    # a limit no AMG set-up can meet: every rank gives up, rank 0 prints the measured line once, all exit with 0
+    d = _run(["--gpus", "2", "--grid", "4", "--steps", "1", "--warmup", "1", "--cg-max-iter", "60", "--no-cpu-baseline"],
+             {"PFX_BENCH_BACKEND": "gloo", "PFX_BENCH_AMG_LIMIT_S": "0.001"})
+    _check_contract(d, 2)
+    assert "no result within" in d["amg_solve"]["error"]
