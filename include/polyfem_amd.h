@@ -65,7 +65,7 @@ enum
 {
 	PFX_PRECOND_IDENTITY = 0,
 	PFX_PRECOND_JACOBI = 1, /* Eigen::DiagonalPreconditioner, polysolve's default for Eigen::ConjugateGradient */
-	PFX_PRECOND_AMG = 2     /* aggregation multigrid with rigid-body modes (see the AMG section below); block size 3 only */
+	PFX_PRECOND_AMG = 2     /* aggregation multigrid (see the AMG section below): rigid-body modes for block size 3, constants for block size 1 */
 };
 
 /* ---- context ------------------------------------------------------------------------------------------------ */
@@ -190,6 +190,46 @@ pfx_status pfx_cg_dev(pfx_ctx *ctx, const double *d_b, double *d_x_inout, int pr
 pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int precond, int max_iter, double tol,
 							   int *iters, double *rel_res);
 
+/* ---- linear solver for a matrix the caller hands in ------------------------------------------------------------------------
+ *
+ * polysolve::LinearSolver::analyzePattern(A, precond_num) / factorize(A) / solve(b, x) as SparseNewtonDescentSolver calls
+ * them (solver/SparseNewtonDescentSolver.tpp:128-155) on `hessian`, the REDUCED SUM of every form's second derivative
+ * (solver/FullNLProblem.cpp:115-135, solver/NLProblem.cpp:92-99, utils::full_to_reduced_matrix), and as
+ * polysolve::dirichlet_solve does for linear problems (state/StateSolveLinear.cpp:27-29,51-54).  A is the reference's
+ * StiffnessMatrix, Eigen::SparseMatrix<double, ColMajor, int> in compressed form (utils/Types.hpp:16-20): outer (n + 1
+ * column offsets; the 64 variant takes POLYSOLVE_LARGE_INDEX's wider type), inner (row of every entry), values.
+ *
+ * These calls need a context of their own (pfx_create; a context that holds a mesh is refused): it becomes a pure solver
+ * context with no mesh behind it.  Any square matrix with a positive diagonal is accepted -- no symmetry of the PATTERN is
+ * assumed (the arrays are transposed to row order on the device) -- CG itself needs a symmetric positive definite matrix.
+ *
+ *   pfx_solver_analyze(64)  once per pattern.  block_size 3: entries are grouped into 3 x 3 node blocks (one column index per
+ *                           nine values in the solver's block-SELL format; entries missing from a block are explicit
+ *                           zeros), n must be a multiple of 3; block_size 1: scalar format; block_size 0: 3 if n is a
+ *                           multiple of 3 and the blocks hold at most 25 % more entries than A, else 1.  A reduced matrix
+ *                           whose constrained dofs are whole nodes, or a stiffness matrix from which a few exact zeros
+ *                           were dropped, is blocked.
+ *   pfx_solver_factorize    once per matrix: values in the order of `inner` (host; _dev: device pointer).  Returns
+ *                           PFX_ERR_NUMERIC if a value is not finite or a diagonal entry is missing, not finite or not
+ *                           positive -- the signal on which the reference regularises (SparseNewtonDescentSolver.tpp:135-150).
+ *   then                    pfx_cg(_dev) = solve(b, x) with vectors of n entries, pfx_spmv(_dev), pfx_set_dirichlet /
+ *                           pfx_dirichlet_solve (polysolve::dirichlet_solve on the unmodified stiffness matrix),
+ *                           pfx_set_diag_shift, pfx_amg_*, pfx_cgs_* work on this matrix as on an assembled one.
+ *   pfx_solver_set_node_positions  xyz[3 * node + c], one position per node (= n / block size): the AMG preconditioner of a
+ *                           block-3 matrix builds its coarse spaces from the rigid-body modes, which need them; for a
+ *                           scalar matrix they only steer the aggregation and may be left out.  NULL drops them.
+ *   pfx_solver_get_layout   what analyze chose (block size, number of blocks, stored entries including explicit zeros).
+ *   pfx_matrix_generation   a counter that changes whenever the matrix values of the context change (any assembly,
+ *                           pfx_solver_factorize, pfx_hessian_add_mass_dev ...): lets a host wrapper check that a matrix
+ *                           object it handed out still describes what the device holds. */
+pfx_status pfx_solver_analyze(pfx_ctx *ctx, int64_t n, const int32_t *outer, const int32_t *inner, int block_size);
+pfx_status pfx_solver_analyze64(pfx_ctx *ctx, int64_t n, const int64_t *outer, const int32_t *inner, int block_size);
+pfx_status pfx_solver_factorize(pfx_ctx *ctx, const double *values);
+pfx_status pfx_solver_factorize_dev(pfx_ctx *ctx, const double *d_values);
+pfx_status pfx_solver_set_node_positions(pfx_ctx *ctx, const double *xyz, int64_t n_nodes);
+pfx_status pfx_solver_get_layout(pfx_ctx *ctx, int *block_size, int64_t *n_blocks, int64_t *stored_entries);
+pfx_status pfx_matrix_generation(pfx_ctx *ctx, int64_t *generation);
+
 /* ---- algebraic multigrid preconditioner -------------------------------------------------------------------------------
  *
  * The role of polysolve's AMG solvers ("AMGCL", "Hypre": CMakeLists.txt:101-102; options input-spec.json:1397-1558 --
@@ -199,7 +239,8 @@ pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int pre
  * rigid-body modes per aggregate; scalar problems: one constant per aggregate; Galerkin coarse matrices in the same
  * node-block format, Chebyshev relaxation), selected
  * with precond = PFX_PRECOND_AMG in pfx_cg(_dev), pfx_dirichlet_solve and pfx_newton_params.cg_precond.  The iteration
- * is still Eigen's ConjugateGradient (same stopping rule); only z = M^-1 r changes.  Single GPU (unpartitioned mesh).
+ * is still Eigen's ConjugateGradient (same stopping rule); only z = M^-1 r changes.  pfx_cg(_dev) runs it on an
+ * unpartitioned mesh; on a partition every rank applies the hierarchy of its own block (pfx_amg_apply_dev below).
  * The hierarchy is rebuilt when the pattern or the Dirichlet set changes; coarse matrices at every new matrix. */
 typedef struct
 {

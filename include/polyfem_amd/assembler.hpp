@@ -31,15 +31,43 @@ namespace polyfem_amd
 	// ---- stand-ins for the Eigen / basis types that appear in the signatures -------------------------------------
 	using VectorXd = std::vector<double>; // Eigen::MatrixXd column, x[node*dim + c]
 
-	struct StiffnessMatrix // Eigen::SparseMatrix<double, ColMajor, int> (utils/Types.hpp:16-20), structurally symmetric
+	struct StiffnessMatrix // Eigen::SparseMatrix<double, ColMajor, int> in compressed form (utils/Types.hpp:16-20)
 	{
 		int n = 0;
-		std::vector<int64_t> outer;
-		std::vector<int32_t> inner;
+		std::vector<int64_t> outer; // column offsets (n + 1); the wide index type of POLYSOLVE_LARGE_INDEX builds
+		std::vector<int32_t> inner; // row of every entry, ascending inside a column
 		std::vector<double> values;
 		int rows() const { return n; }
 		int cols() const { return n; }
 		int64_t nonZeros() const { return (int64_t)inner.size(); }
+
+		// Tag of a matrix that an assembler of this shim has just produced: the context that holds the same matrix on the
+		// device and that context's matrix generation at the time.  polysolve::LinearSolver solves a tagged, unchanged
+		// matrix in place (no values cross PCIe); everything else is uploaded.  Whoever writes to `values` / changes the
+		// pattern (hessian += other forms, regularisation ...) must drop the tag: the helpers below do, direct writes call
+		// untag().  In a PolyFEM build, where this type is the Eigen matrix itself, the tag travels beside it.
+		pfx_ctx *resident = nullptr;
+		int64_t resident_generation = -1;
+		void untag() { resident = nullptr, resident_generation = -1; }
+
+		// hessian += w * I or a diagonal form (SparseNewtonDescentSolver.tpp:116-121; lumped inertia / penalty terms).
+		// Every diagonal entry must be part of the pattern, as it is for every matrix the assemblers produce.
+		void add_to_diagonal(const std::vector<double> &d)
+		{
+			if ((int)d.size() != n)
+				throw std::runtime_error("polyfem_amd: add_to_diagonal needs one value per row");
+			for (int j = 0; j < n; ++j)
+			{
+				int64_t k = outer[(size_t)j];
+				while (k < outer[(size_t)j + 1] && inner[(size_t)k] != j)
+					++k;
+				if (k == outer[(size_t)j + 1])
+					throw std::runtime_error("polyfem_amd: add_to_diagonal: diagonal entry missing from the pattern");
+				values[(size_t)k] += d[(size_t)j];
+			}
+			untag();
+		}
+		void add_to_diagonal(double w) { add_to_diagonal(std::vector<double>((size_t)n, w)); }
 	};
 
 	namespace basis
@@ -445,6 +473,8 @@ namespace polyfem_amd
 				stiffness.inner.assign((size_t)nnz, 0);
 				stiffness.values.assign((size_t)nnz, 0.0);
 				c.check(pfx_get_linear_csr(c.h, &nnz, stiffness.outer.data(), stiffness.inner.data(), stiffness.values.data()));
+				stiffness.resident = c.h;
+				c.check(pfx_matrix_generation(c.h, &stiffness.resident_generation));
 			}
 			LocalAssembler &local_assembler() { return local_assembler_; }
 			const LocalAssembler &local_assembler() const { return local_assembler_; }
@@ -508,6 +538,8 @@ namespace polyfem_amd
 				grad.inner = mat_cache.inner_index_;
 				grad.values.assign(mat_cache.inner_index_.size(), 0.0);
 				c.check(pfx_hessian(c.h, displacement.data(), project_to_psd ? 1 : 0, grad.values.data()));
+				grad.resident = c.h;
+				c.check(pfx_matrix_generation(c.h, &grad.resident_generation));
 			}
 			LocalAssembler &local_assembler() { return local_assembler_; }
 
@@ -542,8 +574,12 @@ namespace polyfem_amd
 
 	namespace polysolve
 	{
-		// polysolve::LinearSolver for "Eigen::ConjugateGradient".  The matrix it solves with is the one the engine
-		// assembled last (it never leaves the device); analyzePattern / factorize only validate the size.
+		// polysolve::LinearSolver for "Eigen::ConjugateGradient" (and, in the slot of "AMGCL" / "Hypre", CG with this
+		// library's AMG).  analyzePattern / factorize / solve work on the matrix they are HANDED -- the reduced sum of all
+		// forms' Hessians at solver/SparseNewtonDescentSolver.tpp:128-155 (built at solver/FullNLProblem.cpp:115-135 and
+		// solver/NLProblem.cpp:92-99), the stiffness matrix at state/StateSolveLinear.cpp:27-29 -- through a solver context
+		// of its own (pfx_solver_analyze64 / pfx_solver_factorize).  Only a matrix that still carries the tag of the
+		// assembling context and whose device copy is unchanged (StiffnessMatrix::resident) is solved in place.
 		class LinearSolver
 		{
 		public:
@@ -554,6 +590,7 @@ namespace polyfem_amd
 					throw std::runtime_error("Unrecognized solver type: " + solver);
 				auto s = std::unique_ptr<LinearSolver>(new LinearSolver());
 				s->name_ = solver.empty() ? "Eigen::ConjugateGradient" : solver;
+				pfx_amg_default_params(&s->amg_params_);
 				if (amg)
 				{
 					// the slot of polysolve's AMG solvers (CMakeLists.txt:101-102): CG preconditioned by this library's own
@@ -565,15 +602,23 @@ namespace polyfem_amd
 					s->precond_ = (precond.empty() || precond == "Eigen::DiagonalPreconditioner") ? PFX_PRECOND_JACOBI : PFX_PRECOND_IDENTITY;
 				return s;
 			}
+			~LinearSolver()
+			{
+				if (own_)
+					pfx_destroy(own_);
+			}
+			LinearSolver(const LinearSolver &) = delete;
+			LinearSolver &operator=(const LinearSolver &) = delete;
 			std::string name() const { return name_; }
 			// AMGCL/precond/{ncycle, max_levels, relax/degree} (input-spec.json:1447-1496)
 			void setAmgParameters(int ncycle, int max_levels, int relax_degree)
 			{
+				amg_params_.ncycle = ncycle, amg_params_.max_levels = max_levels, amg_params_.relax_degree = relax_degree;
+				amg_params_set_ = true;
 				Context &c = Context::instance();
-				pfx_amg_params p;
-				pfx_amg_default_params(&p);
-				p.ncycle = ncycle, p.max_levels = max_levels, p.relax_degree = relax_degree;
-				c.check(pfx_amg_set_params(c.h, &p));
+				c.check(pfx_amg_set_params(c.h, &amg_params_));
+				if (own_)
+					check_own(pfx_amg_set_params(own_, &amg_params_));
 			}
 			// setParameters(json): params[name()]["max_iter"|"tolerance"], defaults input-spec.json:1326-1336
 			void setParameters(int max_iter, double tolerance)
@@ -581,36 +626,101 @@ namespace polyfem_amd
 				max_iter_ = max_iter;
 				tolerance_ = tolerance;
 			}
-			void analyzePattern(const StiffnessMatrix &A, const int /*precond_num*/) { n_ = A.rows(); }
+			// 0: 3 x 3 node blocks where the pattern allows (default), 1: scalar format, 3: blocks
+			void setBlockSize(int bs) { block_size_ = bs; }
+			// positions of the nodes (rows / 3) of a handed-in matrix: the AMG preconditioner's rigid-body modes need them
+			void setNodePositions(const std::vector<double> &xyz) { positions_ = xyz; }
+
+			void analyzePattern(const StiffnessMatrix &A, const int /*precond_num*/)
+			{
+				if (A.rows() <= 0 || (int64_t)A.outer.size() != (int64_t)A.rows() + 1)
+					throw std::runtime_error("polyfem_amd: analyzePattern needs a compressed matrix");
+				n_ = A.rows();
+				nnz_ = A.nonZeros();
+				if (is_resident(A))
+				{
+					active_ = A.resident;
+					resident_ = true;
+					return;
+				}
+				resident_ = false;
+				if (!own_)
+				{
+					if (pfx_create(&own_, 0) != PFX_OK)
+						throw std::runtime_error("polyfem_amd: no usable HIP device (the engine has no CPU fallback)");
+					if (amg_params_set_)
+						check_own(pfx_amg_set_params(own_, &amg_params_));
+				}
+				check_own(pfx_solver_analyze64(own_, A.rows(), A.outer.data(), A.inner.data(), block_size_));
+				if (!positions_.empty())
+					check_own(pfx_solver_set_node_positions(own_, positions_.data(), (int64_t)positions_.size() / 3));
+				active_ = own_;
+			}
+			// throws std::runtime_error when the matrix cannot be solved with (non-finite entries, a diagonal entry that is not
+			// positive): the Newton solver catches exactly that and regularises (SparseNewtonDescentSolver.tpp:135-150)
 			void factorize(const StiffnessMatrix &A)
 			{
-				if (A.rows() != n_)
-					throw std::runtime_error("polyfem_amd: factorize called with a different matrix size");
+				if (!active_)
+					throw std::runtime_error("polyfem_amd: factorize called before analyzePattern");
+				if (resident_)
+				{
+					if (is_resident(A) && A.rows() == n_)
+						return;
+					analyzePattern(A, 0); // the caller changed the matrix since: it is no longer the device copy
+				}
+				if (A.rows() != n_ || A.nonZeros() != nnz_)
+					throw std::runtime_error("polyfem_amd: factorize called with a matrix of another pattern than analyzePattern");
+				check_own(pfx_solver_factorize(own_, A.values.data()));
 			}
-			// reduced solves: the constrained dofs are given once and the solver works on the masked full-size system
+			// full-size solves on the resident matrix: the constrained dofs are given once and the solver works on the masked
+			// system (the reduced matrix is never formed)
 			void setDirichlet(const std::vector<int> &sorted_dofs)
 			{
-				Context &c = Context::instance();
-				c.check(pfx_set_dirichlet(c.h, sorted_dofs.data(), (int64_t)sorted_dofs.size()));
+				pfx_ctx *h = active_ ? active_ : Context::instance().h;
+				check(h, pfx_set_dirichlet(h, sorted_dofs.data(), (int64_t)sorted_dofs.size()));
 			}
 			void solve(const VectorXd &b, VectorXd &x)
 			{
-				Context &c = Context::instance();
+				if (!active_)
+					throw std::runtime_error("polyfem_amd: solve called before analyzePattern / factorize");
+				if ((int)b.size() != n_)
+					throw std::runtime_error("polyfem_amd: right-hand side of the wrong size");
 				if (x.size() != b.size())
 					x.assign(b.size(), 0.0);
-				c.check(pfx_cg(c.h, b.data(), x.data(), precond_, max_iter_, tolerance_, &iters_, &error_));
+				check(active_, pfx_cg(active_, b.data(), x.data(), precond_, max_iter_, tolerance_, &iters_, &error_));
 				if (!std::isfinite(error_))
 					throw std::runtime_error("polyfem_amd: CG broke down (non-finite residual)");
 			}
 			// getInfo(json&): "solver_iter", "solver_error"
 			int solver_iter() const { return iters_; }
 			double solver_error() const { return error_; }
+			bool uses_resident_matrix() const { return resident_; }
 
 		private:
 			LinearSolver() = default;
-			int precond_ = PFX_PRECOND_JACOBI, max_iter_ = 1000, iters_ = 0, n_ = 0;
+			static bool is_resident(const StiffnessMatrix &A)
+			{
+				if (!A.resident || A.resident != Context::instance().h)
+					return false;
+				int64_t gen = -1;
+				return pfx_matrix_generation(A.resident, &gen) == PFX_OK && gen == A.resident_generation;
+			}
+			static void check(pfx_ctx *h, pfx_status rc)
+			{
+				if (rc != PFX_OK)
+					throw std::runtime_error(std::string("polyfem_amd: ") + pfx_last_error(h));
+			}
+			void check_own(pfx_status rc) const { check(own_, rc); }
+			int precond_ = PFX_PRECOND_JACOBI, max_iter_ = 1000, iters_ = 0, n_ = 0, block_size_ = 0;
+			int64_t nnz_ = 0;
 			double tolerance_ = 1e-12, error_ = 0;
 			std::string name_ = "Eigen::ConjugateGradient";
+			pfx_ctx *own_ = nullptr;    // solver context for matrices handed in by value
+			pfx_ctx *active_ = nullptr; // what the next solve runs on
+			bool resident_ = false;
+			pfx_amg_params amg_params_;
+			bool amg_params_set_ = false;
+			std::vector<double> positions_;
 		};
 	} // namespace polysolve
 

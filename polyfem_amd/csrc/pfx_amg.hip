@@ -41,6 +41,7 @@
 #include <cfloat>
 
 #define AMG_MAX_LEVELS 16
+#define AMG_MAX_DENSE 4096 // largest coarsest level the dense inverse is formed for (n^2 doubles on the host and the device)
 #define AMG_NPART 256
 #define AMG_SMALL_NODES 32768 // levels of at most this many node rows multiply through k_rowwave_spmv
 
@@ -863,6 +864,18 @@ namespace
 		// level-0 node positions and the vertices left out of the aggregation
 		if (pfx_alloc(ctx, &A->d_pos, n_nodes * 3))
 			return PFX_ERR_HIP;
+		if (ctx->ext)
+		{
+			// a caller's matrix: positions come from pfx_solver_set_node_positions.  The rigid-body modes of the vector
+			// problem cannot be formed without them; the scalar problem only uses them to prefer near neighbours.
+			if (ctx->d_ext_pos)
+				PFX_HIP(hipMemcpyAsync(A->d_pos, ctx->d_ext_pos, sizeof(double) * (size_t)(n_nodes * 3), hipMemcpyDeviceToDevice, st));
+			else if (scalar)
+				PFX_HIP(hipMemsetAsync(A->d_pos, 0, sizeof(double) * (size_t)(n_nodes * 3), st));
+			else
+				PFX_FAIL(PFX_ERR_ARG, "the AMG preconditioner of a caller's block-3 matrix needs node positions (pfx_solver_set_node_positions), or analyze with block size 1");
+		}
+		else
 		{
 			node_ref ref;
 			double lp[PFX_MAX_LOC][3];
@@ -1208,6 +1221,11 @@ namespace
 			else
 			{
 				pfx_ctx *s = L.m;
+				// The hierarchy can end early (max_levels reached, coarsening stalled) with a last level far above
+				// coarsest_dofs; the dense inverse below is O(n^2) memory and O(n^3) host work: refuse instead.
+				if (L.n_dofs > AMG_MAX_DENSE)
+					PFX_FAIL(PFX_ERR_SIZE, "AMG: the coarsest level has " + std::to_string((long long)L.n_dofs) + " dofs, more than the dense coarse solve takes ("
+											   + std::to_string(AMG_MAX_DENSE) + "): raise max_levels, or the coarsening stalled on this matrix");
 				const int n = (int)L.n_dofs;
 				std::vector<double> vals((size_t)s->nnz);
 				PFX_HIP(hipMemcpyAsync(vals.data(), s->d_values, sizeof(double) * vals.size(), hipMemcpyDeviceToHost, st));
@@ -1573,6 +1591,8 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (!ctx->d_node_ptr)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_build_pattern must be called first");
+		if (ctx->ext && !ctx->ext_factorized)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_factorize must succeed before the matrix is used");
 		PFX_HIP(hipSetDevice(ctx->device));
 		const int64_t nfull = ctx->n_dofs();
 		double *base = amg_workspace(ctx);

@@ -35,8 +35,13 @@ namespace
 				x[k] = b[k];
 	}
 
-	void release_pattern(pfx_ctx *ctx)
+} // namespace
+
+// everything that belongs to the current pattern (the mesh stays)
+void pfx_release_pattern(pfx_ctx *ctx)
+{
 	{
+		pfx_ext_release(ctx);
 		free_dev(ctx, ctx->d_node_ptr);
 		free_dev(ctx, ctx->d_node_col);
 		free_dev(ctx, ctx->d_blk_src);
@@ -84,11 +89,37 @@ namespace
 		ctx->n_dirichlet = 0;
 		ctx->have_mask = false;
 	}
+}
 
+namespace
+{
+	inline void release_pattern(pfx_ctx *ctx) { pfx_release_pattern(ctx); }
+
+	// a matrix to work with: an assembled pattern, or a caller's matrix whose values are in place
 	pfx_status need_pattern(pfx_ctx *ctx)
 	{
 		if (!ctx->d_node_ptr)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_build_pattern must be called first");
+		return PFX_OK;
+	}
+
+	// entry points that run element kernels: the pattern must come from a mesh, not from pfx_solver_analyze
+	pfx_status need_mesh(pfx_ctx *ctx)
+	{
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->ext || ctx->kind < 0)
+			PFX_FAIL(PFX_ERR_ARG, "this context holds a caller's matrix (pfx_solver_analyze), not a mesh");
+		return PFX_OK;
+	}
+
+	// entry points that read the matrix values
+	pfx_status need_matrix(pfx_ctx *ctx)
+	{
+		if (need_pattern(ctx))
+			return PFX_ERR_ARG;
+		if (ctx->ext && !ctx->ext_factorized)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_factorize must succeed before the matrix is used");
 		return PFX_OK;
 	}
 
@@ -484,7 +515,7 @@ extern "C"
 	{
 		if (!ctx || !values)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_matrix(ctx))
 			return PFX_ERR_ARG;
 		return pfx_values_to_csr(ctx, values);
 	}
@@ -493,7 +524,7 @@ extern "C"
 	{
 		if (!ctx)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->model != PFX_LAPLACIAN && ctx->model != PFX_LINEAR_ELASTICITY && ctx->model != PFX_HOOKE_LINEAR)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_assemble_linear needs the Laplacian, LinearElasticity or HookeLinearElasticity model");
@@ -518,7 +549,7 @@ extern "C"
 	{
 		if (!ctx)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		PFX_HIP(hipSetDevice(ctx->device));
 		const bool hex = ctx->kind == PFX_Q1HEX || ctx->kind == PFX_Q2HEX;
@@ -541,7 +572,7 @@ extern "C"
 	// mass matrix with the density evaluated at every point of the mass quadrature rule
 	static pfx_status assemble_mass_pointwise_impl(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts)
 	{
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (n_el != ctx->n_el || n_pts != ctx->h_tab_mass.n_pts)
 			PFX_FAIL(PFX_ERR_ARG, "one density per element and point of the mass quadrature rule expected (see pfx_mass_quadrature_points)");
@@ -611,7 +642,7 @@ extern "C"
 	{
 		if (!ctx || !density_pts || !rhs || (!force == !force_pts))
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_mesh(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		if (n_el != ctx->n_el || n_pts != ctx->n_pts)
 			PFX_FAIL(PFX_ERR_ARG, "one density per element and quadrature point of the stiffness rule expected (see pfx_quadrature_points)");
@@ -642,7 +673,7 @@ extern "C"
 	{
 		if (!ctx || !force || !d_rhs)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		PFX_HIP(hipSetDevice(ctx->device));
 		const double *d_rho = nullptr;
@@ -658,7 +689,7 @@ extern "C"
 	{
 		if (!ctx || !force || !rhs)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_mesh(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		pfx_status rc = pfx_assemble_rhs_dev(ctx, force, density, density_e, ctx->d_vec);
 		if (rc)
@@ -672,7 +703,7 @@ extern "C"
 	{
 		if (!ctx || !d_force_pts || !d_rhs)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		PFX_HIP(hipSetDevice(ctx->device));
 		const double *d_rho = nullptr;
@@ -688,7 +719,7 @@ extern "C"
 	{
 		if (!ctx || !force_pts || !rhs)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_mesh(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const size_t count = (size_t)(ctx->n_el * ctx->n_pts * ctx->bs);
 		pfx_tmp<double> d_f;
@@ -727,7 +758,7 @@ extern "C"
 	{
 		if (!ctx || !nnz)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (!ctx->have_mask)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_assemble_linear must be called first");
@@ -739,7 +770,7 @@ extern "C"
 	{
 		if (!ctx || !d_u || !d_energy)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		{
 			pfx_scoped_timer tm(ctx, "local_energy");
@@ -763,7 +794,7 @@ extern "C"
 	{
 		if (!ctx || !d_u || !d_g)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		{
 			pfx_scoped_timer tm(ctx, "local_grad");
@@ -806,7 +837,7 @@ extern "C"
 	{
 		if (!ctx || !d_u)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		{
 			pfx_scoped_timer tm(ctx, "local");
@@ -834,7 +865,7 @@ extern "C"
 	{
 		if (!ctx || !u || !energy)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_mesh(ctx) || ensure_staging(ctx))
 			return ctx->err.empty() ? PFX_ERR_ARG : PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -855,7 +886,7 @@ extern "C"
 	{
 		if (!ctx || !u || !g)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_mesh(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -870,7 +901,7 @@ extern "C"
 	{
 		if (!ctx || !u)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_mesh(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		PFX_HIP(hipMemcpyAsync(ctx->d_u, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -916,7 +947,7 @@ extern "C"
 	{
 		if (!ctx || !n_reduced || !nnz)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_matrix(ctx))
 			return PFX_ERR_ARG;
 		return pfx_export_compressed(ctx, ctx->have_mask, true, n_reduced, nnz, row_ptr, col_idx, values);
 	}
@@ -925,7 +956,7 @@ extern "C"
 	{
 		if (!ctx || !d_x || !d_y)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_matrix(ctx))
 			return PFX_ERR_ARG;
 		return pfx_launch_spmv(ctx, d_x, d_y);
 	}
@@ -934,7 +965,7 @@ extern "C"
 	{
 		if (!ctx || !x || !y)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_matrix(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		PFX_HIP(hipMemcpyAsync(ctx->d_u, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -950,7 +981,7 @@ extern "C"
 	{
 		if (!ctx)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->bs != 3)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 3)");
@@ -970,7 +1001,7 @@ extern "C"
 			ctx->d_x_tilde = nullptr;
 			return PFX_OK;
 		}
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->mass_count == 0)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
@@ -985,7 +1016,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (!(acceleration_scaling > 0.0) || !x_tilde)
 			return pfx_inertia_enable(ctx, 0.0, nullptr);
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		if (ctx->tstep_count < 2 * n)
@@ -1009,7 +1040,7 @@ extern "C"
 			ctx->d_al_mass = ctx->d_al_target = nullptr;
 			return PFX_OK;
 		}
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->bs != 3)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs block size 3");
@@ -1025,7 +1056,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (!(weight > 0.0) || !masked_lumped_mass || !target)
 			return pfx_al_enable(ctx, 0.0, nullptr, nullptr);
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		for (int64_t k = 0; k < n; ++k)
@@ -1047,7 +1078,7 @@ extern "C"
 	{
 		if (!ctx || !lumped)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->mass_count == 0 || ctx->bs != 3)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
@@ -1066,7 +1097,7 @@ extern "C"
 	{
 		if (!ctx || !d_v || !d_y)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->mass_count == 0)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
@@ -1077,7 +1108,7 @@ extern "C"
 	{
 		if (!ctx || !(weight >= 0.0))
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->mass_count == 0)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
@@ -1091,7 +1122,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (!(dt > 0.0))
 			PFX_FAIL(PFX_ERR_ARG, "pfx_implicit_euler_step: dt must be positive");
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->mass_count == 0)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
@@ -1108,7 +1139,7 @@ extern "C"
 	{
 		if (!ctx || !x || !v || !params || !info)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		PFX_HIP(hipSetDevice(ctx->device));
 		const int64_t n = ctx->n_dofs();
@@ -1173,7 +1204,7 @@ extern "C"
 	{
 		if (!ctx || !d_x || !params || !info)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		if (ctx->model == PFX_LAPLACIAN)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_newton_solve needs an elastic model");
@@ -1187,7 +1218,7 @@ extern "C"
 	{
 		if (!ctx || !x || !params || !info)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		pfx_tmp<double> d;
@@ -1205,7 +1236,7 @@ extern "C"
 	{
 		if (!ctx || !d_b || !d_x || !iters || !rel_res)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx))
+		if (need_matrix(ctx))
 			return PFX_ERR_ARG;
 		if (precond != PFX_PRECOND_IDENTITY && precond != PFX_PRECOND_JACOBI && precond != PFX_PRECOND_AMG)
 			PFX_FAIL(PFX_ERR_ARG, "unknown preconditioner");
@@ -1216,7 +1247,7 @@ extern "C"
 	{
 		if (!ctx || !b || !x || !iters || !rel_res)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_matrix(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		PFX_HIP(hipMemcpyAsync(ctx->d_u, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -1233,7 +1264,7 @@ extern "C"
 	{
 		if (!ctx || !b || !x || !iters || !rel_res)
 			return PFX_ERR_ARG;
-		if (need_pattern(ctx) || ensure_staging(ctx))
+		if (need_matrix(ctx) || ensure_staging(ctx))
 			return PFX_ERR_ARG;
 		const int64_t n = ctx->n_dofs();
 		hipStream_t st = ctx->stream;
@@ -1305,7 +1336,7 @@ extern "C"
 #define PFX_NEED(cond)         \
 	if (!ctx || !(cond))       \
 		return PFX_ERR_ARG;    \
-	if (need_pattern(ctx))     \
+	if (need_matrix(ctx))      \
 		return PFX_ERR_ARG;
 
 	pfx_status pfx_cgs_prepare(pfx_ctx *ctx, double *d_x, int precond)

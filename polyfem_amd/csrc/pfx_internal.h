@@ -209,6 +209,15 @@ struct pfx_ctx
 	pfx_amg *amg = nullptr;
 	int64_t struct_gen = 0;
 
+	// a pattern and values handed in by the caller (pfx_solver_analyze / pfx_solver_factorize, pfx_extmat.hip) instead of
+	// built from a mesh: the context is then a pure solver context (kind < 0)
+	bool ext = false;
+	bool ext_factorized = false;      // values are in place and passed the checks of pfx_solver_factorize
+	int64_t ext_nnz = 0;              // entries of the caller's matrix
+	uint32_t *d_ext_map = nullptr;    // nnz: position in the caller's value array of every stored entry (0xFFFFFFFF: explicit zero)
+	double *d_ext_stage = nullptr;    // ext_nnz: device copy of the caller's host values
+	double *d_ext_pos = nullptr;      // 3 * n_nodes: node positions for the AMG aggregation (optional)
+
 	int64_t bytes_device = 0;                   // device memory currently held through pfx_alloc
 	std::map<const void *, int64_t> alloc_bytes; // size of every live pfx_alloc allocation
 
@@ -390,6 +399,8 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 pfx_status pfx_sell_unpermute(pfx_ctx *ctx, double *d_y);
 pfx_status pfx_cgs_fetch_product_impl(pfx_ctx *ctx);
 void pfx_amg_release(pfx_ctx *ctx);
+void pfx_ext_release(pfx_ctx *ctx);
+void pfx_release_pattern(pfx_ctx *ctx);
 pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res);
 pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag);
 void pfx_launch_sum_partials(pfx_ctx *ctx, const double *part, int count, double *out);

@@ -504,18 +504,20 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 		count = (int)ctx->sell_interior;
 	else if (phase == PFX_SPMV_BOUNDARY)
 		first = (int)ctx->sell_interior, count = (int)(ctx->sell_slices - ctx->sell_interior);
+	// a product goes through the slice-ordered buffer and, unless the caller reads it from there, the un-permute pass; small
+	// matrices, where the second launch costs more than it saves, store their rows directly
+	// (a half product can only stay in slice order: the un-permute pass covers all rows)
+	// Where the product lives is a property of the matrix, not of the phase: a phase without slices (no boundary slices on
+	// a rank without halo) reports the same place as the phase that wrote the rows.
+	const bool sliceout = ctx->n_owned >= 65536 && (phase == PFX_SPMV_ALL || sliced);
+	if (sliced)
+		*sliced = sliceout;
 	if (count <= 0)
 		return PFX_OK;
 	const pfx_xcd_split &split = ctx->sell_split[phase];
 	const int grid = PFX_XCDS * split.widest; // one slice (one wave) per block
 	const int32_t *order = ctx->d_sell_order;
 	pfx_scoped_timer tm(ctx, phase == PFX_SPMV_BOUNDARY ? "spmv_boundary" : "spmv");
-	// a product goes through the slice-ordered buffer and, unless the caller reads it from there, the un-permute pass; small
-	// matrices, where the second launch costs more than it saves, store their rows directly
-	// (a half product can only stay in slice order: the un-permute pass covers all rows)
-	const bool sliceout = ctx->n_owned >= 65536 && (phase == PFX_SPMV_ALL || sliced);
-	if (sliced)
-		*sliced = sliceout;
 #define PFX_GO(BS_, DOT_)                                                                                                                                          \
 	do                                                                                                                                                             \
 	{                                                                                                                                                              \

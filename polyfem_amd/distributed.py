@@ -311,8 +311,16 @@ class HipOps:
     def set_workspace(self, work):
         if work is None:
             self.e.cgs_set_workspace(0, 0)
+            self._installed = 0
         else:
             self.e.cgs_set_workspace(work.data_ptr(), work.numel())
+            self._installed = work.data_ptr()
+
+    def release_workspace(self, work):
+        """Takes `work` out of the engine if it is still the installed workspace: a newer DistributedCG on the same
+        engine may have installed its own since, and that one must stay."""
+        if work is not None and getattr(self, "_installed", 0) == work.data_ptr():
+            self.set_workspace(None)
 
     def prepare(self, x, precond):
         self.e.cgs_prepare(x.data_ptr(), precond)
@@ -499,7 +507,11 @@ class DistributedCG:
         """Hands the solver workspace back to the engine (the engine must not keep a pointer into a freed tensor)."""
         if self.work is not None:
             try:
-                self.ops.set_workspace(None)
+                release = getattr(self.ops, "release_workspace", None)
+                if release is not None:
+                    release(self.work)  # only if the engine still points at THIS object's buffer
+                else:
+                    self.ops.set_workspace(None)
             except Exception:
                 pass
             self.work = None
@@ -512,6 +524,7 @@ class DistributedCG:
         ops, scal, ar = self.ops, self.scal, self.comm.all_reduce_sum
         if hasattr(ops, "check_stream"):
             ops.check_stream()
+        ops.set_workspace(self.work)  # another solver object on the same engine may have installed its own since
         if precond == 2:
             return self._solve_amg(b, x, max_iter, tol)
         ops.prepare(x, precond)

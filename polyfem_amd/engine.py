@@ -46,6 +46,8 @@ EXPORTED_SYMBOLS = [
     "pfx_energy_dev_noalloc",
     "pfx_mass_quadrature_points", "pfx_assemble_mass_pointwise", "pfx_inertia_set_mass_pointwise", "pfx_assemble_rhs_density_pointwise",
     "pfx_amg_default_params", "pfx_amg_set_params", "pfx_amg_setup", "pfx_amg_get_info", "pfx_amg_get_aggregates", "pfx_amg_apply_dev",
+    "pfx_solver_analyze", "pfx_solver_analyze64", "pfx_solver_factorize", "pfx_solver_factorize_dev", "pfx_solver_set_node_positions",
+    "pfx_solver_get_layout", "pfx_matrix_generation",
 ]
 
 
@@ -215,6 +217,13 @@ def load():
         "pfx_amg_get_info": [_vp, C.POINTER(AmgInfo)],
         "pfx_amg_get_aggregates": [_vp, _i32, _pi32],
         "pfx_amg_apply_dev": [_vp, _vp, _vp],
+        "pfx_solver_analyze": [_vp, _i64, _pi32, _pi32, _i32],
+        "pfx_solver_analyze64": [_vp, _i64, _pi64, _pi32, _i32],
+        "pfx_solver_factorize": [_vp, _pd],
+        "pfx_solver_factorize_dev": [_vp, _vp],
+        "pfx_solver_set_node_positions": [_vp, _pd, _i64],
+        "pfx_solver_get_layout": [_vp, C.POINTER(C.c_int), _pi64, _pi64],
+        "pfx_matrix_generation": [_vp, _pi64],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -730,6 +739,46 @@ class Engine:
         self._ck(self.L.pfx_cgs_status(self.h, C.byref(done), C.byref(it), C.byref(rr), C.byref(bb)))
         return bool(done.value), it.value, rr.value, bb.value
 
+    # ---- a caller's matrix (the context is then a pure solver context) ----------------------------------------
+    def solver_analyze(self, n: int, outer, inner, block_size: int = 0):
+        """polysolve analyzePattern for a compressed-column matrix handed in by the caller (pfx_solver_analyze):
+        outer int32 or int64 (n + 1), inner int32.  block_size 0 lets the library choose 3 x 3 node blocks or scalars."""
+        inner = np.ascontiguousarray(inner, dtype=np.int32)
+        outer = np.asarray(outer)
+        if outer.dtype == np.int32:
+            outer = np.ascontiguousarray(outer)
+            self._ck(self.L.pfx_solver_analyze(self.h, int(n), _i(outer), _i(inner), int(block_size)))
+        else:
+            outer = np.ascontiguousarray(outer, dtype=np.int64)
+            self._ck(self.L.pfx_solver_analyze64(self.h, int(n), _l(outer), _i(inner), int(block_size)))
+
+    def solver_factorize(self, values):
+        """Values in the order of `inner`; PfxError with code PFX_ERR_NUMERIC for a non-finite entry or a diagonal entry
+        that is not positive."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._ck(self.L.pfx_solver_factorize(self.h, _d(v)))
+
+    def solver_factorize_dev(self, d_values: int):
+        self._ck(self.L.pfx_solver_factorize_dev(self.h, _vp(d_values)))
+
+    def solver_set_node_positions(self, xyz):
+        if xyz is None:
+            self._ck(self.L.pfx_solver_set_node_positions(self.h, None, 0))
+            return
+        x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        self._ck(self.L.pfx_solver_set_node_positions(self.h, _d(x), x.shape[0]))
+
+    def solver_layout(self):
+        """(block size, number of blocks, stored entries incl. explicit zeros) chosen by solver_analyze."""
+        bs, nb, ne = C.c_int(), C.c_int64(), C.c_int64()
+        self._ck(self.L.pfx_solver_get_layout(self.h, C.byref(bs), C.byref(nb), C.byref(ne)))
+        return bs.value, nb.value, ne.value
+
+    def matrix_generation(self) -> int:
+        g = C.c_int64()
+        self._ck(self.L.pfx_matrix_generation(self.h, C.byref(g)))
+        return g.value
+
     # ---- timing ------------------------------------------------------------------------------------------
     def timing_enable(self, on: bool = True):
         self._ck(self.L.pfx_timing_enable(self.h, int(on)))
@@ -752,8 +801,33 @@ class StiffnessMatrix:
     """Eigen::SparseMatrix<double, ColMajor, int> stand-in (utils/Types.hpp:16-20): compressed arrays of a
     structurally symmetric matrix, so (outer, inner) are both the CSC and the CSR index arrays."""
 
-    def __init__(self, n: int, outer, inner, values):
+    def __init__(self, n: int, outer, inner, values, resident=None):
         self.n, self.outer, self.inner, self.values = n, outer, inner, values
+        # (engine, matrix generation) when this object describes the matrix that engine holds on the device right now:
+        # a LinearSolver handed such a matrix solves with the device copy instead of uploading the values again.  Code
+        # that changes the values (adds another form's Hessian, a regularisation ...) must drop the tag: use
+        # add_diagonal / add, or set .resident = None.
+        self.resident = resident
+
+    def add_diagonal(self, d):
+        """A += diag(d) (d scalar or vector): e.g. the regularisation `hessian += reg_weight * sparse_identity` of
+        solver/SparseNewtonDescentSolver.tpp:116-121, or a lumped mass / penalty form."""
+        import scipy.sparse as sp
+        self._assign(self.to_scipy_csc() + sp.diags(np.broadcast_to(np.asarray(d, dtype=np.float64), (self.n,))))
+
+    def add(self, other):
+        """A += B, the `hessian += tmp` of solver/FullNLProblem.cpp:131 (sum of the forms' second derivatives)."""
+        self._assign(self.to_scipy_csc() + other.to_scipy_csc())
+
+    def _assign(self, m):
+        m = m.tocsc()
+        m.sort_indices()
+        self.outer, self.inner, self.values = m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data.astype(np.float64)
+        self.resident = None
+
+    def to_scipy_csc(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.values, self.inner, self.outer), shape=(self.n, self.n))
 
     def rows(self):
         return self.n
@@ -826,7 +900,7 @@ class Assembler(_AssemblerBase):
         self._bind(mesh)
         self.engine.assemble_linear()
         rp, ci, v = self.engine.get_linear_csr()
-        return StiffnessMatrix(int(rp.size - 1), rp, ci, v)
+        return StiffnessMatrix(int(rp.size - 1), rp, ci, v, resident=(self.engine, self.engine.matrix_generation()))
 
 
 class NLAssembler(_AssemblerBase):
@@ -847,16 +921,28 @@ class NLAssembler(_AssemblerBase):
             mat_cache.engine = self.engine
             mat_cache.outer, mat_cache.inner = self.engine.get_pattern()
         v = self.engine.hessian(np.asarray(displacement).reshape(-1), project_to_psd)
-        return StiffnessMatrix(int(mat_cache.outer.size - 1), mat_cache.outer, mat_cache.inner, v)
+        return StiffnessMatrix(int(mat_cache.outer.size - 1), mat_cache.outer, mat_cache.inner, v,
+                               resident=(self.engine, self.engine.matrix_generation()))
 
 
 class LinearSolver:
-    """polysolve::LinearSolver for solver "Eigen::ConjugateGradient" working on the matrix that the bound
-    engine holds on the device (no copy of the matrix crosses PCIe)."""
+    """polysolve::LinearSolver ("Eigen::ConjugateGradient"; "AMGCL" / "Hypre" = CG with this library's AMG) as
+    SparseNewtonDescentSolver and State::solve_linear use it (solver/SparseNewtonDescentSolver.tpp:128-155,
+    state/StateSolveLinear.cpp:27-29,51-54): analyze_pattern(A) / factorize(A) / solve(b, x) work on the matrix they are
+    HANDED -- the reduced sum of all forms' Hessians, any size -- which is uploaded into a solver context of its own
+    (pfx_solver_analyze / pfx_solver_factorize).  Only a matrix that still carries the tag of the engine holding it on the
+    device (StiffnessMatrix.resident, unchanged since the assembly that produced it) is solved in place, without a copy
+    crossing PCIe; the constrained dofs of such a full-size solve come from set_dirichlet()."""
 
-    def __init__(self, engine: Engine, precond: str, solver: str = "Eigen::ConjugateGradient"):
-        self.engine = engine
+    def __init__(self, engine: Engine | None, precond: str, solver: str = "Eigen::ConjugateGradient", device: int = 0):
+        self.engine = engine          # the assembling engine (may be None: every matrix is then uploaded)
+        self.device = device
+        self.own = None               # solver context for matrices handed in by value
+        self.active = None            # the context the next solve runs on
+        self.block_size = 0           # pfx_solver_analyze's block_size argument (0: choose)
+        self.node_positions = None    # for the AMG preconditioner of a handed-in block-3 matrix
         self.solver = solver or "Eigen::ConjugateGradient"
+        self._amg = {}
         if self.solver in ("AMGCL", "Hypre"):
             # the slot of polysolve's AMG solvers: CG preconditioned by this library's own aggregation AMG (not AMGCL's
             # or Hypre's algorithm); their defaults tol 1e-10, 1000 iterations (input-spec.json:1381-1396, 1423-1434)
@@ -866,12 +952,18 @@ class LinearSolver:
             self.precond = PRECOND_JACOBI if precond in ("", "Eigen::DiagonalPreconditioner", "Jacobi") else PRECOND_IDENTITY
             self.max_iter, self.tolerance = 1000, 1e-12  # input-spec.json:1326-1336
         self._info = {}
+        self._analyzed = None
 
     @staticmethod
-    def create(solver: str, precond: str, engine: Engine) -> "LinearSolver":
+    def create(solver: str, precond: str, engine: Engine | None = None) -> "LinearSolver":
         if solver not in ("Eigen::ConjugateGradient", "", "AMGCL", "Hypre"):
             raise RuntimeError(f"Unrecognized solver type: {solver}")
         return LinearSolver(engine, precond, solver)
+
+    def close(self):
+        if self.own is not None:
+            self.own.close()
+            self.own = None
 
     def name(self) -> str:
         return self.solver
@@ -891,21 +983,66 @@ class LinearSolver:
                 amg["relax_degree"] = int(pp["relax"]["degree"])
             if "power_iters" in pp.get("relax", {}):
                 amg["power_iters"] = int(pp["relax"]["power_iters"])
-            if amg:
-                self.engine.amg_set_params(**amg)
+            self._amg = amg
+            for ctx in (self.engine, self.own):
+                if amg and ctx is not None:
+                    ctx.amg_set_params(**amg)
             return
         self.max_iter = int(p.get("max_iter", self.max_iter))
         self.tolerance = float(p.get("tolerance", self.tolerance))
 
-    def analyze_pattern(self, A=None, precond_num: int = 0):
-        pass  # pattern already resident
+    def _is_resident(self, A) -> bool:
+        r = getattr(A, "resident", None)
+        return (A is not None and r is not None and self.engine is not None and r[0] is self.engine
+                and r[1] == self.engine.matrix_generation())
 
-    def factorize(self, A=None):
-        pass  # Jacobi diagonal is extracted inside solve
+    def analyze_pattern(self, A, precond_num: int = 0):
+        """A: StiffnessMatrix.  precond_num is polysolve's hint for block preconditioners (unused by CG)."""
+        if A is None:
+            raise ValueError("analyze_pattern needs the matrix (polysolve::LinearSolver::analyzePattern(A, precond_num))")
+        if self._is_resident(A):
+            self.active, self._analyzed = self.engine, ("resident", A.rows())
+            return
+        if self.own is None:
+            self.own = Engine(self.device)
+            if self._amg:
+                self.own.amg_set_params(**self._amg)
+        self.own.solver_analyze(A.rows(), A.outer, A.inner, self.block_size)
+        if self.node_positions is not None:
+            self.own.solver_set_node_positions(self.node_positions)
+        self.active, self._analyzed = self.own, ("own", A.rows(), int(A.inner.size))
+
+    def factorize(self, A):
+        """Raises RuntimeError where polysolve's factorize does (the Newton solver catches it and regularises,
+        solver/SparseNewtonDescentSolver.tpp:135-150)."""
+        if self._analyzed is None:
+            raise RuntimeError("factorize called before analyzePattern")
+        if self._analyzed[0] == "resident":
+            if not self._is_resident(A) or A.rows() != self._analyzed[1]:
+                # the caller changed the matrix after analyzePattern: it is no longer the device copy
+                self.analyze_pattern(A)
+            else:
+                return
+        if A.rows() != self._analyzed[1] or int(A.inner.size) != self._analyzed[2]:
+            raise RuntimeError("factorize called with a matrix of another pattern than analyzePattern")
+        try:
+            self.own.solver_factorize(A.values)
+        except PfxError as e:
+            if e.code == PFX_ERR_NUMERIC:
+                raise RuntimeError(f"Factorization failed: {e}") from e
+            raise
+
+    def set_dirichlet(self, sorted_dofs):
+        """Full-size solves on the resident matrix: the constrained dofs (the reduced matrix is never formed)."""
+        (self.active or self.engine).set_dirichlet(sorted_dofs)
 
     def solve(self, b, x):
-        sol, it, err = self.engine.cg(b, x, self.precond, self.max_iter, self.tolerance)
+        if self.active is None:
+            raise RuntimeError("solve called before analyzePattern / factorize")
+        sol, it, err = self.active.cg(b, x, self.precond, self.max_iter, self.tolerance)
         self._info = {"solver_iter": it, "solver_error": err, "solver_tol": self.tolerance, "solver_maxiter": self.max_iter}
+        if not np.isfinite(err):
+            raise RuntimeError("CG broke down (non-finite residual)")
         x[...] = sol
         return x
 

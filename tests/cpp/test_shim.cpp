@@ -160,6 +160,95 @@ int main()
 		}
 		REQUIRE(emax <= 1e-7 * dmax);
 	}
+	REQUIRE(solver->uses_resident_matrix()); // H came straight out of the assembler: solved in place, nothing uploaded
+
+	// The matrix the reference's Newton solver really hands over is the REDUCED SUM of all forms
+	// (SparseNewtonDescentSolver.tpp:128-155, NLProblem.cpp:92-99): (a) full_to_reduced_matrix of H, (b) the same plus a
+	// diagonal second form.  Both go in by value; the solver must use exactly what it is given.
+	{
+		std::vector<char> is_fixed(N, 0);
+		for (int f : fixed)
+			is_fixed[f] = 1;
+		std::vector<int> new_id(N, -1);
+		int nr = 0;
+		for (int i = 0; i < N; ++i)
+			if (!is_fixed[i])
+				new_id[i] = nr++;
+		StiffnessMatrix R; // utils::full_to_reduced_matrix (utils/MatrixUtils.cpp:408-469)
+		R.n = nr;
+		R.outer.push_back(0);
+		for (int j = 0; j < N; ++j)
+		{
+			if (is_fixed[j])
+				continue;
+			for (int64_t k = H.outer[j]; k < H.outer[j + 1]; ++k)
+				if (!is_fixed[H.inner[k]])
+				{
+					R.inner.push_back(new_id[H.inner[k]]);
+					R.values.push_back(H.values[k]);
+				}
+			R.outer.push_back((int64_t)R.inner.size());
+		}
+		VectorXd rr(nr), xa, xb;
+		for (int i = 0; i < N; ++i)
+			if (!is_fixed[i])
+				rr[new_id[i]] = rhs[i];
+		auto byvalue = polysolve::LinearSolver::create("Eigen::ConjugateGradient", "Eigen::DiagonalPreconditioner");
+		byvalue->setParameters(1000, 1e-12);
+		byvalue->analyzePattern(R, R.rows());
+		byvalue->factorize(R);
+		byvalue->solve(rr, xa);
+		REQUIRE(!byvalue->uses_resident_matrix());
+		REQUIRE(byvalue->solver_error() < 1e-10 && std::abs(byvalue->solver_iter() - solver->solver_iter()) <= 2);
+		double dmax = 0, emax = 0;
+		for (int i = 0; i < N; ++i)
+			if (!is_fixed[i])
+			{
+				dmax = std::max(dmax, std::fabs(dx[i]));
+				emax = std::max(emax, std::fabs(dx[i] - xa[new_id[i]]));
+			}
+		REQUIRE(emax <= 1e-8 * dmax);
+		// (b) + diagonal form
+		StiffnessMatrix S = R;
+		std::vector<double> diag(nr);
+		for (int i = 0; i < nr; ++i)
+			diag[i] = 50.0 + (i % 17);
+		S.add_to_diagonal(diag);
+		byvalue->factorize(S); // same pattern: values only
+		byvalue->solve(rr, xb);
+		REQUIRE(byvalue->solver_error() < 1e-10);
+		// residual of the summed system on the host (column-major product), and the two solutions differ
+		std::vector<double> res(nr, 0.0);
+		for (int j = 0; j < nr; ++j)
+			for (int64_t k = S.outer[j]; k < S.outer[j + 1]; ++k)
+				res[S.inner[k]] += S.values[k] * xb[j];
+		double rn = 0, bn = 0, diff = 0, an = 0;
+		for (int i = 0; i < nr; ++i)
+		{
+			rn += (res[i] - rr[i]) * (res[i] - rr[i]), bn += rr[i] * rr[i];
+			diff += (xa[i] - xb[i]) * (xa[i] - xb[i]), an += xa[i] * xa[i];
+		}
+		REQUIRE(std::sqrt(rn) <= 1e-10 * std::sqrt(bn));
+		REQUIRE(std::sqrt(diff) > 1e-3 * std::sqrt(an));
+		// a tagged matrix that the caller changed afterwards is uploaded, not solved in place
+		StiffnessMatrix H2 = H;
+		H2.add_to_diagonal(1.0);
+		REQUIRE(H2.resident == nullptr);
+		// factorization failure -> std::runtime_error, the signal the Newton solver regularises on
+		StiffnessMatrix bad = R;
+		bad.add_to_diagonal(-1e12);
+		bool failed = false;
+		try
+		{
+			byvalue->factorize(bad);
+		}
+		catch (const std::runtime_error &)
+		{
+			failed = true;
+		}
+		REQUIRE(failed);
+	}
+
 	bool threw = false;
 	try
 	{

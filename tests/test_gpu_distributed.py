@@ -464,3 +464,50 @@ def test_coarse_space_over_the_ranks_cuts_the_iterations(world):
     assert it1 < it0
     if world >= 4:
         assert it1 <= 0.8 * it0
+
+
+@pytest.mark.parametrize("precond", [1, 2])
+def test_single_rank_driver_with_slice_ordered_product(precond):
+    """One rank, no halo, more than 65536 owned nodes: the solver copy's product then stays in slice order between the
+    two half products of the distributed loop (interior rows; boundary rows: none on this rank), and the update kernel
+    must read it there.  Reference: pfx_cg_dev on the same engine."""
+    import torch
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        part, bounds, n_nodes = D.slab_part(20, 20, 0, 1, 2)
+        assert part.n_owned == n_nodes > 65536
+        eng = E.Engine(0)
+        try:
+            eng.set_stream(stream.cuda_stream)
+            eng.set_mesh(part.mesh)
+            lam, mu = 1e5 * 0.3 / (1.3 * 0.4), 1e5 / 2.6
+            eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+            eng.build_pattern()
+            eng.assemble_linear()
+            fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 0]) < 1e-12)[0]
+            eng.set_dirichlet(np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+            n = n_nodes * 3
+            b = torch.from_numpy(np.random.default_rng(3).standard_normal(n)).to(dev)
+            tol, max_iter = (1e-10, 300) if precond == 2 else (1e-6, 1000)
+            x_ref = torch.zeros(n, dtype=torch.float64, device=dev)
+            it_ref, err_ref = eng.cg_dev(b.data_ptr(), x_ref.data_ptr(), precond, max_iter, tol)
+            cg = D.DistributedCG(D.HipOps(eng), part, 3, D.Comm(), dev)
+            x = torch.zeros(n, dtype=torch.float64, device=dev)
+            iters, err = cg.solve(b, x, precond, max_iter, tol)
+            torch.cuda.synchronize()
+            assert abs(iters - it_ref) <= 1 and err <= tol, (iters, it_ref, err, err_ref)
+            assert float((x - x_ref).abs().max()) <= 1e-6 * float(x_ref.abs().max())
+            # a second solver object on the same engine, the first one dropped afterwards: the engine keeps the
+            # workspace of the object that is alive
+            cg2 = D.DistributedCG(D.HipOps(eng), part, 3, D.Comm(), dev)
+            cg.close()
+            x2 = torch.zeros(n, dtype=torch.float64, device=dev)
+            iters2, err2 = cg2.solve(b, x2, precond, max_iter, tol)
+            torch.cuda.synchronize()
+            assert iters2 == iters and float((x2 - x).abs().max()) <= 1e-12 * float(x.abs().max())
+            cg2.close()
+        finally:
+            eng.close()
