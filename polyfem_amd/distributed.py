@@ -311,15 +311,13 @@ class HipOps:
     def set_workspace(self, work):
         if work is None:
             self.e.cgs_set_workspace(0, 0)
-            self._installed = 0
         else:
             self.e.cgs_set_workspace(work.data_ptr(), work.numel())
-            self._installed = work.data_ptr()
 
     def release_workspace(self, work):
         """Takes `work` out of the engine if it is still the installed workspace: a newer DistributedCG on the same
         engine may have installed its own since, and that one must stay."""
-        if work is not None and getattr(self, "_installed", 0) == work.data_ptr():
+        if work is not None and getattr(self.e, "cgs_workspace", 0) == work.data_ptr():
             self.set_workspace(None)
 
     def prepare(self, x, precond):

@@ -702,6 +702,7 @@ class Engine:
         """Caller-owned CG workspace of n_doubles >= 4 * n_dofs doubles; d_work = 0 returns to the engine's own."""
         if getattr(self, "h", None):
             self._ck(self.L.pfx_cgs_set_workspace(self.h, _vp(d_work) if d_work else None, int(n_doubles)))
+            self.cgs_workspace = int(d_work) if d_work else 0  # what the context points at now (0: its own)
 
     def cgs_prepare(self, d_x: int, precond: int):
         self._ck(self.L.pfx_cgs_prepare(self.h, _vp(d_x), precond))
