@@ -12,9 +12,11 @@ pattern, vectors) are resident in HBM before the timed region.
 processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before it has touched the GPU, and waits.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel of the step (the CG SpMV): algorithmic bytes / average launch duration (HIP events on
-                the engine's stream) against the 8 TB/s HBM peak; traffic = HBM bytes per launch from the committed
-                rocprofv3 PMC passes of this same workload and grid
+  roofline      dominant kernel of the step (the CG SpMV): the bytes its matrix format must move per launch / average
+                launch duration (HIP events on the engine's stream) against the 8 TB/s HBM peak -- a fraction that cannot
+                exceed one; the same launch priced on a scalar CSR's bytes is kept as csr_equivalent_*; traffic = HBM
+                bytes per launch from the committed rocprofv3 PMC passes of this same workload and grid, quoted only when
+                that recording was made with the library sources this run is built from (hash compared), else null
   assembly      elements/s and the same roofline accounting for the assembly kernels
   cpu_baseline  the CPU oracle (reference-algorithm restatement) on a bounded sample of the same workload
   linear_elasticity_1M   (N = 1 only) the same measurement for the LinearElasticity stiffness + CG configuration on the
@@ -43,17 +45,19 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def spmv_bytes(nnz, n_dofs):
-    """Algorithmic bytes of one product y = A x, the figure the roofline fraction is quoted on: the compulsory traffic
-    of a scalar CSR product -- 8-B value and 4-B column per stored entry, the 4-B row pointers, x read once and y written
-    once."""
+def spmv_csr_bytes(nnz, n_dofs):
+    """What a scalar CSR product y = A x would have to move for the same matrix: 8-B value and 4-B column per stored
+    entry, the 4-B row pointers, x read once and y written once.  Reported as csr_equivalent_*; the node-block format
+    never moves 8 of every 9 of those column indices, so a rate on these bytes can exceed the peak and is no roofline
+    fraction."""
     return 12.0 * nnz + 4.0 * (n_dofs + 1) + 16.0 * n_dofs
 
 
-def spmv_stored_bytes(nnz, n_blocks, n_nodes, n_dofs):
-    """Bytes the node-block format of this library has to move for the same product (padding excluded): 8 B per value,
-    ONE 4-B column per 3x3 block, the 8-B slice bases, x read once and y written once.  Smaller than spmv_bytes: the
-    block format drops 8/9 of the column indices."""
+def spmv_bytes(nnz, n_blocks, n_nodes, n_dofs):
+    """Algorithmic bytes of one product y = A x in the node-block format the solver holds (padding excluded), the figure
+    the roofline fraction is quoted on: 8 B per value, ONE 4-B column per 3x3 block, the 8-B slice bases, x read once
+    and y written once.  Every one of these bytes has to cross the HBM interface once per launch (the matrix is far
+    larger than the caches), so bytes / time is bounded by the peak."""
     return 8.0 * nnz + 4.0 * n_blocks + 8.0 * (n_nodes + 1) + 16.0 * n_dofs
 
 
@@ -79,7 +83,12 @@ def cpu_baseline(args, workload, hexes, oracle, M):
     ConjugateGradient on a column-major matrix multiplies on one thread) and timed on a few iterations, scaled."""
     n = max(args.cpu_n // 2, 2) if hexes else args.cpu_n
     mesh = M.cube_hexes(n, 2) if hexes else M.cube_tets(n, 2)
-    cores = min(os.cpu_count() or 1, 16)
+    # every core this process may use: its affinity mask, cut by the share the machine grants a job (OMP_NUM_THREADS is
+    # set to that share on the GPU box, where os.cpu_count() shows the whole machine's cores)
+    host_cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(avail, share) if share > 0 else avail)
     om = oracle.OMesh(mesh)
     t0 = time.perf_counter()
     if workload == "neohookean":
@@ -101,6 +110,8 @@ def cpu_baseline(args, workload, hexes, oracle, M):
     t_cg = (time.perf_counter() - t0) * (args.cg_max_iter / max(it, 1))
     return {
         "value": mesh.n_el / (t_asm + t_cg), "unit": "elements/s", "cores": cores, "kind": "port",
+        "host_cores": host_cores, "threads_assembly": cores, "threads_cg": 1,
+        "thread_limit": (f"OMP_NUM_THREADS={share} (this job's share of the host)" if share > 0 and share < avail else "affinity mask of the process"),
         "sample": f"{'Q2 hexes' if hexes else 'P2 tets'} {n}^3 grid ({mesh.n_el} elements, {nr} free dofs, {Kr[1].size} non-zeros: out of "
                   f"cache): {'gradient + Hessian' if workload == 'neohookean' else 'stiffness'} assembly with {cores} threads "
                   f"{t_asm:.3f}s + {it} single-thread CG iterations scaled to {args.cg_max_iter} ({t_cg:.3f}s)",
@@ -115,7 +126,8 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     t_setup = time.perf_counter()
     # weak scaling: the global grid is n x n x (n*world) cells; every rank owns the node planes of n cell layers
     # (plus one layer of its lower neighbour's elements, which it assembles redundantly instead of communicating)
-    part, bounds, n_nodes_global = D.slab_part(grid, grid, rank, world, 2, "hex" if hexes else "tet")
+    cpr = args.cells_per_rank or grid
+    part, bounds, n_nodes_global = D.slab_part(grid, cpr, rank, world, 2, "hex" if hexes else "tet")
     mesh = part.mesh
     if rank == 0:
         log(f"{workload} grid {grid}: mesh of {mesh.conn.shape[0]} elements built on the host in {time.perf_counter() - t_setup:.1f}s")
@@ -249,8 +261,8 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     conv_ms, _ = eng.timing_get("sell_convert")
     pre_ms, pre_n = eng.timing_get("precond")
 
-    sb = spmv_bytes(inf.nnz, n)
-    sb_stored = spmv_stored_bytes(inf.nnz, inf.n_blocks, inf.n_nodes, n)
+    sb = spmv_bytes(inf.nnz, inf.n_blocks, inf.n_nodes, n)
+    sb_csr = spmv_csr_bytes(inf.nnz, n)
     ab = assembly_bytes(inf.n_el, inf.n_loc, 8 if hexes else 4, mesh.xyz.shape[0], inf.n_nodes, inf.nnz, nonlinear)
     spmv_gbs = sb / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     af = assembly_flops(inf.n_el, inf.n_loc, inf.n_pts, nonlinear)
@@ -258,22 +270,31 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     asm_gbs = ab / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0
 
     # HBM bytes per SpMV launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, one rocprofv3 run each, corrected
-    # as the gfx950 notes prescribe: 2 * FETCH_SIZE + WRITE_SIZE) of this same workload and grid; null when no
-    # recording matches or the run is partitioned.
+    # as the gfx950 notes prescribe: 2 * FETCH_SIZE + WRITE_SIZE) of this same workload and grid.  A recording carries the
+    # hash of the library sources it was made with; it is quoted only if this run is built from the same sources.  Null
+    # when no recording matches or the run is partitioned.
     traffic, traffic_src = None, None
     if world == 1 and workload in ("neohookean", "linear_elasticity"):
-        for name in (f"r2_pmc_traffic_{workload}_{element}_grid{grid}.json", f"r1_pmc_traffic_grid{grid}.json" if workload == "linear_elasticity" and not hexes else ""):
+        from polyfem_amd.buildinfo import source_sha256
+        here = source_sha256()
+        for rnd in ("r3", "r2"):
+            name = f"{rnd}_pmc_traffic_{workload}_{element}_grid{grid}.json"
             tpath = os.path.join(ROOT, "profiles", name)
-            if name and os.path.exists(tpath):
-                recs = json.load(open(tpath))
-                rec = next((v for k, v in recs.items() if k.startswith("k_sell_spmv<3, true")), None)  # the CG's product (with the p.Ap partials)
-                if rec:
-                    traffic, traffic_src = rec["hbm_bytes"], os.path.relpath(tpath, ROOT)
-                    break
+            if not os.path.exists(tpath):
+                continue
+            recs = json.load(open(tpath))
+            rec = next((v for k, v in recs.items() if k.startswith("k_sell_spmv<3, true")), None)  # the CG's product (with the p.Ap partials)
+            made_with = recs.get("_meta", {}).get("source_sha256")
+            if rec and made_with == here:
+                traffic, traffic_src = rec["hbm_bytes"], os.path.relpath(tpath, ROOT)
+            elif rec:
+                traffic_src = f"{os.path.relpath(tpath, ROOT)} was recorded with other library sources: not quoted"
+            break
 
-    n_el_global = (1 if hexes else 6) * grid * grid * grid * world
+    n_el_global = (1 if hexes else 6) * grid * grid * cpr * world
     owned_el = int(part.elem_owned.sum())
-    shape = f"Q2 hexes, {grid}^3 grid per GPU" if hexes else f"P2 tets, {grid}^3 Kuhn grid per GPU"
+    dims = f"{grid}^3" if cpr == grid else f"{grid} x {grid} x {cpr}"
+    shape = f"Q2 hexes, {dims} grid per GPU" if hexes else f"P2 tets, {dims} Kuhn grid per GPU"
     backend = (dist.get_backend() if world > 1 else None)
     out = None
     if rank == 0:
@@ -300,15 +321,17 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
             },
             "roofline": {"kernel": "k_sell_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src, "avg_ms": spmv_ms, "timed_launches": spmv_n, "timed_every": timed_every, "algorithmic_bytes": sb,
-                         # the same launch priced on what the block format stores, and on the measured HBM traffic
-                         "stored_bytes": sb_stored,
-                         "stored_rate": sb_stored / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0,
-                         "stored_frac": sb_stored / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if spmv_ms > 0 else 0.0,
+                         "traffic_source": traffic_src, "avg_ms": spmv_ms, "timed_launches": spmv_n, "timed_every": timed_every,
+                         # bytes of the node-block format (8 B per value, one 4-B column per 3x3 block, x and y once): what
+                         # `achieved` = algorithmic_bytes / avg_ms is priced on
+                         "algorithmic_bytes": sb,
+                         # the measured HBM traffic of the same launch as a rate and as a fraction of the peak
                          "hbm_rate": traffic / (spmv_ms * 1e-3) / 1e9 if traffic and spmv_ms > 0 else None,
-                         # `frac` prices the launch on the scalar-CSR bytes the metric is defined on and can exceed 1: the block format
-                         # stores one column index per nine values.  The fraction of the peak that physically moved:
-                         "moved_frac": traffic / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and spmv_ms > 0 else None},
+                         "moved_frac": traffic / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and spmv_ms > 0 else None,
+                         # for comparison with scalar-CSR products: the bytes such a product would move for this matrix
+                         # (12 B per entry) over the same time; may exceed the peak, since 8 of 9 column indices do not exist here
+                         "csr_equivalent_bytes": sb_csr,
+                         "csr_equivalent_rate": sb_csr / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0},
             "assembly": {"elements_per_s": world * owned_el / (asm_ms * 1e-3) if asm_ms > 0 else 0.0, "local_ms": loc_ms,
                          "gather_ms": gat_ms, "solver_copy_ms": conv_ms, "gradient_local_ms": lg_ms, "gradient_gather_ms": gv_ms,
                          "roofline": {"bound": "hbm", "achieved": asm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -410,6 +433,56 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     return out
 
 
+def dry_run(args):
+    """Per-rank device memory of a `--gpus N` run, measured on one GPU: the ranks' real meshes and patterns are built one after
+    the other (no assembly, no communication).  The AMG hierarchy cannot be built without matrix values; its share is
+    estimated from the operator complexity measured on this library's hierarchies (1.25: the coarse matrices and their
+    solver copies add a quarter of the fine level's, the transfer lists about as much as the fine level's column indices)."""
+    import torch
+
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+
+    hexes = args.element == "q2hex"
+    world, grid = args.gpus, args.n
+    cpr = args.cells_per_rank or grid
+    total = torch.cuda.get_device_properties(0).total_memory
+    ranks = sorted(set([0, world // 2, world - 1]))
+    rows = []
+    for r in ranks:
+        part, bounds, n_nodes_global = D.slab_part(grid, cpr, r, world, 2, "hex" if hexes else "tet")
+        eng = E.Engine(0)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.NEOHOOKEAN if args.workload != "linear_elasticity" else E.LINEAR_ELASTICITY, 1.0, 1.0)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        inf = eng.info()
+        b_pattern = inf.bytes_device
+        n = inf.n_dofs
+        x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        b = torch.zeros(n, dtype=torch.float64, device="cuda")
+        eng.cg_dev(b.data_ptr(), x.data_ptr(), E.PRECOND_JACOBI, 0, 1e-12)  # zero iterations: allocates the solver copy and the vectors
+        eng.synchronize()
+        b_solver = eng.info().bytes_device
+        values = 8.0 * inf.nnz
+        amg_est = 0.25 * (2.0 * values) + 2.0 * 4.0 * inf.n_blocks
+        caller = 8.0 * n * 8  # vectors a driver keeps beside the context (u, rhs, x, gradient, direction, work copies)
+        held = b_solver + amg_est + caller
+        rows.append({"rank": r, "elements_assembled": inf.n_el, "elements_owned": int(part.elem_owned.sum()), "nodes_local": inf.n_nodes,
+                     "nodes_owned": part.n_owned, "halo_nodes": int(part.halo_global.size), "nnz": inf.nnz, "node_blocks": inf.n_blocks,
+                     "bytes_after_pattern": b_pattern, "bytes_with_solver_copy_and_cg_vectors": b_solver,
+                     "bytes_amg_hierarchy_estimate": amg_est, "bytes_caller_vectors_estimate": caller,
+                     "bytes_total_estimate": held, "fraction_of_device_memory": held / total})
+        log(f"rank {r}: {inf.n_el} elements, nnz {inf.nnz}, {held / 2**30:.1f} GiB of {total / 2**30:.0f} GiB")
+        eng.close()
+        del x, b
+        torch.cuda.empty_cache()
+    worst = max(rw["fraction_of_device_memory"] for rw in rows)
+    print(json.dumps({"dry_run": True, "n_gpus": world, "element": args.element, "grid": [grid, grid, cpr * world],
+                      "elements_global": (1 if hexes else 6) * grid * grid * cpr * world, "device_memory_bytes": total,
+                      "ranks": rows, "fits": worst < 0.9, "largest_fraction": worst}), flush=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -468,11 +541,19 @@ def main():
     ap.add_argument("--cpu-cg-iters", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the LinearElasticity 55^3 measurement that rides along at N = 1")
+    ap.add_argument("--cells-per-rank", type=int, default=0,
+                    help="cell layers (z) per GPU when they differ from --grid: the global grid is grid x grid x (cells-per-rank * gpus)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="memory accounting of a --gpus N run on ONE GPU, without assembling anything: for the first, a middle and the last rank "
+                         "of the partition, builds that rank's mesh and pattern, allocates the solver copy and the CG vectors, and prints what the "
+                         "rank holds against the GPU's memory")
     ap.add_argument("--spawn-check", action="store_true", help="every rank reports its rank/world and exits (no GPU work): checks the launcher")
     args = ap.parse_args()
     if args.n is None:
         args.n = 100 if args.element == "q2hex" else (119 if args.workload == "neohookean" else 55)
 
+    if args.dry_run:
+        return dry_run(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))

@@ -1172,13 +1172,16 @@ namespace
 		return PFX_OK;
 	}
 
-	pfx_status amg_numeric(pfx_ctx *ctx, double *dinv0, double *scratch_v, double *scratch_t)
+	// values_changed = false: only the diagonal shift of the level-0 operator changed (a regularisation retry of the
+	// Newton solver).  The coarse matrices are Galerkin products of the UNSHIFTED matrix and stay as they are; what the
+	// shift changes is the level-0 relaxation: its Jacobi diagonal (the caller's dinv0) and its spectral radius.
+	pfx_status amg_numeric(pfx_ctx *ctx, double *dinv0, double *scratch_v, double *scratch_t, bool values_changed)
 	{
 		const double t_begin = now_s();
 		pfx_amg *A = ctx->amg;
 		hipStream_t st = ctx->stream;
 		const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-		for (size_t l = 0; l + 1 < A->lv.size(); ++l)
+		for (size_t l = 0; values_changed && l + 1 < A->lv.size(); ++l)
 		{
 			pfx_amg_level &F = A->lv[l], &C = A->lv[l + 1];
 			const unsigned grid = (unsigned)((2 * F.n_cpairs * 8 + 255) / 256);
@@ -1202,7 +1205,7 @@ namespace
 		}
 		PFX_HIP(hipGetLastError());
 		// spectral radii of D^-1 A on every level that is relaxed
-		for (size_t l = 0; l + 1 < A->lv.size(); ++l)
+		for (size_t l = 0; l + 1 < A->lv.size() && (values_changed || l == 0); ++l)
 		{
 			pfx_amg_level &L = A->lv[l];
 			if (l == 0 && ctx->n_owned < ctx->n_nodes) // the level-0 operator is the owned-owned block: halo entries of the vector it is applied to are zero
@@ -1212,6 +1215,7 @@ namespace
 				return rc;
 		}
 		// dense inverse of the coarsest matrix (host: Gauss-Jordan with partial pivoting)
+		if (values_changed)
 		{
 			pfx_amg_level &L = A->lv.back();
 			if (A->lv.size() < 2)
@@ -1450,8 +1454,9 @@ pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, doubl
 	// the Jacobi diagonal lives in the solver's workspace, which other solves overwrite: always rebuilt
 	if ((rc = pfx_launch_invdiag(ctx, 1, dinv0)))
 		return rc;
-	if (ctx->amg->values_gen != ctx->values_gen || ctx->amg->shift != ctx->diag_shift)
-		if ((rc = amg_numeric(ctx, dinv0, scratch_v, scratch_t)))
+	const bool values_changed = ctx->amg->values_gen != ctx->values_gen;
+	if (values_changed || ctx->amg->shift != ctx->diag_shift)
+		if ((rc = amg_numeric(ctx, dinv0, scratch_v, scratch_t, values_changed)))
 			return rc;
 	return PFX_OK;
 }

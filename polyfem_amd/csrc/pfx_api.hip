@@ -219,7 +219,7 @@ extern "C"
 			return PFX_ERR_HIP;
 		}
 		ctx->own_stream = true;
-		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_tab_mass, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess || hipMemset(ctx->d_flag, 0, sizeof(int)) != hipSuccess)
+		if (hipMalloc((void **)&ctx->d_tab, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_tab_mass, sizeof(pfx_tables)) != hipSuccess || hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess || hipMalloc((void **)&ctx->d_partials, sizeof(double) * (3 * 2048 + 8)) != hipSuccess || hipMemset(ctx->d_partials, 0, sizeof(double) * (3 * 2048 + 8)) != hipSuccess || hipMemset(ctx->d_flag, 0, sizeof(int)) != hipSuccess)
 		{
 			pfx_destroy(ctx); // releases whatever was allocated so far, and the stream
 			return PFX_ERR_HIP;
@@ -772,6 +772,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
+		PFX_HIP(hipSetDevice(ctx->device));
 		{
 			pfx_scoped_timer tm(ctx, "local_energy");
 			pfx_status rc = pfx_launch_local_nl(ctx, d_u, true, false, false);

@@ -7,6 +7,8 @@
 // counterpart is pfx_rowasm.h.
 #include "pfx_internal.h"
 
+#include <atomic>
+
 namespace
 {
 	template <int NLOC, int BS>
@@ -229,27 +231,31 @@ pfx_status pfx_launch_reduce_energy(pfx_ctx *ctx, double *d_energy, const double
 // device address is looked up once per device (pfx_noalloc_init, called by pfx_create with that device current) and
 // passed to the kernels as an ordinary pointer argument.
 static __device__ __align__(256) double pfx_noalloc_scratch[PFX_NOALLOC_MAX_EL + 256];
-static double *g_noalloc_ptr[PFX_MAX_DEVICES] = {nullptr};
+// one slot per device, published with release / read with acquire: contexts may be created from several host threads
+static std::atomic<double *> g_noalloc_ptr[PFX_MAX_DEVICES];
 
 pfx_status pfx_noalloc_init(pfx_ctx *ctx)
 {
 	if (ctx->device < 0 || ctx->device >= PFX_MAX_DEVICES)
 		PFX_FAIL(PFX_ERR_ARG, "device index beyond PFX_MAX_DEVICES");
-	if (g_noalloc_ptr[ctx->device])
+	if (g_noalloc_ptr[ctx->device].load(std::memory_order_acquire))
 		return PFX_OK;
 	double *ptr = nullptr;
+	PFX_HIP(hipSetDevice(ctx->device));
 	PFX_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(pfx_noalloc_scratch)));
 	if (!ptr)
 		PFX_FAIL(PFX_ERR_HIP, "hipGetSymbolAddress returned a null address for the no-allocation scratch");
-	g_noalloc_ptr[ctx->device] = ptr;
+	// two threads racing here look the same address up: either store is the right one
+	g_noalloc_ptr[ctx->device].store(ptr, std::memory_order_release);
 	return PFX_OK;
 }
 
 pfx_status pfx_energy_noalloc_run(pfx_ctx *ctx, const double *d_u, double *d_energy)
 {
-	double *ptr = (ctx->device >= 0 && ctx->device < PFX_MAX_DEVICES) ? g_noalloc_ptr[ctx->device] : nullptr;
+	double *ptr = (ctx->device >= 0 && ctx->device < PFX_MAX_DEVICES) ? g_noalloc_ptr[ctx->device].load(std::memory_order_acquire) : nullptr;
 	if (!ptr)
 		PFX_FAIL(PFX_ERR_HIP, "the no-allocation scratch of this device was not initialised");
+	PFX_HIP(hipSetDevice(ctx->device)); // sets a thread-local index: no allocation
 	if (ctx->n_el > PFX_NOALLOC_MAX_EL)
 		PFX_FAIL(PFX_ERR_SIZE, "pfx_energy_dev_noalloc: more than PFX_NOALLOC_MAX_EL (1048576) elements; use pfx_energy_dev");
 	// every slot read below is written first in this call (n_el element energies, then all 256 partials): nothing

@@ -24,6 +24,7 @@
 #include <cfloat>
 #include <cmath>
 
+#define PFX_SUM_STAGE 4096 // offset in d_partials (6152 doubles) of the wide partial sum's 128 chunk sums + ticket
 #define PFX_NPART 1024 // number of partial sums (= grid size of the reducing kernels; 1024 measured 1 % faster per CG iteration than 2048, 512 the same)
 
 // device-resident solver state
@@ -167,6 +168,57 @@ namespace
 			for (int w = 0; w < 16; ++w)
 				r += sh[w];
 			*out = r;
+		}
+	}
+
+	// The same for hundreds of thousands of partials (10 M elements: one block needs 38 us, 0.7 % of a CG iteration): SUM_BLOCKS
+	// blocks each sum one contiguous chunk, the block that finishes last (ticket counter) adds the chunk sums in chunk
+	// order.  The result does not depend on which block that is: fixed summation order, one launch.  stage: SUM_BLOCKS
+	// doubles, ticket: zero before the first launch (the last block leaves it zero again).
+	constexpr int SUM_BLOCKS = 128;
+	__global__ __launch_bounds__(256) void k_sum_partials_wide(const double *__restrict__ part, int count, double *__restrict__ stage, unsigned int *__restrict__ ticket,
+															   double *__restrict__ out)
+	{
+		__shared__ double sh[4];
+		__shared__ bool last;
+		const int chunk = (count + SUM_BLOCKS - 1) / SUM_BLOCKS;
+		const int lo = blockIdx.x * chunk, hi = min(lo + chunk, count);
+		double acc = 0;
+		for (int base = lo + threadIdx.x; base < hi; base += 4 * 256)
+		{
+			double v[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+			{
+				const int idx = base + u * 256;
+				v[u] = idx < hi ? part[idx] : 0.0;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				acc += v[u];
+		}
+		const double s = block_sum(acc, sh);
+		if (threadIdx.x == 0)
+		{
+			stage[blockIdx.x] = s;
+			__threadfence(); // the chunk sum is visible before the ticket is taken
+			last = atomicAdd(ticket, 1u) == SUM_BLOCKS - 1;
+		}
+		__syncthreads();
+		if (!last)
+			return;
+		__threadfence();
+		const volatile double *vs = stage; // written by other blocks during this launch: read past the caches of this CU
+		double t = threadIdx.x < SUM_BLOCKS ? vs[threadIdx.x] : 0.0;
+		// 128 values: lanes 0..63 of waves 0 and 1; fixed tree inside each wave, then wave 0 + wave 1
+		t = wave_sum(t);
+		if ((threadIdx.x & 63) == 0)
+			sh[threadIdx.x >> 6] = t;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			*out = sh[0] + sh[1];
+			*ticket = 0u;
 		}
 	}
 
@@ -331,7 +383,14 @@ pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag)
 
 void pfx_launch_sum_partials(pfx_ctx *ctx, const double *part, int count, double *out)
 {
-	hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, part, count, out);
+	if (count < 32768)
+	{
+		hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, part, count, out);
+		return;
+	}
+	// stage and ticket live behind the scalars of d_partials (zeroed at pfx_create)
+	double *stage = ctx->d_partials + PFX_SUM_STAGE;
+	hipLaunchKernelGGL(k_sum_partials_wide, dim3(SUM_BLOCKS), dim3(256), 0, ctx->stream, part, count, stage, (unsigned int *)(stage + SUM_BLOCKS), out);
 }
 
 pfx_status pfx_launch_spmv(pfx_ctx *ctx, const double *d_x, double *d_y)
@@ -474,7 +533,7 @@ pfx_status pfx_cgs_spmv_phase_impl(pfx_ctx *ctx, int phase, double *gscal)
 		return rc;
 	// one partial per slice: summed once here rather than by every block of the update kernel
 	if (phase != PFX_SPMV_INTERIOR)
-		hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_part0, pfx_sell_grid(ctx), gscal ? gscal : ctx->d_partials + 3 * PFX_NPART);
+		pfx_launch_sum_partials(ctx, ctx->d_part0, pfx_sell_grid(ctx), gscal ? gscal : ctx->d_partials + 3 * PFX_NPART);
 	return PFX_OK;
 }
 

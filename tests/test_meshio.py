@@ -122,3 +122,50 @@ def test_first_touch_numbering_and_q2_flattening(kind, oracle):
         A = csc_to_scipy(oracle.assemble_linear(m, oracle.LAPLACIAN, lam, mu), n).toarray()
         B = csc_to_scipy(oracle.assemble_linear(gen, oracle.LAPLACIAN, lam, mu), n).toarray()
         assert np.abs(A[np.ix_(perm, perm)] - B).max() <= 1e-13 * np.abs(B).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("element", ["p2tet", "q2hex"])
+@pytest.mark.parametrize("binary", [False, True])
+def test_file_mesh_through_the_hip_path(tmp_path, oracle, element, binary):
+    """A mesh FILE (jittered tetrahedra / hexahedra, MSH 4.1), loaded with the node numbering MeshNodes hands out while the
+    bases are built (src/polyfem/mesh/MeshNodes.cpp:157-308, src/polyfem/basis/FEBasis3d.cpp:201-395), assembled on the HIP
+    path: NeoHookean Hessian and LinearElasticity stiffness, pattern bit-exact and values to 1e-12 against the oracle on
+    the same flattened arrays.  The reference parses MSH through the un-vendored MshIO and holds no mesh file: the
+    flattening itself stays parity unpinned."""
+    from polyfem_amd import engine as E
+    from tests.helpers import rel_err
+    if element == "p2tet":
+        src = M.cube_tets(3, 1, jitter=0.15, seed=4)
+    else:
+        src = M.cube_hexes(2, 1)
+        rng = np.random.default_rng(5)
+        inner = np.all((src.xyz > 1e-9) & (src.xyz < 1 - 1e-9), axis=1)
+        src.xyz[inner] += 0.08 * (rng.random((int(inner.sum()), 3)) - 0.5)  # trilinear, no longer affine
+    path = tmp_path / "mesh.msh"
+    IO.write_msh(path, src.xyz, src.gconn, None, "4.1", binary=binary)
+    mesh, body = IO.load(path, 2, numbering="first_touch")
+    assert mesh.kind == (M.P2TET if element == "p2tet" else M.Q2HEX) and body.size == src.n_el
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        lam, mu = oracle.lame(2e4, 0.3)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.build_pattern()
+        x = M.seeded_displacement(mesh, 3, 2e-3)
+        v = eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        outer, inner_idx, vals = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner_idx)
+        assert rel_err(v, vals) <= 1e-12
+        assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= 1e-12
+        lam, mu = oracle.lame(1e5, 0.3)
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        eng.build_pattern()
+        eng.assemble_linear()
+        rp, ci, v = eng.get_linear_csr()
+        outer, inner_idx, vals = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner_idx)
+        assert rel_err(v, vals) <= 1e-12
+    finally:
+        eng.close()

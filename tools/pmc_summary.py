@@ -29,4 +29,9 @@ if len(sys.argv) > 2:
             f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
             w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
             out[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": (2.0 * f + w) * 1024.0, "launches": len(d["FETCH_SIZE"])}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from polyfem_amd.buildinfo import source_sha256
+    # which build the counters belong to: bench.py quotes them only while the sources still hash to this
+    out["_meta"] = {"source_sha256": source_sha256()}
     json.dump(out, open(sys.argv[2], "w"), indent=1)
