@@ -317,6 +317,9 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
                                 f"backend '{backend}'" + (" (RCCL over xGMI)" if backend == "nccl" else " -- NOT RCCL: single-card rehearsal of the N > 1 path"))
                                if world > 1 else "single GPU",
                 "halo_bytes_per_exchange_rank0": halo_bytes,
+                # who runs the distributed iteration: the library's own loop (pfx_dist_cg_dev) over its RCCL communicator, or over
+                # a host-staged transport when the process group is gloo (single-card rehearsal)
+                "distributed_iteration": (f"inside the library (pfx_dist_cg_dev), communicator: {dcg.lib.libcomm.kind}" if dcg is not None and dcg.lib is not None else None),
                 "bytes_device": eng.info().bytes_device,  # everything the context holds now: pattern, values, solver copy, vectors
             },
             "roofline": {"kernel": "k_sell_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,

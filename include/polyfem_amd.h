@@ -477,6 +477,65 @@ pfx_status pfx_mass_apply_dev(pfx_ctx *ctx, const double *d_v, double *d_y);
 pfx_status pfx_hessian_add_mass_dev(pfx_ctx *ctx, double weight);
 pfx_status pfx_take_numeric_flag(pfx_ctx *ctx, int *flag);
 
+/* ---- the partitioned solve inside the library (no counterpart in the reference, which is single-process) -----------------
+ *
+ * The step functions above leave the communication to the caller.  The calls below run the whole distributed iteration --
+ * halo exchange of the search direction hidden behind the interior rows, all-reduce of the scalars, convergence flag on the
+ * device looked at every `check_every` iterations -- inside the library, over a communicator object with two
+ * implementations:
+ *
+ *   pfx_comm_create_rccl   RCCL over xGMI: grouped ncclSend / ncclRecv between neighbour ranks on a communication stream of
+ *                          its own (ordered with the context's stream by events, so the interior rows of a product run while
+ *                          the halo travels), ncclAllReduce on the context's stream.  One process per GPU; rank 0 makes the id
+ *                          with pfx_comm_rccl_unique_id and the caller hands it to the other ranks (MPI_Bcast, a file, ...).
+ *   pfx_comm_create_host   the caller's own transport for HOST buffers (MPI_Sendrecv / MPI_Allreduce, gloo, pipes): the
+ *                          library stages device data through pinned host memory and synchronises the stream around every
+ *                          callback.  For tests and for machines without a device-to-device path.
+ *
+ * A communicator belongs to one host thread; its calls are collective (every rank makes the same sequence of calls). */
+typedef struct pfx_comm pfx_comm;
+#define PFX_RCCL_ID_BYTES 128
+
+typedef struct
+{
+	void *user;
+	/* For k = 0 .. n-1: send send_bytes[k] bytes at send[k] to rank peer[k] and receive recv_bytes[k] bytes into recv[k] from
+	 * it (either count may be 0).  Blocking; all pointers are host memory; returns 0 on success. */
+	int (*exchange)(void *user, int n, const int *peer, const void *const *send, const int64_t *send_bytes, void *const *recv, const int64_t *recv_bytes);
+	/* buf[0 .. count) := sum over all ranks, in place, the same bits on every rank.  Blocking; returns 0 on success. */
+	int (*all_reduce_sum)(void *user, double *buf, int count);
+} pfx_host_transport;
+
+pfx_status pfx_comm_rccl_unique_id(void *id /* PFX_RCCL_ID_BYTES bytes */);
+pfx_status pfx_comm_create_rccl(pfx_comm **comm, const void *id, int rank, int world, int device);
+pfx_status pfx_comm_create_host(pfx_comm **comm, const pfx_host_transport *transport, int rank, int world);
+void pfx_comm_destroy(pfx_comm *comm);
+const char *pfx_comm_last_error(const pfx_comm *comm);
+
+/* A partitioned context (pfx_set_mesh of the rank's part, pfx_set_owned) bound to a communicator and its halo lists.
+ * Neighbour k = rank peer[k]: this rank SENDS it the entries of its owned nodes send_nodes[send_ptr[k] .. send_ptr[k+1])
+ * (local ids < n_owned, in the order the neighbour stores them) and RECEIVES from it the halo nodes n_owned + recv_ptr[k] ..
+ * n_owned + recv_ptr[k+1] - 1 (halo nodes are numbered neighbour by neighbour).  The context and the communicator must
+ * outlive the object; pfx_set_mesh / pfx_build_pattern on the context invalidate it. */
+typedef struct pfx_dist pfx_dist;
+pfx_status pfx_dist_create(pfx_dist **dist, pfx_ctx *ctx, pfx_comm *comm, int n_neigh, const int32_t *peer, const int64_t *send_ptr,
+						   const int32_t *send_nodes, const int64_t *recv_ptr);
+void pfx_dist_destroy(pfx_dist *dist);
+const char *pfx_dist_last_error(const pfx_dist *dist);
+/* d_vec[(n_owned + h) * bs + c] := the owner's value, for every halo node h (device vector of n_local * bs doubles) */
+pfx_status pfx_dist_halo_exchange_dev(pfx_dist *dist, double *d_vec);
+/* d_buf[0 .. count) := sum over the ranks (device pointer, count <= 64) */
+pfx_status pfx_dist_all_reduce_dev(pfx_dist *dist, double *d_buf, int count);
+/* NLAssembler::assemble -> energy over the partition: every rank sums the elements pfx_set_owned flagged, one all-reduce */
+pfx_status pfx_dist_energy_dev(pfx_dist *dist, const double *d_u, double *d_energy);
+/* pfx_cg_dev over the partition: d_b, d_x are this rank's local vectors (n_local * bs doubles; the halo entries of d_b are
+ * ignored, those of d_x are current on return).  Same iteration, stopping rule and iteration count convention as pfx_cg_dev;
+ * precond PFX_PRECOND_IDENTITY / _JACOBI / _AMG (see pfx_dist_amg_* below).  check_every <= 0: 50. */
+pfx_status pfx_dist_cg_dev(pfx_dist *dist, const double *d_b, double *d_x, int precond, int max_iter, double tol, int check_every,
+						   int *iters, double *rel_res);
+/* bytes one halo exchange of a vector moves through this rank (sent + received) */
+pfx_status pfx_dist_halo_bytes(pfx_dist *dist, int64_t *bytes);
+
 /* ---- introspection for benchmarks ----------------------------------------------------------------------------- */
 
 typedef struct

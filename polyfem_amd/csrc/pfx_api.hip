@@ -84,6 +84,7 @@ void pfx_release_pattern(pfx_ctx *ctx)
 		pfx_sell_release(ctx);
 		pfx_amg_release(ctx);
 		ctx->struct_gen++;
+		ctx->pattern_gen++;
 		ctx->d_work_ext = nullptr; // a caller-owned workspace was sized for the pattern that is going away
 		ctx->n_blocks = ctx->nnz = 0;
 		ctx->n_dirichlet = 0;

@@ -208,6 +208,7 @@ struct pfx_ctx
 	pfx_amg_params amg_params = {4, 1, 2, 12, 600, 15, 0.1, 1.6};
 	pfx_amg *amg = nullptr;
 	int64_t struct_gen = 0;
+	int64_t pattern_gen = 0; // bumped whenever the pattern is released / rebuilt (objects bound to the pattern check it)
 
 	// a pattern and values handed in by the caller (pfx_solver_analyze / pfx_solver_factorize, pfx_extmat.hip) instead of
 	// built from a mesh: the context is then a pure solver context (kind < 0)
@@ -415,5 +416,6 @@ pfx_status pfx_cgs_spmv_impl(pfx_ctx *ctx, double *gscal);
 pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal);
 pfx_status pfx_cgs_direction_impl(pfx_ctx *ctx, int it, const double *gscal);
 pfx_status pfx_cgs_status_impl(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);
+pfx_status pfx_cg_direction_vector(pfx_ctx *ctx, double **p); // the search direction of the step functions (n_local dofs: its halo part is the caller's to fill)
 pfx_status pfx_export_compressed(pfx_ctx *ctx, bool use_mask, bool drop_fixed, int64_t *n_rows, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values);
 pfx_status pfx_export_pattern(pfx_ctx *ctx, int64_t *row_ptr, int32_t *col_idx);

@@ -582,6 +582,15 @@ pfx_status pfx_cgs_direction_impl(pfx_ctx *ctx, int it, const double *gscal)
 	return PFX_OK;
 }
 
+pfx_status pfx_cg_direction_vector(pfx_ctx *ctx, double **p)
+{
+	cg_vecs w;
+	if (cg_workspace(ctx, &w))
+		return PFX_ERR_HIP;
+	*p = w.p;
+	return PFX_OK;
+}
+
 pfx_status pfx_cgs_status_impl(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb)
 {
 	pfx_cg_state h;

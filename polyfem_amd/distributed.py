@@ -395,6 +395,159 @@ class HipOps:
         self.e.hessian_add_mass_dev(weight)
 
 
+class LibComm:
+    """pfx_comm: the library's communicator.  Under torch.distributed's "nccl" backend the library talks RCCL itself
+    (its own ncclComm, the id made on rank 0 and handed round through the process group); under "gloo" (CPU tests, the
+    single-card rehearsal) it gets a host transport whose two callbacks move host buffers through the process group."""
+
+    def __init__(self, comm: Comm, device_index: int = 0):
+        import ctypes as C
+
+        import torch
+
+        from . import engine as E
+        self.L = E.load()
+        self.comm = comm
+        self.h = C.c_void_p()
+        self.kind = "single"
+        dist = comm.dist
+        if comm.on and dist.get_backend() == "nccl":
+            ident = [bytes(128)]
+            if comm.rank == 0:
+                buf = C.create_string_buffer(128)
+                if self.L.pfx_comm_rccl_unique_id(buf) != 0:
+                    raise RuntimeError("pfx_comm_rccl_unique_id failed")
+                ident = [buf.raw]
+            dist.broadcast_object_list(ident, src=0)
+            buf = C.create_string_buffer(ident[0], 128)
+            rc = self.L.pfx_comm_create_rccl(C.byref(self.h), buf, comm.rank, comm.world, device_index)
+            if rc != 0:
+                raise RuntimeError(f"pfx_comm_create_rccl failed ({rc})")
+            self.kind = "rccl"
+            return
+
+        def exchange(user, n, peer, send, send_bytes, recv, recv_bytes):
+            try:
+                ops, keep = [], []
+                for k in range(n):
+                    if send_bytes[k] > 0:
+                        t = torch.frombuffer((C.c_char * send_bytes[k]).from_address(send[k]), dtype=torch.uint8)
+                        keep.append(t)
+                        ops.append(dist.P2POp(dist.isend, t, int(peer[k])))
+                    if recv_bytes[k] > 0:
+                        t = torch.frombuffer((C.c_char * recv_bytes[k]).from_address(recv[k]), dtype=torch.uint8)
+                        keep.append(t)
+                        ops.append(dist.P2POp(dist.irecv, t, int(peer[k])))
+                for r in (dist.batch_isend_irecv(ops) if ops else []):
+                    r.wait()
+                return 0
+            except Exception as exc:  # an exception must not cross the C frame
+                print(f"[polyfem_amd] host transport exchange failed: {exc!r}", flush=True)
+                return 1
+
+        def all_reduce_sum(user, buf, count):
+            try:
+                t = torch.frombuffer((C.c_double * count).from_address(C.addressof(buf.contents)), dtype=torch.float64)
+                dist.all_reduce(t)
+                return 0
+            except Exception as exc:
+                print(f"[polyfem_amd] host transport all_reduce failed: {exc!r}", flush=True)
+                return 1
+
+        if comm.on:
+            self._cb = (E.EXCHANGE_FN(exchange), E.ALL_REDUCE_FN(all_reduce_sum))  # kept alive with the object
+        else:
+            self._cb = (E.EXCHANGE_FN(lambda *a: 0), E.ALL_REDUCE_FN(lambda *a: 0))
+        self._t = E.HostTransport(None, self._cb[0], self._cb[1])
+        rc = self.L.pfx_comm_create_host(C.byref(self.h), C.byref(self._t), comm.rank, comm.world)
+        if rc != 0:
+            raise RuntimeError(f"pfx_comm_create_host failed ({rc})")
+        self.kind = "host" if comm.on else "single"
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.pfx_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LibDist:
+    """pfx_dist: an engine holding one part of the partition, bound to a LibComm and the halo lists of `part`.  The
+    distributed iteration then runs inside the library (pfx_dist_cg_dev): no Python between the kernels, no host read
+    except the convergence flag every `check_every` iterations."""
+
+    def __init__(self, engine, part: Part, comm: Comm, device, libcomm: LibComm | None = None):
+        import ctypes as C
+        self.L, self.engine, self.part = engine.L, engine, part
+        self.libcomm = libcomm or LibComm(comm, device.index if getattr(device, "index", None) is not None else 0)
+        self._own_comm = libcomm is None
+        hx = HaloExchange(part, comm, "cpu")  # the same lists the Python driver uses: who needs which of my nodes
+        peers = hx.neighbours()
+        send_ptr, recv_ptr, send_nodes = [0], [0], []
+        for s in peers:
+            idx = hx.send_idx.get(s)
+            if idx is not None:
+                send_nodes.append(idx.numpy().astype(np.int32))
+            send_ptr.append(send_ptr[-1] + (0 if idx is None else int(idx.numel())))
+            a, b = hx.recv.get(s, (recv_ptr[-1], recv_ptr[-1]))
+            assert a == recv_ptr[-1], "halo nodes are numbered owner by owner"
+            recv_ptr.append(b)
+        peer = np.asarray(peers, dtype=np.int32)
+        sp, rp = np.asarray(send_ptr, dtype=np.int64), np.asarray(recv_ptr, dtype=np.int64)
+        sn = np.concatenate(send_nodes).astype(np.int32) if send_nodes else np.zeros(0, dtype=np.int32)
+        self.h = C.c_void_p()
+        i32, i64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        rc = self.L.pfx_dist_create(C.byref(self.h), engine.h, self.libcomm.h, int(peer.size), peer.ctypes.data_as(i32), sp.ctypes.data_as(i64),
+                                    sn.ctypes.data_as(i32), rp.ctypes.data_as(i64))
+        if rc != 0:
+            raise RuntimeError(f"pfx_dist_create failed ({rc}): {self.L.pfx_last_error(engine.h).decode()}")
+
+    def _ck(self, rc):
+        if rc != 0:
+            from .engine import PfxError
+            raise PfxError(rc, self.L.pfx_dist_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.pfx_dist_destroy(self.h)
+            self.h = None
+        if self._own_comm and self.libcomm is not None:
+            self.libcomm.close()
+            self.libcomm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def halo_exchange(self, vec):
+        self._ck(self.L.pfx_dist_halo_exchange_dev(self.h, vec.data_ptr()))
+
+    def all_reduce(self, buf):
+        self._ck(self.L.pfx_dist_all_reduce_dev(self.h, buf.data_ptr(), int(buf.numel())))
+
+    def energy(self, u, out):
+        self._ck(self.L.pfx_dist_energy_dev(self.h, u.data_ptr(), out.data_ptr()))
+
+    def halo_bytes(self) -> int:
+        import ctypes as C
+        b = C.c_int64()
+        self._ck(self.L.pfx_dist_halo_bytes(self.h, C.byref(b)))
+        return b.value
+
+    def cg(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 50):
+        import ctypes as C
+        it, err = C.c_int(), C.c_double()
+        self._ck(self.L.pfx_dist_cg_dev(self.h, b.data_ptr(), x.data_ptr(), precond, max_iter, tol, check_every, C.byref(it), C.byref(err)))
+        return it.value, err.value
+
+
 class DistributedCG:
     """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition.
 
@@ -410,19 +563,27 @@ class DistributedCG:
         self.torch, self.ops, self.part, self.bs, self.comm = torch, ops, part, bs, comm
         self.n_local = part.n_local
         self.n = self.n_local * bs
+        self.device = device
         self.halo = HaloExchange(part, comm, device)
-        self.work = torch.zeros(4 * self.n, dtype=torch.float64, device=device)
+        self.work = None  # workspace of the Python-driven loops, made on first use (_ensure_work)
         self.scal = torch.zeros(4, dtype=torch.float64, device=device)
-        self.ops.set_workspace(self.work)
-        self.p_nodes = self.work[self.n: 2 * self.n].view(self.n_local, bs)
         self.cs = None  # coarse space over the ranks (enable_coarse_space)
+        # The product path: the whole iteration inside the library (pfx_dist_cg_dev) over the library's own communicator.
+        # Available when the per-rank compute is the HIP engine; the CPU stand-ins of the tests keep the Python loop.
+        self.lib = LibDist(ops.e, part, comm, device) if isinstance(ops, HipOps) else None
+
+    def _ensure_work(self):
+        if self.work is None:
+            self.work = self.torch.zeros(4 * self.n, dtype=self.torch.float64, device=self.device)
+            self.p_nodes = self.work[self.n: 2 * self.n].view(self.n_local, self.bs)
+        self.ops.set_workspace(self.work)  # another solver object on the same engine may have installed its own since
 
     # ---- coarse space over the ranks for the AMG-preconditioned solve ------------------------------------------
     def enable_coarse_space(self, node_pos, fixed_dofs=None):
         """node_pos: (n_local, 3) positions of this rank's nodes (owned, then halo); fixed_dofs: local indices of the
         constrained dofs (the list given to the engine).  The coarse matrix is rebuilt by every AMG-preconditioned
         solve (6 (1 + neighbours) products with the current matrix)."""
-        t, dev = self.torch, self.work.device
+        t, dev = self.torch, self.device
         bs, nl, no = self.bs, self.n_local, self.part.n_owned
         free = np.ones(nl * bs, dtype=np.float64)
         if fixed_dofs is not None and len(fixed_dofs):
@@ -503,6 +664,9 @@ class DistributedCG:
 
     def close(self):
         """Hands the solver workspace back to the engine (the engine must not keep a pointer into a freed tensor)."""
+        if getattr(self, "lib", None) is not None:
+            self.lib.close()
+            self.lib = None
         if self.work is not None:
             try:
                 release = getattr(self.ops, "release_workspace", None)
@@ -517,12 +681,17 @@ class DistributedCG:
     def __del__(self):
         self.close()
 
-    def solve(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 25):
-        """b, x: local vectors of n_local*bs doubles (halo entries of b are ignored).  Returns (iters, rel_res)."""
+    def solve(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 25, use_library: bool = True):
+        """b, x: local vectors of n_local*bs doubles (halo entries of b are ignored).  Returns (iters, rel_res).
+        With the HIP engine the Jacobi / unpreconditioned iteration runs inside the library (use_library = False keeps
+        the Python-driven loop over the step functions: same kernels, same scalars, for comparison)."""
         ops, scal, ar = self.ops, self.scal, self.comm.all_reduce_sum
         if hasattr(ops, "check_stream"):
             ops.check_stream()
-        ops.set_workspace(self.work)  # another solver object on the same engine may have installed its own since
+        if self.lib is not None and use_library and precond != 2:
+            ops.set_workspace(None)  # the library loop works in the context's own vectors
+            return self.lib.cg(b, x, precond, max_iter, tol, check_every)
+        self._ensure_work()
         if precond == 2:
             return self._solve_amg(b, x, max_iter, tol)
         ops.prepare(x, precond)

@@ -48,6 +48,9 @@ EXPORTED_SYMBOLS = [
     "pfx_amg_default_params", "pfx_amg_set_params", "pfx_amg_setup", "pfx_amg_get_info", "pfx_amg_get_aggregates", "pfx_amg_apply_dev",
     "pfx_solver_analyze", "pfx_solver_analyze64", "pfx_solver_factorize", "pfx_solver_factorize_dev", "pfx_solver_set_node_positions",
     "pfx_solver_get_layout", "pfx_matrix_generation",
+    "pfx_comm_rccl_unique_id", "pfx_comm_create_rccl", "pfx_comm_create_host", "pfx_comm_destroy", "pfx_comm_last_error",
+    "pfx_dist_create", "pfx_dist_destroy", "pfx_dist_last_error", "pfx_dist_halo_exchange_dev", "pfx_dist_all_reduce_dev",
+    "pfx_dist_energy_dev", "pfx_dist_cg_dev", "pfx_dist_halo_bytes",
 ]
 
 
@@ -122,6 +125,16 @@ class Info(C.Structure):
     _fields_ = [("n_el", C.c_int64), ("n_nodes", C.c_int64), ("n_dofs", C.c_int64), ("n_blocks", C.c_int64),
                 ("nnz", C.c_int64), ("n_loc", C.c_int), ("n_pts", C.c_int), ("dim", C.c_int),
                 ("bytes_device", C.c_int64)]
+
+
+# pfx_host_transport: the caller's own transport for host buffers (see include/polyfem_amd.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+
+class HostTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("exchange", EXCHANGE_FN), ("all_reduce_sum", ALL_REDUCE_FN)]
 
 
 _lib = None
@@ -224,6 +237,15 @@ def load():
         "pfx_solver_set_node_positions": [_vp, _pd, _i64],
         "pfx_solver_get_layout": [_vp, C.POINTER(C.c_int), _pi64, _pi64],
         "pfx_matrix_generation": [_vp, _pi64],
+        "pfx_comm_rccl_unique_id": [_vp],
+        "pfx_comm_create_rccl": [C.POINTER(_vp), _vp, _i32, _i32, _i32],
+        "pfx_comm_create_host": [C.POINTER(_vp), C.POINTER(HostTransport), _i32, _i32],
+        "pfx_dist_create": [C.POINTER(_vp), _vp, _vp, _i32, _pi32, _pi64, _pi32, _pi64],
+        "pfx_dist_halo_exchange_dev": [_vp, _vp],
+        "pfx_dist_all_reduce_dev": [_vp, _vp, _i32],
+        "pfx_dist_energy_dev": [_vp, _vp, _vp],
+        "pfx_dist_cg_dev": [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, C.POINTER(C.c_int), _pd],
+        "pfx_dist_halo_bytes": [_vp, _pi64],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -235,6 +257,12 @@ def load():
     L.pfx_amg_default_params.restype = None
     L.pfx_last_error.argtypes = [_vp]
     L.pfx_last_error.restype = C.c_char_p
+    for name in ("pfx_comm_destroy", "pfx_dist_destroy"):
+        getattr(L, name).argtypes = [_vp]
+        getattr(L, name).restype = None
+    for name in ("pfx_comm_last_error", "pfx_dist_last_error"):
+        getattr(L, name).argtypes = [_vp]
+        getattr(L, name).restype = C.c_char_p
     _lib = L
     return L
 

@@ -52,3 +52,18 @@ def test_elasticity_tensor_host_helper(oracle):
     assert np.array_equal(c, c.T) and np.array_equal(c[np.triu_indices(6)], e)
     assert np.array_equal(c, oracle.elasticity_tensor(entries=e))
     assert c[0, 5] == 6.0 and c[1, 1] == 7.0 and c[5, 5] == 21.0  # row by row, as set_from_entries
+
+
+def test_rccl_is_linked_and_its_symbols_resolve():
+    """The partitioned solve talks RCCL from inside the library: librccl is a link-time dependency and the collectives the
+    library calls resolve in the loaded image (no call is made: there is no GPU here)."""
+    import ctypes
+    import subprocess
+    from polyfem_amd import engine as E
+    out = subprocess.run(["readelf", "-d", E.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl.so" in out, "libpolyfem_amd.so does not link RCCL"
+    E.load()
+    rccl = ctypes.CDLL("librccl.so.1")  # the copy the loader already mapped for the library
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv",
+                "ncclAllReduce", "ncclGetErrorString"):
+        assert getattr(rccl, sym) is not None

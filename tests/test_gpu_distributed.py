@@ -60,8 +60,24 @@ def _worker(rank, world, port, ret):
         cg = D.DistributedCG(D.HipOps(eng), part, bs, comm, dev)
         b = torch.from_numpy(b_g[dof_l2g]).to(dev)
         x = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
-        iters, err = cg.solve(b, x, E.PRECOND_JACOBI, 1000, 1e-12, check_every=10)
+        iters, err = cg.solve(b, x, E.PRECOND_JACOBI, 1000, 1e-12, check_every=10)  # the loop inside the library (host transport over gloo)
         torch.cuda.synchronize()
+        assert cg.lib is not None and cg.lib.libcomm.kind == "host"
+        # the Python-driven loop over the step functions: same kernels, same all-reduced scalars -> the same iterates
+        x_py = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        iters_py, err_py = cg.solve(b, x_py, E.PRECOND_JACOBI, 1000, 1e-12, check_every=10, use_library=False)
+        torch.cuda.synchronize()
+        no_ = part.n_owned * bs
+        assert iters_py == iters and torch.equal(x_py[:no_], x[:no_]), (iters_py, iters)
+        # the library returns x with a current halo; energy over the partition through the library equals the all-reduced one
+        xh = x.clone()
+        cg.lib.halo_exchange(xh)
+        assert torch.equal(xh, x)
+        e_lib = torch.zeros(1, dtype=torch.float64, device=dev)
+        cg.lib.energy(u, e_lib)
+        torch.cuda.synchronize()
+        assert float(e_lib.item()) == float(e_loc.item())
+        assert cg.lib.halo_bytes() == cg.halo.bytes_per_exchange(bs)
         no = part.n_owned * bs
         out = [None] * world
         dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no], g_loc.cpu().numpy()[:no]))
@@ -511,3 +527,47 @@ def test_single_rank_driver_with_slice_ordered_product(precond):
             cg2.close()
         finally:
             eng.close()
+
+
+def test_one_rank_rccl_communicator_runs_the_library_loop():
+    """RCCL on the hardware that is there: a ONE-rank communicator made by the library itself (ncclGetUniqueId,
+    ncclCommInitRank), the distributed CG loop with its all-reduces enqueued on the context's stream through ncclAllReduce.
+    No neighbour exists, so ncclSend / ncclRecv stay unexecuted until a multi-GPU node runs the benchmark."""
+    import ctypes as C
+    import torch
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    L = E.load()
+    ident = C.create_string_buffer(128)
+    assert L.pfx_comm_rccl_unique_id(ident) == 0
+    comm = C.c_void_p()
+    assert L.pfx_comm_create_rccl(C.byref(comm), ident, 0, 1, 0) == 0
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        part, bounds, n_nodes = D.slab_part(6, 6, 0, 1, 2)
+        eng = E.Engine(0)
+        try:
+            eng.set_stream(stream.cuda_stream)
+            eng.set_mesh(part.mesh)
+            eng.set_material(E.LINEAR_ELASTICITY, 1e5 * 0.3 / (1.3 * 0.4), 1e5 / 2.6)
+            eng.build_pattern()
+            eng.assemble_linear()
+            fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 0]) < 1e-12)[0]
+            eng.set_dirichlet(np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+            n = n_nodes * 3
+            b = torch.from_numpy(np.random.default_rng(3).standard_normal(n)).to(dev)
+            x_ref = torch.zeros(n, dtype=torch.float64, device=dev)
+            it_ref, err_ref = eng.cg_dev(b.data_ptr(), x_ref.data_ptr(), E.PRECOND_JACOBI, 1000, 1e-12)
+            dist = C.c_void_p()
+            assert L.pfx_dist_create(C.byref(dist), eng.h, comm, 0, None, None, None, None) == 0
+            x = torch.zeros(n, dtype=torch.float64, device=dev)
+            it, err = C.c_int(), C.c_double()
+            rc = L.pfx_dist_cg_dev(dist, b.data_ptr(), x.data_ptr(), E.PRECOND_JACOBI, 1000, 1e-12, 25, C.byref(it), C.byref(err))
+            assert rc == 0, L.pfx_dist_last_error(dist).decode()
+            torch.cuda.synchronize()
+            assert it.value == it_ref and torch.equal(x, x_ref)
+            L.pfx_dist_destroy(dist)
+        finally:
+            eng.close()
+            L.pfx_comm_destroy(comm)
