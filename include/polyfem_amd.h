@@ -533,6 +533,15 @@ pfx_status pfx_dist_energy_dev(pfx_dist *dist, const double *d_u, double *d_ener
  * precond PFX_PRECOND_IDENTITY / _JACOBI / _AMG (see pfx_dist_amg_* below).  check_every <= 0: 50. */
 pfx_status pfx_dist_cg_dev(pfx_dist *dist, const double *d_b, double *d_x, int precond, int max_iter, double tol, int check_every,
 						   int *iters, double *rel_res);
+/* PFX_PRECOND_AMG over a partition: ONE hierarchy that spans the ranks.  Every rank aggregates the vertices it owns, the
+ * Galerkin products include the couplings across the partition boundaries (aggregate ids and offsets of the halo vertices
+ * come from their owners once per level at set-up), every coarse level is again a row-distributed matrix whose products are
+ * preceded by a halo exchange of that level, and the coarsest matrix is gathered and inverted on every rank.  It is the
+ * preconditioner a single context would build from the union of the ranks' aggregates.  pfx_dist_amg_apply_dev applies it once
+ * (d_r, d_z local vectors; collective); pfx_amg_get_info / pfx_amg_get_aggregates on the context then describe this rank's
+ * share (vertices and aggregates it owns; the ids of level >= 1 vertices are local to the rank).  Parameters:
+ * pfx_amg_set_params on the context.  Limit: 32 ranks. */
+pfx_status pfx_dist_amg_apply_dev(pfx_dist *dist, const double *d_r, double *d_z);
 /* bytes one halo exchange of a vector moves through this rank (sent + received) */
 pfx_status pfx_dist_halo_bytes(pfx_dist *dist, int64_t *bytes);
 

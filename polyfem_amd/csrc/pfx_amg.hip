@@ -29,11 +29,22 @@
 // coarse-grid correction is scaled by `coarse_scale` in [1, 2) (the piecewise rigid-body interpolation of plain
 // aggregation underestimates the smooth error; the factor makes up for it and leaves M positive definite).
 //
+// Over a partition (one rank per GPU, pfx_dist_cg_dev) the SAME hierarchy spans the ranks: every rank aggregates the
+// vertices it owns (an aggregate never crosses a rank boundary), learns from its neighbours which aggregate each of its halo
+// vertices went into (one halo exchange of the aggregate ids and of the offsets d per level), and forms the rows of the
+// Galerkin product that belong to its own aggregates -- complete, because its fine rows are.  A coarse level is therefore
+// again a row-distributed matrix with halo columns; every product of the cycle is preceded by a halo exchange of that
+// level's vector, the dot products of the Lanczos estimate are all-reduced, and the coarsest matrix is gathered and
+// inverted on every rank.  The preconditioner is the one a single rank would build from the union of the ranks'
+// aggregates (the tests compare it with exactly that), so the iteration count does not degrade with the number of ranks
+// the way a per-rank (block-Jacobi) hierarchy does.
+//
 // The symbolic part (matching, coarse patterns, Galerkin lists) runs once per pattern and Dirichlet set, the numeric
 // part (Galerkin products, diagonals, spectral radii, coarsest inverse) at every new matrix; both on the device, except
 // for the dense inverse of the coarsest matrix (a few hundred dofs).
 #include "pfx_internal.h"
 #include "pfx_amg_graph.h"
+#include "pfx_dist.h"
 
 #include <algorithm>
 #include <chrono>
@@ -701,6 +712,10 @@ struct pfx_amg_level
 	double *d_b = nullptr, *d_x = nullptr, *d_t = nullptr, *d_r = nullptr, *d_dv = nullptr, *d_b2 = nullptr, *d_x2 = nullptr, *d_dinv = nullptr;
 	double lmax = 0;
 	bool small = false; // products through k_rowwave_spmv on the node-block arrays; no solver copy of the matrix
+	// partitioned hierarchies: vertices are numbered [owned | halo]; n_vert / n_dofs count both, these the owned ones
+	int64_t n_overt = 0, n_odofs = 0;
+	pfx_halo halo;      // halo lists of this level's vertices (levels > 0; level 0 uses the partition's own)
+	int64_t n_agg_all = 0; // owned aggregates + aggregates of neighbour ranks that the halo vertices went into
 };
 
 struct pfx_amg
@@ -716,6 +731,10 @@ struct pfx_amg
 	pcg_state *d_state = nullptr;
 	double symbolic_s = 0, numeric_s = 0;
 	int64_t work_blocks = 0; // sum of the levels' blocks
+	// hierarchy that spans the ranks of a partition
+	pfx_dist *dist = nullptr;
+	int64_t coarse_off = 0;     // first global dof of this rank on the coarsest level
+	double *d_bglob = nullptr;  // coarsest right-hand side of all ranks (n_coarsest doubles)
 };
 
 namespace
@@ -739,6 +758,7 @@ namespace
 		free_dev(ctx, L.d_dv);
 		free_dev(ctx, L.d_b2);
 		free_dev(ctx, L.d_x2);
+		pfx_halo_release(&L.halo);
 		if (L.own_m)
 		{
 			free_dev(ctx, L.d_dinv);
@@ -848,12 +868,118 @@ namespace
 		return PFX_OK;
 	}
 
+	// ---- pieces of a hierarchy that spans the ranks of a partition ------------------------------------------------
+	// v[0 .. n) := sum over the ranks (host numbers, n <= 32; the same bits on every rank)
+	pfx_status dist_sum(pfx_ctx *ctx, pfx_dist *dist, double *v, int n)
+	{
+		if (!dist)
+			return PFX_OK;
+		hipStream_t st = ctx->stream;
+		PFX_HIP(hipMemcpyAsync(dist->d_scal + 32, v, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+		if (pfx_comm_all_reduce(dist->comm, st, dist->d_scal + 32, n))
+			PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+		PFX_HIP(hipMemcpyAsync(v, dist->d_scal + 32, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		return PFX_OK;
+	}
+
+	// the halo entries of a vector of level L (`width` doubles per vertex) from their owners
+	pfx_status level_exchange(pfx_ctx *ctx, pfx_amg *A, pfx_amg_level &L, double *vec, int width)
+	{
+		pfx_dist *dist = A->dist;
+		if (!dist)
+			return PFX_OK;
+		pfx_halo *h = L.m == ctx ? &dist->halo : &L.halo;
+		if (pfx_halo_start(dist->comm, h, ctx->stream, vec, width) || pfx_halo_finish(dist->comm, h, ctx->stream))
+			PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+		return PFX_OK;
+	}
+
+	__global__ void k_excl_halo(int64_t n_vert, int64_t n_overt, uint8_t *__restrict__ excl)
+	{
+		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
+			excl[v] = v >= n_overt;
+	}
+
+	__global__ void k_i32_to_f64(const int32_t *__restrict__ a, int64_t n, double *__restrict__ out)
+	{
+		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x)
+			out[v] = (double)a[v];
+	}
+
+	// After the local aggregation of a level (cur[v] in [0, nc) for owned vertices, -1 for halo and left-out ones): learns
+	// from the neighbours which of THEIR aggregates every halo vertex went into, gives those aggregates local ids nc, nc + 1,
+	// ... (neighbour by neighbour, ascending remote id: both sides derive the same order) and writes them into cur; builds
+	// the halo lists of the coarse level (coarse vertex = aggregate).  *nct = nc + number of such halo aggregates.
+	pfx_status dist_halo_aggregates(pfx_ctx *ctx, pfx_amg *A, pfx_amg_level &L, int32_t *cur, int64_t n_vert, int64_t n_overt, int64_t nc, pfx_halo *coarse,
+									int64_t *nct, int coarse_width)
+	{
+		pfx_dist *dist = A->dist;
+		hipStream_t st = ctx->stream;
+		pfx_halo *h = L.m == ctx ? &dist->halo : &L.halo;
+		const int nn = (int)h->peer.size();
+		pfx_tmp<double> ids;
+		PFX_HIP(ids.alloc((size_t)n_vert));
+		hipLaunchKernelGGL(k_i32_to_f64, dim3(grid_for(n_vert)), dim3(256), 0, st, cur, n_vert, ids.p);
+		pfx_status rc = level_exchange(ctx, A, L, ids.p, 1);
+		if (rc)
+			return rc;
+		const int64_t n_halo = n_vert - n_overt;
+		std::vector<double> hid((size_t)n_halo);
+		std::vector<int32_t> hcur((size_t)n_vert);
+		if (n_halo > 0)
+			PFX_HIP(hipMemcpyAsync(hid.data(), ids.p + n_overt, sizeof(double) * (size_t)n_halo, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipMemcpyAsync(hcur.data(), cur, sizeof(int32_t) * (size_t)n_vert, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		std::vector<int64_t> csend_ptr((size_t)nn + 1, 0), crecv_ptr((size_t)nn + 1, 0);
+		std::vector<int32_t> csend;
+		int64_t next = nc;
+		for (int k = 0; k < nn; ++k)
+		{
+			// what arrives from neighbour k: the distinct aggregates of the halo vertices it owns
+			std::vector<int64_t> u;
+			for (int64_t j = h->recv_ptr[(size_t)k]; j < h->recv_ptr[(size_t)k + 1]; ++j)
+				if (hid[(size_t)j] >= 0.0)
+					u.push_back((int64_t)hid[(size_t)j]);
+			std::sort(u.begin(), u.end());
+			u.erase(std::unique(u.begin(), u.end()), u.end());
+			for (int64_t j = h->recv_ptr[(size_t)k]; j < h->recv_ptr[(size_t)k + 1]; ++j)
+			{
+				const double r = hid[(size_t)j];
+				hcur[(size_t)(n_overt + j)] = r >= 0.0 ? (int32_t)(next + (std::lower_bound(u.begin(), u.end(), (int64_t)r) - u.begin())) : -1;
+			}
+			next += (int64_t)u.size();
+			crecv_ptr[(size_t)k + 1] = next - nc;
+			// what goes to neighbour k: the distinct aggregates of the vertices sent to it, in the same (ascending) order
+			std::vector<int32_t> w;
+			for (int64_t j = h->send_ptr[(size_t)k]; j < h->send_ptr[(size_t)k + 1]; ++j)
+			{
+				const int32_t a = hcur[(size_t)h->h_send_idx[(size_t)j]];
+				if (a >= 0)
+					w.push_back(a);
+			}
+			std::sort(w.begin(), w.end());
+			w.erase(std::unique(w.begin(), w.end()), w.end());
+			csend.insert(csend.end(), w.begin(), w.end());
+			csend_ptr[(size_t)k + 1] = (int64_t)csend.size();
+		}
+		if (n_halo > 0)
+			PFX_HIP(hipMemcpyAsync(cur + n_overt, hcur.data() + n_overt, sizeof(int32_t) * (size_t)n_halo, hipMemcpyHostToDevice, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		*nct = next;
+		if (pfx_halo_setup(dist->comm, coarse, nc, nn, h->peer.data(), csend_ptr.data(), csend.data(), crecv_ptr.data(), coarse_width))
+			PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+		return PFX_OK;
+	}
+
 	pfx_status amg_symbolic(pfx_ctx *ctx)
 	{
 		const double t_begin = now_s();
 		pfx_amg_release(ctx);
 		pfx_amg *A = new pfx_amg();
 		ctx->amg = A;
+		pfx_dist *dist = ctx->amg_dist; // the hierarchy spans the ranks of this partition (null: it is this context's own)
+		A->dist = dist;
 		const pfx_amg_params &par = ctx->amg_params;
 		hipStream_t st = ctx->stream;
 		const int64_t n_nodes = ctx->n_nodes, n_owned = ctx->n_owned;
@@ -901,14 +1027,27 @@ namespace
 		L.own_m = false;
 		L.n_vert = n_vert;
 		L.n_dofs = n_nodes * bs;
+		L.n_overt = n_owned;
+		L.n_odofs = n_owned * bs;
+		int64_t n_overt = n_owned; // owned vertices of the level being coarsened (all of them unless the hierarchy spans ranks)
 		for (int level = 0;; ++level)
 		{
 			const bool level0 = level == 0;
-			const int64_t dofs = level0 ? bs * n_owned : (scalar ? n_vert : 6 * n_vert);
-			if ((!level0 && dofs <= par.coarsest_dofs) || n_vert < 2 || level + 1 >= par.max_levels || level + 1 >= AMG_MAX_LEVELS)
+			// every rank takes the same decisions: they are made on the sums over the ranks
+			double gl[2] = {(double)(level0 ? bs * n_owned : (scalar ? n_overt : 6 * n_overt)), (double)n_overt};
+			if ((rc = dist_sum(ctx, dist, gl, 2)))
+				return rc;
+			if ((!level0 && gl[0] <= (double)par.coarsest_dofs) || gl[1] < 2.0 || level + 1 >= par.max_levels || level + 1 >= AMG_MAX_LEVELS)
 			{
 				A->lv.push_back(L);
 				break;
+			}
+			// halo vertices take no part in the aggregation of a level that spans the ranks (level 0: `excluded` says so already)
+			pfx_tmp<uint8_t> excl_halo;
+			if (dist && !level0)
+			{
+				PFX_HIP(excl_halo.alloc((size_t)n_vert));
+				hipLaunchKernelGGL(k_excl_halo, dim3(grid_for(n_vert)), dim3(256), 0, st, n_vert, n_overt, excl_halo.p);
 			}
 			// ---- aggregation by repeated pairwise matching: every round matches the clusters of the round before
 			pfx_tmp<int32_t> cur, m, csize;
@@ -921,7 +1060,7 @@ namespace
 				const uint64_t seed = (uint64_t)level * 16 + (uint64_t)pass + 1;
 				if (pass == 0)
 				{
-					if ((rc = pfx_graph_match(ctx, g, level0 ? excluded.p : nullptr, vpos, nullptr, seed, cur.p, &nc, &ppos)))
+					if ((rc = pfx_graph_match(ctx, g, level0 ? excluded.p : excl_halo.p, vpos, nullptr, seed, cur.p, &nc, &ppos)))
 						return rc;
 				}
 				else
@@ -954,32 +1093,60 @@ namespace
 			m.reset();
 			csize.reset();
 			ppos.reset();
-			if (nc < 1 || (!level0 && nc * 10 > n_vert * 8)) // no free vertex, or the coarsening stalls
 			{
-				A->lv.push_back(L);
-				break;
+				double ga[2] = {(double)nc, (double)n_overt};
+				if ((rc = dist_sum(ctx, dist, ga, 2)))
+					return rc;
+				if (ga[0] < 1.0 || (!level0 && ga[0] * 10.0 > ga[1] * 8.0)) // no free vertex, or the coarsening stalls
+				{
+					A->lv.push_back(L);
+					break;
+				}
 			}
-			// ---- coarse graph with the Galerkin lists
+			// ---- members, centres, offsets (cur holds -1 for halo vertices here: members are owned vertices)
+			if (pfx_alloc(ctx, &L.d_mptr, nc + 1) || pfx_alloc(ctx, &L.d_mlist, n_vert) || pfx_alloc(ctx, &L.d_dvec, scalar ? 1 : n_vert * 3))
+				return PFX_ERR_HIP;
+			if ((rc = pfx_graph_members(ctx, n_vert, cur.p, nc, L.d_mptr, L.d_mlist)))
+				return rc;
+			// ---- a hierarchy that spans the ranks: the aggregates of the halo vertices, and the coarse level's halo lists
+			int64_t nct = nc; // coarse vertices this rank sees: its own aggregates, then those its halo vertices went into
+			pfx_halo chalo;
+			if (dist)
+				if ((rc = dist_halo_aggregates(ctx, A, L, cur.p, n_vert, n_overt, nc, &chalo, &nct, scalar ? 3 : 6)))
+					return rc;
+			pfx_tmp<double> centre;
+			PFX_HIP(centre.alloc((size_t)nct * 3));
+			PFX_HIP(hipMemsetAsync(centre.p, 0, sizeof(double) * (size_t)nct * 3, st));
+			hipLaunchKernelGGL(k_centres, dim3(grid_for(nc)), dim3(256), 0, st, L.d_mptr, L.d_mlist, vpos, nc, centre.p);
+			if (!scalar)
+			{
+				// offsets of the owned vertices from their aggregates' centres; the owners send those of the halo vertices
+				hipLaunchKernelGGL(k_offsets, dim3(grid_for(n_overt)), dim3(256), 0, st, cur.p, vpos, centre.p, n_overt, L.d_dvec);
+				if (n_vert > n_overt)
+					PFX_HIP(hipMemsetAsync(L.d_dvec + 3 * n_overt, 0, sizeof(double) * (size_t)(3 * (n_vert - n_overt)), st));
+				if ((rc = level_exchange(ctx, A, L, L.d_dvec, 3)))
+					return rc;
+			}
+			// ---- coarse graph with the Galerkin lists: the rows of the owned vertices, all their columns
+			pfx_dgraph g_rows = g;
+			if (dist && n_overt < n_vert)
+			{
+				int64_t ne_owned = 0;
+				PFX_HIP(hipMemcpyAsync(&ne_owned, g.ptr + n_overt, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipStreamSynchronize(st));
+				g_rows.n = n_overt, g_rows.ne = ne_owned;
+			}
 			pfx_dgraph_own gc;
 			pfx_quot_lists lists;
-			if ((rc = pfx_graph_quotient(ctx, g, cur.p, nc, gc, &lists)))
+			if ((rc = pfx_graph_quotient(ctx, g_rows, cur.p, nct, gc, &lists)))
 				return rc;
 			const int64_t n_cp = gc.ne;
 			if (getenv("PFX_AMG_VERBOSE"))
 				fprintf(stderr, "[pfx amg] level %d: %lld vertices, %lld edges -> %lld aggregates, %lld coarse edges, %lld pairs (%.3f s)\n", level, (long long)n_vert,
 						(long long)g.ne, (long long)nc, (long long)n_cp, (long long)lists.n_pairs, now_s() - t_begin);
-			// ---- members, centres, offsets
-			pfx_tmp<double> centre;
-			PFX_HIP(centre.alloc((size_t)nc * 3));
-			if (pfx_alloc(ctx, &L.d_mptr, nc + 1) || pfx_alloc(ctx, &L.d_mlist, n_vert) || pfx_alloc(ctx, &L.d_dvec, scalar ? 1 : n_vert * 3))
-				return PFX_ERR_HIP;
-			if ((rc = pfx_graph_members(ctx, n_vert, cur.p, nc, L.d_mptr, L.d_mlist)))
-				return rc;
-			hipLaunchKernelGGL(k_centres, dim3(grid_for(nc)), dim3(256), 0, st, L.d_mptr, L.d_mlist, vpos, nc, centre.p);
-			if (!scalar)
-				hipLaunchKernelGGL(k_offsets, dim3(grid_for(n_vert)), dim3(256), 0, st, cur.p, vpos, centre.p, n_vert, L.d_dvec);
 			// ---- the transfer data of this level
 			L.n_agg = nc;
+			L.n_agg_all = nct;
 			L.n_cpairs = n_cp;
 			if (keep(ctx, &L.d_agg, cur.p, n_vert) || keep(ctx, &L.d_cp_ptr, lists.pair_ptr.p, n_cp + 1) || keep(ctx, &L.d_cp_src, lists.pair_src.p, lists.n_pairs)
 				|| keep(ctx, &L.d_cp_row, lists.pair_row.p, lists.n_pairs) || keep(ctx, &L.d_cp_arow, lists.arow.p, n_cp))
@@ -997,15 +1164,19 @@ namespace
 			s->own_stream = false;
 			s->bs = scalar ? 1 : 3;
 			s->dim = 3;
-			s->n_nodes = s->n_owned = scalar ? nc : 2 * nc;
+			s->n_owned = scalar ? nc : 2 * nc;
+			s->n_nodes = scalar ? nct : 2 * nct;
 			s->n_blocks = scalar ? n_cp : 4 * n_cp;
 			s->nnz = s->n_blocks * s->bs * s->bs;
 			C.m = s;
 			C.own_m = true;
-			C.n_vert = nc;
-			C.n_dofs = scalar ? nc : 6 * nc;
-			C.small = s->n_nodes <= AMG_SMALL_NODES;
-			if (pfx_alloc(s, &s->d_node_ptr, s->n_nodes + 1) || pfx_alloc(s, &s->d_node_col, s->n_blocks) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nc + 1)
+			C.n_vert = nct;
+			C.n_overt = nc;
+			C.n_dofs = scalar ? nct : 6 * nct;
+			C.n_odofs = scalar ? nc : 6 * nc;
+			C.halo = chalo; // (the lists' device arrays now belong to the level)
+			C.small = s->n_owned <= AMG_SMALL_NODES;
+			if (pfx_alloc(s, &s->d_node_ptr, s->n_nodes + 1) || pfx_alloc(s, &s->d_node_col, s->n_blocks) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nct + 1)
 				|| keep(ctx, &C.d_gcol, gc.col.p, n_cp))
 			{
 				if (ctx->err.empty())
@@ -1015,11 +1186,11 @@ namespace
 			}
 			if (scalar)
 			{
-				hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(nc + 1)), dim3(256), 0, st, C.d_gptr, nc + 1, s->d_node_ptr);
+				hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(nct + 1)), dim3(256), 0, st, C.d_gptr, nct + 1, s->d_node_ptr);
 				PFX_HIP(hipMemcpyAsync(s->d_node_col, C.d_gcol, sizeof(int32_t) * (size_t)n_cp, hipMemcpyDeviceToDevice, st));
 			}
 			else
-				hipLaunchKernelGGL(k_coarse_pattern, dim3(grid_for(nc + 1)), dim3(256), 0, st, C.d_gptr, C.d_gcol, nc, s->d_node_ptr, s->d_node_col);
+				hipLaunchKernelGGL(k_coarse_pattern, dim3(grid_for(nct + 1)), dim3(256), 0, st, C.d_gptr, C.d_gcol, nct, s->d_node_ptr, s->d_node_col);
 			PFX_HIP(hipMemsetAsync(s->d_values, 0, sizeof(double) * (size_t)(s->nnz + 2), st));
 			PFX_HIP(hipStreamSynchronize(st));
 			PFX_HIP(hipGetLastError());
@@ -1028,10 +1199,28 @@ namespace
 			// descend: the coarse graph (with its weights) is the next level's vertex graph, the centres its positions
 			glevel.take(gc);
 			g = glevel.view();
-			n_vert = nc;
+			n_vert = nct;
+			n_overt = nc;
+			// the centres of the neighbours' aggregates from their owners: the positions of the next level's halo vertices
+			if ((rc = level_exchange(ctx, A, L, centre.p, 3)))
+				return rc;
 			centre_prev.reset();
 			centre_prev.p = centre.p, centre.p = nullptr;
 			vpos = centre_prev.p;
+		}
+		// the coarsest level is solved densely on every rank: this rank's place in the global numbering of its dofs
+		A->coarse_off = 0;
+		if (dist && A->lv.size() >= 2)
+		{
+			const int world = pfx_comm_world(dist->comm), rank = pfx_comm_rank(dist->comm);
+			if (world > 32)
+				PFX_FAIL(PFX_ERR_UNSUPPORTED, "a hierarchy over more than 32 ranks is not implemented");
+			double cnt[32] = {0};
+			cnt[rank] = (double)A->lv.back().n_odofs;
+			if ((rc = dist_sum(ctx, dist, cnt, world)))
+				return rc;
+			for (int r = 0; r < rank; ++r)
+				A->coarse_off += (int64_t)cnt[r];
 		}
 		// vectors
 		const int64_t n0 = ctx->n_dofs();
@@ -1100,9 +1289,17 @@ namespace
 		return hi;
 	}
 
-	// y = A_l x on level l (no Dirichlet mask or shift below level 0; level 0 always takes the slice format)
-	pfx_status amg_matvec(pfx_ctx *ctx, pfx_amg_level &L, const double *x, double *y)
+	// y = A_l x on level l (no Dirichlet mask or shift below level 0; level 0 always takes the slice format).  When the
+	// hierarchy spans the ranks the halo entries of x are fetched from their owners first (x: a full local vector).
+	pfx_status amg_matvec(pfx_ctx *ctx, pfx_amg_level &L, double *x, double *y)
 	{
+		pfx_amg *A = ctx->amg;
+		if (A->dist)
+		{
+			pfx_status rc = level_exchange(ctx, A, L, x, L.m == ctx ? ctx->bs : (ctx->bs == 1 ? 1 : 6));
+			if (rc)
+				return rc;
+		}
 		if (!L.small)
 		{
 			pfx_status rc = pfx_sell_spmv(L.m, x, y, nullptr, nullptr);
@@ -1111,11 +1308,23 @@ namespace
 			return rc;
 		}
 		pfx_ctx *s = L.m;
-		const unsigned grid = (unsigned)((s->n_nodes * 64 + 255) / 256);
+		if (s->n_owned <= 0)
+			return PFX_OK;
+		const unsigned grid = (unsigned)((s->n_owned * 64 + 255) / 256);
 		if (s->bs == 1)
-			hipLaunchKernelGGL((k_rowwave_spmv<1>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_nodes, y);
+			hipLaunchKernelGGL((k_rowwave_spmv<1>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_owned, y);
 		else
-			hipLaunchKernelGGL((k_rowwave_spmv<3>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_nodes, y);
+			hipLaunchKernelGGL((k_rowwave_spmv<3>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_owned, y);
+		return PFX_OK;
+	}
+
+	// a scalar a kernel has just written, summed over the ranks (in place, on the stream)
+	pfx_status dist_scalar(pfx_ctx *ctx, pfx_amg *A, double *d_s, int count = 1)
+	{
+		if (!A->dist)
+			return PFX_OK;
+		if (pfx_comm_all_reduce(A->dist->comm, ctx->stream, d_s, count))
+			PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(A->dist->comm));
 		return PFX_OK;
 	}
 
@@ -1127,8 +1336,20 @@ namespace
 		hipStream_t st = ctx->stream;
 		const uint8_t *fixed = (L.m == ctx && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
 		int steps = ctx->amg_params.power_iters;
-		if ((int64_t)steps > n_rows)
-			steps = (int)n_rows;
+		{
+			// no more steps than the operator has rows (over a partition: than all ranks together have)
+			double rows = (double)n_rows;
+			pfx_status rc = dist_sum(ctx, A->dist, &rows, 1);
+			if (rc)
+				return rc;
+			if ((double)steps > rows)
+				steps = (int)rows;
+		}
+		if (steps < 1)
+		{
+			L.lmax = 1.05;
+			return PFX_OK;
+		}
 		pfx_tmp<double> q, qp, w, scal;
 		PFX_HIP(q.alloc((size_t)n_rows));
 		PFX_HIP(qp.alloc((size_t)n_rows));
@@ -1139,6 +1360,9 @@ namespace
 		hipLaunchKernelGGL(k_seed_vector, dim3(grid), dim3(256), 0, st, n_rows, fixed, w.p);
 		hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, w.p, w.p, n_rows, A->d_part);
 		hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, scal.p);
+		pfx_status rcs = dist_scalar(ctx, A, scal.p);
+		if (rcs)
+			return rcs;
 		hipLaunchKernelGGL(k_lz_c, dim3(grid), dim3(256), 0, st, dinv, w.p, scal.p, n_rows, qp.p, q.p, v);
 		for (int j = 0; j < steps; ++j)
 		{
@@ -1149,8 +1373,12 @@ namespace
 			hipLaunchKernelGGL(k_lz_a, dim3(AMG_NPART), dim3(256), 0, st, dinv, t, qp.p, q.p, j > 0 ? (const double *)(alpha - 1) : (const double *)nullptr, n_rows, w.p,
 							   A->d_part);
 			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, alpha);
+			if ((rc = dist_scalar(ctx, A, alpha)))
+				return rc;
 			hipLaunchKernelGGL(k_lz_b, dim3(AMG_NPART), dim3(256), 0, st, q.p, alpha, n_rows, w.p, A->d_part);
 			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part, AMG_NPART, beta2);
+			if ((rc = dist_scalar(ctx, A, beta2)))
+				return rc;
 			hipLaunchKernelGGL(k_lz_c, dim3(grid), dim3(256), 0, st, dinv, w.p, beta2, n_rows, qp.p, q.p, v);
 		}
 		std::vector<double> h((size_t)(2 * steps + 1));
@@ -1210,7 +1438,7 @@ namespace
 			pfx_amg_level &L = A->lv[l];
 			if (l == 0 && ctx->n_owned < ctx->n_nodes) // the level-0 operator is the owned-owned block: halo entries of the vector it is applied to are zero
 				PFX_HIP(hipMemsetAsync(scratch_v + ctx->n_owned * ctx->bs, 0, sizeof(double) * (size_t)((ctx->n_nodes - ctx->n_owned) * ctx->bs), st));
-			pfx_status rc = (l == 0) ? amg_lambda_max(ctx, A, L, scratch_v, scratch_t, dinv0, ctx->n_owned * ctx->bs) : amg_lambda_max(ctx, A, L, L.d_x, L.d_t, L.d_dinv, L.n_dofs);
+			pfx_status rc = (l == 0) ? amg_lambda_max(ctx, A, L, scratch_v, scratch_t, dinv0, ctx->n_owned * ctx->bs) : amg_lambda_max(ctx, A, L, L.d_x, L.d_t, L.d_dinv, L.n_odofs);
 			if (rc)
 				return rc;
 		}
@@ -1227,15 +1455,54 @@ namespace
 				pfx_ctx *s = L.m;
 				// The hierarchy can end early (max_levels reached, coarsening stalled) with a last level far above
 				// coarsest_dofs; the dense inverse below is O(n^2) memory and O(n^3) host work: refuse instead.
-				if (L.n_dofs > AMG_MAX_DENSE)
-					PFX_FAIL(PFX_ERR_SIZE, "AMG: the coarsest level has " + std::to_string((long long)L.n_dofs) + " dofs, more than the dense coarse solve takes ("
+				// Over a partition the coarsest matrix is gathered: every rank places the rows of its own aggregates at its
+				// offset in the global numbering (columns: the global ids of its coarse vertices, those of the halo ones
+				// learned from their owners), the sum over the ranks is the whole matrix, and every rank inverts it.
+				pfx_dist *dist = A->dist;
+				const int per = ctx->bs == 1 ? 1 : 6; // dofs per coarse vertex
+				double total = (double)L.n_odofs;
+				{
+					pfx_status rc = dist_sum(ctx, dist, &total, 1);
+					if (rc)
+						return rc;
+				}
+				if (total > (double)AMG_MAX_DENSE)
+					PFX_FAIL(PFX_ERR_SIZE, "AMG: the coarsest level has " + std::to_string((long long)total) + " dofs, more than the dense coarse solve takes ("
 											   + std::to_string(AMG_MAX_DENSE) + "): raise max_levels, or the coarsening stalled on this matrix");
-				const int n = (int)L.n_dofs;
+				const int n = (int)total;
+				std::vector<int64_t> gvert((size_t)L.n_vert); // global id of every local coarse vertex
+				for (int64_t v = 0; v < L.n_overt; ++v)
+					gvert[(size_t)v] = A->coarse_off / per + v;
+				if (dist && L.n_vert > L.n_overt)
+				{
+					pfx_tmp<double> gid;
+					PFX_HIP(gid.alloc((size_t)L.n_vert));
+					std::vector<double> hg((size_t)L.n_vert, -1.0);
+					for (int64_t v = 0; v < L.n_overt; ++v)
+						hg[(size_t)v] = (double)gvert[(size_t)v];
+					PFX_HIP(hipMemcpyAsync(gid.p, hg.data(), sizeof(double) * hg.size(), hipMemcpyHostToDevice, st));
+					pfx_status rc = level_exchange(ctx, A, L, gid.p, 1);
+					if (rc)
+						return rc;
+					PFX_HIP(hipMemcpyAsync(hg.data(), gid.p, sizeof(double) * hg.size(), hipMemcpyDeviceToHost, st));
+					PFX_HIP(hipStreamSynchronize(st));
+					for (int64_t v = L.n_overt; v < L.n_vert; ++v)
+						gvert[(size_t)v] = (int64_t)hg[(size_t)v];
+				}
+				else if (dist)
+				{
+					// (every rank takes part in the exchange, also one without halo vertices on this level)
+					pfx_tmp<double> gid;
+					PFX_HIP(gid.alloc((size_t)(L.n_vert > 0 ? L.n_vert : 1)));
+					pfx_status rc = level_exchange(ctx, A, L, gid.p, 1);
+					if (rc)
+						return rc;
+				}
 				std::vector<double> vals((size_t)s->nnz);
 				PFX_HIP(hipMemcpyAsync(vals.data(), s->d_values, sizeof(double) * vals.size(), hipMemcpyDeviceToHost, st));
 				PFX_HIP(hipStreamSynchronize(st));
 				std::vector<double> M((size_t)n * n, 0.0), I((size_t)n * n, 0.0);
-				const int64_t nv = L.n_vert;
+				const int64_t nv = L.n_overt; // rows: the aggregates this rank owns
 				// the coarsest level's vertex graph, read back for the dense matrix
 				std::vector<int64_t> h_gptr((size_t)nv + 1);
 				PFX_HIP(hipMemcpyAsync(h_gptr.data(), L.d_gptr, sizeof(int64_t) * h_gptr.size(), hipMemcpyDeviceToHost, st));
@@ -1248,10 +1515,11 @@ namespace
 				for (int64_t a = 0; a < nv; ++a)
 				{
 					const int64_t g0 = h_gptr[(size_t)a], deg = h_gptr[(size_t)a + 1] - g0;
+					const int64_t ga = gvert[(size_t)a];
 					if (ctx->bs == 1)
 					{
 						for (int64_t k = 0; k < deg; ++k)
-							M[(size_t)(a * n + h_gcol[(size_t)(g0 + k)])] = vals[(size_t)(g0 + k)];
+							M[(size_t)(ga * n + gvert[(size_t)h_gcol[(size_t)(g0 + k)]])] = vals[(size_t)(g0 + k)];
 						continue;
 					}
 					for (int64_t k = 0; k < deg; ++k)
@@ -1259,11 +1527,22 @@ namespace
 							for (int be = 0; be < 2; ++be)
 							{
 								const double *blk = vals.data() + (4 * g0 + al * 2 * deg + 2 * k + be) * 9;
-								const int64_t r0 = (2 * a + al) * 3, c0 = (2 * (int64_t)h_gcol[(size_t)(g0 + k)] + be) * 3;
+								const int64_t r0 = (2 * ga + al) * 3, c0 = (2 * gvert[(size_t)h_gcol[(size_t)(g0 + k)]] + be) * 3;
 								for (int m = 0; m < 3; ++m)
 									for (int q = 0; q < 3; ++q)
 										M[(size_t)((r0 + m) * n + c0 + q)] = blk[3 * m + q];
 							}
+				}
+				if (dist)
+				{
+					// the rows of the other ranks: sum of everybody's contribution (each row is written by exactly one rank)
+					pfx_tmp<double> dM;
+					PFX_HIP(dM.alloc((size_t)n * n));
+					PFX_HIP(hipMemcpyAsync(dM.p, M.data(), sizeof(double) * M.size(), hipMemcpyHostToDevice, st));
+					if (pfx_comm_all_reduce(dist->comm, st, dM.p, n * n))
+						PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+					PFX_HIP(hipMemcpyAsync(M.data(), dM.p, sizeof(double) * M.size(), hipMemcpyDeviceToHost, st));
+					PFX_HIP(hipStreamSynchronize(st));
 				}
 				for (int k = 0; k < n; ++k)
 					dmax = std::max(dmax, std::fabs(M[(size_t)k * n + k]));
@@ -1314,7 +1593,7 @@ namespace
 				}
 				if (A->n_coarsest != n)
 				{
-					if (pfx_alloc(ctx, &A->d_ainv, (int64_t)n * n))
+					if (pfx_alloc(ctx, &A->d_ainv, (int64_t)n * n) || pfx_alloc(ctx, &A->d_bglob, (int64_t)n))
 						return PFX_ERR_HIP;
 					A->n_coarsest = n;
 				}
@@ -1373,11 +1652,25 @@ namespace
 		pfx_amg_level &L = A->lv[l];
 		if (l + 1 == A->lv.size())
 		{
-			hipLaunchKernelGGL(k_dense_matvec, dim3(A->n_coarsest), dim3(64), 0, st, A->d_ainv, b, A->n_coarsest, x);
+			if (!A->dist)
+			{
+				hipLaunchKernelGGL(k_dense_matvec, dim3(A->n_coarsest), dim3(64), 0, st, A->d_ainv, b, A->n_coarsest, x);
+				return PFX_OK;
+			}
+			// gathered right-hand side (every rank adds its part at its offset), then the rows of the inverse that belong to
+			// this rank's dofs
+			PFX_HIP(hipMemsetAsync(A->d_bglob, 0, sizeof(double) * (size_t)A->n_coarsest, st));
+			if (L.n_odofs > 0)
+				PFX_HIP(hipMemcpyAsync(A->d_bglob + A->coarse_off, b, sizeof(double) * (size_t)L.n_odofs, hipMemcpyDeviceToDevice, st));
+			pfx_status rc = dist_scalar(ctx, A, A->d_bglob, A->n_coarsest);
+			if (rc)
+				return rc;
+			if (L.n_odofs > 0)
+				hipLaunchKernelGGL(k_dense_matvec, dim3((unsigned)L.n_odofs), dim3(64), 0, st, A->d_ainv + A->coarse_off * A->n_coarsest, A->d_bglob, A->n_coarsest, x);
 			return PFX_OK;
 		}
 		const bool level0 = l == 0;
-		const int64_t n = level0 ? ctx->n_owned * ctx->bs : L.n_dofs;
+		const int64_t n = level0 ? ctx->n_owned * ctx->bs : L.n_odofs;
 		const bool scalar = ctx->bs == 1;
 		relax_vecs v{b, x, level0 ? t0 : L.d_t, L.d_r, L.d_dv, level0 ? dinv0 : L.d_dinv, n};
 		pfx_status rc = amg_relax(ctx, L, v, true);
@@ -1402,20 +1695,20 @@ namespace
 			{
 				if ((rc = amg_matvec(ctx, C, C.d_x, C.d_t)))
 					return rc;
-				hipLaunchKernelGGL(k_vec_sub, dim3(grid_for(C.n_dofs)), dim3(256), 0, st, C.d_b, C.d_t, C.n_dofs, C.d_b2);
+				hipLaunchKernelGGL(k_vec_sub, dim3(grid_for(C.n_odofs)), dim3(256), 0, st, C.d_b, C.d_t, C.n_odofs, C.d_b2);
 				if ((rc = amg_cycle(ctx, A, l + 1, C.d_b2, C.d_x2, nullptr, nullptr)))
 					return rc;
-				hipLaunchKernelGGL(k_vec_add, dim3(grid_for(C.n_dofs)), dim3(256), 0, st, C.d_x2, C.n_dofs, C.d_x);
+				hipLaunchKernelGGL(k_vec_add, dim3(grid_for(C.n_odofs)), dim3(256), 0, st, C.d_x2, C.n_odofs, C.d_x);
 			}
 		}
 		const uint8_t *fixed = (level0 && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
 		const double omega = ctx->amg_params.coarse_scale;
 		if (scalar)
-			hipLaunchKernelGGL(k_prolong_scalar, dim3(grid_for(level0 ? ctx->n_owned : L.n_vert)), dim3(256), 0, st, L.d_agg, C.d_x, level0 ? ctx->n_owned : L.n_vert, omega, x);
+			hipLaunchKernelGGL(k_prolong_scalar, dim3(grid_for(level0 ? ctx->n_owned : L.n_overt)), dim3(256), 0, st, L.d_agg, C.d_x, level0 ? ctx->n_owned : L.n_overt, omega, x);
 		else if (level0)
 			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, omega, x);
 		else
-			hipLaunchKernelGGL((k_prolong<false>), dim3(grid_for(L.n_vert)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_vert, omega, x);
+			hipLaunchKernelGGL((k_prolong<false>), dim3(grid_for(L.n_overt)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_overt, omega, x);
 		return amg_relax(ctx, L, v, false);
 	}
 } // namespace
@@ -1435,6 +1728,7 @@ void pfx_amg_release(pfx_ctx *ctx)
 	free_dev(ctx, A->d_dv0);
 	free_dev(ctx, A->d_pos);
 	free_dev(ctx, A->d_state);
+	free_dev(ctx, A->d_bglob);
 	delete A;
 	ctx->amg = nullptr;
 }
@@ -1448,7 +1742,7 @@ pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, doubl
 	pfx_status rc = pfx_sell_refresh(ctx);
 	if (rc)
 		return rc;
-	if (!ctx->amg || ctx->amg->struct_gen != ctx->struct_gen)
+	if (!ctx->amg || ctx->amg->struct_gen != ctx->struct_gen || ctx->amg->dist != ctx->amg_dist)
 		if ((rc = amg_symbolic(ctx)))
 			return rc;
 	// the Jacobi diagonal lives in the solver's workspace, which other solves overwrite: always rebuilt
@@ -1480,72 +1774,162 @@ pfx_status pfx_amg_apply(pfx_ctx *ctx, const double *d_r, double *d_z, double *t
 	return PFX_OK;
 }
 
-pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res)
+namespace
 {
-	hipStream_t st = ctx->stream;
-	const int64_t n = ctx->n_owned * ctx->bs;
-	const int64_t nfull = ctx->n_dofs();
-	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
-	if (ctx->n_owned != ctx->n_nodes)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "this loop has no halo exchange: on a partitioned mesh the caller drives the iteration and applies the preconditioner with pfx_amg_apply_dev");
-	if (ctx->d_work_ext)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG-preconditioned solve uses the context's own workspace (clear pfx_cgs_set_workspace first)");
-	if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * nfull))
-		return PFX_ERR_HIP;
-	double *r = ctx->d_work, *p = ctx->d_work + nfull, *t = ctx->d_work + 2 * nfull, *dinv = ctx->d_work + 3 * nfull;
-	pfx_status rc = pfx_amg_prepare(ctx, dinv, p, t);
-	if (rc)
-		return rc;
-	pfx_amg *A = ctx->amg;
-	if (ctx->part0_count < pfx_sell_grid(ctx))
+	// part[0] = *s, part[1 ..] = 0: an all-reduced scalar put back where the kernels expect per-block partial sums
+	__global__ void k_spread_scalar(const double *__restrict__ s, double *__restrict__ part)
 	{
-		if (pfx_alloc(ctx, &ctx->d_part0, pfx_sell_grid(ctx)))
-			return PFX_ERR_HIP;
-		ctx->part0_count = pfx_sell_grid(ctx);
+		for (int k = threadIdx.x; k < AMG_NPART; k += blockDim.x)
+			part[k] = k == 0 ? *s : 0.0;
 	}
-	pcg_state *state = A->d_state;
-	PFX_HIP(hipMemsetAsync(state, 0, sizeof(pcg_state), st));
-	if (fixed)
-		hipLaunchKernelGGL(k_mask, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n);
-	if ((rc = pfx_sell_spmv(ctx, d_x, t, nullptr, nullptr)))
-		return rc;
-	hipLaunchKernelGGL(k_pcg_init, dim3(AMG_NPART), dim3(256), 0, st, d_b, t, fixed, n, r, A->d_part);
-	hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(256), 0, st, A->d_part, tol, n, d_x, state);
-	// z = M^-1 r ; p = z ; abs_new = r.z
-	if ((rc = pfx_amg_apply(ctx, r, A->d_z, t, dinv)))
-		return rc;
-	hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, r, A->d_z, n, A->d_part + 2 * AMG_NPART);
-	hipLaunchKernelGGL(k_pcg_direction, dim3(AMG_NPART), dim3(256), 0, st, A->d_z, A->d_part, 1, n, p, state);
-	hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, st, state);
-	const int check_every = 8;
-	int it = 0;
-	pcg_state h;
-	memset(&h, 0, sizeof(h));
-	PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
-	PFX_HIP(hipStreamSynchronize(st));
-	while (it < max_iter && !h.done)
+
+	// partial-sum arrays q0 .. q0 + nq - 1 of the PCG kernels -> their sums over the ranks (no-op on one rank)
+	pfx_status reduce_partials(pfx_ctx *ctx, pfx_amg *A, int q0, int nq)
 	{
-		const int stop = (it + check_every < max_iter) ? it + check_every : max_iter;
-		for (; it < stop; ++it)
+		if (!A->dist)
+			return PFX_OK;
+		hipStream_t st = ctx->stream;
+		for (int q = q0; q < q0 + nq; ++q)
+			hipLaunchKernelGGL(k_dot_finish, dim3(1), dim3(256), 0, st, A->d_part + q * AMG_NPART, AMG_NPART, A->d_scal + 4 + q);
+		pfx_status rc = dist_scalar(ctx, A, A->d_scal + 4 + q0, nq);
+		if (rc)
+			return rc;
+		for (int q = q0; q < q0 + nq; ++q)
+			hipLaunchKernelGGL(k_spread_scalar, dim3(1), dim3(256), 0, st, A->d_scal + 4 + q, A->d_part + q * AMG_NPART);
+		return PFX_OK;
+	}
+
+	// Preconditioned CG in Eigen's operation order with z = M^-1 r from the hierarchy.  dist = null: one context, the whole
+	// mesh.  Otherwise the iteration over a partition: the halo entries of the search direction travel while the interior
+	// rows are multiplied, the scalars are all-reduced (two all-reduces per iteration), and the hierarchy spans the ranks.
+	pfx_status pcg_amg_impl(pfx_ctx *ctx, pfx_dist *dist, const double *d_b, double *d_x, int max_iter, double tol, int check_every, int *iters, double *rel_res)
+	{
+		hipStream_t st = ctx->stream;
+		const int64_t n = ctx->n_owned * ctx->bs;
+		const int64_t nfull = ctx->n_dofs();
+		const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
+		if (!dist && ctx->n_owned != ctx->n_nodes)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "this loop has no halo exchange: on a partitioned mesh use pfx_dist_cg_dev, or drive the iteration and apply the preconditioner with pfx_amg_apply_dev");
+		if (ctx->d_work_ext)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG-preconditioned solve uses the context's own workspace (clear pfx_cgs_set_workspace first)");
+		if (!ctx->d_work && pfx_alloc(ctx, &ctx->d_work, 4 * nfull))
+			return PFX_ERR_HIP;
+		double *r = ctx->d_work, *p = ctx->d_work + nfull, *t = ctx->d_work + 2 * nfull, *dinv = ctx->d_work + 3 * nfull;
+		pfx_status rc = pfx_amg_prepare(ctx, dinv, p, t);
+		if (rc)
+			return rc;
+		pfx_amg *A = ctx->amg;
+		pfx_comm *comm = dist ? dist->comm : nullptr;
+		auto comm_fail = [&]() {
+			ctx->err = pfx_comm_error(comm);
+			return PFX_ERR_HIP;
+		};
+		if (ctx->part0_count < pfx_sell_grid(ctx))
 		{
-			if ((rc = pfx_sell_spmv(ctx, p, t, ctx->d_part0, &state->done)))
-				return rc;
-			pfx_launch_sum_partials(ctx, ctx->d_part0, pfx_sell_grid(ctx), A->d_scal);
-			hipLaunchKernelGGL(k_pcg_update, dim3(AMG_NPART), dim3(256), 0, st, p, t, A->d_scal, n, d_x, r, A->d_part, state);
-			hipLaunchKernelGGL(k_pcg_test, dim3(1), dim3(256), 0, st, A->d_part, it, state);
-			if ((rc = pfx_amg_apply(ctx, r, A->d_z, t, dinv)))
-				return rc;
-			hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, r, A->d_z, n, A->d_part + 2 * AMG_NPART);
-			hipLaunchKernelGGL(k_pcg_direction, dim3(AMG_NPART), dim3(256), 0, st, A->d_z, A->d_part, 0, n, p, state);
-			hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, st, state);
+			if (pfx_alloc(ctx, &ctx->d_part0, pfx_sell_grid(ctx)))
+				return PFX_ERR_HIP;
+			ctx->part0_count = pfx_sell_grid(ctx);
 		}
+		pcg_state *state = A->d_state;
+		PFX_HIP(hipMemsetAsync(state, 0, sizeof(pcg_state), st));
+		if (fixed)
+			hipLaunchKernelGGL(k_mask, dim3(grid_for(n)), dim3(256), 0, st, d_x, fixed, n);
+		if (dist && (pfx_halo_start(comm, &dist->halo, st, d_x, ctx->bs) || pfx_halo_finish(comm, &dist->halo, st)))
+			return comm_fail();
+		if ((rc = pfx_sell_spmv(ctx, d_x, t, nullptr, nullptr)))
+			return rc;
+		hipLaunchKernelGGL(k_pcg_init, dim3(AMG_NPART), dim3(256), 0, st, d_b, t, fixed, n, r, A->d_part);
+		if ((rc = reduce_partials(ctx, A, 0, 2)))
+			return rc;
+		hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(256), 0, st, A->d_part, tol, n, d_x, state);
+		// z = M^-1 r ; p = z ; abs_new = r.z
+		if ((rc = pfx_amg_apply(ctx, r, A->d_z, t, dinv)))
+			return rc;
+		hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, r, A->d_z, n, A->d_part + 2 * AMG_NPART);
+		if ((rc = reduce_partials(ctx, A, 2, 1)))
+			return rc;
+		hipLaunchKernelGGL(k_pcg_direction, dim3(AMG_NPART), dim3(256), 0, st, A->d_z, A->d_part, 1, n, p, state);
+		hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, st, state);
+		if (check_every <= 0)
+			check_every = 8;
+		int it = 0;
+		pcg_state h;
+		memset(&h, 0, sizeof(h));
 		PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
 		PFX_HIP(hipStreamSynchronize(st));
+		while (it < max_iter && !h.done)
+		{
+			const int stop = (it + check_every < max_iter) ? it + check_every : max_iter;
+			for (; it < stop; ++it)
+			{
+				if (dist)
+				{
+					// the rows that need no halo entry of p are multiplied while the exchange is in flight
+					bool sliced = false;
+					if (pfx_halo_start(comm, &dist->halo, st, p, ctx->bs))
+						return comm_fail();
+					if ((rc = pfx_sell_spmv(ctx, p, t, ctx->d_part0, &state->done, PFX_SPMV_INTERIOR, &sliced)))
+						return rc;
+					if (pfx_halo_finish(comm, &dist->halo, st))
+						return comm_fail();
+					if ((rc = pfx_sell_spmv(ctx, p, t, ctx->d_part0, &state->done, PFX_SPMV_BOUNDARY, &sliced)))
+						return rc;
+					if (sliced && (rc = pfx_sell_unpermute(ctx, t)))
+						return rc;
+				}
+				else if ((rc = pfx_sell_spmv(ctx, p, t, ctx->d_part0, &state->done)))
+					return rc;
+				pfx_launch_sum_partials(ctx, ctx->d_part0, pfx_sell_grid(ctx), A->d_scal);
+				if ((rc = dist_scalar(ctx, A, A->d_scal)))
+					return rc;
+				hipLaunchKernelGGL(k_pcg_update, dim3(AMG_NPART), dim3(256), 0, st, p, t, A->d_scal, n, d_x, r, A->d_part, state);
+				if ((rc = pfx_amg_apply(ctx, r, A->d_z, t, dinv)))
+					return rc;
+				hipLaunchKernelGGL(k_dot_part, dim3(AMG_NPART), dim3(256), 0, st, r, A->d_z, n, A->d_part + 2 * AMG_NPART);
+				if ((rc = reduce_partials(ctx, A, 1, 2))) // r.r and r.z in one all-reduce
+					return rc;
+				hipLaunchKernelGGL(k_pcg_test, dim3(1), dim3(256), 0, st, A->d_part, it, state);
+				hipLaunchKernelGGL(k_pcg_direction, dim3(AMG_NPART), dim3(256), 0, st, A->d_z, A->d_part, 0, n, p, state);
+				hipLaunchKernelGGL(k_pcg_commit, dim3(1), dim3(1), 0, st, state);
+			}
+			PFX_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+			PFX_HIP(hipStreamSynchronize(st));
+		}
+		if (dist && (pfx_halo_start(comm, &dist->halo, st, d_x, ctx->bs) || pfx_halo_finish(comm, &dist->halo, st)))
+			return comm_fail();
+		PFX_HIP(hipGetLastError());
+		*iters = h.iters;
+		*rel_res = (h.rhs_norm2 == 0.0) ? 0.0 : std::sqrt(h.rr / h.rhs_norm2);
+		return PFX_OK;
 	}
-	PFX_HIP(hipGetLastError());
-	*iters = h.iters;
-	*rel_res = (h.rhs_norm2 == 0.0) ? 0.0 : std::sqrt(h.rr / h.rhs_norm2);
-	return PFX_OK;
+} // namespace
+
+pfx_status pfx_pcg_amg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int max_iter, double tol, int *iters, double *rel_res)
+{
+	ctx->amg_dist = nullptr;
+	return pcg_amg_impl(ctx, nullptr, d_b, d_x, max_iter, tol, 8, iters, rel_res);
+}
+
+// the same over a partition (pfx_dist_cg_dev with PFX_PRECOND_AMG): the hierarchy spans the ranks while this call runs
+pfx_status pfx_dist_pcg_amg_run(pfx_dist *dist, const double *d_b, double *d_x, int max_iter, double tol, int check_every, int *iters, double *rel_res)
+{
+	pfx_ctx *ctx = dist->ctx;
+	ctx->amg_dist = pfx_comm_world(dist->comm) > 1 ? dist : nullptr;
+	const pfx_status rc = pcg_amg_impl(ctx, ctx->amg_dist, d_b, d_x, max_iter, tol, check_every > 0 ? (check_every < 8 ? check_every : 8) : 8, iters, rel_res);
+	ctx->amg_dist = nullptr; // calls on the context alone (pfx_amg_apply_dev ...) are again about its own block
+	if (rc)
+		dist->err = ctx->err;
+	return rc;
+}
+
+// the hierarchy holds the partition's communicator: gone before the partition object is
+void pfx_dist_amg_release(pfx_dist *dist)
+{
+	pfx_ctx *ctx = dist->ctx;
+	if (ctx->amg && ctx->amg->dist == dist)
+		pfx_amg_release(ctx);
+	if (ctx->amg_dist == dist)
+		ctx->amg_dist = nullptr;
 }
 
 namespace
@@ -1560,6 +1944,26 @@ namespace
 		return ctx->d_work;
 	}
 } // namespace
+
+// one application of the hierarchy that spans the ranks (d_r, d_z: local vectors [owned | halo]; the halo part of d_z is current on return)
+pfx_status pfx_dist_amg_apply_run(pfx_dist *dist, const double *d_r, double *d_z)
+{
+	pfx_ctx *ctx = dist->ctx;
+	if (ctx->d_work_ext)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "clear pfx_cgs_set_workspace first");
+	ctx->amg_dist = pfx_comm_world(dist->comm) > 1 ? dist : nullptr;
+	const int64_t nfull = ctx->n_dofs();
+	double *base = amg_workspace(ctx);
+	pfx_status rc = base ? pfx_amg_prepare(ctx, base + 3 * nfull, base + nfull, base + 2 * nfull) : PFX_ERR_HIP;
+	if (!rc)
+		rc = pfx_amg_apply(ctx, d_r, d_z, base + 2 * nfull, base + 3 * nfull);
+	if (!rc && ctx->amg_dist && ctx->amg->lv.size() >= 2)
+		rc = level_exchange(ctx, ctx->amg, ctx->amg->lv[0], d_z, ctx->bs);
+	ctx->amg_dist = nullptr;
+	if (rc)
+		dist->err = ctx->err;
+	return rc;
+}
 
 extern "C"
 {
@@ -1617,7 +2021,7 @@ extern "C"
 		info->n_levels = (int)A->lv.size();
 		for (size_t l = 0; l < A->lv.size() && l < 16; ++l)
 		{
-			info->n_vertices[l] = l == 0 ? ctx->n_owned : A->lv[l].n_vert;
+			info->n_vertices[l] = l == 0 ? ctx->n_owned : A->lv[l].n_overt;
 			info->n_aggregates[l] = A->lv[l].n_agg;
 			info->n_blocks[l] = A->lv[l].m->n_blocks;
 			info->lambda_max[l] = A->lv[l].lmax;
@@ -1636,7 +2040,7 @@ extern "C"
 		if (!A || level < 0 || level + 1 >= (int)A->lv.size())
 			PFX_FAIL(PFX_ERR_ARG, "pfx_amg_get_aggregates: no such level");
 		PFX_HIP(hipSetDevice(ctx->device));
-		const int64_t n = level == 0 ? ctx->n_nodes : A->lv[(size_t)level].n_vert;
+		const int64_t n = level == 0 ? ctx->n_nodes : A->lv[(size_t)level].n_overt;
 		PFX_HIP(hipMemcpyAsync(agg, A->lv[(size_t)level].d_agg, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		return PFX_OK;

@@ -16,6 +16,7 @@ struct pfx_halo
 	std::vector<int32_t> peer;
 	std::vector<int64_t> send_ptr, recv_ptr;
 	int32_t *d_send_idx = nullptr;
+	std::vector<int32_t> h_send_idx; // host copy (the set-up of a coarser level derives its lists from it)
 	double *d_sendbuf = nullptr; // n_send * max_width
 };
 
@@ -43,3 +44,4 @@ pfx_status pfx_halo_start(pfx_comm *comm, pfx_halo *h, hipStream_t st, double *d
 pfx_status pfx_halo_finish(pfx_comm *comm, pfx_halo *h, hipStream_t st);
 void pfx_dist_amg_release(pfx_dist *dist);
 pfx_status pfx_dist_pcg_amg_run(pfx_dist *dist, const double *d_b, double *d_x, int max_iter, double tol, int check_every, int *iters, double *rel_res);
+pfx_status pfx_dist_amg_apply_run(pfx_dist *dist, const double *d_r, double *d_z);

@@ -190,6 +190,7 @@ void pfx_halo_release(pfx_halo *h)
 	h->d_send_idx = nullptr;
 	h->d_sendbuf = nullptr;
 	h->peer.clear();
+	h->h_send_idx.clear();
 	h->send_ptr.clear();
 	h->recv_ptr.clear();
 	h->n_send = h->n_recv = 0;
@@ -207,6 +208,8 @@ pfx_status pfx_halo_setup(pfx_comm *comm, pfx_halo *h, int64_t n_owned, int n_ne
 	h->recv_ptr.assign(recv_ptr, recv_ptr + n_neigh + 1);
 	h->n_send = n_neigh > 0 ? send_ptr[n_neigh] : 0;
 	h->n_recv = n_neigh > 0 ? recv_ptr[n_neigh] : 0;
+	if (h->n_send > 0)
+		h->h_send_idx.assign(send_idx, send_idx + h->n_send);
 	if (h->n_send > 0)
 	{
 		COMM_HIP(hipMalloc((void **)&h->d_send_idx, sizeof(int32_t) * (size_t)h->n_send));
@@ -483,6 +486,17 @@ extern "C"
 		return pfx_dist_cg_run(dist, d_b, d_x, precond, max_iter, tol, check_every, iters, rel_res);
 	}
 
+	pfx_status pfx_dist_amg_apply_dev(pfx_dist *dist, const double *d_r, double *d_z)
+	{
+		if (!dist || !d_r || !d_z)
+			return PFX_ERR_ARG;
+		if (dist_valid(dist))
+			return PFX_ERR_ARG;
+		if (hipSetDevice(dist->ctx->device) != hipSuccess)
+			DIST_FAIL(PFX_ERR_HIP, "hipSetDevice failed");
+		return pfx_dist_amg_apply_run(dist, d_r, d_z);
+	}
+
 	pfx_status pfx_dist_halo_bytes(pfx_dist *dist, int64_t *bytes)
 	{
 		if (!dist || !bytes)
@@ -492,9 +506,3 @@ extern "C"
 	}
 }
 
-// ---- placeholders until the hierarchy that spans the ranks is in place ----
-void pfx_dist_amg_release(pfx_dist *) {}
-pfx_status pfx_dist_pcg_amg_run(pfx_dist *dist, const double *, double *, int, double, int, int *, double *)
-{
-	DIST_FAIL(PFX_ERR_UNSUPPORTED, "PFX_PRECOND_AMG over a partition is not available in this build");
-}

@@ -207,6 +207,7 @@ struct pfx_ctx
 	// Dirichlet set, owned range)
 	pfx_amg_params amg_params = {4, 1, 2, 12, 600, 15, 0.1, 1.6};
 	pfx_amg *amg = nullptr;
+	struct pfx_dist *amg_dist = nullptr; // set while a solve over a partition runs: the hierarchy then spans the ranks (pfx_dist.hip)
 	int64_t struct_gen = 0;
 	int64_t pattern_gen = 0; // bumped whenever the pattern is released / rebuilt (objects bound to the pattern check it)
 

@@ -541,6 +541,10 @@ class LibDist:
         self._ck(self.L.pfx_dist_halo_bytes(self.h, C.byref(b)))
         return b.value
 
+    def amg_apply(self, r, z):
+        """z = M^-1 r with the hierarchy that spans the ranks (collective; r, z local vectors)."""
+        self._ck(self.L.pfx_dist_amg_apply_dev(self.h, r.data_ptr(), z.data_ptr()))
+
     def cg(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 50):
         import ctypes as C
         it, err = C.c_int(), C.c_double()
@@ -688,7 +692,8 @@ class DistributedCG:
         ops, scal, ar = self.ops, self.scal, self.comm.all_reduce_sum
         if hasattr(ops, "check_stream"):
             ops.check_stream()
-        if self.lib is not None and use_library and precond != 2:
+        if self.lib is not None and use_library:
+            # precond = 2: ONE hierarchy that spans the ranks (use_library = False: the per-rank hierarchies of _solve_amg)
             ops.set_workspace(None)  # the library loop works in the context's own vectors
             return self.lib.cg(b, x, precond, max_iter, tol, check_every)
         self._ensure_work()

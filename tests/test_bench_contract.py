@@ -41,8 +41,10 @@ def test_spmv_byte_accounting():
     sys.path.insert(0, ROOT)
     import bench
     nnz, n = 348165189, 4102893
-    assert bench.spmv_bytes(nnz, n) == 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
-    assert bench.spmv_stored_bytes(nnz, nnz // 9, n // 3, n) < bench.spmv_bytes(nnz, n)
+    assert bench.spmv_csr_bytes(nnz, n) == 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
+    # the roofline is priced on what the node-block format moves: one column index per nine values
+    assert bench.spmv_bytes(nnz, nnz // 9, n // 3, n) == 8.0 * nnz + 4.0 * (nnz // 9) + 8.0 * (n // 3 + 1) + 16.0 * n
+    assert bench.spmv_bytes(nnz, nnz // 9, n // 3, n) < bench.spmv_csr_bytes(nnz, n)
     # P2 tets: 55 pairs per element, 6 points
     assert bench.assembly_flops(10, 10, 6, False) == 10 * 55 * 6 * 94.0
 
@@ -59,6 +61,8 @@ def _check_contract(d, n_gpus):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.0 < r["frac"] <= 1.0 and r["csr_equivalent_bytes"] > r["algorithmic_bytes"]
+    assert r["traffic"] is None or r["traffic_source"].startswith("profiles/")
     assert abs(d["value"] - d["config"]["elements"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
@@ -84,6 +88,28 @@ def test_bench_two_ranks_on_one_card_over_gloo():
     # the converged leg: per-rank AMG hierarchies + the coarse space over the ranks
     a = d["amg_solve"]
     assert "error" not in a and a["cg_rel_residual"] <= 1e-10 and "coarse space" in a["preconditioner"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_card_over_gloo():
+    """The launch shape of the 8-GPU run, rehearsed on one card: eight ranks, the distributed iteration inside the library
+    (host-staged transport), halo traffic on rank 0, the converged AMG leg."""
+    d = _run(["--gpus", "8", "--grid", "6", "--steps", "1", "--warmup", "1", "--cg-max-iter", "60", "--no-cpu-baseline"],
+             {"PFX_BENCH_BACKEND": "gloo"})
+    _check_contract(d, 8)
+    assert d["config"]["elements"] == 8 * 6 * 6 ** 3
+    assert d["config"]["halo_bytes_per_exchange_rank0"] > 0 and "pfx_dist_cg_dev" in d["config"]["distributed_iteration"]
+    a = d["amg_solve"]
+    assert "error" not in a and a["cg_rel_residual"] <= 1e-10
+
+
+@pytest.mark.gpu
+def test_bench_dry_run_reports_per_rank_memory():
+    d = _run(["--dry-run", "--gpus", "8", "--grid", "8", "--cells-per-rank", "2"])
+    assert d["dry_run"] and d["n_gpus"] == 8 and d["fits"] and len(d["ranks"]) == 3
+    assert d["elements_global"] == 6 * 8 * 8 * 16
+    for r in d["ranks"]:
+        assert r["bytes_with_solver_copy_and_cg_vectors"] > r["bytes_after_pattern"] > 0 and r["halo_nodes"] > 0
 
 
 @pytest.mark.gpu

@@ -571,3 +571,140 @@ def test_one_rank_rccl_communicator_runs_the_library_loop():
         finally:
             eng.close()
             L.pfx_comm_destroy(comm)
+
+
+def _span_worker(rank, world, port, ret, n, cpr):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        part, bounds, n_nodes = D.slab_part(n, cpr, rank, world, 2)
+        lam, mu = 1e5 * 0.3 / (1.3 * 0.4), 1e5 / 2.6
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        eng.assemble_linear()
+        eng.amg_set_params(coarsest_dofs=120)
+        bs, nl = 3, part.n_local
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
+        fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 0]) < 1e-12)[0]
+        fixed_dofs = np.sort((fixed[:, None] * bs + np.arange(bs)[None]).reshape(-1)).astype(np.int32)
+        eng.set_dirichlet(fixed_dofs)
+        comm = D.Comm()
+        cg = D.DistributedCG(D.HipOps(eng), part, bs, comm, dev)
+        rng = np.random.default_rng(11)
+        r_g = rng.standard_normal(n_nodes * bs)
+        b_g = rng.standard_normal(n_nodes * bs)
+        r = torch.from_numpy(r_g[dof_l2g]).to(dev)
+        r[torch.from_numpy(fixed_dofs.astype(np.int64)).to(dev)] = 0.0
+        z = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        cg.lib.amg_apply(r, z)
+        torch.cuda.synchronize()
+        info = eng.amg_info()
+        aggs = [eng.amg_aggregates(l) for l in range(info["n_levels"] - 1)]
+        aggs[0] = aggs[0][:part.n_owned]
+        b = torch.from_numpy(b_g[dof_l2g]).to(dev)
+        x = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        iters, err = cg.solve(b, x, E.PRECOND_AMG, 500, 1e-10)
+        # the per-rank hierarchies + the ranks' rigid-body modes, for comparison
+        cg.enable_coarse_space(part.mesh.node_xyz, fixed_dofs)
+        x2 = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        iters_bj, err_bj = cg.solve(b, x2, E.PRECOND_AMG, 500, 1e-10, use_library=False)
+        torch.cuda.synchronize()
+        no = part.n_owned * bs
+        out = [None] * world
+        dist.all_gather_object(out, dict(lo=int(part.lo), z=z.cpu().numpy()[:no], x=x.cpu().numpy()[:no], aggs=aggs, n_vertices=info["n_vertices"],
+                                         n_aggregates=info["n_aggregates"], lambda_max=info["lambda_max"], n_levels=info["n_levels"]))
+        if rank == 0:
+            ret["ranks"], ret["iters"], ret["err"], ret["iters_bj"] = out, iters, err, iters_bj
+        cg.close()
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,cpr", [(2, 6, 3), (3, 5, 2)])
+def test_hierarchy_that_spans_the_ranks_is_the_serial_one_with_the_same_aggregates(oracle, world, n, cpr):
+    """PFX_PRECOND_AMG over a partition (pfx_dist_cg_dev): the ranks share one card and talk through the host transport.
+    The preconditioner must be the one a single context builds from the union of the ranks' aggregates: one application
+    against the scipy mirror of the serial algorithm fed with those aggregates (1e-10), PCG iteration count within +-2 of
+    the mirror's, and fewer iterations than the per-rank hierarchies need."""
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    from polyfem_amd import mesh as M
+    from tests import amg_mirror as AM
+    from tests.helpers import csc_to_scipy
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_span_worker, args=(world, _free_port(), ret, n, cpr), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        ranks, iters, err, iters_bj = ret["ranks"], ret["iters"], ret["err"], ret["iters_bj"]
+    part, bounds, n_nodes = D.slab_part(n, cpr * world, 0, 1, 2)
+    mesh = part.mesh
+    lam, mu = oracle.lame(1e5, 0.3)
+    N = n_nodes * 3
+    A = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), N).tocsr()
+    fixed_nodes = np.nonzero(np.abs(mesh.node_xyz[:, 0]) < 1e-12)[0]
+    fixed = np.zeros(N, dtype=bool)
+    fixed[(fixed_nodes[:, None] * 3 + np.arange(3)[None]).reshape(-1)] = True
+    Dm = sp.diags((~fixed).astype(float))
+    Am = (Dm @ A @ Dm + sp.diags(fixed.astype(float))).tocsr()
+    # the union of the ranks' aggregates in a global numbering: rank r's vertices of a level follow rank r-1's
+    n_levels = ranks[0]["n_levels"]
+    assert n_levels >= 3 and all(rk["n_levels"] == n_levels for rk in ranks)
+    assert all(rk["lambda_max"] == ranks[0]["lambda_max"] for rk in ranks), "every rank must relax with the same spectral radius"
+    aggs_global = []
+    for l in range(n_levels - 1):
+        off_agg = np.cumsum([0] + [rk["n_aggregates"][l] for rk in ranks])
+        parts = []
+        for r, rk in enumerate(ranks):
+            a = np.asarray(rk["aggs"][l]).astype(np.int64)
+            assert a.size == rk["n_vertices"][l] and (a < rk["n_aggregates"][l]).all()
+            parts.append(np.where(a >= 0, a + off_agg[r], -1))
+        aggs_global.append(np.concatenate(parts))
+    assert aggs_global[0].size == n_nodes
+    levels = AM.build(Am, M.node_positions(mesh), fixed, aggs_global, ranks[0]["lambda_max"], ncycle=2)
+    rng = np.random.default_rng(11)
+    r_g = rng.standard_normal(N)
+    b_g = rng.standard_normal(N)
+    r_g[fixed] = 0
+    z_ref = AM.cycle(levels, 0, r_g)
+    z = np.zeros(N)
+    x = np.zeros(N)
+    for rk in ranks:
+        z[rk["lo"] * 3: rk["lo"] * 3 + rk["z"].size] = rk["z"]
+        x[rk["lo"] * 3: rk["lo"] * 3 + rk["x"].size] = rk["x"]
+    assert np.abs(z - z_ref).max() <= 1e-10 * np.abs(z_ref).max()
+    bm = np.where(fixed, 0.0, b_g)
+    x_ref, it_ref, _ = AM.pcg(Am, bm, lambda v: AM.cycle(levels, 0, v), 1e-10, 500)
+    assert abs(iters - it_ref) <= 2 and err <= 1e-10, (iters, it_ref, err)
+    assert np.linalg.norm(Am @ x - bm) <= 1.01e-10 * np.linalg.norm(bm)
+    # one context on the whole mesh, its own aggregates: the partition costs (almost) nothing
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        eng.build_pattern()
+        eng.assemble_linear()
+        eng.amg_set_params(coarsest_dofs=120)
+        eng.set_dirichlet(np.nonzero(fixed)[0].astype(np.int32))
+        _, it_one, _ = eng.cg(b_g, None, E.PRECOND_AMG, 500, 1e-10)
+    finally:
+        eng.close()
+    assert iters <= 1.3 * it_one + 2, (iters, it_one)
+    assert iters <= iters_bj, (iters, iters_bj)
