@@ -378,9 +378,9 @@ def _amg_worker(rank, world, port, ret):
 
 
 def test_block_jacobi_amg_two_ranks_converges_to_the_single_engine_solution():
-    """PFX_PRECOND_AMG over a partition: every rank preconditions with the hierarchy of its owned block.  The solution
-    is that of the single-engine AMG solve (both to 1e-10); the couplings across the partition boundary are left to the
-    Krylov iteration, which costs iterations (80 against 43 on this mesh) but stays far below Jacobi-CG."""
+    """PFX_PRECOND_AMG over a partition through DistributedCG (the hierarchy that spans the ranks, inside the library): the
+    solution is that of the single-engine AMG solve (both to 1e-10) at about its iteration count, a second solve reuses the
+    hierarchy and honours the initial guess."""
     import torch.multiprocessing as mp
     from polyfem_amd import distributed as D
     from polyfem_amd import engine as E
@@ -446,16 +446,19 @@ def _coarse_space_worker(rank, world, port, ret):
         cg = D.DistributedCG(D.HipOps(eng), part, bs, comm, dev)
         b = torch.from_numpy(b_g[dof_l2g]).to(dev)
         x0 = torch.zeros(part.n_local * bs, dtype=torch.float64, device=dev)
-        it0, err0 = cg.solve(b, x0, E.PRECOND_AMG, 1000, 1e-10)
+        it0, err0 = cg.solve(b, x0, E.PRECOND_AMG, 1000, 1e-10, use_library=False)  # one hierarchy per rank (block-Jacobi)
         cg.enable_coarse_space(M.node_positions(part.mesh), fixed_dofs)
         x1 = torch.zeros_like(x0)
-        it1, err1 = cg.solve(b, x1, E.PRECOND_AMG, 1000, 1e-10)
+        it1, err1 = cg.solve(b, x1, E.PRECOND_AMG, 1000, 1e-10, use_library=False)  # + the ranks' rigid-body modes
+        x2 = torch.zeros_like(x0)
+        it2, err2 = cg.solve(b, x2, E.PRECOND_AMG, 1000, 1e-10)  # ONE hierarchy that spans the ranks (pfx_dist_cg_dev)
         torch.cuda.synchronize()
         no = part.n_owned * bs
-        diff = torch.tensor([float((x1[:no] - x0[:no]).abs().max()), float(x0[:no].abs().max())], dtype=torch.float64)
+        diff = torch.tensor([float((x1[:no] - x0[:no]).abs().max()), float(x0[:no].abs().max()), float((x2[:no] - x0[:no]).abs().max())], dtype=torch.float64)
         dist.all_reduce(diff, op=dist.ReduceOp.MAX)
         if rank == 0:
             ret["it0"], ret["err0"], ret["it1"], ret["err1"], ret["diff"], ret["scale"] = it0, err0, it1, err1, float(diff[0]), float(diff[1])
+            ret["it2"], ret["err2"], ret["diff2"] = it2, err2, float(diff[2])
         cg.close()
         eng.close()
         ret[f"ok{rank}"] = True
@@ -474,12 +477,31 @@ def test_coarse_space_over_the_ranks_cuts_the_iterations(world):
         mp.spawn(_coarse_space_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert all(ret.get(f"ok{r}") for r in range(world))
         it0, err0, it1, err1, diff, scale = (ret[k] for k in ("it0", "err0", "it1", "err1", "diff", "scale"))
-    print(f"world {world}: block-Jacobi AMG {it0} iterations, with the coarse space {it1}")
-    assert err0 < 1e-10 and err1 < 1e-10
-    assert diff <= 1e-6 * scale
+        it2, err2, diff2 = ret["it2"], ret["err2"], ret["diff2"]
+    # one context on the whole bar
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    part, bounds, n_nodes = D.slab_part(6, 6 * world, 0, 1, 2)
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.LINEAR_ELASTICITY, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+        eng.build_pattern()
+        eng.assemble_linear()
+        fixed = np.nonzero(np.abs(part.mesh.node_xyz[:, 2]) < 1e-12)[0]
+        eng.set_dirichlet(np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32))
+        b_g = np.random.default_rng(21).standard_normal(n_nodes * 3)
+        _, it_one, _ = eng.cg(b_g, None, E.PRECOND_AMG, 1000, 1e-10)
+    finally:
+        eng.close()
+    print(f"world {world}: block-Jacobi AMG {it0} iterations, with the coarse space {it1}, one hierarchy over the ranks {it2}, one context {it_one}")
+    assert err0 < 1e-10 and err1 < 1e-10 and err2 < 1e-10
+    assert diff <= 1e-6 * scale and diff2 <= 1e-6 * scale
     assert it1 < it0
     if world >= 4:
         assert it1 <= 0.8 * it0
+    # the hierarchy that spans the ranks keeps the iteration count of the unpartitioned solve
+    assert it2 <= 1.5 * it_one and it2 <= it1, (it2, it_one, it1)
 
 
 @pytest.mark.parametrize("precond", [1, 2])
