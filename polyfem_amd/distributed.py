@@ -574,7 +574,55 @@ class DistributedCG:
         self.cs = None  # coarse space over the ranks (enable_coarse_space)
         # The product path: the whole iteration inside the library (pfx_dist_cg_dev) over the library's own communicator.
         # Available when the per-rank compute is the HIP engine; the CPU stand-ins of the tests keep the Python loop.
-        self.lib = LibDist(ops.e, part, comm, device) if isinstance(ops, HipOps) else None
+        self.lib = None
+        if isinstance(ops, HipOps):
+            self._open_library()
+
+    def _open_library(self):
+        """Binds the engine to the library's own communicator and checks it against torch.distributed before it is
+        trusted: one halo exchange of a vector of global node ids and one all-reduce, compared on every rank with what
+        the process group delivers.  The verdict is taken collectively, so either every rank runs the library loop or
+        every rank keeps the Python-driven one (a transport that errs on one rank must not split the ranks)."""
+        t, ok = self.torch, 1.0
+        try:
+            self.lib = LibDist(self.ops.e, self.part, self.comm, self.device)
+        except Exception as exc:
+            print(f"[polyfem_amd] rank {self.comm.rank}: the library communicator could not be created ({exc!r})", flush=True)
+            self.lib, ok = None, 0.0
+        flag = t.tensor([ok], dtype=t.float64, device=self.device)
+        if self.comm.on:
+            self._all_min(flag)
+        if float(flag.item()) >= 1.0 and self.comm.on:
+            try:
+                ids = t.from_numpy(self.part.local_to_global().astype(np.float64)).to(self.device)
+                v = (ids[:, None] * self.bs + t.arange(self.bs, dtype=t.float64, device=self.device)[None]).contiguous()
+                w = v.clone()
+                w[self.part.n_owned:] = -1.0
+                self.lib.halo_exchange(w.view(-1))
+                s = t.tensor([float(self.comm.rank + 1), 1.0], dtype=t.float64, device=self.device)
+                self.lib.all_reduce(s)
+                self.torch.cuda.synchronize() if w.is_cuda else None
+                want = self.comm.world * (self.comm.world + 1) / 2.0
+                good = bool(t.equal(w, v)) and float(s[0].item()) == want and float(s[1].item()) == float(self.comm.world)
+            except Exception as exc:
+                print(f"[polyfem_amd] rank {self.comm.rank}: the library transport failed its check ({exc!r})", flush=True)
+                good = False
+            flag[0] = 1.0 if good else 0.0
+            self._all_min(flag)
+        if float(flag.item()) < 1.0 and self.lib is not None:
+            if self.comm.rank == 0:
+                print("[polyfem_amd] the library's communicator is not used: the distributed loops are driven from Python over torch.distributed", flush=True)
+            self.lib.close()
+            self.lib = None
+
+    def _all_min(self, flag):
+        dist = self.comm.dist
+        if self.comm.stage_cpu and flag.is_cuda:
+            c = flag.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MIN)
+            flag.copy_(c)
+        else:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 
     def _ensure_work(self):
         if self.work is None:

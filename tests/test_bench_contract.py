@@ -85,9 +85,9 @@ def test_bench_two_ranks_on_one_card_over_gloo():
     _check_contract(d, 2)
     assert d["config"]["elements"] == 2 * 6 * 4 ** 3
     assert "NOT RCCL" in d["config"]["parallelism"] and d["config"]["halo_bytes_per_exchange_rank0"] > 0
-    # the converged leg: per-rank AMG hierarchies + the coarse space over the ranks
+    # the converged leg: one AMG hierarchy that spans the ranks
     a = d["amg_solve"]
-    assert "error" not in a and a["cg_rel_residual"] <= 1e-10 and "coarse space" in a["preconditioner"]
+    assert "error" not in a and a["cg_rel_residual"] <= 1e-10 and "spans" in a["preconditioner"]
 
 
 @pytest.mark.gpu
