@@ -256,6 +256,9 @@ typedef struct
 	                         underestimates the smooth error it corrects; over-correcting makes up for most of it
 	                         (1 M quadratic tetrahedra: 44 iterations at 1.7, 67 at 1) and keeps the preconditioner
 	                         symmetric positive definite below 2 */
+	int mixed_precision;  /* 1: the products inside the preconditioner read single-precision copies of the level matrices (half
+	                         the bytes per product; vectors, accumulation, Galerkin products and the outer PCG stay double, so the
+	                         solution is the same and the iteration count changes by a few at most); 0: everything double */
 } pfx_amg_params;
 
 typedef struct

@@ -1302,7 +1302,7 @@ namespace
 		}
 		if (!L.small)
 		{
-			pfx_status rc = pfx_sell_spmv(L.m, x, y, nullptr, nullptr);
+			pfx_status rc = pfx_sell_spmv(L.m, x, y, nullptr, nullptr, PFX_SPMV_ALL, nullptr, ctx->amg_params.mixed_precision != 0);
 			if (rc)
 				ctx->err = L.m->err;
 			return rc;
@@ -1422,7 +1422,8 @@ namespace
 				hipLaunchKernelGGL((k_galerkin<false>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.d_gptr, F.d_gcol, F.m->d_values, F.d_dvec,
 								   (const uint8_t *)nullptr, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
 			C.m->values_gen++;
-			pfx_status rc = C.small ? PFX_OK : pfx_sell_refresh(C.m);
+			// the solver copy of a coarse matrix serves the preconditioner's products only: single precision unless asked otherwise
+			pfx_status rc = C.small ? PFX_OK : (ctx->amg_params.mixed_precision ? pfx_sell_refresh32(C.m) : pfx_sell_refresh(C.m));
 			if (!rc)
 				rc = pfx_launch_invdiag(C.m, 1, C.d_dinv);
 			if (rc)
@@ -1742,6 +1743,8 @@ pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, doubl
 	pfx_status rc = pfx_sell_refresh(ctx);
 	if (rc)
 		return rc;
+	if (ctx->amg_params.mixed_precision && (rc = pfx_sell_refresh32(ctx)))
+		return rc;
 	if (!ctx->amg || ctx->amg->struct_gen != ctx->struct_gen || ctx->amg->dist != ctx->amg_dist)
 		if ((rc = amg_symbolic(ctx)))
 			return rc;
@@ -1979,6 +1982,7 @@ extern "C"
 		p->power_iters = 15;
 		p->relax_lower = 0.1;
 		p->coarse_scale = 1.6;
+		p->mixed_precision = 1;
 	}
 
 	pfx_status pfx_amg_set_params(pfx_ctx *ctx, const pfx_amg_params *p)
@@ -1986,7 +1990,7 @@ extern "C"
 		if (!ctx || !p)
 			return PFX_ERR_ARG;
 		if (p->aggregate_passes < 1 || p->aggregate_passes > 8 || p->relax_degree < 1 || p->relax_degree > 16 || p->ncycle < 1 || p->ncycle > 4 || p->max_levels < 2
-			|| p->coarsest_dofs < 6 || p->coarsest_dofs > 3000 || p->power_iters < 1 || !(p->relax_lower > 0.0 && p->relax_lower < 1.0) || !(p->coarse_scale >= 1.0 && p->coarse_scale < 2.0))
+			|| p->coarsest_dofs < 6 || p->coarsest_dofs > 3000 || p->power_iters < 1 || !(p->relax_lower > 0.0 && p->relax_lower < 1.0) || !(p->coarse_scale >= 1.0 && p->coarse_scale < 2.0) || (p->mixed_precision != 0 && p->mixed_precision != 1))
 			PFX_FAIL(PFX_ERR_ARG, "pfx_amg_set_params: parameter out of range");
 		ctx->amg_params = *p;
 		PFX_HIP(hipSetDevice(ctx->device));

@@ -198,6 +198,8 @@ struct pfx_ctx
 	pfx_xcd_split sell_split[3];     // positions of the slice list per XCD for PFX_SPMV_ALL / _INTERIOR / _BOUNDARY, cut by stored slots
 	int64_t *d_sell_base = nullptr;
 	double *d_sell_vals = nullptr;
+	float *d_sell_vals32 = nullptr;  // single-precision copy for the products inside the AMG preconditioner
+	int64_t sell32_gen = -1;
 	int64_t sell_slices = 0, sell_rows = 0, sell_owned = -1;
 	int64_t values_gen = 0, sell_gen = -1; // assembly counter / counter value the solver copy was made from
 	int *d_cgstate = nullptr;
@@ -205,7 +207,7 @@ struct pfx_ctx
 
 	// AMG preconditioner: parameters, hierarchy, and a counter of everything its symbolic part depends on (pattern,
 	// Dirichlet set, owned range)
-	pfx_amg_params amg_params = {4, 1, 2, 12, 600, 15, 0.1, 1.6};
+	pfx_amg_params amg_params = {4, 1, 2, 12, 600, 15, 0.1, 1.6, 1};
 	pfx_amg *amg = nullptr;
 	struct pfx_dist *amg_dist = nullptr; // set while a solve over a partition runs: the hierarchy then spans the ranks (pfx_dist.hip)
 	int64_t struct_gen = 0;
@@ -397,7 +399,8 @@ enum
 };
 // sliced: where given, a product that went through the slice-ordered buffer is LEFT there (*sliced = true; d_y untouched):
 // the caller reads entry r of the product as ys[((pos[r / bs] >> 6) * bs + r % bs) * 64 + (pos[r / bs] & 63)]
-pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL, bool *sliced = nullptr);
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase = PFX_SPMV_ALL, bool *sliced = nullptr, bool fp32 = false);
+pfx_status pfx_sell_refresh32(pfx_ctx *ctx);
 pfx_status pfx_sell_unpermute(pfx_ctx *ctx, double *d_y);
 pfx_status pfx_cgs_fetch_product_impl(pfx_ctx *ctx);
 void pfx_amg_release(pfx_ctx *ctx);

@@ -62,12 +62,17 @@ namespace
 		}
 	}
 
-	// entry offset inside one slot of a slice
-	template <int BS>
+	// entry offset inside one slot of a slice.  Block size 3: entries 0..7 are stored lane-interleaved in 16-byte groups
+	// (two doubles / four floats per group), entry 8 after them, so that a lane fetches its nine entries with 16-byte loads.
+	template <int BS, typename V>
 	__device__ __forceinline__ int entry_offset(int c, int lane)
 	{
 		if (BS == 3)
-			return c < 8 ? (c >> 1) * 128 + lane * 2 + (c & 1) : 512 + lane;
+		{
+			if (sizeof(V) == 8)
+				return c < 8 ? (c >> 1) * 128 + lane * 2 + (c & 1) : 512 + lane;
+			return c < 8 ? (c >> 2) * 256 + lane * 4 + (c & 3) : 512 + lane;
+		}
 		return c * SL + lane;
 	}
 
@@ -75,13 +80,13 @@ namespace
 	// (JB * bs*bs contiguous doubles per row) are read with the lanes running over consecutive doubles -- cached loads, so
 	// that a 128-byte line shared by two neighbouring blocks of a row is fetched once --, transposed through LDS and
 	// written with streaming stores as the slots' contiguous runs of the slice.
-	template <int BS, int JB, int WPB>
+	template <int BS, int JB, int WPB, typename V>
 	__global__ __launch_bounds__(64 * WPB) void k_sell_values(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
 															   const int64_t *__restrict__ slice_base, int64_t n_slices,
-															   const double *__restrict__ blocks, double *__restrict__ out)
+															   const double *__restrict__ blocks, V *__restrict__ out)
 	{
-		constexpr int B2 = BS * BS, RUN = JB * B2; // doubles per row and pass
-		__shared__ double tile[WPB][JB * SL * B2];
+		constexpr int B2 = BS * BS, RUN = JB * B2; // entries per row and pass
+		__shared__ V tile[WPB][JB * SL * B2];
 		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 		const int64_t s = (int64_t)blockIdx.x * WPB + w;
 		const bool active = s < n_slices;
@@ -90,7 +95,7 @@ namespace
 		const int g_mine = active ? perm[s * SL + lane] : -1;
 		const int64_t b0_mine = g_mine >= 0 ? node_ptr[g_mine] : 0;
 		const int deg_mine = g_mine >= 0 ? (int)(node_ptr[g_mine + 1] - b0_mine) : 0;
-		double *o = out + base * (SL * B2);
+		V *o = out + base * (SL * B2);
 		for (int j = 0; j < len; j += JB)
 		{
 #pragma unroll
@@ -102,7 +107,7 @@ namespace
 				const int64_t b0 = __shfl(b0_mine, l);
 				const int deg = __shfl(deg_mine, l);
 				const double v = j + jj < deg ? blocks[(b0 + j) * B2 + r] : 0.0;
-				tile[w][jj * (SL * B2) + entry_offset<BS>(c, l)] = v;
+				tile[w][jj * (SL * B2) + entry_offset<BS, V>(c, l)] = (V)v;
 			}
 			// one wave reads back what it wrote itself: LDS operations of a wave complete in order
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -148,9 +153,11 @@ namespace
 	// and k_sell_unpermute brings them into row order afterwards.  Stored directly, a lane's rows sit 24 bytes each in a
 	// cache line of their own (the rows of a slice are sorted by degree, not neighbours): every line is fetched to be
 	// merged and written back, ten times the useful bytes, 16 % of the kernel.
-	template <int BS, bool DOT, bool SLICEOUT>
+	// V: the type the matrix values are stored in.  double: the solver's matrix.  float: the copy the AMG preconditioner
+	// multiplies with (half the bytes per product; the vectors and the accumulation stay double).
+	template <int BS, bool DOT, bool SLICEOUT, typename V>
 	__global__ __launch_bounds__(64) void k_sell_spmv(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ perm,
-														const int32_t *__restrict__ cols, const double *__restrict__ values,
+														const int32_t *__restrict__ cols, const V *__restrict__ values,
 														const int32_t *__restrict__ order, int first, pfx_xcd_split split,
 														const uint8_t *__restrict__ fixed, double shift, const double *__restrict__ x,
 														double *__restrict__ y, double *__restrict__ part, const int *__restrict__ done)
@@ -170,7 +177,7 @@ namespace
 		{
 			const int64_t base = slice_base[s];
 			const int len = (int)(slice_base[s + 1] - base);
-			const double *v = values + base * (SL * B2);
+			const V *v = values + base * (SL * B2);
 			const int32_t *c = cols + base * SL + lane;
 			double a0 = 0, a1 = 0, a2 = 0;
 			// what the end of the slice needs -- the row this lane owns, its entries of x and its constraint flags -- is
@@ -185,7 +192,76 @@ namespace
 				xr[m] = g >= 0 ? x[(int64_t)g * BS + m] : 0.0;
 				fx[m] = (g >= 0 && fixed) ? fixed[(int64_t)g * BS + m] != 0 : false;
 			}
-			if (BS == 3)
+			if constexpr (BS == 3 && sizeof(V) == 4)
+			{
+				// single-precision values: two 16-byte loads (entries 0-3, 4-7) and one 4-byte load per slot, ten slots per
+				// batch (about the bytes in flight of the double-precision batches below)
+				typedef float f4 __attribute__((ext_vector_type(4)));
+				constexpr int U = 10;
+				int cn[U];
+#pragma unroll
+				for (int u = 0; u < U; ++u)
+					cn[u] = u < len ? __builtin_nontemporal_load(c + u * SL) : 0;
+				int j = 0;
+				for (; j + U <= len; j += U)
+				{
+					f4 p0[U], p1[U];
+					float p4[U];
+					double x0[U], x1[U], x2[U];
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+					{
+						const float *vj = v + (int64_t)(j + u) * (SL * 9);
+						const f4 *vp = reinterpret_cast<const f4 *>(vj) + lane;
+						p0[u] = __builtin_nontemporal_load(vp);
+						p1[u] = __builtin_nontemporal_load(vp + 64);
+						p4[u] = __builtin_nontemporal_load(vj + 512 + lane);
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+					{
+						const int64_t cc = (int64_t)cn[u] * 3;
+						x0[u] = x[cc], x1[u] = x[cc + 1], x2[u] = x[cc + 2];
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+						cn[u] = j + U + u < len ? __builtin_nontemporal_load(c + (j + U + u) * SL) : 0;
+#pragma unroll
+					for (int u = 0; u < U; ++u)
+					{
+						a0 += (double)p0[u].x * x0[u] + (double)p0[u].y * x1[u] + (double)p0[u].z * x2[u];
+						a1 += (double)p0[u].w * x0[u] + (double)p1[u].x * x1[u] + (double)p1[u].y * x2[u];
+						a2 += (double)p1[u].z * x0[u] + (double)p1[u].w * x1[u] + (double)p4[u] * x2[u];
+					}
+				}
+				if (j < len)
+				{
+					f4 p0[U], p1[U];
+					float p4[U];
+					double x0[U], x1[U], x2[U];
+#pragma unroll
+					for (int u = 0; u < U - 1; ++u)
+						if (j + u < len)
+						{
+							const float *vj = v + (int64_t)(j + u) * (SL * 9);
+							const f4 *vp = reinterpret_cast<const f4 *>(vj) + lane;
+							p0[u] = __builtin_nontemporal_load(vp);
+							p1[u] = __builtin_nontemporal_load(vp + 64);
+							p4[u] = __builtin_nontemporal_load(vj + 512 + lane);
+							const int64_t cc = (int64_t)cn[u] * 3;
+							x0[u] = x[cc], x1[u] = x[cc + 1], x2[u] = x[cc + 2];
+						}
+#pragma unroll
+					for (int u = 0; u < U - 1; ++u)
+						if (j + u < len)
+						{
+							a0 += (double)p0[u].x * x0[u] + (double)p0[u].y * x1[u] + (double)p0[u].z * x2[u];
+							a1 += (double)p0[u].w * x0[u] + (double)p1[u].x * x1[u] + (double)p1[u].y * x2[u];
+							a2 += (double)p1[u].z * x0[u] + (double)p1[u].w * x1[u] + (double)p4[u] * x2[u];
+						}
+				}
+			}
+			else if constexpr (BS == 3)
 			{
 				// matrix values and column ids are read once per product: non-temporal loads keep them from evicting
 				// the gathered x entries out of the L2
@@ -269,7 +345,7 @@ namespace
 			{
 #pragma unroll 8
 				for (int j = 0; j < len; ++j)
-					a0 += __builtin_nontemporal_load(v + (int64_t)j * SL + lane) * x[__builtin_nontemporal_load(c + j * SL)];
+					a0 += (double)__builtin_nontemporal_load(v + (int64_t)j * SL + lane) * x[__builtin_nontemporal_load(c + j * SL)];
 			}
 			{
 				const double acc[3] = {a0, a1, a2};
@@ -329,6 +405,8 @@ void pfx_sell_release(pfx_ctx *ctx)
 	free_dev(ctx, ctx->d_sell_base);
 	free_dev(ctx, ctx->d_sell_cols);
 	free_dev(ctx, ctx->d_sell_vals);
+	free_dev(ctx, ctx->d_sell_vals32);
+	ctx->sell32_gen = -1;
 	free_dev(ctx, ctx->d_sell_order);
 	ctx->sell_slices = 0;
 	ctx->sell_interior = 0;
@@ -380,7 +458,8 @@ static pfx_status sell_build(pfx_ctx *ctx)
 	ctx->sell_rows = total;
 	ctx->sell_slices = n_slices;
 	const int b2 = ctx->bs * ctx->bs;
-	if (pfx_alloc(ctx, &ctx->d_sell_cols, total * SL) || pfx_alloc(ctx, &ctx->d_sell_vals, total * SL * b2 + 2))
+	(void)b2; // the value arrays (double for the solver, float for the preconditioner) are made by whoever first needs them
+	if (pfx_alloc(ctx, &ctx->d_sell_cols, total * SL))
 		return PFX_ERR_HIP;
 	int64_t blocks = (n_slices + 3) / 4;
 	if (blocks > 256 * 32)
@@ -441,6 +520,7 @@ static pfx_status sell_build(pfx_ctx *ctx)
 	}
 	ctx->sell_owned = n_owned;
 	ctx->sell_gen = -1;
+	ctx->sell32_gen = -1;
 	return PFX_OK;
 }
 
@@ -453,23 +533,51 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 		if (rc)
 			return rc;
 	}
-	if (ctx->sell_gen != ctx->values_gen)
+	if (ctx->sell_gen != ctx->values_gen || !ctx->d_sell_vals)
 	{
+		if (!ctx->d_sell_vals && pfx_alloc(ctx, &ctx->d_sell_vals, ctx->sell_rows * SL * ctx->bs * ctx->bs + 2))
+			return PFX_ERR_HIP;
 		pfx_scoped_timer tm(ctx, "sell_convert");
 		// one wave per slice
-#define PFX_CONVERT(BS_, JB_, WPB_)                                                                                                         \
-	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_>), dim3((unsigned)((ctx->sell_slices + WPB_ - 1) / WPB_ > 0 ? (ctx->sell_slices + WPB_ - 1) / WPB_ : 1)), \
-					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, ctx->d_sell_vals)
+#define PFX_CONVERT(BS_, JB_, WPB_, V_, OUT_)                                                                                                     \
+	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_, V_>), dim3((unsigned)((ctx->sell_slices + WPB_ - 1) / WPB_ > 0 ? (ctx->sell_slices + WPB_ - 1) / WPB_ : 1)), \
+					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, OUT_)
 		// (measured at 1 M P2 tets: one slot per pass 1.68 ms, two 1.70 ms, four with half the waves 2.40 ms)
 		if (ctx->bs == 1)
-			PFX_CONVERT(1, 4, 4);
+			PFX_CONVERT(1, 4, 4, double, ctx->d_sell_vals);
 		else if (ctx->bs == 3)
-			PFX_CONVERT(3, 1, 4);
+			PFX_CONVERT(3, 1, 4, double, ctx->d_sell_vals);
+		else
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+		PFX_HIP(hipGetLastError());
+		ctx->sell_gen = ctx->values_gen;
+	}
+	return PFX_OK;
+}
+
+// the single-precision copy of the matrix the AMG preconditioner multiplies with (structure shared with the solver copy)
+pfx_status pfx_sell_refresh32(pfx_ctx *ctx)
+{
+	if (ctx->sell_owned != ctx->n_owned || !ctx->d_sell_perm)
+	{
+		pfx_status rc = sell_build(ctx);
+		if (rc)
+			return rc;
+	}
+	if (ctx->sell32_gen != ctx->values_gen || !ctx->d_sell_vals32)
+	{
+		if (!ctx->d_sell_vals32 && pfx_alloc(ctx, &ctx->d_sell_vals32, ctx->sell_rows * SL * ctx->bs * ctx->bs + 4))
+			return PFX_ERR_HIP;
+		pfx_scoped_timer tm(ctx, "sell_convert32");
+		if (ctx->bs == 1)
+			PFX_CONVERT(1, 4, 4, float, ctx->d_sell_vals32);
+		else if (ctx->bs == 3)
+			PFX_CONVERT(3, 1, 4, float, ctx->d_sell_vals32);
 		else
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
 #undef PFX_CONVERT
 		PFX_HIP(hipGetLastError());
-		ctx->sell_gen = ctx->values_gen;
+		ctx->sell32_gen = ctx->values_gen;
 	}
 	return PFX_OK;
 }
@@ -496,8 +604,10 @@ int pfx_sell_grid(const pfx_ctx *ctx)
 
 // phase: PFX_SPMV_ALL, or the two halves of a distributed product: PFX_SPMV_INTERIOR (slices that read owned entries of
 // x only) and PFX_SPMV_BOUNDARY (the rest, after the halo entries have arrived)
-pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase, bool *sliced)
+pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *part, const int *done, int phase, bool *sliced, bool fp32)
 {
+	if (fp32 ? !ctx->d_sell_vals32 : !ctx->d_sell_vals)
+		PFX_FAIL(PFX_ERR_ARG, "the solver copy of the matrix has not been made (pfx_sell_refresh)");
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	int first = 0, count = (int)ctx->sell_slices;
 	if (phase == PFX_SPMV_INTERIOR)
@@ -518,20 +628,28 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	const int grid = PFX_XCDS * split.widest; // one slice (one wave) per block
 	const int32_t *order = ctx->d_sell_order;
 	pfx_scoped_timer tm(ctx, phase == PFX_SPMV_BOUNDARY ? "spmv_boundary" : "spmv");
-#define PFX_GO(BS_, DOT_)                                                                                                                                          \
+#define PFX_GO2(BS_, DOT_, V_, VALS_)                                                                                                                              \
 	do                                                                                                                                                             \
 	{                                                                                                                                                              \
 		if (sliceout)                                                                                                                                              \
 		{                                                                                                                                                          \
-			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, true>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,        \
-							   ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, ctx->d_sell_ys, part, done);                                      \
+			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, true, V_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,    \
+							   VALS_, order, first, split, fixed, ctx->diag_shift, d_x, ctx->d_sell_ys, part, done);                                                   \
 			if (!sliced)                                                                                                                                           \
 				hipLaunchKernelGGL((k_sell_unpermute<BS_>), dim3(grid_for(ctx->n_owned * BS_)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys,        \
 								   ctx->n_owned * BS_, d_y, done);                                                                                                       \
 		}                                                                                                                                                          \
 		else                                                                                                                                                       \
-			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, false>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,       \
-							   ctx->d_sell_vals, order, first, split, fixed, ctx->diag_shift, d_x, d_y, part, done);                                                 \
+			hipLaunchKernelGGL((k_sell_spmv<BS_, DOT_, false, V_>), dim3(grid), dim3(64), 0, ctx->stream, ctx->d_sell_base, ctx->d_sell_perm, ctx->d_sell_cols,   \
+							   VALS_, order, first, split, fixed, ctx->diag_shift, d_x, d_y, part, done);                                                              \
+	} while (0)
+#define PFX_GO(BS_, DOT_)                                          \
+	do                                                             \
+	{                                                              \
+		if (fp32)                                                  \
+			PFX_GO2(BS_, DOT_, float, ctx->d_sell_vals32);         \
+		else                                                       \
+			PFX_GO2(BS_, DOT_, double, ctx->d_sell_vals);          \
 	} while (0)
 	if (ctx->bs == 1)
 	{
@@ -550,5 +668,6 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 	else
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
 #undef PFX_GO
+#undef PFX_GO2
 	return PFX_OK;
 }

@@ -112,7 +112,8 @@ NEWTON_STATUS = ["continue", "iteration_limit", "f_delta", "grad_norm", "not_sta
 class AmgParams(C.Structure):
     """pfx_amg_params (the options of polysolve's AMGCL block that have a counterpart here, input-spec.json:1397-1558)."""
     _fields_ = [("aggregate_passes", C.c_int), ("relax_degree", C.c_int), ("ncycle", C.c_int), ("max_levels", C.c_int),
-                ("coarsest_dofs", C.c_int), ("power_iters", C.c_int), ("relax_lower", C.c_double), ("coarse_scale", C.c_double)]
+                ("coarsest_dofs", C.c_int), ("power_iters", C.c_int), ("relax_lower", C.c_double), ("coarse_scale", C.c_double),
+                ("mixed_precision", C.c_int)]
 
 
 class AmgInfo(C.Structure):
@@ -526,7 +527,7 @@ class Engine:
 
     # ---- AMG preconditioner (precond = PRECOND_AMG) -----------------------------------------------------------
     def amg_set_params(self, **params):
-        """aggregate_passes, relax_degree, ncycle, max_levels, coarsest_dofs, power_iters, relax_lower, coarse_scale (see pfx_amg_params)."""
+        """aggregate_passes, relax_degree, ncycle, max_levels, coarsest_dofs, power_iters, relax_lower, coarse_scale, mixed_precision (see pfx_amg_params)."""
         p = AmgParams()
         self.L.pfx_amg_default_params(C.byref(p))
         for k, v in params.items():

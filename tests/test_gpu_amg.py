@@ -57,7 +57,7 @@ def test_amg_matches_scipy_mirror(oracle, model):
     try:
         mesh = M.cube_tets(6, 2, jitter=0.1)
         Am, fixed = _problem(eng, oracle, mesh, model)
-        eng.amg_set_params(coarsest_dofs=120)  # several levels on this small mesh
+        eng.amg_set_params(coarsest_dofs=120, mixed_precision=0)  # several levels on this small mesh; double everywhere: compared at 1e-10
         eng.amg_setup()
         levels, info, aggs = _mirror(eng, Am, fixed, mesh, ncycle=2)  # the default is the W cycle
         assert info["n_levels"] >= 3 and info["operator_complexity"] < 1.6
@@ -111,7 +111,7 @@ def test_amg_variants_match_mirror(oracle, params):
     try:
         mesh = M.cube_tets(5, 2, jitter=0.15, seed=4)
         Am, fixed = _problem(eng, oracle, mesh)
-        eng.amg_set_params(coarsest_dofs=100, **params)
+        eng.amg_set_params(coarsest_dofs=100, mixed_precision=0, **params)
         eng.amg_setup()
         mk = {k: v for k, v in params.items() if k in ("ncycle", "relax_degree", "coarse_scale")}
         mk.setdefault("ncycle", 2)
@@ -194,7 +194,7 @@ def test_amg_scalar_laplacian_matches_mirror(oracle, order):
     try:
         mesh = M.cube_tets(8 if order == 2 else 14, order, jitter=0.1)
         Am, fixed = _laplace_problem(eng, oracle, mesh)
-        eng.amg_set_params(coarsest_dofs=40)
+        eng.amg_set_params(coarsest_dofs=40, mixed_precision=0)
         eng.amg_setup()
         info = eng.amg_info()
         aggs = [eng.amg_aggregates(l) for l in range(info["n_levels"] - 1)]
@@ -387,5 +387,37 @@ def test_relaxation_interval_covers_the_spectrum(oracle, kind):
         x, it, err = eng.cg(b, precond=E.PRECOND_AMG, max_iter=200, tol=1e-10)
         assert it < 60 and err <= 1e-10
         assert np.linalg.norm(Am @ x - b) <= 1e-9 * np.linalg.norm(b)
+    finally:
+        eng.close()
+
+
+def test_single_precision_level_matrices_change_the_iteration_count_by_a_few_at_most(oracle):
+    """mixed_precision = 1 (the default): the products inside the preconditioner read float copies of the level matrices.
+    The outer PCG, its residual and the matrix it multiplies with stay double: same solution to the tolerance, iteration
+    count within +3 of the all-double hierarchy, one application equal to single-precision accuracy."""
+    eng = E.Engine(0)
+    try:
+        mesh = M.cube_tets(8, 2, jitter=0.1)
+        Am, fixed = _problem(eng, oracle, mesh, "nh")
+        rng = np.random.default_rng(5)
+        b = rng.standard_normal(Am.shape[0])
+        r = np.where(fixed, 0.0, rng.standard_normal(Am.shape[0]))
+        out = {}
+        for mixed in (0, 1):
+            eng.amg_set_params(coarsest_dofs=120, mixed_precision=mixed)
+            d_r = torch.from_numpy(r).cuda()
+            d_z = torch.zeros_like(d_r)
+            eng.amg_apply_dev(d_r.data_ptr(), d_z.data_ptr())
+            eng.synchronize()
+            x, it, err = eng.cg(b, None, E.PRECOND_AMG, 500, 1e-10)
+            out[mixed] = (d_z.cpu().numpy(), x, it, err)
+        z0, x0, it0, err0 = out[0]
+        z1, x1, it1, err1 = out[1]
+        assert err0 <= 1e-10 and err1 <= 1e-10
+        assert abs(it1 - it0) <= 3, (it0, it1)
+        assert 0 < np.abs(z1 - z0).max() <= 1e-5 * np.abs(z0).max()
+        bm = np.where(fixed, 0.0, b)
+        assert np.linalg.norm(Am @ x1 - bm) <= 1.01e-10 * np.linalg.norm(bm)
+        assert np.abs(x1 - x0).max() <= 1e-8 * np.abs(x0).max()
     finally:
         eng.close()

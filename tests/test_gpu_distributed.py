@@ -617,7 +617,7 @@ def _span_worker(rank, world, port, ret, n, cpr):
         eng.build_pattern()
         eng.set_owned(part.n_owned, part.elem_owned)
         eng.assemble_linear()
-        eng.amg_set_params(coarsest_dofs=120)
+        eng.amg_set_params(coarsest_dofs=120, mixed_precision=0)  # double everywhere: compared with the mirror at 1e-10
         bs, nl = 3, part.n_local
         l2g = part.local_to_global()
         dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
