@@ -555,11 +555,15 @@ class LibDist:
 class DistributedCG:
     """Jacobi-CG in Eigen's operation order (see polyfem_amd/csrc/pfx_solve.hip) over a node partition.
 
-    precond = 2 (PFX_PRECOND_AMG) preconditions with one AMG hierarchy per rank, built on the block of the matrix whose
-    rows and columns the rank owns (block-Jacobi over the ranks: couplings across a partition boundary are left to the
-    Krylov iteration; no communication inside the hierarchy).  enable_coarse_space() adds what block-Jacobi lacks, a
-    coarse problem that spans the ranks: the rigid-body modes of every rank's block (six per rank for bs = 3, the
-    constant for bs = 1), z = M_bj^-1 r + Z (Z^T A Z)^-1 Z^T r -- additive, hence symmetric positive definite; one more
+    With the HIP engine the iteration runs inside the library (pfx_dist_cg_dev); precond = 2 (PFX_PRECOND_AMG) then
+    preconditions with ONE hierarchy that spans the ranks (aggregates local to a rank, Galerkin products across the
+    partition boundaries, row-distributed coarse levels, gathered coarsest solve).
+
+    solve(..., use_library=False) keeps the loop driven from Python over the engine's step functions; there precond = 2
+    uses one hierarchy per rank, built on the block of the matrix whose rows and columns the rank owns (block-Jacobi
+    over the ranks, no communication inside the hierarchy), and enable_coarse_space() adds a small coarse problem
+    that spans the ranks: the rigid-body modes of every rank's block (six per rank for bs = 3, the constant for
+    bs = 1), z = M_bj^-1 r + Z (Z^T A Z)^-1 Z^T r -- additive, hence symmetric positive definite; one more
     all-reduce of 6 N doubles per iteration, the 6 N x 6 N coarse matrix is inverted redundantly on every rank."""
 
     def __init__(self, ops, part: Part, bs: int, comm: Comm, device):
