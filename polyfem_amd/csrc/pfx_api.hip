@@ -48,6 +48,8 @@ void pfx_release_pattern(pfx_ctx *ctx)
 		free_dev(ctx, ctx->d_blk_slot);
 		free_dev(ctx, ctx->d_grp_c0);
 		free_dev(ctx, ctx->d_grp_win);
+		free_dev(ctx, ctx->d_grp_order);
+		ctx->h_grp_work.clear();
 		free_dev(ctx, ctx->d_win);
 		free_dev(ctx, ctx->d_desc);
 		ctx->n_ublocks = ctx->n_upair = ctx->n_groups = ctx->n_windows = 0;

@@ -135,7 +135,13 @@ struct pfx_ctx
 	uint32_t *d_grp_win = nullptr; // n_groups+1: first window of each group
 	uint2 *d_win = nullptr;        // n_windows: (first upper block bl, number of blocks nb) of the window
 	uint4 *d_desc = nullptr;       // n_ublocks + n_windows: block bl+s of window W at bl + s + W, see PFX_DESC_*
-	std::vector<uint32_t> h_grp_win; // host copy of d_grp_win (the XCD split of the row assembly is cut by windows)
+	std::vector<uint32_t> h_grp_win; // host copy of d_grp_win
+	// The assembly takes the row groups in the order d_grp_order (n_groups): along a Morton curve through the groups'
+	// positions, so that the groups resident on an XCD at one time form a compact region and share their elements' states
+	// in its L2 whatever the caller's node numbering is.  h_grp_work[k] = windows (+ 1 per group) of the first k groups
+	// of that order: the XCD ranges are cut by it.
+	uint32_t *d_grp_order = nullptr;
+	std::vector<double> h_grp_work;
 	pfx_xcd_split gv_split;          // XCD ranges of the vector gather's blocks (256 scalar rows each), cut by incidences
 	// Inside each window the contributions are stored reordered by
 	// element (lanes that read the same element state sit next to each other): d_blk_src[c] = e*n_loc^2 + i*n_loc + j of

@@ -15,6 +15,7 @@
 //   4. the same grouping is done per node for (element, local index) incidences, used by the gradient.
 // The scalar CSR of a block size bs > 1 is implied: row node*bs+m owns, per neighbour slot s, the bs columns
 // node_col[s]*bs+n; it is materialised only when the caller asks for it (pfx_export_pattern).
+#include <cmath>
 #include "pfx_internal.h"
 
 #include <rocprim/rocprim.hpp>
@@ -234,6 +235,64 @@ namespace
 	}
 
 	__global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
+
+#ifndef PFX_ROWASM_MORTON
+#define PFX_ROWASM_MORTON 1
+#endif
+	// position of a row group: centroid of the geometry vertices of the first element incident to its middle row
+	__global__ void k_group_pos(const int64_t *__restrict__ ne_ptr, const uint32_t *__restrict__ ne_src, const int32_t *__restrict__ gconn,
+								const double *__restrict__ xyz, int n_loc, int n_gloc, int64_t n_nodes, int64_t n_groups, double *__restrict__ gpos)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			int64_t r = g * PFX_ROWS_PER_GROUP + PFX_ROWS_PER_GROUP / 2;
+			if (r >= n_nodes)
+				r = n_nodes - 1;
+			// a node without elements (never the case for a mesh's own nodes) takes the nearest row that has one
+			int64_t q = r;
+			while (q > 0 && ne_ptr[q + 1] == ne_ptr[q])
+				--q;
+			double c[3] = {0, 0, 0};
+			if (ne_ptr[q + 1] > ne_ptr[q])
+			{
+				const int64_t e = (int64_t)(ne_src[ne_ptr[q]] / (uint32_t)n_loc);
+				for (int v = 0; v < n_gloc; ++v)
+				{
+					const double *x = xyz + 3 * (int64_t)gconn[e * n_gloc + v];
+					c[0] += x[0], c[1] += x[1], c[2] += x[2];
+				}
+				c[0] /= n_gloc, c[1] /= n_gloc, c[2] /= n_gloc;
+			}
+			gpos[3 * g] = c[0], gpos[3 * g + 1] = c[1], gpos[3 * g + 2] = c[2];
+		}
+	}
+
+	__device__ __forceinline__ uint64_t spread21(uint64_t v)
+	{
+		v &= 0x1fffffull;
+		v = (v | v << 32) & 0x1f00000000ffffull;
+		v = (v | v << 16) & 0x1f0000ff0000ffull;
+		v = (v | v << 8) & 0x100f00f00f00f00full;
+		v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+		v = (v | v << 2) & 0x1249249249249249ull;
+		return v;
+	}
+
+	// Morton key of a group's position on a lattice of cells of size h from the corner (x0, y0, z0); `on` = 0 keeps the
+	// caller's order
+	__global__ void k_group_morton(const double *__restrict__ gpos, double x0, double y0, double z0, double inv_h, int64_t n_groups, int on,
+								   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+	{
+		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x)
+		{
+			const double fx = (gpos[3 * g] - x0) * inv_h, fy = (gpos[3 * g + 1] - y0) * inv_h, fz = (gpos[3 * g + 2] - z0) * inv_h;
+			const uint64_t ix = (uint64_t)(fx < 0 ? 0 : fx > 2097151.0 ? 2097151.0 : fx);
+			const uint64_t iy = (uint64_t)(fy < 0 ? 0 : fy > 2097151.0 ? 2097151.0 : fy);
+			const uint64_t iz = (uint64_t)(fz < 0 ? 0 : fz > 2097151.0 ? 2097151.0 : fz);
+			keys[g] = on ? (spread21(ix) | spread21(iy) << 1 | spread21(iz) << 2) : (uint64_t)g;
+			vals[g] = (uint32_t)g;
+		}
+	}
 
 	// scalar CSR export: one thread per scalar row
 	__global__ void k_export_pattern(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes, int bs,
@@ -469,6 +528,64 @@ pfx_status pfx_pattern_build(pfx_ctx *ctx)
 	PFX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, deg.p, ctx->d_ne_ptr, (int64_t)0, (size_t)(n_nodes + 1), rocprim::plus<int64_t>(), st));
 	PFX_HIP(hipStreamSynchronize(st));
 	PFX_HIP(hipGetLastError());
+	// ---- order in which the row assembly takes the row groups ---------------------------------------------------------
+	{
+		const int64_t n_groups = ctx->n_groups;
+		pfx_tmp<double> gpos;
+		pfx_tmp<uint64_t> gk_a, gk_b;
+		pfx_tmp<uint32_t> gv_a;
+		PFX_HIP(gpos.alloc((size_t)(3 * n_groups)));
+		PFX_HIP(gk_a.alloc((size_t)n_groups));
+		PFX_HIP(gk_b.alloc((size_t)n_groups));
+		PFX_HIP(gv_a.alloc((size_t)n_groups));
+		if (pfx_alloc(ctx, &ctx->d_grp_order, n_groups))
+			return PFX_ERR_HIP;
+		hipLaunchKernelGGL(k_group_pos, dim3(grid_for(n_groups)), dim3(256), 0, st, ctx->d_ne_ptr, ctx->d_ne_src, ctx->d_gconn, ctx->d_xyz, n_loc, ctx->n_gloc, n_nodes,
+						   n_groups, gpos.p);
+		std::vector<double> h_pos((size_t)(3 * n_groups));
+		PFX_HIP(hipMemcpyAsync(h_pos.data(), gpos.p, sizeof(double) * h_pos.size(), hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+		for (int64_t g = 0; g < n_groups; ++g)
+			for (int d = 0; d < 3; ++d)
+			{
+				lo[d] = std::min(lo[d], h_pos[(size_t)(3 * g + d)]);
+				hi[d] = std::max(hi[d], h_pos[(size_t)(3 * g + d)]);
+			}
+		// cells of about one group each: the cube root of the bounding volume per group (flat directions do not count)
+		double vol = 1.0, longest = 0.0;
+		int dims = 0;
+		for (int d = 0; d < 3; ++d)
+			longest = std::max(longest, hi[d] - lo[d]);
+		for (int d = 0; d < 3; ++d)
+			if (hi[d] - lo[d] > 1e-9 * longest && longest > 0)
+				vol *= hi[d] - lo[d], ++dims;
+		double h = dims > 0 ? std::pow(vol / (double)n_groups, 1.0 / dims) : 1.0;
+		if (!(h > 0) || !std::isfinite(h))
+			h = 1.0;
+		if (longest / h > 2.0e6)
+			h = longest / 2.0e6;
+		// Elements of more than ten nodes (Q2) keep the caller's order: their functors' tables are shared by workgroups of
+		// several waves, which take consecutive groups and should finish together -- neighbours along a lattice line are of
+		// similar length, neighbours along the curve are not (measured: 8 % slower with the curve, which their
+		// arithmetic-bound kernels have no use for).
+		const int reorder = (PFX_ROWASM_MORTON && n_loc <= 10) ? 1 : 0;
+		hipLaunchKernelGGL(k_group_morton, dim3(grid_for(n_groups)), dim3(256), 0, st, gpos.p, lo[0], lo[1], lo[2], 1.0 / h, n_groups, reorder, gk_a.p, gv_a.p);
+		tmp_bytes = 0;
+		PFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, gk_a.p, gk_b.p, gv_a.p, ctx->d_grp_order, (size_t)n_groups, 0, 64, st));
+		PFX_HIP(tmp.alloc(tmp_bytes));
+		PFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, gk_a.p, gk_b.p, gv_a.p, ctx->d_grp_order, (size_t)n_groups, 0, 64, st));
+		std::vector<uint32_t> h_order((size_t)n_groups);
+		PFX_HIP(hipMemcpyAsync(h_order.data(), ctx->d_grp_order, sizeof(uint32_t) * (size_t)n_groups, hipMemcpyDeviceToHost, st));
+		PFX_HIP(hipStreamSynchronize(st));
+		tmp.reset();
+		ctx->h_grp_work.assign((size_t)(n_groups + 1), 0.0);
+		for (int64_t k = 0; k < n_groups; ++k)
+		{
+			const uint32_t g = h_order[(size_t)k];
+			ctx->h_grp_work[(size_t)(k + 1)] = ctx->h_grp_work[(size_t)k] + (double)(ctx->h_grp_win[g + 1] - ctx->h_grp_win[g]) + 1.0;
+		}
+	}
 	// XCD ranges of the vector gather (one block per 256 scalar rows), cut by the number of incidences the rows sum: the
 	// few entries of ne_ptr the bisection looks at are read from the device one by one
 	{

@@ -53,6 +53,9 @@
 #ifndef PFX_ROWASM_XCD
 #define PFX_ROWASM_XCD 1
 #endif
+#ifndef PFX_ROWASM_NT_STORE
+#define PFX_ROWASM_NT_STORE 1
+#endif
 #ifndef PFX_ROWASM_WPB_BIG
 #define PFX_ROWASM_WPB_BIG 4
 #endif
@@ -74,7 +77,8 @@ struct pfx_min_waves<Op, std::void_t<decltype(Op::MIN_WAVES)>>
 template <int NLOC, int BS, bool MASK, int WPB, class Op>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(pfx_min_waves<Op>::value))) void k_assemble_rows(const uint32_t *__restrict__ grp_c0, const uint32_t *__restrict__ grp_win, const uint2 *__restrict__ win,
 															 const uint4 *__restrict__ desc, const uint32_t *__restrict__ blk_src, const uint8_t *__restrict__ blk_slot,
-															 Op op, int64_t n_groups, pfx_xcd_split split, double *__restrict__ values, uint8_t *__restrict__ mask)
+															 const uint32_t *__restrict__ grp_order, Op op, int64_t n_groups, pfx_xcd_split split, double *__restrict__ values,
+															 uint8_t *__restrict__ mask)
 {
 	constexpr int B2 = BS * BS;
 	constexpr uint32_t NL2 = NLOC * NLOC;
@@ -91,16 +95,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(pfx_mi
 	double(*const carry)[B2] = carry_[wv];
 	uint8_t(*const carry_any)[B2] = carry_any_[wv];
 	op.load_tables(optab, lane); // every wave writes the same values
-	// Every XCD takes one contiguous range of the row groups (rows that are close in the numbering share elements: the
-	// element states its resident workgroups read are then fetched into one L2 instead of into all eight); the ranges are
-	// cut by the host so that they hold equal numbers of windows.
+	// The row groups are taken in the order grp_order (a space-filling curve through their positions) and every XCD takes
+	// one contiguous range of that order: groups that are close in space share elements, and the element states the
+	// resident workgroups of an XCD read are then fetched into one L2 instead of into all eight, whatever the caller's
+	// node numbering is.  The ranges are cut by the host so that they hold equal numbers of windows.
 	const int xcd = blockIdx.x % PFX_XCDS;
 	const int64_t wg_in = blockIdx.x / PFX_XCDS;
 	const int64_t wg = PFX_ROWASM_XCD ? (wg_in < split.first[xcd + 1] - split.first[xcd] ? split.first[xcd] + wg_in : (int64_t)-1) : (int64_t)blockIdx.x;
-	const int64_t g = wg * WPB + wv;
+	const int64_t turn = wg * WPB + wv;
 	__syncthreads();
-	if (wg < 0 || g >= n_groups)
+	if (wg < 0 || turn >= n_groups)
 		return;
+	const int64_t g = grp_order[turn];
 	const uint32_t c_begin = grp_c0[g], c_end = grp_c0[g + 1];
 	const uint32_t W_begin = grp_win[g], W_end = grp_win[g + 1];
 	if (W_begin == W_end)
@@ -212,7 +218,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(pfx_mi
 				else
 				{
 					const int64_t at = (int64_t)dd.x * B2;
+					// the entries of the upper blocks leave in full contiguous runs and are not read again by this kernel: stored past
+					// the caches, they do not push the element states out of the L2 (the transposed copies below are pieces of
+					// cache lines that other rows complete: those merge in the L2)
+#if PFX_ROWASM_NT_STORE
+					__builtin_nontemporal_store(acc, val_mn + at);
+#else
 					val_mn[at] = acc;
+#endif
 					if (MASK)
 						mask_mn[at] = (uint8_t)any;
 					if (dd.y != 0xFFFFFFFFu)
@@ -235,13 +248,13 @@ inline void pfx_launch_assemble_rows(pfx_ctx *ctx, const Op &op, bool write_mask
 	constexpr int WPB = (Op::LDS_DOUBLES * 8 > 12 * 1024) ? PFX_ROWASM_WPB_BIG : 1; // share large tables between the waves of a workgroup
 	// workgroup k holds the row groups k*WPB .. k*WPB+WPB-1; the XCD ranges are cut by the number of windows
 	const int64_t n_groups = ctx->n_groups, n_wg = (n_groups + WPB - 1) / WPB;
-	const std::vector<uint32_t> &gw = ctx->h_grp_win;
-	const pfx_xcd_split split = pfx_make_xcd_split(n_wg, [&](int64_t k) { return (double)gw[(size_t)(k * WPB < n_groups ? k * WPB : n_groups)] + (double)k; });
+	const std::vector<double> &work = ctx->h_grp_work;
+	const pfx_xcd_split split = pfx_make_xcd_split(n_wg, [&](int64_t k) { return work[(size_t)(k * WPB < n_groups ? k * WPB : n_groups)]; });
 	const unsigned grid = PFX_ROWASM_XCD ? (unsigned)(PFX_XCDS * split.widest) : (unsigned)n_wg;
 	if (write_mask)
 		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, true, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_grp_c0, ctx->d_grp_win, ctx->d_win,
-						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_groups, split, ctx->d_values, ctx->d_mask);
+						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, ctx->d_grp_order, op, ctx->n_groups, split, ctx->d_values, ctx->d_mask);
 	else
 		hipLaunchKernelGGL((k_assemble_rows<NLOC, BS, false, WPB, Op>), dim3(grid), dim3(64 * WPB), 0, ctx->stream, ctx->d_grp_c0, ctx->d_grp_win, ctx->d_win,
-						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, op, ctx->n_groups, split, ctx->d_values, ctx->d_mask);
+						   ctx->d_desc, ctx->d_blk_src, ctx->d_blk_slot, ctx->d_grp_order, op, ctx->n_groups, split, ctx->d_values, ctx->d_mask);
 }

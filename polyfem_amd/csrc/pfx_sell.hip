@@ -197,7 +197,10 @@ namespace
 				// single-precision values: two 16-byte loads (entries 0-3, 4-7) and one 4-byte load per slot, ten slots per
 				// batch (about the bytes in flight of the double-precision batches below)
 				typedef float f4 __attribute__((ext_vector_type(4)));
-				constexpr int U = 10;
+#ifndef PFX_SPMV_BATCH32
+#define PFX_SPMV_BATCH32 10
+#endif
+				constexpr int U = PFX_SPMV_BATCH32;
 				int cn[U];
 #pragma unroll
 				for (int u = 0; u < U; ++u)
