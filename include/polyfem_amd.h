@@ -462,7 +462,8 @@ pfx_status pfx_cgs_direction(pfx_ctx *ctx, int it, const double *d_scal);
 pfx_status pfx_cgs_status(pfx_ctx *ctx, int *done, int *iters, double *rr, double *bb);
 
 /* Pieces a Newton iteration over the partition needs beside the step functions (the serial counterpart is
- * pfx_newton_solve_dev; the distributed driver is polyfem_amd.distributed.DistributedNewton):
+ * pfx_newton_solve_dev; the whole iteration over a partition is pfx_dist_newton_dev, these pieces are for callers that
+ * drive it themselves, as polyfem_amd.distributed.DistributedNewton does for transient steps):
  * pfx_set_diag_shift: from now on pfx_spmv*, pfx_cg* and the step functions work with A + shift * I on the free dofs --
  *   the regularised Hessian `hessian += reg_weight * sparse_identity` of SparseNewtonDescentSolver.tpp:116-121 without
  *   touching the assembled values.  shift = 0 switches it off.
@@ -545,6 +546,16 @@ pfx_status pfx_dist_cg_dev(pfx_dist *dist, const double *d_b, double *d_x, int p
  * share (vertices and aggregates it owns; the ids of level >= 1 vertices are local to the rank).  Parameters:
  * pfx_amg_set_params on the context.  Limit: 32 ranks. */
 pfx_status pfx_dist_amg_apply_dev(pfx_dist *dist, const double *d_r, double *d_z);
+/* pfx_newton_solve_dev over the partition (SparseNewtonDescentSolver::minimize with NLProblem = ElasticForm + BodyForm,
+ * src/polyfem/solver/SparseNewtonDescentSolver.tpp:63-193, src/polyfem/solver/NonlinearSolver.tpp:33-275): the same control
+ * flow on every rank, every decision taken on all-reduced scalars (energy of the owned elements, sums and maxima over the
+ * owned dofs, the inverted-element flag), the linear solve is pfx_dist_cg_dev with params->cg_precond.  d_rhs (may be NULL)
+ * and d_x are this rank's local vectors; the halo entries of d_rhs are ignored, those of d_x are made current on entry and
+ * are current on return.  Statuses, errors and counters as pfx_newton_solve_dev, identical on all ranks.  The inertia and
+ * augmented-Lagrangian terms (pfx_inertia_enable, pfx_al_enable) are not available over a partition through this call.
+ * Limit: 38 ranks. */
+pfx_status pfx_dist_newton_dev(pfx_dist *dist, const double *d_rhs, double *d_x_inout, const pfx_newton_params *params,
+							   pfx_newton_info *info);
 /* bytes one halo exchange of a vector moves through this rank (sent + received) */
 pfx_status pfx_dist_halo_bytes(pfx_dist *dist, int64_t *bytes);
 

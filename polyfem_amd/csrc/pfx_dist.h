@@ -45,3 +45,5 @@ pfx_status pfx_halo_finish(pfx_comm *comm, pfx_halo *h, hipStream_t st);
 void pfx_dist_amg_release(pfx_dist *dist);
 pfx_status pfx_dist_pcg_amg_run(pfx_dist *dist, const double *d_b, double *d_x, int max_iter, double tol, int check_every, int *iters, double *rel_res);
 pfx_status pfx_dist_amg_apply_run(pfx_dist *dist, const double *d_r, double *d_z);
+pfx_status pfx_dist_cg_run(pfx_dist *dist, const double *d_b, double *d_x, int precond, int max_iter, double tol, int check_every, int *iters, double *rel_res);
+pfx_status pfx_dist_newton_run(pfx_dist *dist, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info);

@@ -486,6 +486,26 @@ extern "C"
 		return pfx_dist_cg_run(dist, d_b, d_x, precond, max_iter, tol, check_every, iters, rel_res);
 	}
 
+	pfx_status pfx_dist_newton_dev(pfx_dist *dist, const double *d_rhs, double *d_x, const pfx_newton_params *params, pfx_newton_info *info)
+	{
+		if (!dist || !d_x || !params || !info)
+			return PFX_ERR_ARG;
+		if (dist_valid(dist))
+			return PFX_ERR_ARG;
+		pfx_ctx *ctx = dist->ctx;
+		if (ctx->kind < 0)
+			DIST_FAIL(PFX_ERR_ARG, "the context holds no mesh");
+		if (ctx->model == PFX_LAPLACIAN || ctx->bs != 3)
+			DIST_FAIL(PFX_ERR_UNSUPPORTED, "pfx_dist_newton_dev needs an elastic model");
+		if (ctx->d_work_ext)
+			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_newton_dev uses the context's own workspace (clear pfx_cgs_set_workspace first)");
+		if (params->cg_precond != PFX_PRECOND_IDENTITY && params->cg_precond != PFX_PRECOND_JACOBI && params->cg_precond != PFX_PRECOND_AMG)
+			DIST_FAIL(PFX_ERR_ARG, "unknown preconditioner");
+		if (hipSetDevice(ctx->device) != hipSuccess)
+			DIST_FAIL(PFX_ERR_HIP, "hipSetDevice failed");
+		return pfx_dist_newton_run(dist, d_rhs, d_x, params, info);
+	}
+
 	pfx_status pfx_dist_amg_apply_dev(pfx_dist *dist, const double *d_r, double *d_z)
 	{
 		if (!dist || !d_r || !d_z)

@@ -18,6 +18,12 @@
 // The reference keeps x, grad and delta_x in host Eigen vectors and crosses to the GPU for every energy evaluation
 // (its USE_NONLINEAR_GPU path copies x and delta_x per line-search step, BacktrackingLineSearch.cu).  Here the three
 // vectors live on the device for the whole solve; the host only sees the scalars that steer the iteration.
+//
+// Over a partition (pfx_dist_newton_run: one context per rank holding its part, local numbering [owned | halo]) the same
+// control flow runs on every rank with every decision taken on all-reduced scalars, so all ranks branch alike: sums over
+// the owned dofs / owned elements + one all-reduce per evaluation, the linear solve is the partitioned CG, which hands
+// the direction back with a current halo, so that every trial point x + a dx is halo-consistent without further exchanges.
+#include "pfx_dist.h"
 #include "pfx_internal.h"
 
 #include <cmath>
@@ -245,9 +251,40 @@ namespace
 			out[0] = sh[0][0], out[1] = sh[1][0], out[2] = sh[2][0];
 	}
 
+	// buf[0] = s[0], buf[1] = s[1] (sums), buf[2 + r] = s[2] for r == rank, 0 for the other ranks: summed over the ranks,
+	// buf[2 ..] holds every rank's maximum
+	__global__ void k_pack_reduce3(const double *__restrict__ s, int rank, int world, double *__restrict__ buf)
+	{
+		const int k = threadIdx.x;
+		if (k < 2)
+			buf[k] = s[k];
+		else if (k < 2 + world)
+			buf[k] = (k - 2 == rank) ? s[2] : 0.0;
+	}
+	__global__ void k_unpack_reduce3(const double *__restrict__ buf, int world, double *__restrict__ s)
+	{
+		if (threadIdx.x == 0)
+		{
+			double m = 0;
+			for (int r = 0; r < world; ++r)
+				m = buf[2 + r] > m ? buf[2 + r] : m;
+			s[0] = buf[0], s[1] = buf[1], s[2] = m;
+		}
+	}
+	// buf[0] = energy of the owned elements, buf[1] = 1 if an element of this rank is inverted
+	__global__ void k_pack_energy(const double *__restrict__ e, const int *__restrict__ flag, double *__restrict__ buf)
+	{
+		if (threadIdx.x == 0)
+			buf[0] = e ? *e : 0.0, buf[1] = *flag ? 1.0 : 0.0;
+	}
+
+	constexpr int DIST_BUF = 40; // doubles of the all-reduce staging area: 2 sums + one maximum per rank
 	struct newton
 	{
 		pfx_ctx *ctx;
+		pfx_dist *dist = nullptr; // the partition this context is one part of (null: the whole problem is here)
+		int64_t n_red = 0;        // dofs the reductions run over: the owned ones
+		double *dbuf = nullptr;   // DIST_BUF doubles
 		const pfx_newton_params *par;
 		pfx_newton_info *info;
 		int64_t n;
@@ -285,10 +322,45 @@ namespace
 		pfx_status reduce(const double *a, const double *b, const double *c, double out[3])
 		{
 			hipStream_t st = ctx->stream;
-			hipLaunchKernelGGL(k_reduce3, dim3(NB), dim3(256), 0, st, a, b, c, n, partial);
+			hipLaunchKernelGGL(k_reduce3, dim3(NB), dim3(256), 0, st, a, b, c, n_red, partial);
 			hipLaunchKernelGGL(k_reduce3_finish, dim3(1), dim3(256), 0, st, partial, scal);
+			if (dist)
+			{
+				const int world = pfx_comm_world(dist->comm);
+				hipLaunchKernelGGL(k_pack_reduce3, dim3(1), dim3(64), 0, st, scal, pfx_comm_rank(dist->comm), world, dbuf);
+				if (pfx_comm_all_reduce(dist->comm, st, dbuf, 2 + world))
+					PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+				hipLaunchKernelGGL(k_unpack_reduce3, dim3(1), dim3(64), 0, st, dbuf, world, scal);
+			}
 			PFX_HIP(hipMemcpyAsync(out, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
 			PFX_HIP(hipStreamSynchronize(st));
+			return PFX_OK;
+		}
+
+		// the energy a kernel left at `d_e` (null: none) and the inverted-element flag, over all ranks; the flag is cleared
+		pfx_status read_energy_flag(const double *d_e, double *e, int *flag)
+		{
+			hipStream_t st = ctx->stream;
+			*e = 0;
+			if (dist)
+			{
+				hipLaunchKernelGGL(k_pack_energy, dim3(1), dim3(64), 0, st, d_e, ctx->d_flag, dbuf);
+				if (pfx_comm_all_reduce(dist->comm, st, dbuf, 2))
+					PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+				double h[2];
+				PFX_HIP(hipMemcpyAsync(h, dbuf, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipStreamSynchronize(st));
+				*e = h[0], *flag = h[1] != 0.0;
+			}
+			else
+			{
+				if (d_e)
+					PFX_HIP(hipMemcpyAsync(e, d_e, sizeof(double), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipMemcpyAsync(flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+				PFX_HIP(hipStreamSynchronize(st));
+			}
+			if (*flag)
+				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
 			return PFX_OK;
 		}
 
@@ -308,14 +380,10 @@ namespace
 				return rc;
 			double e = 0;
 			int flag = 0;
-			PFX_HIP(hipMemcpyAsync(&e, scal + 3, sizeof(double), hipMemcpyDeviceToHost, st));
-			PFX_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-			PFX_HIP(hipStreamSynchronize(st));
+			if ((rc = read_energy_flag(scal + 3, &e, &flag)))
+				return rc;
 			if (flag)
-			{
-				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
 				e = std::nan("");
-			}
 			double r[3];
 			if (rhs && std::isfinite(e))
 			{
@@ -352,20 +420,15 @@ namespace
 		// non-positive determinant)
 		pfx_status value(const double *x, double *val)
 		{
-			hipStream_t st = ctx->stream;
 			pfx_status rc = pfx_energy_dev(ctx, x, scal + 3);
 			if (rc)
 				return rc;
 			double e = 0;
 			int flag = 0;
-			PFX_HIP(hipMemcpyAsync(&e, scal + 3, sizeof(double), hipMemcpyDeviceToHost, st));
-			PFX_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-			PFX_HIP(hipStreamSynchronize(st));
+			if ((rc = read_energy_flag(scal + 3, &e, &flag)))
+				return rc;
 			if (flag)
-			{
-				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
 				e = std::nan("");
-			}
 			if (rhs && std::isfinite(e))
 			{
 				double r[3];
@@ -406,13 +469,11 @@ namespace
 			if ((rc = reduce(out, out, nullptr, r)))
 				return rc;
 			int flag = 0;
-			PFX_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-			PFX_HIP(hipStreamSynchronize(st));
+			double unused = 0;
+			if ((rc = read_energy_flag(nullptr, &unused, &flag)))
+				return rc;
 			if (flag)
-			{
-				PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
 				r[0] = std::nan("");
-			}
 			*norm2 = r[0];
 			return PFX_OK;
 		}
@@ -515,21 +576,25 @@ namespace
 	}
 } // namespace
 
-pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
+static pfx_status newton_impl(pfx_ctx *ctx, pfx_dist *dist, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
 {
 	const int64_t n = ctx->n_dofs();
-	if (ctx->newton_count < 8 * n + 3 * NB + 8)
+	if (ctx->newton_count < 8 * n + 3 * NB + 8 + DIST_BUF)
 	{
-		if (pfx_alloc(ctx, &ctx->d_newton, 8 * n + 3 * NB + 8))
+		if (pfx_alloc(ctx, &ctx->d_newton, 8 * n + 3 * NB + 8 + DIST_BUF))
 			return PFX_ERR_HIP;
-		ctx->newton_count = 8 * n + 3 * NB + 8;
+		ctx->newton_count = 8 * n + 3 * NB + 8 + DIST_BUF;
 	}
+	if (!dist && ctx->n_owned != ctx->n_nodes)
+		PFX_FAIL(PFX_ERR_ARG, "a partitioned context is solved through pfx_dist_newton_dev");
+	if (dist && 2 + pfx_comm_world(dist->comm) > DIST_BUF)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the partitioned Newton solve is limited to 38 ranks");
 	newton S;
-	S.ctx = ctx, S.par = par, S.info = info, S.n = n, S.rhs = d_rhs;
+	S.ctx = ctx, S.dist = dist, S.par = par, S.info = info, S.n = n, S.n_red = ctx->n_owned * ctx->bs, S.rhs = d_rhs;
 	S.fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	S.g = ctx->d_newton, S.dx = S.g + n, S.xn = S.dx + n, S.w = S.xn + n, S.gls = S.w + n;
 	S.d = S.gls + n, S.md = S.d + n, S.alq = S.md + n;
-	S.partial = S.alq + n, S.scal = S.partial + 3 * NB;
+	S.partial = S.alq + n, S.scal = S.partial + 3 * NB, S.dbuf = S.scal + 8;
 	if (ctx->inertia_weight > 0.0 && ctx->d_x_tilde && ctx->mass_count > 0)
 	{
 		if (ctx->bs != 3 || ctx->n_owned != ctx->n_nodes)
@@ -547,6 +612,12 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 	PFX_HIP(hipMemsetAsync(S.dx, 0, sizeof(double) * (size_t)n, st));
 	PFX_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
 	const double saved_shift = ctx->diag_shift;
+	if (dist)
+	{
+		// the caller's iterate with a current halo: from here on every update adds a halo-consistent direction
+		if (pfx_halo_start(dist->comm, &dist->halo, st, d_x, ctx->bs) || pfx_halo_finish(dist->comm, &dist->halo, st))
+			PFX_FAIL(PFX_ERR_HIP, pfx_comm_error(dist->comm));
+	}
 
 	pfx_status rc;
 	double old_energy = std::nan(""), energy = std::nan(""), gn2 = 0;
@@ -618,6 +689,11 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 			if (strategy == 2)
 			{
 				hipLaunchKernelGGL(k_negate, dim3(NB), dim3(256), 0, st, S.g, n, S.dx);
+				if (dist && (pfx_halo_start(dist->comm, &dist->halo, st, S.dx, ctx->bs) || pfx_halo_finish(dist->comm, &dist->halo, st)))
+				{
+					ctx->err = pfx_comm_error(dist->comm);
+					return finish(PFX_ERR_HIP, ctx->err.c_str());
+				}
 				double r[3];
 				if ((rc = S.reduce(S.dx, S.g, nullptr, r)))
 					return finish(rc, ctx->err.c_str());
@@ -643,7 +719,17 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 			int its = 0;
 			double err = 0;
 			// the previous direction is the initial guess (the iterative solver is called with solveWithGuess)
-			if ((rc = pfx_cg_dev(ctx, S.w, S.dx, par->cg_precond, par->cg_max_iter, par->cg_tol, &its, &err)))
+			if (dist)
+			{
+				// the partitioned solve returns the direction with a current halo
+				rc = par->cg_precond == PFX_PRECOND_AMG ? pfx_dist_pcg_amg_run(dist, S.w, S.dx, par->cg_max_iter, par->cg_tol, 0, &its, &err)
+														: pfx_dist_cg_run(dist, S.w, S.dx, par->cg_precond, par->cg_max_iter, par->cg_tol, 0, &its, &err);
+				if (rc)
+					ctx->err = dist->err;
+			}
+			else
+				rc = pfx_cg_dev(ctx, S.w, S.dx, par->cg_precond, par->cg_max_iter, par->cg_tol, &its, &err);
+			if (rc)
 				return finish(rc, ctx->err.c_str());
 			info->cg_iterations += its;
 			// check_direction: || H dx + g || and g.dx
@@ -712,6 +798,19 @@ pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const 
 	if (status == PFX_NEWTON_ITERATION_LIMIT)
 		return finish(PFX_ERR_NUMERIC, "Reached iteration limit");
 	return finish(PFX_OK, "");
+}
+
+pfx_status pfx_newton_run(pfx_ctx *ctx, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
+{
+	return newton_impl(ctx, nullptr, d_rhs, d_x, par, info);
+}
+
+pfx_status pfx_dist_newton_run(pfx_dist *dist, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info)
+{
+	pfx_status rc = newton_impl(dist->ctx, dist, d_rhs, d_x, par, info);
+	if (rc)
+		dist->err = dist->ctx->err;
+	return rc;
 }
 
 pfx_status pfx_capture_mass(pfx_ctx *ctx)

@@ -545,6 +545,21 @@ class LibDist:
         """z = M^-1 r with the hierarchy that spans the ranks (collective; r, z local vectors)."""
         self._ck(self.L.pfx_dist_amg_apply_dev(self.h, r.data_ptr(), z.data_ptr()))
 
+    def newton(self, x, rhs=None, **params):
+        """pfx_dist_newton_dev: the whole Newton solve over the partition inside the library.  Returns (rc, message, info
+        dict); rc != 0 with info['status'] FAILED / ITERATION_LIMIT where the reference throws."""
+        import ctypes as C
+
+        from . import engine as E
+        p = E.NewtonParams()
+        self.L.pfx_newton_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        info = E.NewtonInfo()
+        rc = self.L.pfx_dist_newton_dev(self.h, C.c_void_p(rhs.data_ptr()) if rhs is not None else None, C.c_void_p(x.data_ptr()), C.byref(p), C.byref(info))
+        out = {f[0]: getattr(info, f[0]) for f in E.NewtonInfo._fields_}
+        return rc, (self.L.pfx_dist_last_error(self.h).decode() if rc else ""), out
+
     def cg(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 50):
         import ctypes as C
         it, err = C.c_int(), C.c_double()
@@ -996,18 +1011,34 @@ class DistributedNewton:
             return GRAD_NORM
         return CONTINUE
 
-    def solve(self, x, rhs=None, x_tilde=None, weight: float = 1.0, **params):
+    def solve(self, x, rhs=None, x_tilde=None, weight: float = 1.0, use_library: bool = True, **params):
         """x: local vector [owned | halo] of n_local*bs doubles, starting point in, minimiser out (the halo part is
         kept current); rhs: local vector or None.  With `x_tilde` (local vector with a current halo) the objective is
         weight * (E(x) - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde), M being the mass matrix the back end holds
         (Engine.inertia_set_mass on every rank).  Returns the info dict; raises NewtonFailure where the reference
-        throws."""
+        throws.
+
+        With the HIP engine the static solve runs inside the library (pfx_dist_newton_dev); use_library = False, and the
+        transient objective, keep the loop below, driven from Python over the engine's step functions."""
         self.x_tilde, self.weight = x_tilde, (float(weight) if x_tilde is not None else 1.0)
         par = dict(NEWTON_DEFAULTS)
         for k in params:
             if k not in par:
                 raise TypeError(f"unknown Newton parameter {k!r}")
         par.update(params)
+        if use_library and x_tilde is None and self.cg.lib is not None:
+            if hasattr(self.ops, "check_stream"):
+                self.ops.check_stream()
+            self.ops.set_workspace(None)  # the library's loops work in the context's own vectors
+            rc, msg, out = self.cg.lib.newton(x, rhs, **{k: v for k, v in par.items() if k != "cg_check_every"})
+            out["objective_evaluations"] = None  # not counted by the library
+            self.info = out
+            if rc != 0:
+                from .engine import PFX_ERR_NUMERIC, PfxError
+                if rc == PFX_ERR_NUMERIC:
+                    raise NewtonFailure(msg, out)
+                raise PfxError(rc, msg)
+            return out
         ops, t, no, bs = self.ops, self.torch, self.no, self.bs
         if hasattr(ops, "check_stream"):
             ops.check_stream()

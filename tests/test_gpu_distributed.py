@@ -178,9 +178,26 @@ def _newton_worker(rank, world, port, ret):
         rhs_g[0::3] = -6e3 / n_nodes
         newton = D.DistributedNewton(D.HipOps(eng), part, 3, D.Comm(), dev, fixed_dofs)
         x = torch.zeros(part.n_local * 3, dtype=torch.float64, device=dev)
-        info = newton.solve(x, torch.from_numpy(rhs_g[dof_l2g]).to(dev), cg_check_every=16)
+        rhs_l = torch.from_numpy(rhs_g[dof_l2g]).to(dev)
+        info = newton.solve(x, rhs_l, cg_check_every=16)  # the whole solve inside the library (pfx_dist_newton_dev)
         torch.cuda.synchronize()
+        assert newton.cg.lib is not None and info["objective_evaluations"] is None
         assert not eng.take_numeric_flag(), "the driver must leave the numeric flag cleared"
+        # the loop driven from Python over the step functions takes the same decisions and ends at the same point
+        x_py = torch.zeros_like(x)
+        info_py = newton.solve(x_py, rhs_l, cg_check_every=16, use_library=False)
+        torch.cuda.synchronize()
+        for key in ("status", "iterations", "line_search_iterations", "descent_strategy"):
+            assert info_py[key] == info[key], (key, info_py, info)
+        assert abs(info_py["cg_iterations"] - info["cg_iterations"]) <= 2 * info["iterations"]
+        assert float((x_py - x).abs().max()) <= 1e-10 * float(x.abs().max())
+        # the same solve with the AMG hierarchy that spans the ranks as the linear solver
+        x_amg = torch.zeros_like(x)
+        info_amg = newton.solve(x_amg, rhs_l, cg_precond=E.PRECOND_AMG, cg_tol=1e-10)
+        torch.cuda.synchronize()
+        assert info_amg["status"] in (D.F_DELTA, D.GRAD_NORM) and info_amg["iterations"] == info["iterations"]
+        assert info_amg["cg_iterations"] < info["cg_iterations"]
+        assert float((x_amg - x).abs().max()) <= 1e-7 * float(x.abs().max())
         no = part.n_owned * 3
         out = [None] * world
         dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no]))
