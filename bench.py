@@ -181,6 +181,8 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
     load[2::3] = -50.0 / (n_nodes_global / world)
     dnewton = (D.DistributedNewton(D.HipOps(eng), part, 3, comm, dev, fixed_dofs)
                if world > 1 and workload == "newton" else None)
+    if dnewton is not None:
+        halo_bytes = dnewton.cg.halo.bytes_per_exchange(3)
 
     if workload == "transient":
         rho = 1000.0
@@ -319,7 +321,9 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
                 "halo_bytes_per_exchange_rank0": halo_bytes,
                 # who runs the distributed iteration: the library's own loop (pfx_dist_cg_dev) over its RCCL communicator, or over
                 # a host-staged transport when the process group is gloo (single-card rehearsal)
-                "distributed_iteration": (f"inside the library (pfx_dist_cg_dev), communicator: {dcg.lib.libcomm.kind}" if dcg is not None and dcg.lib is not None else None),
+                "distributed_iteration": (f"inside the library (pfx_dist_cg_dev), communicator: {dcg.lib.libcomm.kind}" if dcg is not None and dcg.lib is not None
+                                          else f"inside the library (pfx_dist_newton_dev), communicator: {dnewton.cg.lib.libcomm.kind}" if dnewton is not None and dnewton.cg.lib is not None
+                                          else None),
                 "bytes_device": eng.info().bytes_device,  # everything the context holds now: pattern, values, solver copy, vectors
             },
             "roofline": {"kernel": "k_sell_spmv (CG matrix-vector product)", "bound": "hbm", "achieved": spmv_gbs,
