@@ -551,11 +551,15 @@ pfx_status pfx_dist_amg_apply_dev(pfx_dist *dist, const double *d_r, double *d_z
  * flow on every rank, every decision taken on all-reduced scalars (energy of the owned elements, sums and maxima over the
  * owned dofs, the inverted-element flag), the linear solve is pfx_dist_cg_dev with params->cg_precond.  d_rhs (may be NULL)
  * and d_x are this rank's local vectors; the halo entries of d_rhs are ignored, those of d_x are made current on entry and
- * are current on return.  Statuses, errors and counters as pfx_newton_solve_dev, identical on all ranks.  The inertia and
- * augmented-Lagrangian terms (pfx_inertia_enable, pfx_al_enable) are not available over a partition through this call.
- * Limit: 38 ranks. */
+ * are current on return.  Statuses, errors and counters as pfx_newton_solve_dev, identical on all ranks.  The inertia term
+ * (pfx_inertia_set_mass + pfx_inertia_enable on every rank, d_x_tilde a local vector with a current halo) is honoured; the
+ * augmented-Lagrangian term (pfx_al_enable) is not available over a partition.  Limit: 38 ranks.
+ * pfx_dist_implicit_euler_step_dev is pfx_implicit_euler_step_dev over the partition (ImplicitEuler.cpp:5-33 around that
+ * solve): d_x, d_v local vectors with current halos on entry and on return, d_a (may be NULL) likewise on return. */
 pfx_status pfx_dist_newton_dev(pfx_dist *dist, const double *d_rhs, double *d_x_inout, const pfx_newton_params *params,
 							   pfx_newton_info *info);
+pfx_status pfx_dist_implicit_euler_step_dev(pfx_dist *dist, double dt, const double *d_rhs, double *d_x_inout, double *d_v_inout,
+											double *d_a_out, const pfx_newton_params *params, pfx_newton_info *info);
 /* bytes one halo exchange of a vector moves through this rank (sent + received) */
 pfx_status pfx_dist_halo_bytes(pfx_dist *dist, int64_t *bytes);
 

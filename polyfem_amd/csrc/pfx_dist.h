@@ -47,3 +47,5 @@ pfx_status pfx_dist_pcg_amg_run(pfx_dist *dist, const double *d_b, double *d_x, 
 pfx_status pfx_dist_amg_apply_run(pfx_dist *dist, const double *d_r, double *d_z);
 pfx_status pfx_dist_cg_run(pfx_dist *dist, const double *d_b, double *d_x, int precond, int max_iter, double tol, int check_every, int *iters, double *rel_res);
 pfx_status pfx_dist_newton_run(pfx_dist *dist, const double *d_rhs, double *d_x, const pfx_newton_params *par, pfx_newton_info *info);
+pfx_status pfx_dist_implicit_euler_run(pfx_dist *dist, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a, const pfx_newton_params *params,
+									   pfx_newton_info *info);

@@ -506,6 +506,27 @@ extern "C"
 		return pfx_dist_newton_run(dist, d_rhs, d_x, params, info);
 	}
 
+	pfx_status pfx_dist_implicit_euler_step_dev(pfx_dist *dist, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+												const pfx_newton_params *params, pfx_newton_info *info)
+	{
+		if (!dist || !d_x || !d_v || !params || !info)
+			return PFX_ERR_ARG;
+		if (dist_valid(dist))
+			return PFX_ERR_ARG;
+		pfx_ctx *ctx = dist->ctx;
+		if (!(dt > 0.0))
+			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_implicit_euler_step_dev: dt must be positive");
+		if (ctx->kind < 0 || ctx->model == PFX_LAPLACIAN || ctx->bs != 3)
+			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_implicit_euler_step_dev needs a mesh and an elastic model");
+		if (ctx->mass_count == 0)
+			DIST_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
+		if (ctx->d_work_ext)
+			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_implicit_euler_step_dev uses the context's own workspace (clear pfx_cgs_set_workspace first)");
+		if (hipSetDevice(ctx->device) != hipSuccess)
+			DIST_FAIL(PFX_ERR_HIP, "hipSetDevice failed");
+		return pfx_dist_implicit_euler_run(dist, dt, d_rhs, d_x, d_v, d_a, params, info);
+	}
+
 	pfx_status pfx_dist_amg_apply_dev(pfx_dist *dist, const double *d_r, double *d_z)
 	{
 		if (!dist || !d_r || !d_z)

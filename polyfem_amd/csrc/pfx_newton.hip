@@ -315,7 +315,8 @@ namespace
 		void mass_apply(const double *x)
 		{
 			hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, ctx->stream, x, xt, -1.0, n, d);
-			hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, (const double *)d, ctx->n_nodes, md);
+			// owned rows (all of them on an unpartitioned mesh); d carries a current halo because x and x_tilde do
+			hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, (const double *)d, ctx->n_owned, md);
 		}
 
 		// a.b, |a + c|^2 (c may be null), max|a|
@@ -597,13 +598,13 @@ static pfx_status newton_impl(pfx_ctx *ctx, pfx_dist *dist, const double *d_rhs,
 	S.partial = S.alq + n, S.scal = S.partial + 3 * NB, S.dbuf = S.scal + 8;
 	if (ctx->inertia_weight > 0.0 && ctx->d_x_tilde && ctx->mass_count > 0)
 	{
-		if (ctx->bs != 3 || ctx->n_owned != ctx->n_nodes)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs block size 3 and an unpartitioned mesh");
+		if (ctx->bs != 3)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs block size 3");
 		S.iw = ctx->inertia_weight, S.mass = ctx->d_mass_blk, S.xt = ctx->d_x_tilde;
 	}
 	if (ctx->al_weight > 0.0 && ctx->d_al_mass && ctx->d_al_target)
 	{
-		if (ctx->bs != 3 || ctx->n_owned != ctx->n_nodes)
+		if (ctx->bs != 3 || dist)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs block size 3 and an unpartitioned mesh");
 		S.alw = ctx->al_weight, S.alm = ctx->d_al_mass, S.alt = ctx->d_al_target;
 	}
@@ -826,8 +827,9 @@ pfx_status pfx_capture_mass(pfx_ctx *ctx)
 	return PFX_OK;
 }
 
-pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
-								  const pfx_newton_params *params, pfx_newton_info *info)
+// one implicit Euler step; over a partition (dist != null) x and v come with current halos and leave with current halos
+static pfx_status euler_impl(pfx_ctx *ctx, pfx_dist *dist, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+							 const pfx_newton_params *params, pfx_newton_info *info)
 {
 	const int64_t n = ctx->n_dofs();
 	hipStream_t st = ctx->stream;
@@ -845,7 +847,7 @@ pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, 
 	const double *saved_xt = ctx->d_x_tilde;
 	ctx->inertia_weight = dt * dt; // ImplicitEuler::acceleration_scaling
 	ctx->d_x_tilde = x_tilde;
-	const pfx_status rc = pfx_newton_run(ctx, d_rhs, d_x, params, info);
+	const pfx_status rc = newton_impl(ctx, dist, d_rhs, d_x, params, info);
 	ctx->inertia_weight = saved_w;
 	ctx->d_x_tilde = saved_xt;
 	if (rc)
@@ -854,6 +856,21 @@ pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, 
 	PFX_HIP(hipGetLastError());
 	PFX_HIP(hipStreamSynchronize(st));
 	return PFX_OK;
+}
+
+pfx_status pfx_implicit_euler_run(pfx_ctx *ctx, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+								  const pfx_newton_params *params, pfx_newton_info *info)
+{
+	return euler_impl(ctx, nullptr, dt, d_rhs, d_x, d_v, d_a, params, info);
+}
+
+pfx_status pfx_dist_implicit_euler_run(pfx_dist *dist, double dt, const double *d_rhs, double *d_x, double *d_v, double *d_a,
+									   const pfx_newton_params *params, pfx_newton_info *info)
+{
+	const pfx_status rc = euler_impl(dist->ctx, dist, dt, d_rhs, d_x, d_v, d_a, params, info);
+	if (rc)
+		dist->err = dist->ctx->err;
+	return rc;
 }
 
 // y[owned rows] = M v with the captured mass matrix (v needs a current halo on a partitioned mesh)

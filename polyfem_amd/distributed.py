@@ -560,6 +560,22 @@ class LibDist:
         out = {f[0]: getattr(info, f[0]) for f in E.NewtonInfo._fields_}
         return rc, (self.L.pfx_dist_last_error(self.h).decode() if rc else ""), out
 
+    def implicit_euler_step(self, dt, x, v, a=None, rhs=None, **params):
+        """pfx_dist_implicit_euler_step_dev: one implicit Euler step over the partition inside the library; same return
+        convention as newton()."""
+        import ctypes as C
+
+        from . import engine as E
+        p = E.NewtonParams()
+        self.L.pfx_newton_default_params(C.byref(p))
+        for k, val in params.items():
+            setattr(p, k, val)
+        info = E.NewtonInfo()
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        rc = self.L.pfx_dist_implicit_euler_step_dev(self.h, float(dt), ptr(rhs), ptr(x), ptr(v), ptr(a), C.byref(p), C.byref(info))
+        out = {f[0]: getattr(info, f[0]) for f in E.NewtonInfo._fields_}
+        return rc, (self.L.pfx_dist_last_error(self.h).decode() if rc else ""), out
+
     def cg(self, b, x, precond: int = 1, max_iter: int = 1000, tol: float = 1e-12, check_every: int = 50):
         import ctypes as C
         it, err = C.c_int(), C.c_double()
@@ -1001,6 +1017,16 @@ class DistributedNewton:
             return float("nan")
         return step
 
+    def _library_result(self, rc, msg, out):
+        out["objective_evaluations"] = None  # not counted by the library
+        self.info = out
+        if rc != 0:
+            from .engine import PFX_ERR_NUMERIC, PfxError
+            if rc == PFX_ERR_NUMERIC:
+                raise NewtonFailure(msg, out)
+            raise PfxError(rc, msg)
+        return out
+
     @staticmethod
     def _check(par, iterations, f_delta, grad_norm, grad_tol):
         if par["max_iterations"] > 0 and iterations > par["max_iterations"]:
@@ -1018,27 +1044,27 @@ class DistributedNewton:
         (Engine.inertia_set_mass on every rank).  Returns the info dict; raises NewtonFailure where the reference
         throws.
 
-        With the HIP engine the static solve runs inside the library (pfx_dist_newton_dev); use_library = False, and the
-        transient objective, keep the loop below, driven from Python over the engine's step functions."""
+        With the HIP engine the solve runs inside the library (pfx_dist_newton_dev, the inertia term through
+        pfx_inertia_enable); use_library = False keeps the loop below, driven from Python over the engine's step
+        functions."""
         self.x_tilde, self.weight = x_tilde, (float(weight) if x_tilde is not None else 1.0)
         par = dict(NEWTON_DEFAULTS)
         for k in params:
             if k not in par:
                 raise TypeError(f"unknown Newton parameter {k!r}")
         par.update(params)
-        if use_library and x_tilde is None and self.cg.lib is not None:
+        if use_library and self.cg.lib is not None:
             if hasattr(self.ops, "check_stream"):
                 self.ops.check_stream()
             self.ops.set_workspace(None)  # the library's loops work in the context's own vectors
-            rc, msg, out = self.cg.lib.newton(x, rhs, **{k: v for k, v in par.items() if k != "cg_check_every"})
-            out["objective_evaluations"] = None  # not counted by the library
-            self.info = out
-            if rc != 0:
-                from .engine import PFX_ERR_NUMERIC, PfxError
-                if rc == PFX_ERR_NUMERIC:
-                    raise NewtonFailure(msg, out)
-                raise PfxError(rc, msg)
-            return out
+            if x_tilde is not None:
+                self.ops.e.inertia_enable(self.weight, x_tilde.data_ptr())
+            try:
+                rc, msg, out = self.cg.lib.newton(x, rhs, **{k: v for k, v in par.items() if k != "cg_check_every"})
+            finally:
+                if x_tilde is not None:
+                    self.ops.e.inertia_disable()
+            return self._library_result(rc, msg, out)
         ops, t, no, bs = self.ops, self.torch, self.no, self.bs
         if hasattr(ops, "check_stream"):
             ops.check_stream()
@@ -1163,12 +1189,25 @@ class DistributedImplicitEuler:
         self.x_prev = torch.zeros(n, dtype=torch.float64, device=dev)
         self.x_tilde = torch.zeros(n, dtype=torch.float64, device=dev)
 
-    def step(self, x, v, a=None, rhs=None, **params):
-        """Advances (x, v) in place; writes the acceleration into `a` if given.  Returns the Newton info dict."""
+    def step(self, x, v, a=None, rhs=None, use_library: bool = True, **params):
+        """Advances (x, v) in place; writes the acceleration into `a` if given.  Returns the Newton info dict.  With the
+        HIP engine the whole step runs inside the library (pfx_dist_implicit_euler_step_dev)."""
         t, dt = self.torch, self.dt
+        nw = self.newton
+        if use_library and nw.cg.lib is not None:
+            par = dict(NEWTON_DEFAULTS)
+            for k in params:
+                if k not in par:
+                    raise TypeError(f"unknown Newton parameter {k!r}")
+            par.update(params)
+            if hasattr(nw.ops, "check_stream"):
+                nw.ops.check_stream()
+            nw.ops.set_workspace(None)
+            rc, msg, out = nw.cg.lib.implicit_euler_step(dt, x, v, a, rhs, **{k: val for k, val in par.items() if k != "cg_check_every"})
+            return nw._library_result(rc, msg, out)
         self.x_prev.copy_(x)
         t.add(x, v, alpha=dt, out=self.x_tilde)
-        info = self.newton.solve(x, rhs, x_tilde=self.x_tilde, weight=dt * dt, **params)
+        info = self.newton.solve(x, rhs, x_tilde=self.x_tilde, weight=dt * dt, use_library=False, **params)
         v_new = (x - self.x_prev) / dt
         if a is not None:
             t.sub(v_new, v, out=a)

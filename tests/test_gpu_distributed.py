@@ -280,8 +280,25 @@ def _euler_worker(rank, world, port, ret):
         v = torch.from_numpy(v_l).to(dev)
         a = torch.zeros_like(x)
         rhs = torch.from_numpy(rhs_l).to(dev)
-        infos = [dict(stepper.step(x, v, a, rhs, cg_check_every=16)) for _ in range(2)]
+        x0, v0 = x.clone(), v.clone()
+        infos = [dict(stepper.step(x, v, a, rhs, cg_check_every=16)) for _ in range(2)]  # inside the library
         torch.cuda.synchronize()
+        assert newton.cg.lib is not None
+        # the steps driven from Python (Newton loop over the step functions, integrator bookkeeping in torch) agree
+        x_py, v_py, a_py = x0.clone(), v0.clone(), torch.zeros_like(x)
+        infos_py = [dict(stepper.step(x_py, v_py, a_py, rhs, cg_check_every=16, use_library=False)) for _ in range(2)]
+        torch.cuda.synchronize()
+        for i_lib, i_py in zip(infos, infos_py):
+            for key in ("status", "iterations", "line_search_iterations"):
+                assert i_lib[key] == i_py[key], (key, i_lib, i_py)
+        for lib_vec, py_vec in ((x, x_py), (v, v_py), (a, a_py)):
+            assert float((lib_vec - py_vec).abs().max()) <= 1e-9 * float(lib_vec.abs().max())
+        # one Newton solve with the inertia term through pfx_inertia_enable + pfx_dist_newton_dev
+        xt = (x + dt * v).contiguous()
+        x_a, x_b = x.clone(), x.clone()
+        i_a = newton.solve(x_a, rhs, x_tilde=xt, weight=dt * dt)
+        i_b = newton.solve(x_b, rhs, x_tilde=xt, weight=dt * dt, use_library=False)
+        assert i_a["iterations"] == i_b["iterations"] and float((x_a - x_b).abs().max()) <= 1e-10 * float(x_b.abs().max())
         no = part.n_owned * 3
         out = [None] * world
         dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no], v.cpu().numpy()[:no], a.cpu().numpy()[:no]))
