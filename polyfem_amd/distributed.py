@@ -616,7 +616,7 @@ class DistributedCG:
     def _open_library(self):
         """Binds the engine to the library's own communicator and checks it against torch.distributed before it is
         trusted: one halo exchange of a vector of global node ids and one all-reduce, compared on every rank with what
-        the process group delivers.  The verdict is taken collectively, so either every rank runs the library loop or
+        the process group delivers.  The decision is taken collectively, so either every rank runs the library loop or
         every rank keeps the Python-driven one (a transport that errs on one rank must not split the ranks)."""
         t, ok = self.torch, 1.0
         try:
