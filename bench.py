@@ -218,9 +218,13 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
 
     if rank == 0:
         log(f"set-up done in {time.perf_counter() - t_setup:.1f}s (pattern {t_pattern:.2f}s, nnz {inf.nnz}); {warmup} warm-up + {steps} timed steps")
+    t_first = None  # the first step also allocates the solver's arrays and searches a placement for the value array
     for k in range(warmup):
+        t_w = time.perf_counter()
         step()
         eng.synchronize()
+        if k == 0:
+            t_first = time.perf_counter() - t_w
         if rank == 0:
             log(f"warm-up step {k + 1}/{warmup}")
     eng.synchronize()
@@ -354,6 +358,8 @@ def run_workload(args, workload, grid, element, steps, warmup, world, rank, loca
                    "update_gbs": 56.0 * n / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0,
                    "direction_gbs": 32.0 * n / (dir_ms * 1e-3) / 1e9 if dir_ms > 0 else 0.0},
             "pattern_build_s": t_pattern,
+            "first_step_s": t_first,
+            "placement_tries": int(os.environ.get("PFX_PLACEMENT_TRIES", "6")),
         }
         if workload == "transient":
             out["config"]["workload"] = (f"NeoHookean implicit Euler time step (dt {args.dt:g}, Newton + backtracking, {pname}-CG tol {args.cg_tol:g} "

@@ -528,6 +528,130 @@ static pfx_status sell_build(pfx_ctx *ctx)
 }
 
 // makes the solver copy of the matrix current (structure and values)
+// values of the node-block array -> slices (one wave per slice)
+// (measured at 1 M P2 tets: one slot per pass 1.68 ms, two 1.70 ms, four with half the waves 2.40 ms)
+template <typename V>
+static pfx_status sell_convert(pfx_ctx *ctx, V *out)
+{
+#define PFX_CONVERT(BS_, JB_, WPB_)                                                                                                                         \
+	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_, V>), dim3((unsigned)((ctx->sell_slices + WPB_ - 1) / WPB_ > 0 ? (ctx->sell_slices + WPB_ - 1) / WPB_ : 1)), \
+					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, out)
+	if (ctx->bs == 1)
+		PFX_CONVERT(1, 4, 4);
+	else if (ctx->bs == 3)
+		PFX_CONVERT(3, 1, 4);
+	else
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+#undef PFX_CONVERT
+	PFX_HIP(hipGetLastError());
+	return PFX_OK;
+}
+
+// Placement search for a freshly allocated value array.  The speed of the product depends on WHICH physical pages the
+// value stream lies in: re-allocating nothing but this array moves a 30 GB product between 4.85 and 5.35 ms at one and
+// the same virtual address (the single-precision copy: 2.7 to 3.3 ms), and the allocator hands out a different set of pages
+// each time while the previous array is still held.  So the first allocation per pattern tries a few placements -- allocate
+// a candidate beside the current array, fill it, time three products, keep the faster, free the other -- and keeps the
+// best (or the first that streams the values at 0.74 of the HBM peak).  Costs one conversion and four products per try, once
+// per pattern; more than about eight tries make the allocator itself slow.  Skipped for arrays below PFX_PLACEMENT_MIN_BYTES
+// (PFX_PLACEMENT_MIN_MB in the environment overrides it),
+// when the device has no room for a second copy, and with PFX_PLACEMENT_TRIES=0 in the environment (default 6).
+#ifndef PFX_PLACEMENT_MIN_BYTES
+#define PFX_PLACEMENT_MIN_BYTES ((size_t)1 << 30)
+#endif
+template <typename V>
+static pfx_status sell_place(pfx_ctx *ctx, V *&array, int64_t count, bool fp32)
+{
+	const char *env = getenv("PFX_PLACEMENT_TRIES");
+	const int tries = env ? atoi(env) : 6;
+	const size_t bytes = sizeof(V) * (size_t)count;
+	const char *env_min = getenv("PFX_PLACEMENT_MIN_MB");
+	const size_t min_bytes = env_min ? (size_t)atoll(env_min) << 20 : PFX_PLACEMENT_MIN_BYTES;
+	if (tries <= 0 || bytes < min_bytes || ctx->n_owned < 65536)
+		return PFX_OK;
+	const int64_t n = ctx->n_dofs();
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + sizeof(double) * (size_t)n + ((size_t)2 << 30))
+	{
+		(void)hipGetLastError();
+		return PFX_OK;
+	}
+	pfx_scoped_timer tm(ctx, "placement");
+	// the trial products and conversions are not the caller's: kept out of the per-family timings
+	struct timing_off
+	{
+		pfx_ctx *c;
+		bool was;
+		explicit timing_off(pfx_ctx *ctx_) : c(ctx_), was(ctx_->timing) { c->timing = false; }
+		~timing_off() { c->timing = was; }
+	} quiet(ctx);
+	hipStream_t st = ctx->stream;
+	pfx_tmp<double> xv;
+	PFX_HIP(xv.alloc((size_t)n));
+	PFX_HIP(hipMemsetAsync(xv.p, 0, sizeof(double) * (size_t)n, st));
+	hipEvent_t e0, e1;
+	PFX_HIP(hipEventCreate(&e0));
+	PFX_HIP(hipEventCreate(&e1));
+	pfx_status rc = PFX_OK;
+	auto measure = [&](float *ms) -> pfx_status {
+		bool sliced = false; // the products stay in the slice-ordered buffer: no second vector needed
+		pfx_status r = pfx_sell_spmv(ctx, xv.p, nullptr, nullptr, nullptr, PFX_SPMV_ALL, &sliced, fp32);
+		if (r)
+			return r;
+		PFX_HIP(hipEventRecord(e0, st));
+		for (int k = 0; k < 3 && !r; ++k)
+			r = pfx_sell_spmv(ctx, xv.p, nullptr, nullptr, nullptr, PFX_SPMV_ALL, &sliced, fp32);
+		if (r)
+			return r;
+		PFX_HIP(hipEventRecord(e1, st));
+		PFX_HIP(hipEventSynchronize(e1));
+		PFX_HIP(hipEventElapsedTime(ms, e0, e1));
+		return PFX_OK;
+	};
+	float best = 0;
+	rc = measure(&best);
+	// three products with the value stream alone at 0.74 of the HBM peak (0.80 with the index and vector bytes of the 3 x 3
+	// double-precision format): as good as it gets, stop looking
+	const float good_ms = 3.0f * (float)((double)bytes / (0.74 * 8.0e9));
+	for (int k = 0; k < tries && !rc && best > good_ms; ++k)
+	{
+		V *cand = nullptr;
+		if (hipMalloc((void **)&cand, bytes) != hipSuccess)
+		{
+			(void)hipGetLastError(); // the earlier candidates have not come back to the allocator yet: enough tried
+			break;
+		}
+		V *held = array;
+		array = cand;
+		float ms = 0;
+		if ((rc = sell_convert<V>(ctx, cand)) || (rc = measure(&ms)))
+		{
+			array = held;
+			(void)hipFree(cand);
+			break;
+		}
+		if (ms < best)
+		{
+			best = ms;
+			// the candidate takes the place of the held array in the context's allocation record
+			auto it = ctx->alloc_bytes.find((const void *)held);
+			const int64_t recorded = it != ctx->alloc_bytes.end() ? it->second : (int64_t)bytes;
+			if (it != ctx->alloc_bytes.end())
+				ctx->alloc_bytes.erase(it);
+			ctx->alloc_bytes[(const void *)cand] = recorded;
+			(void)hipFree(held);
+		}
+		else
+		{
+			array = held;
+			(void)hipFree(cand);
+		}
+	}
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return rc;
+}
+
 pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 {
 	if (ctx->sell_owned != ctx->n_owned || !ctx->d_sell_perm)
@@ -538,22 +662,19 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 	}
 	if (ctx->sell_gen != ctx->values_gen || !ctx->d_sell_vals)
 	{
-		if (!ctx->d_sell_vals && pfx_alloc(ctx, &ctx->d_sell_vals, ctx->sell_rows * SL * ctx->bs * ctx->bs + 2))
+		const bool fresh = !ctx->d_sell_vals;
+		const int64_t count = ctx->sell_rows * SL * ctx->bs * ctx->bs + 2;
+		if (fresh && pfx_alloc(ctx, &ctx->d_sell_vals, count))
 			return PFX_ERR_HIP;
-		pfx_scoped_timer tm(ctx, "sell_convert");
-		// one wave per slice
-#define PFX_CONVERT(BS_, JB_, WPB_, V_, OUT_)                                                                                                     \
-	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_, V_>), dim3((unsigned)((ctx->sell_slices + WPB_ - 1) / WPB_ > 0 ? (ctx->sell_slices + WPB_ - 1) / WPB_ : 1)), \
-					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, OUT_)
-		// (measured at 1 M P2 tets: one slot per pass 1.68 ms, two 1.70 ms, four with half the waves 2.40 ms)
-		if (ctx->bs == 1)
-			PFX_CONVERT(1, 4, 4, double, ctx->d_sell_vals);
-		else if (ctx->bs == 3)
-			PFX_CONVERT(3, 1, 4, double, ctx->d_sell_vals);
-		else
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
-		PFX_HIP(hipGetLastError());
+		pfx_status rc;
+		{
+			pfx_scoped_timer tm(ctx, "sell_convert");
+			if ((rc = sell_convert<double>(ctx, ctx->d_sell_vals)))
+				return rc;
+		}
 		ctx->sell_gen = ctx->values_gen;
+		if (fresh && (rc = sell_place<double>(ctx, ctx->d_sell_vals, count, false)))
+			return rc;
 	}
 	return PFX_OK;
 }
@@ -569,18 +690,19 @@ pfx_status pfx_sell_refresh32(pfx_ctx *ctx)
 	}
 	if (ctx->sell32_gen != ctx->values_gen || !ctx->d_sell_vals32)
 	{
-		if (!ctx->d_sell_vals32 && pfx_alloc(ctx, &ctx->d_sell_vals32, ctx->sell_rows * SL * ctx->bs * ctx->bs + 4))
+		const bool fresh = !ctx->d_sell_vals32;
+		const int64_t count = ctx->sell_rows * SL * ctx->bs * ctx->bs + 4;
+		if (fresh && pfx_alloc(ctx, &ctx->d_sell_vals32, count))
 			return PFX_ERR_HIP;
-		pfx_scoped_timer tm(ctx, "sell_convert32");
-		if (ctx->bs == 1)
-			PFX_CONVERT(1, 4, 4, float, ctx->d_sell_vals32);
-		else if (ctx->bs == 3)
-			PFX_CONVERT(3, 1, 4, float, ctx->d_sell_vals32);
-		else
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
-#undef PFX_CONVERT
-		PFX_HIP(hipGetLastError());
+		pfx_status rc;
+		{
+			pfx_scoped_timer tm(ctx, "sell_convert32");
+			if ((rc = sell_convert<float>(ctx, ctx->d_sell_vals32)))
+				return rc;
+		}
 		ctx->sell32_gen = ctx->values_gen;
+		if (fresh && (rc = sell_place<float>(ctx, ctx->d_sell_vals32, count, true)))
+			return rc;
 	}
 	return PFX_OK;
 }

@@ -235,3 +235,45 @@ def test_ten_million_p2_tets_on_one_gpu():
         assert abs(np.linalg.norm(r) / np.linalg.norm(b[free]) - err1) <= 1e-6 * err1
     finally:
         eng.close()
+
+
+def test_placement_search_changes_nothing_but_where_the_values_lie(monkeypatch):
+    """The first solver copy of a large matrix tries several allocations of its value array and keeps the fastest
+    (polyfem_amd/csrc/pfx_sell.hip: sell_place).  Results, the context's memory record and the device's free memory must
+    be what they are without the search."""
+    import torch
+    mesh = M.cube_tets(24, 2)  # 82 944 P2 tets, 117 649 nodes (the search needs the slice-ordered product: >= 65 536 rows)
+    monkeypatch.setenv("PFX_PLACEMENT_MIN_MB", "16")  # default threshold: 1 GiB of values
+    n = mesh.n_nodes * 3
+    b = np.random.default_rng(5).standard_normal(n)
+    out = {}
+    for tries in ("0", "4"):
+        monkeypatch.setenv("PFX_PLACEMENT_TRIES", tries)
+        torch.cuda.synchronize()
+        eng = E.Engine(0)
+        try:
+            eng.set_mesh(mesh)
+            lam, mu = 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6
+            eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+            eng.build_pattern()
+            eng.assemble_linear()
+            eng.set_dirichlet(M.boundary_dofs(mesh, 3, "x0"))
+            eng.timing_enable(True)
+            x, it, err = eng.cg(b, None, E.PRECOND_JACOBI, 40, 1e-12)
+            held = eng.info().bytes_device
+            eng.amg_setup()  # the single-precision copy goes through the same search
+            xa, ita, erra = eng.cg(b, None, E.PRECOND_AMG, 200, 1e-10)
+            _, searches = eng.timing_get("placement")
+            _, products = eng.timing_get("spmv")
+            eng.timing_enable(False)
+            # one search per value array (double, single precision) when it is on; its trial products are not the caller's
+            assert searches == (2 if tries != "0" else 0), searches
+            out[tries] = (x, it, err, held, xa, ita, erra, products)
+        finally:
+            eng.close()
+    x0, it0, err0, held0, xa0, ita0, erra0, products0 = out["0"]
+    x4, it4, err4, held4, xa4, ita4, erra4, products4 = out["4"]
+    assert products0 == products4
+    assert it0 == it4 == 40 and err0 == err4 and np.array_equal(x0, x4)
+    assert held0 == held4
+    assert ita0 == ita4 and erra0 == erra4 and np.array_equal(xa0, xa4) and erra4 <= 1e-10
