@@ -53,7 +53,7 @@
 
 #define AMG_MAX_LEVELS 16
 #define AMG_MAX_DENSE 4096 // largest coarsest level the dense inverse is formed for (n^2 doubles on the host and the device)
-#define AMG_NPART 256
+#define AMG_NPART 1024 // blocks of the reducing vector kernels (256 left the streaming kernels of the PCG at 2.4 - 3 TB/s: 110 ms of a 1.02 s solve)
 #define AMG_SMALL_NODES 32768 // levels of at most this many node rows multiply through k_rowwave_spmv
 
 namespace
