@@ -563,6 +563,19 @@ pfx_status pfx_dist_implicit_euler_step_dev(pfx_dist *dist, double dt, const dou
 /* bytes one halo exchange of a vector moves through this rank (sent + received) */
 pfx_status pfx_dist_halo_bytes(pfx_dist *dist, int64_t *bytes);
 
+/* ---- placement of the solver's value arrays (no counterpart in the reference) --------------------------------------
+ *
+ * The speed of the matrix-vector product depends on which physical pages its value array lies in (measured: +-5 % for a
+ * 30 GB array at unchanged virtual addresses).  The CG loops (pfx_cg*, pfx_dist_cg_dev with Jacobi / no preconditioner)
+ * therefore try a few allocations of the array once a solve has run 192 iterations with at least 256 to go, and keep the
+ * fastest.  pfx_tune_placement does the same on request, at once, and also for the single-precision copies of an existing
+ * AMG hierarchy (whose solves are too short to trigger a search): call it after the first assembly / pfx_amg_setup of a
+ * simulation that will solve many times on this pattern.  Cost: one copy of the array + four products per try (default
+ * six tries, PFX_PLACEMENT_TRIES in the environment; 0 = never), room for a second copy of the array while it runs, and a
+ * driver allocator that answers slowly for a few seconds afterwards (about a second per 12 GB the search freed).  Arrays
+ * below 1 GiB are left alone.  Results do not change. */
+pfx_status pfx_tune_placement(pfx_ctx *ctx);
+
 /* ---- introspection for benchmarks ----------------------------------------------------------------------------- */
 
 typedef struct

@@ -2014,6 +2014,31 @@ extern "C"
 		return pfx_amg_prepare(ctx, base + 3 * nfull, base + nfull, base + 2 * nfull);
 	}
 
+	pfx_status pfx_tune_placement(pfx_ctx *ctx)
+	{
+		if (!ctx)
+			return PFX_ERR_ARG;
+		if (!ctx->d_node_ptr || !ctx->d_values)
+			PFX_FAIL(PFX_ERR_ARG, "no matrix: assemble or pfx_solver_factorize first");
+		if (ctx->ext && !ctx->ext_factorized)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_factorize must succeed before the matrix is used");
+		PFX_HIP(hipSetDevice(ctx->device));
+		pfx_status rc = pfx_sell_refresh(ctx);
+		if (rc || (rc = pfx_sell_place(ctx)))
+			return rc;
+		// the single-precision copies of an existing hierarchy: level 0 and every level that multiplies through the slice format
+		pfx_amg *A = ctx->amg;
+		if (A && ctx->amg_params.mixed_precision)
+			for (auto &L : A->lv)
+				if (!L.small && L.m && L.m->d_sell_vals32 && (rc = pfx_sell_place32(L.m)))
+				{
+					if (L.m != ctx)
+						ctx->err = L.m->err;
+					return rc;
+				}
+		return PFX_OK;
+	}
+
 	pfx_status pfx_amg_get_info(pfx_ctx *ctx, pfx_amg_info *info)
 	{
 		if (!ctx || !info)

@@ -301,6 +301,9 @@ pfx_status pfx_dist_cg_run(pfx_dist *dist, const double *d_b, double *d_x, int p
 			DIST_CTX(pfx_cgs_direction_impl(ctx, it, scal));
 		}
 		DIST_CTX(pfx_cgs_status_impl(ctx, &done, &its, &rr, &bb));
+		// every rank reaches this point at the same iteration and searches for itself (no communication inside)
+		if (!done && !ctx->sell_placed && it >= PFX_PLACE_AFTER && max_iter - it >= PFX_PLACE_WORTH)
+			DIST_CTX(pfx_sell_place(ctx));
 	}
 	if (max_iter <= 0)
 		DIST_CTX(pfx_cgs_status_impl(ctx, &done, &its, &rr, &bb));

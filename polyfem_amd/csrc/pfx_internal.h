@@ -205,6 +205,8 @@ struct pfx_ctx
 	int64_t *d_sell_base = nullptr;
 	double *d_sell_vals = nullptr;
 	float *d_sell_vals32 = nullptr;  // single-precision copy for the products inside the AMG preconditioner
+	bool sell_placed = false;        // the placement search has run for the current d_sell_vals (pfx_sell_place)
+	bool sell32_placed = false;      // ... for the current d_sell_vals32 (pfx_sell_place32)
 	int64_t sell32_gen = -1;
 	int64_t sell_slices = 0, sell_rows = 0, sell_owned = -1;
 	int64_t values_gen = 0, sell_gen = -1; // assembly counter / counter value the solver copy was made from
@@ -367,6 +369,10 @@ struct pfx_scoped_timer
 void pfx_fill_tables(int kind, int quad_order, pfx_tables *t);
 void pfx_fill_tables_mass(int kind, pfx_tables *t);
 pfx_status pfx_pattern_build(pfx_ctx *ctx);
+pfx_status pfx_sell_place32(pfx_ctx *ctx);
+pfx_status pfx_sell_place(pfx_ctx *ctx); // placement search for the solver's value array; the CG loops call it once a solve has proven long
+#define PFX_PLACE_AFTER 192             // CG iterations of one solve before the search
+#define PFX_PLACE_WORTH 256             // ... and only if at least this many iterations may still follow
 pfx_status pfx_launch_local_linear(pfx_ctx *ctx);                                                   // strict arithmetic
 // d_eloc_out: where the per-element energies go (null: the context's buffer)
 pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, bool grad, bool hess, double *d_eloc_out = nullptr);

@@ -415,6 +415,8 @@ void pfx_sell_release(pfx_ctx *ctx)
 	ctx->sell_interior = 0;
 	ctx->sell_owned = -1;
 	ctx->sell_gen = -1;
+	ctx->sell_placed = false;
+	ctx->sell32_placed = false;
 }
 
 // structure: once per (pattern, owned range)
@@ -550,11 +552,13 @@ static pfx_status sell_convert(pfx_ctx *ctx, V *out)
 // Placement search for a freshly allocated value array.  The speed of the product depends on WHICH physical pages the
 // value stream lies in: re-allocating nothing but this array moves a 30 GB product between 4.85 and 5.35 ms at one and
 // the same virtual address (the single-precision copy: 2.7 to 3.3 ms), and the allocator hands out a different set of pages
-// each time while the previous array is still held.  So the first allocation per pattern tries a few placements -- allocate
-// a candidate beside the current array, fill it, time three products, keep the faster, free the other -- and keeps the
-// best (or the first that streams the values at 0.74 of the HBM peak).  Costs one conversion and four products per try, once
-// per pattern; more than about eight tries make the allocator itself slow.  Skipped for arrays below PFX_PLACEMENT_MIN_BYTES
-// (PFX_PLACEMENT_MIN_MB in the environment overrides it),
+// each time while the previous array is still held.  So a solve that has proven long (pfx_sell_place, called by the CG loops
+// after their first 192 iterations) tries a few placements -- allocate a candidate beside the current array, fill it, time
+// three products, keep the faster, free the other -- and keeps the best (or the first that streams the values at 0.74 of the
+// HBM peak).  Costs one conversion and four products per try, once per pattern.  Not done at allocation: the freed candidates
+// keep the driver's allocator busy for seconds (about one second per 12 GB freed), which a CG loop in flight does not
+// notice and a set-up phase that allocates right afterwards does (an AMG set-up after an eager search took 3 - 6 s instead
+// of 0.4 s).  Skipped for arrays below PFX_PLACEMENT_MIN_BYTES (PFX_PLACEMENT_MIN_MB in the environment overrides it),
 // when the device has no room for a second copy, and with PFX_PLACEMENT_TRIES=0 in the environment (default 6).
 #ifndef PFX_PLACEMENT_MIN_BYTES
 #define PFX_PLACEMENT_MIN_BYTES ((size_t)1 << 30)
@@ -673,10 +677,28 @@ pfx_status pfx_sell_refresh(pfx_ctx *ctx)
 				return rc;
 		}
 		ctx->sell_gen = ctx->values_gen;
-		if (fresh && (rc = sell_place<double>(ctx, ctx->d_sell_vals, count, false)))
-			return rc;
+		if (fresh)
+			ctx->sell_placed = false;
 	}
 	return PFX_OK;
+}
+
+// placement search for the solver's value array, once per allocation (see sell_place)
+pfx_status pfx_sell_place(pfx_ctx *ctx)
+{
+	if (ctx->sell_placed || !ctx->d_sell_vals)
+		return PFX_OK;
+	ctx->sell_placed = true;
+	return sell_place<double>(ctx, ctx->d_sell_vals, ctx->sell_rows * SL * ctx->bs * ctx->bs + 2, false);
+}
+
+// the same for the single-precision copy (only on request, pfx_tune_placement: the preconditioner's solves are short)
+pfx_status pfx_sell_place32(pfx_ctx *ctx)
+{
+	if (ctx->sell32_placed || !ctx->d_sell_vals32)
+		return PFX_OK;
+	ctx->sell32_placed = true;
+	return sell_place<float>(ctx, ctx->d_sell_vals32, ctx->sell_rows * SL * ctx->bs * ctx->bs + 4, true);
 }
 
 // the single-precision copy of the matrix the AMG preconditioner multiplies with (structure shared with the solver copy)
@@ -690,10 +712,13 @@ pfx_status pfx_sell_refresh32(pfx_ctx *ctx)
 	}
 	if (ctx->sell32_gen != ctx->values_gen || !ctx->d_sell_vals32)
 	{
-		const bool fresh = !ctx->d_sell_vals32;
 		const int64_t count = ctx->sell_rows * SL * ctx->bs * ctx->bs + 4;
-		if (fresh && pfx_alloc(ctx, &ctx->d_sell_vals32, count))
-			return PFX_ERR_HIP;
+		if (!ctx->d_sell_vals32)
+		{
+			if (pfx_alloc(ctx, &ctx->d_sell_vals32, count))
+				return PFX_ERR_HIP;
+			ctx->sell32_placed = false;
+		}
 		pfx_status rc;
 		{
 			pfx_scoped_timer tm(ctx, "sell_convert32");
@@ -701,8 +726,6 @@ pfx_status pfx_sell_refresh32(pfx_ctx *ctx)
 				return rc;
 		}
 		ctx->sell32_gen = ctx->values_gen;
-		if (fresh && (rc = sell_place<float>(ctx, ctx->d_sell_vals32, count, true)))
-			return rc;
 	}
 	return PFX_OK;
 }

@@ -624,6 +624,10 @@ pfx_status pfx_cg_run(pfx_ctx *ctx, const double *d_b, double *d_x, int precond,
 				return rc;
 		if ((rc = pfx_cgs_status_impl(ctx, &done, &its, &rr, &bb)))
 			return rc;
+		// a long solve: worth finding a good placement for the value array (between two iterations the slice-ordered
+		// product buffer is free)
+		if (!done && !ctx->sell_placed && it >= PFX_PLACE_AFTER && max_iter - it >= PFX_PLACE_WORTH && (rc = pfx_sell_place(ctx)))
+			return rc;
 	}
 	if (max_iter <= 0 && (rc = pfx_cgs_status_impl(ctx, &done, &its, &rr, &bb)))
 		return rc;

@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "pfx_solver_get_layout", "pfx_matrix_generation",
     "pfx_comm_rccl_unique_id", "pfx_comm_create_rccl", "pfx_comm_create_host", "pfx_comm_destroy", "pfx_comm_last_error",
     "pfx_dist_create", "pfx_dist_destroy", "pfx_dist_last_error", "pfx_dist_halo_exchange_dev", "pfx_dist_all_reduce_dev",
-    "pfx_dist_energy_dev", "pfx_dist_cg_dev", "pfx_dist_halo_bytes", "pfx_dist_amg_apply_dev", "pfx_dist_newton_dev", "pfx_dist_implicit_euler_step_dev",
+    "pfx_dist_energy_dev", "pfx_dist_cg_dev", "pfx_dist_halo_bytes", "pfx_dist_amg_apply_dev", "pfx_dist_newton_dev", "pfx_dist_implicit_euler_step_dev", "pfx_tune_placement",
 ]
 
 
@@ -248,6 +248,7 @@ def load():
         "pfx_dist_cg_dev": [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, C.POINTER(C.c_int), _pd],
         "pfx_dist_newton_dev": [_vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
         "pfx_dist_implicit_euler_step_dev": [_vp, _dbl, _vp, _vp, _vp, _vp, C.POINTER(NewtonParams), C.POINTER(NewtonInfo)],
+        "pfx_tune_placement": [_vp],
         "pfx_dist_halo_bytes": [_vp, _pi64],
         "pfx_dist_amg_apply_dev": [_vp, _vp, _vp],
     }
@@ -806,6 +807,11 @@ class Engine:
         bs, nb, ne = C.c_int(), C.c_int64(), C.c_int64()
         self._ck(self.L.pfx_solver_get_layout(self.h, C.byref(bs), C.byref(nb), C.byref(ne)))
         return bs.value, nb.value, ne.value
+
+    def tune_placement(self):
+        """pfx_tune_placement: search a fast placement for the solver's value array and the single-precision copies of an
+        existing AMG hierarchy now (the CG loops do it by themselves for the former once a solve has proven long)."""
+        self._ck(self.L.pfx_tune_placement(self.h))
 
     def matrix_generation(self) -> int:
         g = C.c_int64()
