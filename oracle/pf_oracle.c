@@ -44,20 +44,27 @@ int pfo_n_loc(int kind)
 		return 8;
 	case PFO_Q2HEX:
 		return 27;
+	case PFO_P1TRI:
+		return 3;
+	case PFO_P2TRI:
+		return 6;
 	}
 	return -1;
 }
 
 int pfo_order_of(int kind)
 {
-	return (kind == PFO_P1TET || kind == PFO_Q1HEX) ? 1 : 2;
+	return (kind == PFO_P1TET || kind == PFO_Q1HEX || kind == PFO_P1TRI) ? 1 : 2;
 }
 
 static int is_hex(int kind) { return kind == PFO_Q1HEX || kind == PFO_Q2HEX; }
+static int is_tri(int kind) { return kind == PFO_P1TRI || kind == PFO_P2TRI; }
+int pfo_kind_dim(int kind) { return is_tri(kind) ? 2 : 3; }
 
 /* utils/ElasticityUtils.cpp:203-214 */
 double pfo_lambda_from_E_nu(double E, double nu) { return (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu)); }
 double pfo_mu_from_E_nu(double E, double nu) { return E / (2.0 * (1.0 + nu)); }
+double pfo_lambda_from_E_nu_2d(double E, double nu) { return (nu * E) / (1.0 - nu * nu); } /* :208, is_volume == false */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* quadrature                                                                                       */
@@ -95,6 +102,42 @@ int pfo_tet_quadrature(int order, pfo_quad *q)
 		q->pts[k][1] = p[3 * k + 1];
 		q->pts[k][2] = p[3 * k + 2];
 		q->w[k] = w[k] / 6;
+	}
+	return 0;
+}
+
+/* quadrature/TriQuadrature.cpp:30-43 : table lookup (autogen/auto_triangle.ipp), then weights /= 2 */
+int pfo_tri_quadrature(int order, pfo_quad *q)
+{
+	const double *p = NULL, *w = NULL;
+	int n = 0;
+	switch (order)
+	{
+	case 1:
+		p = pf_tri_pts_1, w = pf_tri_wts_1, n = PF_TRI_NPTS_1;
+		break;
+	case 2:
+		p = pf_tri_pts_2, w = pf_tri_wts_2, n = PF_TRI_NPTS_2;
+		break;
+	case 3:
+		p = pf_tri_pts_3, w = pf_tri_wts_3, n = PF_TRI_NPTS_3;
+		break;
+	case 4:
+		p = pf_tri_pts_4, w = pf_tri_wts_4, n = PF_TRI_NPTS_4;
+		break;
+	case 5:
+		p = pf_tri_pts_5, w = pf_tri_wts_5, n = PF_TRI_NPTS_5;
+		break;
+	default:
+		return -1;
+	}
+	q->n_pts = n;
+	for (int k = 0; k < n; ++k)
+	{
+		q->pts[k][0] = p[2 * k + 0];
+		q->pts[k][1] = p[2 * k + 1];
+		q->pts[k][2] = 0;
+		q->w[k] = w[k] / 2;
 	}
 	return 0;
 }
@@ -167,13 +210,15 @@ int pfo_hex_quadrature(int order, pfo_quad *q)
 	return 0;
 }
 
-/* basis/FEBasis3d.cpp:1467 (hex), :1506 (tet): real_order = max(quadrature_order, 2(p-1)+1) */
+/* basis/FEBasis3d.cpp:1467 (hex), :1506 (tet), basis/FEBasis2d.cpp:797 (triangle): real_order = max(quadrature_order, 2(p-1)+1) */
 int pfo_element_quadrature(int kind, int quad_order, pfo_quad *q)
 {
 	const int p = pfo_order_of(kind);
 	int real_order = (p - 1) * 2 + 1;
 	if (quad_order > real_order)
 		real_order = quad_order;
+	if (is_tri(kind))
+		return pfo_tri_quadrature(real_order, q);
 	return is_hex(kind) ? pfo_hex_quadrature(real_order, q) : pfo_tet_quadrature(real_order, q);
 }
 
@@ -183,6 +228,8 @@ int pfo_mass_quadrature(int kind, pfo_quad *q)
 {
 	const int p = pfo_order_of(kind);
 	const int real_mass_order = p * 2 + 1;
+	if (is_tri(kind)) /* basis/FEBasis2d.cpp:798 */
+		return pfo_tri_quadrature(real_mass_order, q);
 	return is_hex(kind) ? pfo_hex_quadrature(real_mass_order, q) : pfo_tet_quadrature(real_mass_order, q);
 }
 
@@ -350,6 +397,18 @@ void pfo_basis_nodes(int kind, double *nodes)
 			for (int c = 0; c < 3; ++c)
 				nodes[3 * i + c] = q2_node[i][c] / 2.0;
 		break;
+	case PFO_P1TRI: /* auto_p_bases.cpp:138-144 (third coordinate 0) */
+	{
+		static const double t1[3][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
+		memcpy(nodes, t1, sizeof(t1));
+		break;
+	}
+	case PFO_P2TRI: /* auto_p_bases.cpp:275-284 */
+	{
+		static const double t2[6][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {1.0 / 2.0, 0, 0}, {1.0 / 2.0, 1.0 / 2.0, 0}, {0, 1.0 / 2.0, 0}};
+		memcpy(nodes, t2, sizeof(t2));
+		break;
+	}
 	}
 }
 
@@ -426,6 +485,43 @@ void pfo_basis_value(int kind, int li, const double *pt, double *val)
 	case PFO_Q2HEX: /* auto_q_bases.cpp:1277-1418, factors multiplied in the printed order (pf_q2_tables.h) */
 		*val = qeval2(&pf_q2_val[li], pt);
 		break;
+	case PFO_P1TRI: /* auto_p_bases.cpp:60-86 */
+		switch (li)
+		{
+		case 0:
+			*val = -x - y + 1;
+			break;
+		case 1:
+			*val = x;
+			break;
+		case 2:
+			*val = y;
+			break;
+		}
+		break;
+	case PFO_P2TRI: /* auto_p_bases.cpp:146-187 */
+		switch (li)
+		{
+		case 0:
+			*val = (x + y - 1) * (2 * x + 2 * y - 1);
+			break;
+		case 1:
+			*val = x * (2 * x - 1);
+			break;
+		case 2:
+			*val = y * (2 * y - 1);
+			break;
+		case 3:
+			*val = -4 * x * (x + y - 1);
+			break;
+		case 4:
+			*val = 4 * x * y;
+			break;
+		case 5:
+			*val = -4 * y * (x + y - 1);
+			break;
+		}
+		break;
 	}
 }
 
@@ -483,6 +579,36 @@ void pfo_basis_grad(int kind, int li, const double *pt, double *g)
 		for (int c = 0; c < 3; ++c)
 			g[c] = qeval2(&pf_q2_grad[li][c], pt);
 		break;
+	case PFO_P1TRI: /* auto_p_bases.cpp:87-136 */
+	{
+		static const double t[3][2] = {{-1, -1}, {1, 0}, {0, 1}};
+		g[0] = t[li][0], g[1] = t[li][1], g[2] = 0;
+		break;
+	}
+	case PFO_P2TRI: /* auto_p_bases.cpp:188-273 */
+		g[2] = 0;
+		switch (li)
+		{
+		case 0:
+			g[0] = g[1] = 4 * x + 4 * y - 3;
+			break;
+		case 1:
+			g[0] = 4 * x - 1, g[1] = 0;
+			break;
+		case 2:
+			g[0] = 0, g[1] = 4 * y - 1;
+			break;
+		case 3:
+			g[0] = 4 * (-2 * x - y + 1), g[1] = -4 * x;
+			break;
+		case 4:
+			g[0] = 4 * y, g[1] = 4 * x;
+			break;
+		case 5:
+			g[0] = -4 * y, g[1] = 4 * (-x - 2 * y + 1);
+			break;
+		}
+		break;
 	}
 }
 
@@ -536,6 +662,44 @@ double pfo_determinant3(const double *m)
 /* ElementAssemblyValues::compute + finalize3d                                                      */
 /* ------------------------------------------------------------------------------------------------ */
 
+/* ElementAssemblyValues::finalize2d (assembler/ElementAssemblyValues.cpp:161-197): Jacobian rows summed over the
+ * geometry bases, det = Eigen's 2x2 determinant (Eigen/src/LU/Determinant.h: m(0,0) m(1,1) - m(1,0) m(0,1)), jac_it =
+ * transposed 2x2 inverse (Eigen/src/LU/InverseImpl.h compute_inverse_size2_helper: invdet = 1/det; (0,0) = m(1,1) invdet,
+ * (1,0) = -m(1,0) invdet, (0,1) = -m(0,1) invdet, (1,1) = m(0,0) invdet), physical gradients grad.row(k) * jac_it.  The 2x2
+ * matrices sit in the upper left of the 3x3 slots, everything else is zero.  Eigen un-vendored: parity unpinned. */
+static void finalize2d(const pfo_mesh *mesh, int64_t e, const pfo_quad *quad, pfo_vals *v)
+{
+	const int n_g = pfo_n_loc(mesh->gkind);
+	for (int k = 0; k < quad->n_pts; ++k)
+	{
+		double t00 = 0, t01 = 0, t10 = 0, t11 = 0;
+		for (int j = 0; j < n_g; ++j)
+		{
+			double gg[3];
+			pfo_basis_grad(mesh->gkind, j, quad->pts[k], gg);
+			const double *node = mesh->xyz + 2 * (int64_t)mesh->gconn[e * n_g + j];
+			const double gval = 1.0; /* Local2Global.val */
+			t00 += gg[0] * node[0] * gval, t01 += gg[0] * node[1] * gval;
+			t10 += gg[1] * node[0] * gval, t11 += gg[1] * node[1] * gval;
+		}
+		const double det = t00 * t11 - t10 * t01;
+		v->det[k] = det;
+		const double invdet = 1.0 / det;
+		const double i00 = t11 * invdet, i10 = -t10 * invdet, i01 = -t01 * invdet, i11 = t00 * invdet;
+		double *jt = v->jac_it[k];
+		for (int q = 0; q < 9; ++q)
+			jt[q] = 0;
+		M(jt, 0, 0) = i00, M(jt, 0, 1) = i10, M(jt, 1, 0) = i01, M(jt, 1, 1) = i11;
+		for (int j = 0; j < v->n_loc; ++j)
+		{
+			const double *g = v->grad[j][k];
+			v->grad_t_m[j][k][0] = g[0] * M(jt, 0, 0) + g[1] * M(jt, 1, 0);
+			v->grad_t_m[j][k][1] = g[0] * M(jt, 0, 1) + g[1] * M(jt, 1, 1);
+			v->grad_t_m[j][k][2] = 0;
+		}
+	}
+}
+
 /* assembler/ElementAssemblyValues.cpp:205-351 and :94-133.  Local2Global lists have size 1, val 1.0. */
 void pfo_compute_vals(const pfo_mesh *mesh, int64_t e, const pfo_quad *quad, pfo_vals *v)
 {
@@ -544,6 +708,7 @@ void pfo_compute_vals(const pfo_mesh *mesh, int64_t e, const pfo_quad *quad, pfo
 	const int m = quad->n_pts;
 	v->n_pts = m;
 	v->n_loc = n_loc;
+	v->dim = pfo_kind_dim(mesh->kind);
 	v->quad = *quad;
 
 	for (int j = 0; j < n_loc; ++j)
@@ -553,6 +718,11 @@ void pfo_compute_vals(const pfo_mesh *mesh, int64_t e, const pfo_quad *quad, pfo
 			pfo_basis_grad(mesh->kind, j, quad->pts[k], v->grad[j][k]);
 		}
 
+	if (v->dim == 2)
+	{
+		finalize2d(mesh, e, quad, v);
+		return;
+	}
 	for (int k = 0; k < m; ++k)
 	{
 		double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -997,8 +1167,13 @@ void pfo_local_saint_venant_hessian(const pfo_vals *v, const double *da, const d
 static int is_nl_model(int model) { return model == PFO_NEOHOOKEAN || model == PFO_LINEAR_ELASTICITY || model == PFO_SAINT_VENANT || model == PFO_MULTI_MODEL; }
 /* MultiModel (assembler/MultiModel.cpp:42-96) picks the local assembler by the element id */
 static int mat_model(const pfo_material *mat, int64_t e) { return (mat->model == PFO_MULTI_MODEL && mat->model_e) ? mat->model_e[e] : mat->model; }
+static double local_linear_elasticity_energy_2d(const pfo_vals *v, const double *da, const double *ld, double lambda, double mu);
+static void local_linear_elasticity_grad_2d(const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *G);
+static void local_linear_elasticity_hessian_2d(const pfo_vals *v, const double *da, double lambda, double mu, double *H);
 static double nl_local_energy(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu)
 {
+	if (v->dim == 2) /* triangles: NeoHookean and LinearElasticity only (checked by the callers) */
+		return model == PFO_NEOHOOKEAN ? pfo_local_neohookean_energy_2d(v, da, ld, lambda, mu) : local_linear_elasticity_energy_2d(v, da, ld, lambda, mu);
 	if (model == PFO_NEOHOOKEAN)
 		return pfo_local_neohookean_energy(v, da, ld, lambda, mu);
 	if (model == PFO_SAINT_VENANT)
@@ -1167,6 +1342,173 @@ void pfo_local_neohookean_hessian(const pfo_vals *v, const double *da, const dou
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* 2-D (triangles): the dim == 2 branches of the local assemblers                                   */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* F = local_disp^T * grad(p) * jac_it(p) + id * I, 2 x 2 row-major; local_disp is n_loc x 2 */
+static void def_grad_at_2d(const pfo_vals *v, int p, const double *local_disp, double *F, double id)
+{
+	double A[4];
+	for (int d = 0; d < 2; ++d)
+		for (int c = 0; c < 2; ++c)
+		{
+			double s = 0;
+			for (int i = 0; i < v->n_loc; ++i)
+				s += local_disp[2 * i + d] * v->grad[i][p][c];
+			A[2 * d + c] = s;
+		}
+	const double *jt = v->jac_it[p];
+	for (int d = 0; d < 2; ++d)
+		for (int c = 0; c < 2; ++c)
+		{
+			const double s = A[2 * d] * M(jt, 0, c) + A[2 * d + 1] * M(jt, 1, c);
+			F[2 * d + c] = (id != 0.0) ? s + (d == c ? id : 0.0) : s;
+		}
+}
+
+/* NeoHookeanElasticity.cpp:250-331 with size() == 2; determinant of utils/MatrixUtils.hpp:16-30 (2 x 2 branch) */
+double pfo_local_neohookean_energy_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu)
+{
+	double energy = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[4];
+		def_grad_at_2d(v, p, local_disp, F, 1.0);
+		const double log_det_j = log(F[0] * F[3] - F[1] * F[2]);
+		double tr = 0;
+		for (int k = 0; k < 4; ++k)
+			tr += F[k] * F[k];
+		const double val = mu / 2 * (tr - 2 - 2 * log_det_j) + lambda / 2 * log_det_j * log_det_j;
+		energy += val * da[p];
+	}
+	return energy;
+}
+
+/* NeoHookeanElasticity.cpp:364-453, dim == 2 branch (:410-417): delJ_delF = [[F11, -F10], [-F01, F00]].
+ * G is n_loc x 2 flattened node-major. */
+void pfo_local_neohookean_grad_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G)
+{
+	const int n = v->n_loc;
+	for (int k = 0; k < 2 * n; ++k)
+		G[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[4], dJ[4], T[4];
+		def_grad_at_2d(v, p, local_disp, F, 1.0);
+		const double J = F[0] * F[3] - F[2] * F[1]; /* Eigen 2x2 determinant */
+		const double log_det_j = log(J);
+		dJ[0] = F[3], dJ[1] = -F[2], dJ[2] = -F[1], dJ[3] = F[0];
+		for (int k = 0; k < 4; ++k)
+			T[k] = mu * F[k] - mu * (1 / J) * dJ[k] + lambda * log_det_j * (1 / J) * dJ[k];
+		const double *jt = v->jac_it[p];
+		for (int i = 0; i < n; ++i)
+		{
+			double dFdU[2];
+			for (int c = 0; c < 2; ++c)
+				dFdU[c] = v->grad[i][p][0] * M(jt, 0, c) + v->grad[i][p][1] * M(jt, 1, c);
+			for (int d = 0; d < 2; ++d)
+				G[2 * i + d] += (dFdU[0] * T[2 * d] + dFdU[1] * T[2 * d + 1]) * da[p];
+		}
+	}
+}
+
+/* NeoHookeanElasticity.cpp:455-565, dim == 2 branch (:501-512).  vec() is column-major: index(r,c) = c*2 + r;
+ * del2J_delF2(0,3) = del2J_delF2(3,0) = 1, (1,2) = (2,1) = -1.  H is (2n x 2n) row-major, index i*2 + d. */
+void pfo_local_neohookean_hessian_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H)
+{
+	const int n = v->n_loc, N = 2 * n;
+	for (int k = 0; k < N * N; ++k)
+		H[k] = 0;
+	double *B = (double *)malloc(sizeof(double) * 4 * N);
+	double *HB = (double *)malloc(sizeof(double) * 4 * N);
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double F[4];
+		def_grad_at_2d(v, p, local_disp, F, 1.0);
+		const double J = F[0] * F[3] - F[2] * F[1];
+		const double log_det_j = log(J);
+		/* delJ_delF row-major [[F11, -F10], [-F01, F00]], flattened column-major */
+		const double gj[4] = {F[3], -F[1], -F[2], F[0]};
+		double d2[16];
+		for (int k = 0; k < 16; ++k)
+			d2[k] = 0;
+		d2[0 * 4 + 3] = 1, d2[1 * 4 + 2] = -1, d2[2 * 4 + 1] = -1, d2[3 * 4 + 0] = 1;
+		const double c1 = (mu + lambda * (1 - log_det_j)) / (J * J);
+		const double c2 = (lambda * log_det_j - mu) / (J);
+		double ht[16];
+		for (int r = 0; r < 4; ++r)
+			for (int c = 0; c < 4; ++c)
+				ht[r * 4 + c] = (r == c ? mu : 0.0) + c1 * (gj[r] * gj[c]) + c2 * d2[r * 4 + c];
+		const double *jt = v->jac_it[p];
+		for (int k = 0; k < 4 * N; ++k)
+			B[k] = 0;
+		for (int i = 0; i < n; ++i)
+		{
+			double dFdU[2];
+			for (int c = 0; c < 2; ++c)
+				dFdU[c] = v->grad[i][p][0] * M(jt, 0, c) + v->grad[i][p][1] * M(jt, 1, c);
+			/* column (i*2+j) = vec(temp), temp.row(j) = dFdU */
+			for (int j = 0; j < 2; ++j)
+				for (int c = 0; c < 2; ++c)
+					B[(c * 2 + j) * N + (i * 2 + j)] = dFdU[c];
+		}
+		for (int r = 0; r < 4; ++r)
+			for (int c = 0; c < N; ++c)
+			{
+				double s = 0;
+				for (int k = 0; k < 4; ++k)
+					s += ht[r * 4 + k] * B[k * N + c];
+				HB[r * N + c] = s;
+			}
+		for (int r = 0; r < N; ++r)
+			for (int c = 0; c < N; ++c)
+			{
+				double s = 0;
+				for (int k = 0; k < 4; ++k)
+					s += B[k * N + r] * HB[k * N + c];
+				H[r * N + c] += s * da[p];
+			}
+	}
+	free(B);
+	free(HB);
+}
+
+/* LinearElasticity through the nonlinear interface in 2-D (LinearElasticity.cpp:56-169 is written for any size()): the
+ * 3-D routines applied to the displacements padded with a zero third component (jac_it and the gradients carry zeros
+ * there), in-plane entries taken */
+static void pad_disp_2d(const pfo_vals *v, const double *ld2, double *ld3)
+{
+	for (int i = 0; i < v->n_loc; ++i)
+		ld3[3 * i] = ld2[2 * i], ld3[3 * i + 1] = ld2[2 * i + 1], ld3[3 * i + 2] = 0;
+}
+static double local_linear_elasticity_energy_2d(const pfo_vals *v, const double *da, const double *ld, double lambda, double mu)
+{
+	double ld3[3 * PFO_MAX_LOC];
+	pad_disp_2d(v, ld, ld3);
+	return pfo_local_linear_elasticity_energy(v, da, ld3, lambda, mu);
+}
+static void local_linear_elasticity_grad_2d(const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *G)
+{
+	double ld3[3 * PFO_MAX_LOC], G3[3 * PFO_MAX_LOC];
+	pad_disp_2d(v, ld, ld3);
+	pfo_local_linear_elasticity_grad(v, da, ld3, lambda, mu, G3);
+	for (int i = 0; i < v->n_loc; ++i)
+		G[2 * i] = G3[3 * i], G[2 * i + 1] = G3[3 * i + 1];
+}
+static void local_linear_elasticity_hessian_2d(const pfo_vals *v, const double *da, double lambda, double mu, double *H)
+{
+	const int n = v->n_loc, N3 = 3 * n, N = 2 * n;
+	double *H3 = (double *)malloc(sizeof(double) * (size_t)(N3 * N3));
+	pfo_local_linear_elasticity_hessian(v, da, lambda, mu, H3);
+	for (int i = 0; i < n; ++i)
+		for (int a = 0; a < 2; ++a)
+			for (int j = 0; j < n; ++j)
+				for (int b = 0; b < 2; ++b)
+					H[(2 * i + a) * N + 2 * j + b] = H3[(3 * i + a) * N3 + 3 * j + b];
+	free(H3);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* triplets -> CSC  (Eigen::SparseMatrix::setFromTriplets: duplicates summed in insertion order,     */
 /* explicit zeros kept, inner indices ascending)                                                     */
 /* ------------------------------------------------------------------------------------------------ */
@@ -1319,6 +1661,14 @@ static double nl_local_energy_mat(int model, const pfo_vals *v, const double *da
 }
 static void nl_local_grad(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *G)
 {
+	if (v->dim == 2)
+	{
+		if (model == PFO_NEOHOOKEAN)
+			pfo_local_neohookean_grad_2d(v, da, ld, lambda, mu, G);
+		else
+			local_linear_elasticity_grad_2d(v, da, ld, lambda, mu, G);
+		return;
+	}
 	if (model == PFO_NEOHOOKEAN)
 		pfo_local_neohookean_grad(v, da, ld, lambda, mu, G);
 	else if (model == PFO_SAINT_VENANT)
@@ -1328,6 +1678,14 @@ static void nl_local_grad(int model, const pfo_vals *v, const double *da, const 
 }
 static void nl_local_hessian(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *H)
 {
+	if (v->dim == 2)
+	{
+		if (model == PFO_NEOHOOKEAN)
+			pfo_local_neohookean_hessian_2d(v, da, ld, lambda, mu, H);
+		else
+			local_linear_elasticity_hessian_2d(v, da, lambda, mu, H);
+		return;
+	}
 	if (model == PFO_NEOHOOKEAN)
 		pfo_local_neohookean_hessian(v, da, ld, lambda, mu, H);
 	else if (model == PFO_SAINT_VENANT)
@@ -1342,7 +1700,7 @@ static void nl_local_grad_mat(int model, const pfo_vals *v, const double *da, co
 		pfo_local_saint_venant_grad_t(v, da, ld, 0, 0, mat->tensor, G);
 		return;
 	}
-	const int np = mat_points(mat), N = v->n_loc * 3;
+	const int np = mat_points(mat), N = v->n_loc * v->dim;
 	if (!np)
 	{
 		nl_local_grad(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), G);
@@ -1366,7 +1724,7 @@ static void nl_local_hessian_mat(int model, const pfo_vals *v, const double *da,
 		pfo_local_saint_venant_hessian_t(v, da, ld, 0, 0, mat->tensor, H);
 		return;
 	}
-	const int np = mat_points(mat), N = v->n_loc * 3;
+	const int np = mat_points(mat), N = v->n_loc * v->dim;
 	if (!np)
 	{
 		nl_local_hessian(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e), H);
@@ -1387,6 +1745,15 @@ static void nl_local_hessian_mat(int model, const pfo_vals *v, const double *da,
 }
 
 static int block_size(const pfo_material *mat) { return mat->model == PFO_LAPLACIAN ? 1 : mat->dim; }
+/* triangles: Laplacian, LinearElasticity and NeoHookean with dim == 2; every other mesh: dim == 3 */
+static int model_fits_mesh(const pfo_mesh *mesh, const pfo_material *mat)
+{
+	if (!is_tri(mesh->kind))
+		return mat->model == PFO_LAPLACIAN || mat->dim == 3;
+	if (mat->model == PFO_LAPLACIAN)
+		return 1;
+	return mat->dim == 2 && (mat->model == PFO_LINEAR_ELASTICITY || mat->model == PFO_NEOHOOKEAN);
+}
 
 typedef struct
 {
@@ -1473,9 +1840,10 @@ void pfo_project_to_psd(double *a, int n)
 static void gather_local_disp(const pfo_mesh *mesh, int64_t e, int n_loc, const double *x, double *ld)
 {
 	/* NeoHookeanElasticity.cpp:371-383 ; global list of size 1 with val 1.0 */
+	const int size = pfo_kind_dim(mesh->kind);
 	for (int i = 0; i < n_loc; ++i)
-		for (int d = 0; d < 3; ++d)
-			ld[3 * i + d] = 0 + 1.0 * x[(int64_t)mesh->conn[e * n_loc + i] * 3 + d];
+		for (int d = 0; d < size; ++d)
+			ld[size * i + d] = 0 + 1.0 * x[(int64_t)mesh->conn[e * n_loc + i] * size + d];
 }
 
 static void *job_run(void *arg)
@@ -1512,6 +1880,8 @@ static void *job_run(void *arg)
 						pfo_local_hooke(v, i, j, da, mat->tensor, sv);
 					else
 						local_linear_elasticity_mat(v, i, j, da, mat, e, sv);
+					if (size == 2) /* LinearElasticity::assemble with size() == 2: the in-plane entries, index jj*2+ii (the third components of the gradients are zero) */
+						sv[2] = sv[3], sv[3] = sv[4];
 					for (int n = 0; n < size; ++n)
 						for (int m = 0; m < size; ++m)
 						{
@@ -1640,6 +2010,8 @@ int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_thr
 {
 	if (mat->model != PFO_LAPLACIAN && mat->model != PFO_LINEAR_ELASTICITY && !(mat->model == PFO_HOOKE_LINEAR && mat->tensor))
 		return -1;
+	if (!model_fits_mesh(mesh, mat))
+		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, NULL, 0, &nt, 0);
 	run_jobs(jobs, nt);
@@ -1651,6 +2023,8 @@ int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_thr
 /* assembler/Assembler.cpp:638-678 */
 double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads)
 {
+	if (!model_fits_mesh(mesh, mat))
+		return NAN;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 1, &nt, 0);
 	run_jobs(jobs, nt);
@@ -1664,7 +2038,7 @@ double pfo_assemble_energy(const pfo_mesh *mesh, const pfo_material *mat, const 
 /* assembler/Assembler.cpp:427-504 */
 int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, double *rhs)
 {
-	if (!is_nl_model(mat->model))
+	if (!is_nl_model(mat->model) || !model_fits_mesh(mesh, mat))
 		return -1;
 	const int64_t N = mesh->n_nodes * block_size(mat);
 	int nt = n_threads;
@@ -1685,7 +2059,7 @@ int pfo_assemble_gradient(const pfo_mesh *mesh, const pfo_material *mat, const d
 /* assembler/Assembler.cpp:506-636, first (pattern-building) pass: triplets of every local entry */
 int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
 {
-	if (!is_nl_model(mat->model))
+	if (!is_nl_model(mat->model) || !model_fits_mesh(mesh, mat))
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 3, &nt, 0);
@@ -1697,7 +2071,7 @@ int pfo_assemble_hessian(const pfo_mesh *mesh, const pfo_material *mat, const do
 
 int pfo_assemble_hessian_psd(const pfo_mesh *mesh, const pfo_material *mat, const double *x, int n_threads, pfo_csc *out)
 {
-	if (!is_nl_model(mat->model))
+	if (!is_nl_model(mat->model) || !model_fits_mesh(mesh, mat))
 		return -1;
 	int nt = n_threads;
 	job *jobs = make_jobs(mesh, mat, x, 4, &nt, 0);
@@ -2775,7 +3149,7 @@ int pfo_mass_quadrature_points(const pfo_mesh *mesh, double *pts)
 
 static int quadrature_points_impl(const pfo_mesh *mesh, int mass_rule, double *pts)
 {
-	const int n_g = pfo_n_loc(mesh->gkind);
+	const int n_g = pfo_n_loc(mesh->gkind), dim = pfo_kind_dim(mesh->kind);
 	pfo_quad quad;
 	if (mass_rule)
 		pfo_mass_quadrature(mesh->kind, &quad);
@@ -2789,12 +3163,12 @@ static int quadrature_points_impl(const pfo_mesh *mesh, int mass_rule, double *p
 			{
 				double nv;
 				pfo_basis_value(mesh->gkind, j, quad.pts[q], &nv);
-				const double *node = mesh->xyz + 3 * (int64_t)mesh->gconn[e * n_g + j];
-				for (int c = 0; c < 3; ++c)
+				const double *node = mesh->xyz + dim * (int64_t)mesh->gconn[e * n_g + j];
+				for (int c = 0; c < dim; ++c)
 					p[c] += nv * node[c];
 			}
-			for (int c = 0; c < 3; ++c)
-				pts[((int64_t)e * quad.n_pts + q) * 3 + c] = p[c];
+			for (int c = 0; c < dim; ++c)
+				pts[((int64_t)e * quad.n_pts + q) * dim + c] = p[c];
 		}
 	return quad.n_pts;
 }

@@ -18,8 +18,8 @@
 extern "C" {
 #endif
 
-/* element kinds: number of local bases 4 / 10 / 8 / 27 */
-enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3 };
+/* element kinds: number of local bases 4 / 10 / 8 / 27, and the 2-D triangles 3 / 6 */
+enum { PFO_P1TET = 0, PFO_P2TET = 1, PFO_Q1HEX = 2, PFO_Q2HEX = 3, PFO_P1TRI = 4, PFO_P2TRI = 5 };
 /* local assemblers */
 enum { PFO_LAPLACIAN = 0, PFO_LINEAR_ELASTICITY = 1, PFO_NEOHOOKEAN = 2, PFO_SAINT_VENANT = 3, PFO_HOOKE_LINEAR = 4, PFO_MULTI_MODEL = 5 };
 
@@ -37,6 +37,7 @@ typedef struct
 typedef struct
 {
 	int n_pts, n_loc;
+	int dim;                                       /* 3, or 2 for triangles: third components are zero, jac_it holds the 2x2 in its upper left */
 	double val[PFO_MAX_LOC][PFO_MAX_PTS];          /* basis value at each point */
 	double grad[PFO_MAX_LOC][PFO_MAX_PTS][3];      /* reference-space gradient  */
 	double grad_t_m[PFO_MAX_LOC][PFO_MAX_PTS][3];  /* physical gradient          */
@@ -54,14 +55,14 @@ typedef struct
 	int64_t n_gnodes;
 	const int32_t *conn;   /* n_el x n_loc  global basis index per local basis (Local2Global.index) */
 	const int32_t *gconn;  /* n_el x n_gloc geometry node index                                      */
-	const double *xyz;     /* n_gnodes x 3  geometry node positions (Local2Global.node)               */
+	const double *xyz;     /* n_gnodes x dim geometry node positions (Local2Global.node): 3 per node, 2 for triangles */
 	int quad_order;        /* -1: reference default max(-1, 2(p-1)+1)                                 */
 } pfo_mesh;
 
 typedef struct
 {
 	int model;
-	int dim;          /* problem dimension (3) ; block size is 1 for the Laplacian, dim otherwise */
+	int dim;          /* problem dimension (3; 2 for triangle meshes) ; block size is 1 for the Laplacian, dim otherwise */
 	double lambda, mu; /* uniform Lame parameters */
 	const double *lambda_e, *mu_e; /* optional per-element values (LameParameters with one entry per element,
 	                                  utils/ElasticityUtils.cpp:490-517); NULL = uniform */
@@ -89,9 +90,12 @@ void pfo_csc_free(pfo_csc *m);
 int pfo_n_loc(int kind);
 int pfo_order_of(int kind);
 double pfo_lambda_from_E_nu(double E, double nu); /* 3-D */
+double pfo_lambda_from_E_nu_2d(double E, double nu);
+int pfo_kind_dim(int kind);
 double pfo_mu_from_E_nu(double E, double nu);
 
 int pfo_tet_quadrature(int order, pfo_quad *q);
+int pfo_tri_quadrature(int order, pfo_quad *q);
 int pfo_line_quadrature(int order, pfo_quad *q);
 int pfo_hex_quadrature(int order, pfo_quad *q);
 int pfo_element_quadrature(int kind, int quad_order, pfo_quad *q);
@@ -114,6 +118,10 @@ void pfo_local_neohookean_hessian(const pfo_vals *v, const double *da, const dou
 double pfo_local_linear_elasticity_energy(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu);
 void pfo_local_linear_elasticity_grad(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G);
 void pfo_local_linear_elasticity_hessian(const pfo_vals *v, const double *da, double lambda, double mu, double *H);
+/* 2-D (triangles): local_disp is n_loc x 2, G has n_loc*2 entries, H is (n_loc*2)^2 row-major */
+double pfo_local_neohookean_energy_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu);
+void pfo_local_neohookean_grad_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *G);
+void pfo_local_neohookean_hessian_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, double *H);
 
 /* global assemblers; n_threads > 1 uses thread-local storages merged like the reference does */
 int pfo_assemble_linear(const pfo_mesh *mesh, const pfo_material *mat, int n_threads, pfo_csc *out);

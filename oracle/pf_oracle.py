@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpf_oracle.so")
 
-P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
+P1TET, P2TET, Q1HEX, Q2HEX, P1TRI, P2TRI = 0, 1, 2, 3, 4, 5
 LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
 MAX_PTS, MAX_LOC = 125, 27
 
@@ -22,7 +22,7 @@ class Quad(C.Structure):
 
 class Vals(C.Structure):
     _fields_ = [
-        ("n_pts", C.c_int), ("n_loc", C.c_int),
+        ("n_pts", C.c_int), ("n_loc", C.c_int), ("dim", C.c_int),
         ("val", C.c_double * MAX_PTS * MAX_LOC),
         ("grad", C.c_double * 3 * MAX_PTS * MAX_LOC),
         ("grad_t_m", C.c_double * 3 * MAX_PTS * MAX_LOC),
@@ -78,6 +78,17 @@ def make_material(model: int, lam, mu, tensor=None):
     return Material(model, 3, float(la.flat[0]), float(ma.flat[0]), _dp(la), _dp(ma), None, per_point, None), (la, ma)
 
 
+def kind_dim(kind: int) -> int:
+    return 2 if kind in (P1TRI, P2TRI) else 3
+
+
+def _material_for(om, model, lam, mu):
+    """make_material with the problem dimension of the mesh (2 for triangles)."""
+    mat, keep = make_material(model, lam, mu)
+    mat.dim = kind_dim(om.s.kind)
+    return mat, keep
+
+
 def elasticity_tensor(lam=None, mu=None, entries=None):
     """ElasticityTensor (utils/ElasticityUtils.cpp): set_from_lambda_mu (:372-413) or set_from_entries with the 21
     upper-triangular entries row by row (:298-370), or with the 9 orthotropic constants Ex Ey Ez nuYX nuZX nuZY muYZ muZX
@@ -129,6 +140,8 @@ def lib():
         L.pfo_lambda_from_E_nu.restype = C.c_double
         L.pfo_mu_from_E_nu.restype = C.c_double
         L.pfo_lambda_from_E_nu.argtypes = [C.c_double, C.c_double]
+        L.pfo_lambda_from_E_nu_2d.restype = C.c_double
+        L.pfo_lambda_from_E_nu_2d.argtypes = [C.c_double, C.c_double]
         L.pfo_mu_from_E_nu.argtypes = [C.c_double, C.c_double]
         L.pfo_local_neohookean_energy.restype = C.c_double
         L.pfo_cache_create.restype = C.c_void_p
@@ -146,9 +159,9 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
-def lame(E: float, nu: float):
+def lame(E: float, nu: float, dim: int = 3):
     L = lib()
-    return L.pfo_lambda_from_E_nu(E, nu), L.pfo_mu_from_E_nu(E, nu)
+    return (L.pfo_lambda_from_E_nu(E, nu) if dim == 3 else L.pfo_lambda_from_E_nu_2d(E, nu)), L.pfo_mu_from_E_nu(E, nu)
 
 
 def quadrature(kind: int, quad_order: int = -1):
@@ -166,6 +179,13 @@ def tet_quadrature(order: int):
     assert lib().pfo_tet_quadrature(order, C.byref(q)) == 0
     n = q.n_pts
     return np.array([[q.pts[k][c] for c in range(3)] for k in range(n)]), np.array([q.w[k] for k in range(n)])
+
+
+def tri_quadrature(order: int):
+    q = Quad()
+    assert lib().pfo_tri_quadrature(order, C.byref(q)) == 0
+    n = q.n_pts
+    return np.array([[q.pts[k][c] for c in range(2)] for k in range(n)]), np.array([q.w[k] for k in range(n)])
 
 
 def line_quadrature(order: int):
@@ -257,7 +277,7 @@ def compute_vals(mesh, e: int, quad_order: int = -1):
 
 def assemble_linear(mesh, model: int, lam: float, mu: float, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     out = Csc()
     rc = lib().pfo_assemble_linear(C.byref(om.s), C.byref(mat), n_threads, C.byref(out))
     assert rc == 0
@@ -266,16 +286,16 @@ def assemble_linear(mesh, model: int, lam: float, mu: float, n_threads: int = 1)
 
 def assemble_energy(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1) -> float:
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     return lib().pfo_assemble_energy(C.byref(om.s), C.byref(mat), _dp(x), n_threads)
 
 
 def assemble_gradient(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
-    rhs = np.zeros(om.n_nodes * 3)
+    rhs = np.zeros(om.n_nodes * kind_dim(om.s.kind))
     rc = lib().pfo_assemble_gradient(C.byref(om.s), C.byref(mat), _dp(x), n_threads, _dp(rhs))
     assert rc == 0
     return rhs
@@ -283,7 +303,7 @@ def assemble_gradient(mesh, model: int, lam: float, mu: float, x, n_threads: int
 
 def assemble_hessian(mesh, model: int, lam: float, mu: float, x, n_threads: int = 1):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = Csc()
     rc = lib().pfo_assemble_hessian(C.byref(om.s), C.byref(mat), _dp(x), n_threads, C.byref(out))
@@ -294,7 +314,7 @@ def assemble_hessian(mesh, model: int, lam: float, mu: float, x, n_threads: int 
 def assemble_hessian_psd(mesh, model: int, lam, mu, x, n_threads: int = 1):
     """NLAssembler::assemble_hessian with project_to_psd = true."""
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = Csc()
     rc = lib().pfo_assemble_hessian_psd(C.byref(om.s), C.byref(mat), _dp(x), int(n_threads), C.byref(out))
@@ -342,7 +362,7 @@ class Cache:
 
 def assemble_hessian_cached(mesh, model, lam, mu, x, cache: Cache):
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = Csc()
     rc = lib().pfo_assemble_hessian_cached(C.byref(om.s), C.byref(mat), _dp(x), cache.p, C.byref(out))
@@ -408,7 +428,7 @@ def newton_solve(mesh, model, lam, mu, rhs, boundary_nodes, x0, n_threads: int =
     With `mass` (CSC tuple) and `x_tilde` the objective is weight * (E - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde)
     (one implicit time step: InertiaForm + weighted ElasticForm / BodyForm)."""
     om = mesh if isinstance(mesh, OMesh) else OMesh(mesh)
-    mat, _keep_mat = make_material(model, lam, mu)
+    mat, _keep_mat = _material_for(om, model, lam, mu)
     p = NewtonParams()
     lib().pfo_newton_default_params(C.byref(p))
     for k, v in params.items():
@@ -483,7 +503,8 @@ def quadrature_points(mesh):
     lib().pfo_quadrature_points.restype = C.c_int
     n_pts = lib().pfo_quadrature_points(C.byref(om.s), _dp(buf))
     assert n_pts > 0
-    return buf[: om.s.n_el * n_pts * 3].reshape(om.s.n_el, n_pts, 3).copy()
+    d = kind_dim(om.s.kind)
+    return buf[: om.s.n_el * n_pts * d].reshape(om.s.n_el, n_pts, d).copy()
 
 
 def mass_quadrature_points(mesh):
@@ -493,7 +514,8 @@ def mass_quadrature_points(mesh):
     lib().pfo_mass_quadrature_points.restype = C.c_int
     n_pts = lib().pfo_mass_quadrature_points(C.byref(om.s), _dp(buf))
     assert n_pts > 0
-    return buf[: om.s.n_el * n_pts * 3].reshape(om.s.n_el, n_pts, 3).copy()
+    d = kind_dim(om.s.kind)
+    return buf[: om.s.n_el * n_pts * d].reshape(om.s.n_el, n_pts, d).copy()
 
 
 def assemble_rhs_pointwise(mesh, size: int, force_pts, density=1.0):

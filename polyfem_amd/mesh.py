@@ -19,10 +19,13 @@ import itertools
 
 import numpy as np
 
-P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
-N_LOC = {P1TET: 4, P2TET: 10, Q1HEX: 8, Q2HEX: 27}
-GEOM_KIND = {P1TET: P1TET, P2TET: P1TET, Q1HEX: Q1HEX, Q2HEX: Q1HEX}
-KIND_NAME = {P1TET: "P1TET", P2TET: "P2TET", Q1HEX: "Q1HEX", Q2HEX: "Q2HEX"}
+P1TET, P2TET, Q1HEX, Q2HEX, P1TRI, P2TRI = 0, 1, 2, 3, 4, 5
+N_LOC = {P1TET: 4, P2TET: 10, Q1HEX: 8, Q2HEX: 27, P1TRI: 3, P2TRI: 6}
+GEOM_KIND = {P1TET: P1TET, P2TET: P1TET, Q1HEX: Q1HEX, Q2HEX: Q1HEX, P1TRI: P1TRI, P2TRI: P1TRI}
+KIND_NAME = {P1TET: "P1TET", P2TET: "P2TET", Q1HEX: "Q1HEX", Q2HEX: "Q2HEX", P1TRI: "P1TRI", P2TRI: "P2TRI"}
+KIND_DIM = {P1TET: 3, P2TET: 3, Q1HEX: 3, Q2HEX: 3, P1TRI: 2, P2TRI: 2}
+# local P2 triangle nodes 3..5 are the midpoints of these vertex pairs (autogen/auto_p_bases.cpp:275-284)
+_P2_TRI_EDGES = ((0, 1), (1, 2), (2, 0))
 
 # local P2 edge nodes 4..9 are the midpoints of these vertex pairs
 _P2_EDGES = ((0, 1), (1, 2), (2, 0), (0, 3), (1, 3), (2, 3))
@@ -41,9 +44,9 @@ class Mesh:
     gkind: int
     conn: np.ndarray      # (n_el, n_loc) int32, global basis index per local basis
     gconn: np.ndarray     # (n_el, n_gloc) int32, geometry node per local geometry basis
-    xyz: np.ndarray       # (n_gnodes, 3) float64 geometry node positions
+    xyz: np.ndarray       # (n_gnodes, dim) float64 geometry node positions (dim = 2 for triangles)
     n_nodes: int          # number of global (scalar) bases
-    node_xyz: np.ndarray  # (n_nodes, 3) position of every basis node (for boundary conditions only)
+    node_xyz: np.ndarray  # (n_nodes, dim) position of every basis node (for boundary conditions only)
     quad_order: int = -1
 
     @property
@@ -175,9 +178,63 @@ def cube_hexes(n: int, order: int = 1, numbering: str = "lattice", scale=(1.0, 1
     return m
 
 
+def square_tris(n: int, order: int = 1, numbering: str = "lattice", scale=(1.0, 1.0), jitter: float = 0.0, seed: int = 0) -> Mesh:
+    """Unit square split in n^2 cells, each cell into two counter-clockwise triangles along its diagonal; P1 (order=1) or
+    P2 (order=2) bases on the linear geometry, local node order of `autogen/auto_p_bases.cpp:138-144, 275-284`.  The 2-D
+    meshes of the reference's own assembler tests (`tests/test_assembler.cpp:12-64`, `tests/test_form_derivatives.cpp:31-81`)
+    are triangle meshes of this kind.  `jitter` moves the interior vertices as in cube_tets."""
+    assert order in (1, 2)
+    kind = P1TRI if order == 1 else P2TRI
+    tris = np.array([[(0, 0), (1, 0), (1, 1)], [(0, 0), (1, 1), (0, 1)]])
+    ky, kx = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    cell = np.stack([kx, ky], axis=-1).reshape(-1, 1, 1, 2)
+    corners = (cell + tris[None]).reshape(-1, 3, 2)
+    nv = n + 1
+    gconn = corners[..., 0] + nv * corners[..., 1]
+    gy, gx = np.meshgrid(np.arange(nv), np.arange(nv), indexing="ij")
+    xyz = np.stack([gx, gy], axis=-1).reshape(-1, 2).astype(np.float64) / n
+    if jitter > 0:
+        rng = np.random.default_rng(seed)
+        interior = np.all((xyz > 0) & (xyz < 1), axis=1)
+        xyz[interior] += rng.uniform(-jitter / n, jitter / n, size=(int(interior.sum()), 2))
+    xyz = xyz * np.asarray(scale, dtype=np.float64)
+    if order == 1:
+        L, conn_lat, h_lat = nv, gconn.copy(), 1.0 / n
+    else:
+        L = 2 * n + 1
+        c2 = 2 * corners
+        loc = [c2[:, k] for k in range(3)] + [(c2[:, a] + c2[:, b]) // 2 for a, b in _P2_TRI_EDGES]
+        loc = np.stack(loc, axis=1)
+        conn_lat = loc[..., 0] + L * loc[..., 1]
+        h_lat = 0.5 / n
+    used = np.unique(conn_lat)
+    if numbering == "lattice":
+        new_id = np.full(int(conn_lat.max()) + 1, -1, dtype=np.int64)
+        new_id[used] = np.arange(used.size)
+    elif numbering == "polyfem":
+        ii = np.arange(0, L, order)
+        vy, vx = np.meshgrid(ii, ii, indexing="ij")
+        new_id = _renumber_first_touch(conn_lat, (vx + L * vy).reshape(-1))
+    else:
+        raise ValueError("numbering must be 'lattice' or 'polyfem'")
+    node_xyz = np.zeros((used.size, 2))
+    node_xyz[new_id[used]] = np.stack([used % L, used // L], axis=1) * h_lat * np.asarray(scale, dtype=np.float64)
+    return Mesh(kind, P1TRI, np.ascontiguousarray(new_id[conn_lat].astype(np.int32)), np.ascontiguousarray(gconn.astype(np.int32)),
+                np.ascontiguousarray(xyz), int(used.size), node_xyz)
+
+
 def node_positions(mesh: Mesh) -> np.ndarray:
     """Physical position of every basis node (the geometry map at the node's reference position); on tetrahedra with
     moved vertices these differ from the lattice positions kept in mesh.node_xyz."""
+    if mesh.kind in (P1TRI, P2TRI):
+        v = mesh.xyz[mesh.gconn]
+        pos = np.zeros((mesh.n_nodes, 2))
+        for k in range(3):
+            pos[mesh.conn[:, k]] = v[:, k]
+        if mesh.kind == P2TRI:
+            for e, (a, b) in enumerate(_P2_TRI_EDGES):
+                pos[mesh.conn[:, 3 + e]] = 0.5 * (v[:, a] + v[:, b])
+        return pos
     if mesh.kind not in (P1TET, P2TET):
         return np.asarray(mesh.node_xyz, dtype=float)
     v = mesh.xyz[mesh.gconn]
