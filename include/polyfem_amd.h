@@ -39,13 +39,20 @@ enum
 };
 
 /* element kinds: local node order of autogen/auto_p_bases.cpp:1080-1087,1328-1341 and
- * autogen/auto_q_bases.cpp:1262-1275,1873-1903; geometry map is P1 (tets) / Q1 (hexes). */
+ * autogen/auto_q_bases.cpp:1262-1275,1873-1903; geometry map is P1 (tets) / Q1 (hexes).
+ * 2-D problems: triangles with the local node order of autogen/auto_p_bases.cpp:138-144, 275-284 and a P1 geometry
+ * map (the (3,2) and (6,2) instantiations of NeoHookeanElasticity.cpp:47-115); dim = 2, two coordinates per geometry
+ * node, two displacement components per node.  They support the Laplacian, LinearElasticity (both interfaces) and
+ * NeoHookean, uniform / per-element / per-point parameters, mass matrix and right-hand side, the Jacobi-CG and the
+ * Newton solver; the other entry points return PFX_ERR_UNSUPPORTED for them. */
 enum
 {
 	PFX_P1TET = 0,
 	PFX_P2TET = 1,
 	PFX_Q1HEX = 2,
-	PFX_Q2HEX = 3
+	PFX_Q2HEX = 3,
+	PFX_P1TRI = 4,
+	PFX_P2TRI = 5
 };
 
 /* local assemblers: Laplacian.cpp:7-18, LinearElasticity.cpp:21-54, NeoHookeanElasticity.cpp:250-565,
@@ -83,13 +90,14 @@ pfx_status pfx_synchronize(pfx_ctx *ctx);
 
 /* Flattened std::vector<ElementBases> bases / gbases (basis/ElementBases.hpp:16-104): conn[e*n_loc + j] =
  * bases[e].bases[j].global()[0].index, gconn[e*n_gloc + j] = geometry node of gbases[e].bases[j],
- * geom_xyz[3*g + c] = Local2Global.node.  Only conforming bases (global().size()==1, val==1) are accepted.
- * quad_order: -1 = the reference default max(-1, 2(p-1)+1) (basis/FEBasis3d.cpp:1467,1506). */
+ * geom_xyz[dim*g + c] = Local2Global.node (dim = 3; 2 for the triangle kinds).  Only conforming bases
+ * (global().size()==1, val==1) are accepted.
+ * quad_order: -1 = the reference default max(-1, 2(p-1)+1) (basis/FEBasis3d.cpp:1467,1506, basis/FEBasis2d.cpp:797). */
 pfx_status pfx_set_mesh(pfx_ctx *ctx, int elem_kind, int64_t n_el, int64_t n_nodes, int64_t n_gnodes,
 						const int32_t *conn, const int32_t *gconn, const double *geom_xyz, int quad_order);
 
 /* Uniform Lame parameters (LameParameters::lambda_mu with constant expressions, utils/ElasticityUtils.cpp:490-517).
- * dim = 3.  The block size of the system is 1 for the Laplacian and dim otherwise. */
+ * dim = 3 (2 for the triangle kinds).  The block size of the system is 1 for the Laplacian and dim otherwise. */
 pfx_status pfx_set_material(pfx_ctx *ctx, int model, int dim, double lambda, double mu);
 /* One (lambda, mu) per element: LameParameters holding one entry per element id, which is how the reference stores
  * multi-material bodies (add_multimaterial, utils/ElasticityUtils.cpp:490-517, 521-560; AssemblerUtils.cpp:604-672).
@@ -305,7 +313,7 @@ pfx_status pfx_assemble_rhs_dev(pfx_ctx *ctx, const double *force, double densit
 /* The same with a force density that varies in space: force_pts holds what problem.rhs() returns in the reference
  * (RhsAssembler.cpp:66-75), one vector per (element, quadrature point), n_el x n_pts x d doubles.  pfx_quadrature_points
  * gives the physical positions of those points (ElementAssemblyValues::val, ElementAssemblyValues.cpp:328-345;
- * n_el x n_pts x 3 doubles, pts may be NULL to ask for n_pts only) for the caller to evaluate its function at. */
+ * n_el x n_pts x dim doubles, pts may be NULL to ask for n_pts only) for the caller to evaluate its function at. */
 pfx_status pfx_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts);
 pfx_status pfx_assemble_rhs_pointwise(pfx_ctx *ctx, const double *force_pts, double density, const double *density_e, double *rhs);
 pfx_status pfx_assemble_rhs_pointwise_dev(pfx_ctx *ctx, const double *d_force_pts, double density, const double *density_e, double *d_rhs);
@@ -313,11 +321,11 @@ pfx_status pfx_assemble_rhs_pointwise_dev(pfx_ctx *ctx, const double *d_force_pt
 /* Density evaluated per quadrature point, as Density::operator() is in the reference (utils/ElasticityUtils.cpp:561-570,
  * called per point at assembler/Mass.cpp:10 and assembler/RhsAssembler.cpp:81): the host evaluates its density function at
  * the positions the library reports and passes one value per (element, point), point fastest.
- *   pfx_mass_quadrature_points        positions of the points of the MASS quadrature rule (n_el x n_pts x 3; pts may be NULL)
+ *   pfx_mass_quadrature_points        positions of the points of the MASS quadrature rule (n_el x n_pts x dim; pts may be NULL)
  *   pfx_assemble_mass_pointwise       pfx_assemble_mass with n_el x n_pts densities at those points
  *   pfx_inertia_set_mass_pointwise    pfx_inertia_set_mass likewise
  *   pfx_assemble_rhs_density_pointwise  the body-force vector with n_el x n_pts densities at the points of the STIFFNESS rule
- *                                     (pfx_quadrature_points) and either a constant force (force, 3 doubles) or a force per
+ *                                     (pfx_quadrature_points) and either a constant force (force, one double per dof of a node) or a force per
  *                                     point (force_pts, n_el x n_pts x d); exactly one of the two is non-NULL */
 pfx_status pfx_mass_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts);
 pfx_status pfx_assemble_mass_pointwise(pfx_ctx *ctx, const double *density_pts, int64_t n_el, int n_pts);

@@ -300,8 +300,10 @@ extern "C"
 	{
 		if (!ctx)
 			return PFX_ERR_ARG;
-		if (elem_kind < PFX_P1TET || elem_kind > PFX_Q2HEX)
+		if (elem_kind < PFX_P1TET || elem_kind > PFX_P2TRI)
 			PFX_FAIL(PFX_ERR_ARG, "unknown element kind");
+		const bool tri = elem_kind == PFX_P1TRI || elem_kind == PFX_P2TRI;
+		const int mesh_dim = tri ? 2 : 3;
 		if (n_el <= 0 || n_nodes <= 0 || n_gnodes <= 0 || !conn || !gconn || !geom_xyz)
 			PFX_FAIL(PFX_ERR_ARG, "empty mesh or null pointer");
 		if (n_nodes >= ((int64_t)1 << 31) / 3)
@@ -326,7 +328,8 @@ extern "C"
 		ctx->h_tab = tab;
 		ctx->h_tab_mass = tab_mass;
 		ctx->kind = elem_kind;
-		ctx->gkind = (elem_kind == PFX_Q1HEX || elem_kind == PFX_Q2HEX) ? PFX_Q1HEX : PFX_P1TET;
+		ctx->gkind = (elem_kind == PFX_Q1HEX || elem_kind == PFX_Q2HEX) ? PFX_Q1HEX : tri ? PFX_P1TRI : PFX_P1TET;
+		ctx->mesh_dim = mesh_dim;
 		ctx->n_loc = n_loc;
 		ctx->n_gloc = n_gloc;
 		ctx->n_pts = ctx->h_tab.n_pts;
@@ -343,6 +346,16 @@ extern "C"
 			return PFX_ERR_HIP;
 		PFX_HIP(hipMemcpyAsync(ctx->d_conn, conn, sizeof(int32_t) * (size_t)(n_el * n_loc), hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipMemcpyAsync(ctx->d_gconn, gconn, sizeof(int32_t) * (size_t)(n_el * n_gloc), hipMemcpyHostToDevice, ctx->stream));
+		// the device copy holds three coordinates per geometry node; triangle meshes get a zero third one (the kernels then
+		// work with the 2 x 2 Jacobian sitting in the upper left of a 3 x 3 matrix whose last diagonal entry is one)
+		std::vector<double> padded;
+		if (tri)
+		{
+			padded.resize((size_t)n_gnodes * 3);
+			for (int64_t g = 0; g < n_gnodes; ++g)
+				padded[3 * g] = geom_xyz[2 * g], padded[3 * g + 1] = geom_xyz[2 * g + 1], padded[3 * g + 2] = 0.0;
+			geom_xyz = padded.data();
+		}
 		PFX_HIP(hipMemcpyAsync(ctx->d_xyz, geom_xyz, sizeof(double) * (size_t)(n_gnodes * 3), hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipMemcpyAsync(ctx->d_tab, &ctx->h_tab, sizeof(pfx_tables), hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipMemcpyAsync(ctx->d_tab_mass, &ctx->h_tab_mass, sizeof(pfx_tables), hipMemcpyHostToDevice, ctx->stream));
@@ -356,8 +369,12 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (model < PFX_LAPLACIAN || model > PFX_SAINT_VENANT)
 			PFX_FAIL(PFX_ERR_ARG, "unknown model (PFX_HOOKE_LINEAR is selected by pfx_set_elasticity_tensor)");
-		if (dim != 3)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "only dim = 3 is implemented");
+		if (dim != 3 && dim != 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "dim is 3, or 2 for triangle meshes");
+		if (dim == 2 && model != PFX_LAPLACIAN && model != PFX_LINEAR_ELASTICITY && model != PFX_NEOHOOKEAN)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "2-D problems: Laplacian, LinearElasticity and NeoHookean");
+		if (ctx->kind >= 0 && model != PFX_LAPLACIAN && dim != ctx->mesh_dim)
+			PFX_FAIL(PFX_ERR_ARG, "dim does not match the mesh (2 for triangles, 3 otherwise)");
 		const int bs = (model == PFX_LAPLACIAN) ? 1 : dim;
 		if (ctx->d_node_ptr && bs != ctx->bs)
 			release_pattern(ctx); // block size changes the layout
@@ -486,6 +503,8 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (ctx->kind < 0 || ctx->model < 0)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_set_mesh and pfx_set_material must be called first");
+		if (ctx->model != PFX_LAPLACIAN && ctx->dim != ctx->mesh_dim)
+			PFX_FAIL(PFX_ERR_ARG, "the material's dim does not match the mesh (2 for triangles, 3 otherwise)");
 		PFX_HIP(hipSetDevice(ctx->device));
 		release_pattern(ctx);
 		pfx_status rc = pfx_pattern_build(ctx);
@@ -619,6 +638,23 @@ extern "C"
 		return pfx_capture_mass(ctx);
 	}
 
+	// the kernels write three coordinates per point; a 2-D mesh hands out two
+	static pfx_status copy_points_out(pfx_ctx *ctx, const double *d_p, size_t n_points, double *pts)
+	{
+		if (ctx->mesh_dim == 3)
+		{
+			PFX_HIP(hipMemcpyAsync(pts, d_p, sizeof(double) * n_points * 3, hipMemcpyDeviceToHost, ctx->stream));
+			PFX_HIP(hipStreamSynchronize(ctx->stream));
+			return PFX_OK;
+		}
+		std::vector<double> h(n_points * 3);
+		PFX_HIP(hipMemcpyAsync(h.data(), d_p, sizeof(double) * n_points * 3, hipMemcpyDeviceToHost, ctx->stream));
+		PFX_HIP(hipStreamSynchronize(ctx->stream));
+		for (size_t k = 0; k < n_points; ++k)
+			pts[2 * k] = h[3 * k], pts[2 * k + 1] = h[3 * k + 1];
+		return PFX_OK;
+	}
+
 	pfx_status pfx_mass_quadrature_points(pfx_ctx *ctx, int *n_pts, double *pts)
 	{
 		if (!ctx || !n_pts)
@@ -635,9 +671,7 @@ extern "C"
 		pfx_status rc = pfx_launch_mass_quadrature_points(ctx, d_p.p);
 		if (rc)
 			return rc;
-		PFX_HIP(hipMemcpyAsync(pts, d_p.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
-		PFX_HIP(hipStreamSynchronize(ctx->stream));
-		return PFX_OK;
+		return copy_points_out(ctx, d_p.p, count / 3, pts);
 	}
 
 	pfx_status pfx_assemble_rhs_density_pointwise(pfx_ctx *ctx, const double *force, const double *force_pts, const double *density_pts, int64_t n_el,
@@ -752,9 +786,7 @@ extern "C"
 		pfx_status rc = pfx_launch_quadrature_points(ctx, d_p.p);
 		if (rc)
 			return rc;
-		PFX_HIP(hipMemcpyAsync(pts, d_p.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
-		PFX_HIP(hipStreamSynchronize(ctx->stream));
-		return PFX_OK;
+		return copy_points_out(ctx, d_p.p, count / 3, pts);
 	}
 
 	pfx_status pfx_get_linear_csr(pfx_ctx *ctx, int64_t *nnz, int64_t *row_ptr, int32_t *col_idx, double *values)

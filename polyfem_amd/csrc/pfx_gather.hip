@@ -200,6 +200,18 @@ namespace
 	case 273:                                                  \
 		FN<27, 3>(__VA_ARGS__);                                \
 		break;                                                 \
+	case 31:                                                   \
+		FN<3, 1>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 32:                                                   \
+		FN<3, 2>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 61:                                                   \
+		FN<6, 1>(__VA_ARGS__);                                 \
+		break;                                                 \
+	case 62:                                                   \
+		FN<6, 2>(__VA_ARGS__);                                 \
+		break;                                                 \
 	default:                                                   \
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "unsupported n_loc/bs"); \
 	}

@@ -100,6 +100,7 @@ struct pfx_ctx
 
 	// mesh
 	int kind = -1, gkind = -1, n_loc = 0, n_gloc = 0, n_pts = 0, quad_order = -1;
+	int mesh_dim = 3; // 2 for the triangle kinds (the device copy of the geometry nodes still has three coordinates, the third zero)
 	int64_t n_el = 0, n_nodes = 0, n_gnodes = 0;
 	int64_t n_owned = 0; // rows [0, n_owned) belong to this rank (== n_nodes unless the mesh is one part of a partition)
 	int32_t *d_conn = nullptr, *d_gconn = nullptr;

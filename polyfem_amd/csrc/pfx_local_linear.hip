@@ -72,6 +72,12 @@ namespace
 				for (int c = 0; c < 3; ++c)
 					tmp[3 * r + c] += tab->ggrad[k][j][r] * x[c] * 1.0;
 		}
+		// Triangles (ElementAssemblyValues::finalize2d, ElementAssemblyValues.cpp:161-197): the third row and column of tmp
+		// are exact zeros; with a one in the corner the 3 x 3 cofactor formulas below reduce, operation by operation, to
+		// Eigen's 2 x 2 determinant m00 m11 - m10 m01 and inverse (adjugate times 1/det): every extra term is a product
+		// with an exact zero or one
+		if (NGLOC == 3)
+			tmp[8] = 1.0;
 		double out[10];
 		inv3_transposed(tmp, out);
 		out[9] = det3_fixed(tmp);
@@ -360,7 +366,7 @@ namespace
 	template <int NGLOC, int NPTS>
 	void launch_geometry(pfx_ctx *ctx, const pfx_tables *d_tab)
 	{
-		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		constexpr int SP = (NGLOC == 4 || NGLOC == 3) ? 1 : NPTS; // affine geometry: one Jacobian per element
 		const int64_t n = ctx->n_el * SP;
 		hipLaunchKernelGGL((k_element_geometry<NGLOC, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz,
 						   d_tab, ctx->n_el, ctx->d_estate);
@@ -369,40 +375,46 @@ namespace
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_mass_rows(pfx_ctx *ctx, double density, const double *d_density_e, const double *d_density_pts)
 	{
-		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		constexpr int SP = (NGLOC == 4 || NGLOC == 3) ? 1 : NPTS; // affine geometry: one Jacobian per element
+		constexpr int DIM = (NGLOC == 3) ? 2 : 3;
 		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab_mass);
 		if (ctx->bs == 1)
 			pfx_launch_assemble_rows<NLOC, 1>(ctx, mass_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e, d_density_pts}, true);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, mass_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e, d_density_pts}, true);
+			pfx_launch_assemble_rows<NLOC, DIM>(ctx, mass_block<NLOC, NPTS, DIM, SP>{ctx->d_estate, ctx->d_tab_mass, density, d_density_e, d_density_pts}, true);
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_rhs(pfx_ctx *ctx, const double *f, const double *d_force_pts, double density, const double *d_density_e, const double *d_density_pts)
 	{
-		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		constexpr int SP = (NGLOC == 4 || NGLOC == 3) ? 1 : NPTS; // affine geometry: one Jacobian per element
+		constexpr int DIM = (NGLOC == 3) ? 2 : 3;
 		launch_geometry<NGLOC, NPTS>(ctx, ctx->d_tab);
 		const int64_t n = ctx->n_el * NLOC;
 		if (ctx->bs == 1)
 			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 1, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
 							   ctx->n_el, f ? f[0] : 0.0, 0.0, 0.0, d_force_pts, density, d_density_e, d_density_pts, ctx->d_gloc);
 		else
-			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, 3, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
-							   ctx->n_el, f ? f[0] : 0.0, f ? f[1] : 0.0, f ? f[2] : 0.0, d_force_pts, density, d_density_e, d_density_pts, ctx->d_gloc);
+			hipLaunchKernelGGL((k_local_rhs<NLOC, NPTS, DIM, SP>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_estate, ctx->d_tab,
+							   ctx->n_el, f ? f[0] : 0.0, f ? f[1] : 0.0, (f && DIM == 3) ? f[2] : 0.0, d_force_pts, density, d_density_e, d_density_pts, ctx->d_gloc);
 	}
 
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_rows(pfx_ctx *ctx, bool write_mask)
 	{
-		constexpr int SP = (NGLOC == 4) ? 1 : NPTS;
+		constexpr int SP = (NGLOC == 4 || NGLOC == 3) ? 1 : NPTS; // affine geometry: one Jacobian per element
+		constexpr int DIM = (NGLOC == 3) ? 2 : 3;
 		if (ctx->model == PFX_HOOKE_LINEAR)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, hooke_block<NLOC, NPTS, SP>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, write_mask);
+		{
+			if constexpr (DIM == 3)
+				pfx_launch_assemble_rows<NLOC, 3>(ctx, hooke_block<NLOC, NPTS, SP>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, write_mask);
+		}
 		else if (ctx->bs == 1)
 			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 		else if (ctx->mat_per_point && ctx->d_lambda_e)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP, true>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
+			pfx_launch_assemble_rows<NLOC, DIM>(ctx, linear_block<NLOC, NPTS, DIM, SP, true>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, linear_block<NLOC, NPTS, 3, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
+			pfx_launch_assemble_rows<NLOC, DIM>(ctx, linear_block<NLOC, NPTS, DIM, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);
 	}
 
 	bool supported(const pfx_ctx *ctx)
@@ -416,6 +428,10 @@ namespace
 			return ctx->n_pts == 6;
 		case PFX_Q2HEX:
 			return ctx->n_pts == 27;
+		case PFX_P1TRI:
+			return ctx->n_pts == 1;
+		case PFX_P2TRI:
+			return ctx->n_pts == 4;
 		}
 		return false;
 	}
@@ -436,6 +452,12 @@ pfx_status pfx_launch_local_linear(pfx_ctx *ctx)
 		break;
 	case PFX_Q1HEX:
 		launch_geometry<8, 1>(ctx, ctx->d_tab);
+		break;
+	case PFX_P1TRI:
+		launch_geometry<3, 1>(ctx, ctx->d_tab);
+		break;
+	case PFX_P2TRI:
+		launch_geometry<3, 4>(ctx, ctx->d_tab);
 		break;
 	default:
 		launch_geometry<8, 27>(ctx, ctx->d_tab);
@@ -461,6 +483,12 @@ pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask)
 	case PFX_Q1HEX:
 		launch_rows<8, 8, 1>(ctx, write_mask);
 		break;
+	case PFX_P1TRI:
+		launch_rows<3, 3, 1>(ctx, write_mask);
+		break;
+	case PFX_P2TRI:
+		launch_rows<6, 3, 4>(ctx, write_mask);
+		break;
 	default:
 		launch_rows<27, 8, 27>(ctx, write_mask);
 	}
@@ -472,8 +500,8 @@ pfx_status pfx_launch_rows_linear(pfx_ctx *ctx, bool write_mask)
 // the points of the mass quadrature rule, then the row assembly with mass_block
 pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density_e, const double *d_density_pts)
 {
-	static const int expect[4] = {6, 14, 27, 125}; // mass rules: tet order 3 / 5, hex order 3 / 5
-	if (ctx->kind < 0 || ctx->kind > 3 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
+	static const int expect[6] = {6, 14, 27, 125, 4, 7}; // mass rules: tet order 3 / 5, hex order 3 / 5, triangle order 3 / 5
+	if (ctx->kind < 0 || ctx->kind > 5 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "mass assembly: unsupported element kind");
 	switch (ctx->kind)
 	{
@@ -485,6 +513,12 @@ pfx_status pfx_launch_mass(pfx_ctx *ctx, double density, const double *d_density
 		break;
 	case PFX_Q1HEX:
 		launch_mass_rows<8, 8, 27>(ctx, density, d_density_e, d_density_pts);
+		break;
+	case PFX_P1TRI:
+		launch_mass_rows<3, 3, 4>(ctx, density, d_density_e, d_density_pts);
+		break;
+	case PFX_P2TRI:
+		launch_mass_rows<6, 3, 7>(ctx, density, d_density_e, d_density_pts);
 		break;
 	default:
 		launch_mass_rows<27, 8, 125>(ctx, density, d_density_e, d_density_pts);
@@ -510,6 +544,12 @@ pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double 
 	case PFX_Q1HEX:
 		launch_rhs<8, 8, 1>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
 		break;
+	case PFX_P1TRI:
+		launch_rhs<3, 3, 1>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
+		break;
+	case PFX_P2TRI:
+		launch_rhs<6, 3, 4>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
+		break;
 	default:
 		launch_rhs<27, 8, 27>(ctx, force, d_force_pts, density, d_density_e, d_density_pts);
 	}
@@ -521,8 +561,8 @@ pfx_status pfx_launch_local_rhs(pfx_ctx *ctx, const double *force, const double 
 // positions of the points of the mass quadrature rule (n_el x n_pts_mass x 3)
 pfx_status pfx_launch_mass_quadrature_points(pfx_ctx *ctx, double *d_pts)
 {
-	static const int expect[4] = {6, 14, 27, 125};
-	if (ctx->kind < 0 || ctx->kind > 3 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
+	static const int expect[6] = {6, 14, 27, 125, 4, 7};
+	if (ctx->kind < 0 || ctx->kind > 5 || ctx->h_tab_mass.n_pts != expect[ctx->kind])
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "mass quadrature points: unsupported element kind");
 	const int64_t n = ctx->n_el * ctx->h_tab_mass.n_pts;
 	const unsigned grid = (unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
@@ -536,6 +576,12 @@ pfx_status pfx_launch_mass_quadrature_points(pfx_ctx *ctx, double *d_pts)
 		break;
 	case PFX_Q1HEX:
 		hipLaunchKernelGGL((k_quadrature_points<8, 27>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
+		break;
+	case PFX_P1TRI:
+		hipLaunchKernelGGL((k_quadrature_points<3, 4>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
+		break;
+	case PFX_P2TRI:
+		hipLaunchKernelGGL((k_quadrature_points<3, 7>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
 		break;
 	default:
 		hipLaunchKernelGGL((k_quadrature_points<8, 125>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab_mass, ctx->n_el, d_pts);
@@ -560,6 +606,12 @@ pfx_status pfx_launch_quadrature_points(pfx_ctx *ctx, double *d_pts)
 		break;
 	case PFX_Q1HEX:
 		hipLaunchKernelGGL((k_quadrature_points<8, 1>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
+		break;
+	case PFX_P1TRI:
+		hipLaunchKernelGGL((k_quadrature_points<3, 1>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
+		break;
+	case PFX_P2TRI:
+		hipLaunchKernelGGL((k_quadrature_points<3, 4>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);
 		break;
 	default:
 		hipLaunchKernelGGL((k_quadrature_points<8, 27>), dim3(grid), dim3(256), 0, ctx->stream, ctx->d_gconn, ctx->d_xyz, ctx->d_tab, ctx->n_el, d_pts);

@@ -91,7 +91,7 @@ namespace
 	struct nl_state
 	{
 		// J^{-T} takes 10 doubles (one of padding) so that every group starts on a 16-byte boundary
-		static constexpr bool affine = (NGLOC == 4);
+		static constexpr bool affine = (NGLOC == 4 || NGLOC == 3); // tetrahedra and triangles with the linear geometric map
 		static constexpr int stride = affine ? 10 + 12 * NPTS : 22 * NPTS;
 		__host__ __device__ static constexpr int jt_at(int k) { return affine ? 0 : 22 * k; }
 		__host__ __device__ static constexpr int f_at(int k) { return affine ? 10 + 12 * k : 22 * k + 10; }
@@ -101,7 +101,10 @@ namespace
 	// for M_LINEAR), da = det J * weight.  dJ receives what the gradient contracts with the physical basis gradients (NeoHookean:
 	// the cofactor matrix of F; otherwise the first Piola-Kirchhoff / Cauchy stress), c0..c2 the coefficients the gradient
 	// and the Hessian functor use; returns the point's energy.
-	template <int MODEL>
+	// DIM = 2 (triangles): F holds the 2 x 2 deformation gradient in its upper left, zeros beside it and a one in the corner
+	// (zero for M_LINEAR), so that J, the cofactors and the in-plane part of every formula are those of the 2-D problem
+	// (NeoHookeanElasticity.cpp:410-417, 501-512); only the trace term of the energy counts the corner and is corrected.
+	template <int MODEL, int DIM = 3>
 	__device__ __forceinline__ double nl_point(int model, const double *F, double lambda, double mu, const double *__restrict__ tensor, double da, double *dJ,
 											   double &c0, double &c1, double &c2, bool &bad)
 	{
@@ -116,12 +119,15 @@ namespace
 				bad = true;
 			const double lj = log(J);
 			double tr = 0;
-			for (int q = 0; q < 9; ++q)
-				tr += F[q] * F[q];
+			if (DIM == 2)
+				tr = F[0] * F[0] + F[1] * F[1] + F[3] * F[3] + F[4] * F[4];
+			else
+				for (int q = 0; q < 9; ++q)
+					tr += F[q] * F[q];
 			c0 = mu * da;
 			c1 = (mu + lambda * (1.0 - lj)) / (J * J) * da;
 			c2 = (lambda * lj - mu) / J * da;
-			en = (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+			en = (mu / 2 * (tr - DIM - 2 * lj) + lambda / 2 * lj * lj) * da;
 		}
 		else if (model == M_STVK || model == M_STVKT)
 		{
@@ -175,6 +181,8 @@ namespace
 															   double mu_u, const double *__restrict__ lambda_e, const double *__restrict__ mu_e,
 															   const uint8_t *__restrict__ model_e, const double *__restrict__ tensor, double *__restrict__ eloc, int *__restrict__ flag)
 	{
+		constexpr int DIM = (NGLOC == 3) ? 2 : 3;           // triangles: two displacement components per node
+		constexpr bool AFF = (NGLOC == 4 || NGLOC == 3);    // linear geometric map: one Jacobian per element
 		const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 		if (e >= n_el)
 			return;
@@ -193,13 +201,15 @@ namespace
 		double jt[9], det = 0.0;
 		for (int k = 0; k < NPTS; ++k)
 		{
-			if (k == 0 || NGLOC != 4) // affine geometry: one Jacobian per element
+			if (k == 0 || !AFF) // affine geometry: one Jacobian per element
 			{
 				double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 				for (int j = 0; j < NGLOC; ++j)
 					for (int r = 0; r < 3; ++r)
 						for (int c = 0; c < 3; ++c)
-							tmp[3 * r + c] += tab->ggrad[NGLOC == 4 ? 0 : k][j][r] * xs[3 * j + c];
+							tmp[3 * r + c] += tab->ggrad[AFF ? 0 : k][j][r] * xs[3 * j + c];
+				if (DIM == 2)
+					tmp[8] = 1.0; // the 2 x 2 Jacobian in the upper left of a 3 x 3 matrix: same determinant, same inverse there
 				inv3_transposed_det(tmp, jt, &det);
 			}
 			const double da = det * tab->w[k];
@@ -212,8 +222,8 @@ namespace
 				double G[3];
 				for (int c = 0; c < 3; ++c)
 					G[c] = g0 * jt[c] + g1 * jt[3 + c] + g2 * jt[6 + c];
-				const double *ui = u + 3 * (int64_t)nd[i];
-				for (int d = 0; d < 3; ++d)
+				const double *ui = u + DIM * (int64_t)nd[i];
+				for (int d = 0; d < DIM; ++d)
 					for (int c = 0; c < 3; ++c)
 						F[3 * d + c] += ui[d] * G[c];
 			}
@@ -225,9 +235,12 @@ namespace
 					bad = true;
 				const double lj = log(J);
 				double tr = 0;
-				for (int q = 0; q < 9; ++q)
-					tr += F[q] * F[q];
-				en += (mu / 2 * (tr - 3 - 2 * lj) + lambda / 2 * lj * lj) * da;
+				if (DIM == 2)
+					tr = F[0] * F[0] + F[1] * F[1] + F[3] * F[3] + F[4] * F[4];
+				else
+					for (int q = 0; q < 9; ++q)
+						tr += F[q] * F[q];
+				en += (mu / 2 * (tr - DIM - 2 * lj) + lambda / 2 * lj * lj) * da;
 			}
 			else if (model == M_STVK || model == M_STVKT)
 			{
@@ -281,6 +294,8 @@ namespace
 															double *__restrict__ gloc, double *__restrict__ estate, int *__restrict__ flag)
 	{
 		typedef nl_state<NGLOC, NPTS> ST;
+		constexpr int DIM = (NGLOC == 3) ? 2 : 3;           // triangles: two displacement components per node
+		constexpr bool AFF = (NGLOC == 4 || NGLOC == 3);    // linear geometric map: one Jacobian per element
 		const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 		if (e >= n_el)
 			return;
@@ -304,13 +319,15 @@ namespace
 		double jt[9], det = 0.0;
 		for (int k = 0; k < NPTS; ++k)
 		{
-			if (k == 0 || NGLOC != 4)
+			if (k == 0 || !AFF)
 			{
 				double tmp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 				for (int j = 0; j < NGLOC; ++j)
 					for (int r = 0; r < 3; ++r)
 						for (int c = 0; c < 3; ++c)
-							tmp[3 * r + c] += tab->ggrad[NGLOC == 4 ? 0 : k][j][r] * xs[3 * j + c];
+							tmp[3 * r + c] += tab->ggrad[AFF ? 0 : k][j][r] * xs[3 * j + c];
+				if (DIM == 2)
+					tmp[8] = 1.0; // the 2 x 2 Jacobian in the upper left of a 3 x 3 matrix: same determinant, same inverse there
 				inv3_transposed_det(tmp, jt, &det);
 				if (WH)
 				{
@@ -329,14 +346,14 @@ namespace
 				double G[3];
 				for (int c = 0; c < 3; ++c)
 					G[c] = g0 * jt[c] + g1 * jt[3 + c] + g2 * jt[6 + c];
-				const double *ui = u + 3 * (int64_t)nd[i];
-				for (int d = 0; d < 3; ++d)
+				const double *ui = u + DIM * (int64_t)nd[i];
+				for (int d = 0; d < DIM; ++d)
 					for (int c = 0; c < 3; ++c)
 						F[3 * d + c] += ui[d] * G[c];
 			}
 			const double lambda = lambda_e ? lambda_e[PP ? e * NPTS + k : e] : lambda_u, mu = mu_e ? mu_e[PP ? e * NPTS + k : e] : mu_u;
 			double dJ[9], c0, c1, c2;
-			en += nl_point<MODEL>(model, F, lambda, mu, tensor, da, dJ, c0, c1, c2, bad);
+			en += nl_point<MODEL, DIM>(model, F, lambda, mu, tensor, da, dJ, c0, c1, c2, bad);
 			if (WH)
 			{
 				for (int q = 0; q < 9; ++q)
@@ -362,8 +379,9 @@ namespace
 		}
 		eloc[e] = en;
 		if (WG)
-			for (int t = 0; t < NLOC * 3; ++t)
-				gloc[e * (NLOC * 3) + t] = g[t];
+			for (int i = 0; i < NLOC; ++i)
+				for (int d = 0; d < DIM; ++d)
+					gloc[e * (NLOC * DIM) + i * DIM + d] = g[3 * i + d];
 		if (bad)
 			atomicOr(flag, 1);
 	}
@@ -513,6 +531,7 @@ namespace
 		const double *tensor = nullptr;                                                   // M_STVKT: the 6 x 6 elasticity tensor
 		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + (MODEL == M_STVKT ? 36 : 0); // grad[k][i][3], tensor
 		static constexpr int MIN_WAVES = MODEL == M_STVKT ? 2 : PFX_ROWASM_MINWAVES; // the tensor products want the registers of a third wave
+		static constexpr int BS = (NGLOC == 3) ? 2 : 3; // triangles: the in-plane 2 x 2 part of the block computed below
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
 		{
@@ -522,7 +541,7 @@ namespace
 				lds[NPTS * NLOC * 3 + lane] = tensor[lane];
 		}
 
-		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[9]) const
+		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[BS * BS]) const
 		{
 			typedef nl_state<NGLOC, NPTS> ST;
 			typedef double d2 __attribute__((ext_vector_type(2)));
@@ -665,8 +684,9 @@ namespace
 				b[7] += wi2 * wj1 - t0;
 				b[8] += dot + wi2 * wj2;
 			}
-			for (int q = 0; q < 9; ++q)
-				out[q] = b[q];
+			for (int m = 0; m < BS; ++m)
+				for (int n = 0; n < BS; ++n)
+					out[m * BS + n] = b[3 * m + n];
 		}
 	};
 
@@ -773,7 +793,15 @@ namespace
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_rows(pfx_ctx *ctx)
 	{
-		if (ctx->model == PFX_NEOHOOKEAN)
+		if constexpr (NGLOC == 3) // triangles: NeoHookean and LinearElasticity
+		{
+			if (ctx->model == PFX_NEOHOOKEAN)
+				pfx_launch_assemble_rows<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
+			else
+				pfx_launch_assemble_rows<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
+			return;
+		}
+		else if (ctx->model == PFX_NEOHOOKEAN)
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
 		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
 			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, false);
@@ -840,6 +868,18 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 		else
 			launch<27, 8, 27>(ctx, d_u, energy, grad, hess, eloc);
 		break;
+	case PFX_P1TRI:
+		if (np != 1 || (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY))
+			ok = false;
+		else
+			launch<3, 3, 1>(ctx, d_u, energy, grad, hess, eloc);
+		break;
+	case PFX_P2TRI:
+		if (np != 4 || (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY))
+			ok = false;
+		else
+			launch<6, 3, 4>(ctx, d_u, energy, grad, hess, eloc);
+		break;
 	default:
 		ok = false;
 	}
@@ -870,6 +910,12 @@ pfx_status pfx_launch_rows_nl(pfx_ctx *ctx)
 	case PFX_Q2HEX:
 		launch_rows<27, 8, 27>(ctx);
 		break;
+	case PFX_P1TRI:
+		launch_rows<3, 3, 1>(ctx);
+		break;
+	case PFX_P2TRI:
+		launch_rows<6, 3, 4>(ctx);
+		break;
 	default:
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: unsupported element kind");
 	}
@@ -883,6 +929,8 @@ pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx)
 {
 	if (ctx->estate_kind != PFX_ESTATE_NL)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: element state missing");
+	if (ctx->mesh_dim != 3)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "project_to_psd is implemented for the 3-D element kinds");
 	const int64_t need = ctx->n_el * (int64_t)(ctx->n_loc * (ctx->n_loc + 1) / 2) * 9;
 	if (ctx->kloc_count < need)
 	{

@@ -344,6 +344,19 @@ namespace
 						}
 				}
 			}
+			else if constexpr (BS == 2)
+			{
+				// 2-D problems: four entries per slot, entry c of the lane's block at c * 64 + lane
+#pragma unroll 4
+				for (int j = 0; j < len; ++j)
+				{
+					const V *vj = v + (int64_t)j * (SL * 4) + lane;
+					const int64_t cc = (int64_t)__builtin_nontemporal_load(c + j * SL) * 2;
+					const double x0 = x[cc], x1 = x[cc + 1];
+					a0 += (double)__builtin_nontemporal_load(vj) * x0 + (double)__builtin_nontemporal_load(vj + SL) * x1;
+					a1 += (double)__builtin_nontemporal_load(vj + 2 * SL) * x0 + (double)__builtin_nontemporal_load(vj + 3 * SL) * x1;
+				}
+			}
 			else
 			{
 #pragma unroll 8
@@ -542,8 +555,10 @@ static pfx_status sell_convert(pfx_ctx *ctx, V *out)
 		PFX_CONVERT(1, 4, 4);
 	else if (ctx->bs == 3)
 		PFX_CONVERT(3, 1, 4);
+	else if (ctx->bs == 2)
+		PFX_CONVERT(2, 2, 4);
 	else
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1, 2 or 3");
 #undef PFX_CONVERT
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
@@ -739,8 +754,10 @@ pfx_status pfx_sell_unpermute(pfx_ctx *ctx, double *d_y)
 		hipLaunchKernelGGL((k_sell_unpermute<3>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys, n, d_y, (const int *)nullptr);
 	else if (ctx->bs == 1)
 		hipLaunchKernelGGL((k_sell_unpermute<1>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys, n, d_y, (const int *)nullptr);
+	else if (ctx->bs == 2)
+		hipLaunchKernelGGL((k_sell_unpermute<2>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_sell_pos, ctx->d_sell_ys, n, d_y, (const int *)nullptr);
 	else
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1, 2 or 3");
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
@@ -813,8 +830,15 @@ pfx_status pfx_sell_spmv(pfx_ctx *ctx, const double *d_x, double *d_y, double *p
 		else
 			PFX_GO(3, false);
 	}
+	else if (ctx->bs == 2)
+	{
+		if (part)
+			PFX_GO(2, true);
+		else
+			PFX_GO(2, false);
+	}
 	else
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1 or 3");
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "block size must be 1, 2 or 3");
 #undef PFX_GO
 #undef PFX_GO2
 	return PFX_OK;

@@ -375,6 +375,8 @@ pfx_status pfx_launch_invdiag(pfx_ctx *ctx, int jacobi, double *d_invdiag)
 	const uint8_t *fixed = ctx->n_dirichlet > 0 ? ctx->d_fixed : nullptr;
 	if (ctx->bs == 1)
 		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jacobi, ctx->diag_shift, d_invdiag);
+	else if (ctx->bs == 2)
+		hipLaunchKernelGGL((k_invdiag<2>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jacobi, ctx->diag_shift, d_invdiag);
 	else
 		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jacobi, ctx->diag_shift, d_invdiag);
 	PFX_HIP(hipGetLastError());
@@ -470,6 +472,8 @@ pfx_status pfx_cgs_prepare_impl(pfx_ctx *ctx, double *d_x, int precond)
 	const int jac = precond == PFX_PRECOND_JACOBI ? 1 : 0;
 	if (ctx->bs == 1)
 		hipLaunchKernelGGL((k_invdiag<1>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, ctx->diag_shift, w.invdiag);
+	else if (ctx->bs == 2)
+		hipLaunchKernelGGL((k_invdiag<2>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, ctx->diag_shift, w.invdiag);
 	else
 		hipLaunchKernelGGL((k_invdiag<3>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, fixed, ctx->n_owned, jac, ctx->diag_shift, w.invdiag);
 	PFX_HIP(hipGetLastError());
@@ -564,6 +568,8 @@ pfx_status pfx_cgs_update_impl(pfx_ctx *ctx, int it, double *d_x, double *gscal)
 			hipLaunchKernelGGL((k_cg_update<3>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, ctx->d_sell_ys, ctx->d_sell_pos, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
 		else if (ctx->cg_tmp_sliced && ctx->bs == 1)
 			hipLaunchKernelGGL((k_cg_update<1>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, ctx->d_sell_ys, ctx->d_sell_pos, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
+		else if (ctx->cg_tmp_sliced && ctx->bs == 2)
+			hipLaunchKernelGGL((k_cg_update<2>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, ctx->d_sell_ys, ctx->d_sell_pos, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
 		else
 			hipLaunchKernelGGL((k_cg_update<0>), dim3(PFX_NPART), dim3(256), 0, ctx->stream, w.p, w.tmp, (const int32_t *)nullptr, w.invdiag, n, it, d_x, w.r, ctx->d_partials, pap, (pfx_cg_state *)ctx->d_cgstate);
 	}

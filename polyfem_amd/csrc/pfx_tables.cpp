@@ -5,9 +5,10 @@
 // expression is written in the operation order of the reference's generated code
 //   tets : src/polyfem/autogen/auto_p_bases.cpp:1000-1078 (P1), :1152-1326 (P2)
 //   hexes: src/polyfem/autogen/auto_q_bases.cpp:1115-1260 (Q1), :1277-1871 (Q2, factor order recorded in pf_q2_tables.h)
+//   triangles: src/polyfem/autogen/auto_p_bases.cpp:60-136 (P1), :146-273 (P2); third components are zero
 // and of the quadrature set-up
 //   src/polyfem/quadrature/TetQuadrature.cpp:31-43, LineQuadrature.cpp:4707-4734, HexQuadrature.cpp:17-45,
-//   order rule src/polyfem/basis/FEBasis3d.cpp:1467,1506.
+//   TriQuadrature.cpp:30-43, order rule src/polyfem/basis/FEBasis3d.cpp:1467,1506, basis/FEBasis2d.cpp:797-798.
 #include "pfx_internal.h"
 #include "pf_quad_tables.h"
 #include "pf_q2_tables.h"
@@ -52,6 +53,37 @@ namespace
 			for (int c = 0; c < 3; ++c)
 				r.p[k][c] = p[3 * k + c];
 			r.w[k] = w[k] / 6;
+		}
+		return true;
+	}
+
+	bool tri_rule(int order, rule &r)
+	{
+		const double *p = nullptr, *w = nullptr;
+		switch (order)
+		{
+		case 1:
+			p = pf_tri_pts_1, w = pf_tri_wts_1, r.n = PF_TRI_NPTS_1;
+			break;
+		case 2:
+			p = pf_tri_pts_2, w = pf_tri_wts_2, r.n = PF_TRI_NPTS_2;
+			break;
+		case 3:
+			p = pf_tri_pts_3, w = pf_tri_wts_3, r.n = PF_TRI_NPTS_3;
+			break;
+		case 4:
+			p = pf_tri_pts_4, w = pf_tri_wts_4, r.n = PF_TRI_NPTS_4;
+			break;
+		case 5:
+			p = pf_tri_pts_5, w = pf_tri_wts_5, r.n = PF_TRI_NPTS_5;
+			break;
+		default:
+			return false;
+		}
+		for (int k = 0; k < r.n; ++k)
+		{
+			r.p[k][0] = p[2 * k], r.p[k][1] = p[2 * k + 1], r.p[k][2] = 0;
+			r.w[k] = w[k] / 2;
 		}
 		return true;
 	}
@@ -156,6 +188,39 @@ namespace
 		}
 	}
 
+	void p1tri_grad(int li, double *g)
+	{
+		static const double t[3][2] = {{-1, -1}, {1, 0}, {0, 1}};
+		g[0] = t[li][0], g[1] = t[li][1], g[2] = 0;
+	}
+
+	void p2tri_grad(int li, const double *pt, double *g)
+	{
+		const double x = pt[0], y = pt[1];
+		g[2] = 0;
+		switch (li)
+		{
+		case 0:
+			g[0] = g[1] = 4 * x + 4 * y - 3;
+			break;
+		case 1:
+			g[0] = 4 * x - 1, g[1] = 0;
+			break;
+		case 2:
+			g[0] = 0, g[1] = 4 * y - 1;
+			break;
+		case 3:
+			g[0] = 4 * (-2 * x - y + 1), g[1] = -4 * x;
+			break;
+		case 4:
+			g[0] = 4 * y, g[1] = 4 * x;
+			break;
+		case 5:
+			g[0] = -4 * y, g[1] = 4 * (-x - 2 * y + 1);
+			break;
+		}
+	}
+
 	// Q1: corner c has reference position q1c[c]; N_c = prod_axis (s ? t : -(t-1)); printed factor order differs
 	// per corner in the reference, which only reorders exact-sign factors of two-term products.
 	const int q1c[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
@@ -242,6 +307,12 @@ namespace
 		case PFX_Q2HEX:
 			q2_grad(li, pt, g);
 			break;
+		case PFX_P1TRI:
+			p1tri_grad(li, g);
+			break;
+		case PFX_P2TRI:
+			p2tri_grad(li, pt, g);
+			break;
 		}
 	}
 	// values: auto_p_bases.cpp:967-999 (P1), :1089-1151 (P2); auto_q_bases.cpp:1067-1110 (Q1, printed factor order),
@@ -253,6 +324,24 @@ namespace
 		{
 		case PFX_P1TET:
 			return li == 0 ? -x - y - z + 1 : pt[li - 1];
+		case PFX_P1TRI:
+			return li == 0 ? -x - y + 1 : pt[li - 1];
+		case PFX_P2TRI:
+			switch (li)
+			{
+			case 0:
+				return (x + y - 1) * (2 * x + 2 * y - 1);
+			case 1:
+				return x * (2 * x - 1);
+			case 2:
+				return y * (2 * y - 1);
+			case 3:
+				return -4 * x * (x + y - 1);
+			case 4:
+				return 4 * x * y;
+			default:
+				return -4 * y * (x + y - 1);
+			}
 		case PFX_P2TET:
 			switch (li)
 			{
@@ -301,7 +390,7 @@ namespace
 
 void pfx_fill_tables(int kind, int quad_order, pfx_tables *t)
 {
-	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX) ? 1 : 2;
+	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX || kind == PFX_P1TRI) ? 1 : 2;
 	int real_order = (p - 1) * 2 + 1;
 	if (quad_order > real_order)
 		real_order = quad_order;
@@ -311,7 +400,7 @@ void pfx_fill_tables(int kind, int quad_order, pfx_tables *t)
 // mass quadrature: order max(mass_quadrature_order = -1, 2p+1)  (basis/FEBasis3d.cpp:1468, 1507)
 void pfx_fill_tables_mass(int kind, pfx_tables *t)
 {
-	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX) ? 1 : 2;
+	const int p = (kind == PFX_P1TET || kind == PFX_Q1HEX || kind == PFX_P1TRI) ? 1 : 2;
 	fill(kind, 2 * p + 1, t);
 }
 
@@ -320,11 +409,11 @@ namespace
 void fill(int kind, int real_order, pfx_tables *t)
 {
 	std::memset(t, 0, sizeof(*t));
-	static const int nloc[4] = {4, 10, 8, 27};
-	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX);
-	const int gkind = hex ? PFX_Q1HEX : PFX_P1TET;
+	static const int nloc[6] = {4, 10, 8, 27, 3, 6};
+	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX), tri = (kind == PFX_P1TRI || kind == PFX_P2TRI);
+	const int gkind = hex ? PFX_Q1HEX : tri ? PFX_P1TRI : PFX_P1TET;
 	rule r;
-	const bool ok = hex ? hex_rule(real_order, r) : tet_rule(real_order, r);
+	const bool ok = hex ? hex_rule(real_order, r) : tri ? tri_rule(real_order, r) : tet_rule(real_order, r);
 	if (!ok)
 	{
 		t->n_pts = 0;
@@ -355,9 +444,9 @@ void fill(int kind, int real_order, pfx_tables *t)
 // check, tests/test_bases.cpp:716-776).  Used to place the basis nodes in space (aggregation-AMG rigid-body modes).
 void pfx_local_node_positions(int kind, int *n_loc, int *n_gloc, double (*pos)[3], double (*gval)[PFX_MAX_GLOC])
 {
-	static const int nloc[4] = {4, 10, 8, 27};
-	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX);
-	const int gkind = hex ? PFX_Q1HEX : PFX_P1TET;
+	static const int nloc[6] = {4, 10, 8, 27, 3, 6};
+	const bool hex = (kind == PFX_Q1HEX || kind == PFX_Q2HEX), tri = (kind == PFX_P1TRI || kind == PFX_P2TRI);
+	const int gkind = hex ? PFX_Q1HEX : tri ? PFX_P1TRI : PFX_P1TET;
 	*n_loc = nloc[kind];
 	*n_gloc = nloc[gkind];
 	for (int j = 0; j < *n_loc; ++j)

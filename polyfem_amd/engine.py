@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PFX_LIBRARY selects another build of the same ABI (e.g. one with host-side sanitizers)
 LIB_PATH = os.environ.get("PFX_LIBRARY") or os.path.join(_HERE, "libpolyfem_amd.so")
 
-P1TET, P2TET, Q1HEX, Q2HEX = 0, 1, 2, 3
+P1TET, P2TET, Q1HEX, Q2HEX, P1TRI, P2TRI = 0, 1, 2, 3, 4, 5
 LAPLACIAN, LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT, HOOKE_LINEAR, MULTI_MODEL = 0, 1, 2, 3, 4, 5
 PRECOND_IDENTITY, PRECOND_JACOBI, PRECOND_AMG = 0, 1, 2
 PFX_ERR_ARG, PFX_ERR_HIP, PFX_ERR_UNSUPPORTED, PFX_ERR_NUMERIC, PFX_ERR_SIZE = -1, -2, -3, -4, -5
@@ -326,9 +326,15 @@ class Engine:
                                      _d(xyz), mesh.quad_order))
         self.mesh = mesh
 
-    def set_material(self, model: int, lam=1.0, mu=1.0, dim: int = 3):
+    def _mesh_dim(self) -> int:
+        return 2 if self.mesh is not None and self.mesh.kind in (P1TRI, P2TRI) else 3
+
+    def set_material(self, model: int, lam=1.0, mu=1.0, dim: int | None = None):
         """Scalars: uniform Lame parameters; 1-D arrays: one value per element (multi-material bodies); 2-D arrays
-        (n_el, n_pts): one value per quadrature point (space-dependent materials)."""
+        (n_el, n_pts): one value per quadrature point (space-dependent materials).  dim: 3, or 2 on a triangle mesh
+        (default: that of the mesh set before)."""
+        if dim is None:
+            dim = self._mesh_dim()
         if np.ndim(lam) == 0:
             self._ck(self.L.pfx_set_material(self.h, model, dim, float(lam), float(mu)))
         else:
@@ -561,10 +567,10 @@ class Engine:
         self._ck(self.L.pfx_amg_apply_dev(self.h, _vp(d_r), _vp(d_z)))
 
     def mass_quadrature_points(self):
-        """Physical positions of the points of the mass quadrature rule, shape (n_el, n_pts, 3)."""
+        """Physical positions of the points of the mass quadrature rule, shape (n_el, n_pts, dim)."""
         n_pts = C.c_int()
         self._ck(self.L.pfx_mass_quadrature_points(self.h, C.byref(n_pts), None))
-        out = np.zeros((self.info().n_el, n_pts.value, 3))
+        out = np.zeros((self.info().n_el, n_pts.value, self._mesh_dim()))
         self._ck(self.L.pfx_mass_quadrature_points(self.h, C.byref(n_pts), _d(out)))
         return out
 
@@ -582,10 +588,10 @@ class Engine:
             self._ck(self.L.pfx_assemble_mass(self.h, float(rho[0]), _d(rho)))
 
     def quadrature_points(self):
-        """Physical positions of the quadrature points of the stiffness rule, shape (n_el, n_pts, 3)."""
+        """Physical positions of the quadrature points of the stiffness rule, shape (n_el, n_pts, dim)."""
         n_pts = C.c_int()
         self._ck(self.L.pfx_quadrature_points(self.h, C.byref(n_pts), None))
-        out = np.zeros((self.info().n_el, n_pts.value, 3))
+        out = np.zeros((self.info().n_el, n_pts.value, self._mesh_dim()))
         self._ck(self.L.pfx_quadrature_points(self.h, C.byref(n_pts), _d(out)))
         return out
 

@@ -1,0 +1,276 @@
+"""GPU parity tests of the 2-D element kinds (P1 / P2 triangles) through the C ABI, against the CPU oracle.
+
+The reference instantiates its NeoHookean kernels for (3,2) and (6,2) (`NeoHookeanElasticity.cpp:47-115`) and its two
+assembler property tests run on 2-D triangle meshes: `hessian_lin` (`tests/test_assembler.cpp:12-64`) and the
+finite-difference test of the elastic form (`tests/test_form_derivatives.cpp:84-143, 200-227`).  Their mesh files
+(`plane_hole.obj`, `circle36.obj`) are not part of the reference tree, so both run here on seeded triangle meshes:
+parity unpinned beyond the oracle, the properties themselves are oracle-independent.
+
+Bars as for the 3-D kinds: pattern bit-exact, values / energies / gradients 1e-12, CG +-2 iterations and 1e-10."""
+import numpy as np
+import pytest
+
+from polyfem_amd import engine as E
+from polyfem_amd import mesh as M
+from tests.helpers import csc_to_scipy, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+MESHES = {
+    "p1_aligned": lambda: M.square_tris(6, 1),
+    "p1_jitter": lambda: M.square_tris(7, 1, jitter=0.25, seed=1),
+    "p2_aligned": lambda: M.square_tris(5, 2),
+    "p2_jitter_polyfem": lambda: M.square_tris(6, 2, numbering="polyfem", jitter=0.2, seed=2),
+    "p2_stretched": lambda: M.square_tris(4, 2, scale=(2.0, 0.5)),
+    "p2_one_cell": lambda: M.square_tris(1, 2),
+}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+def _setup(eng, mesh, model, lam, mu):
+    eng.set_mesh(mesh)
+    eng.set_material(model, lam, mu)
+    return eng.build_pattern()
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+@pytest.mark.parametrize("model", ["Laplacian", "LinearElasticity"])
+def test_linear_assembly_pattern_bit_exact_and_values(eng, oracle, name, model):
+    mesh = MESHES[name]()
+    mid = E.MODEL_BY_NAME[model]
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    _setup(eng, mesh, mid, lam, mu)
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    outer, inner, vals = oracle.assemble_linear(mesh, mid, lam, mu)
+    assert rp.size == mesh.n_nodes * (1 if mid == E.LAPLACIAN else 2) + 1
+    assert np.array_equal(rp, outer.astype(np.int64)), "row_ptr differs from the oracle"
+    assert np.array_equal(ci, inner), "col_idx differs from the oracle"
+    assert rel_err(v, vals) <= TOL
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+@pytest.mark.parametrize("model", ["NeoHookean", "LinearElasticity"])
+def test_energy_gradient_hessian(eng, oracle, name, model):
+    mesh = MESHES[name]()
+    mid = E.MODEL_BY_NAME[model]
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    nnz = _setup(eng, mesh, mid, lam, mu)
+    h = 1.0 / round((mesh.n_el / 2) ** 0.5)
+    for amp in (0.0, 2e-2 * h):
+        x = M.seeded_displacement(mesh, 2, amp)
+        e_ref = oracle.assemble_energy(mesh, mid, lam, mu, x)
+        g_ref = oracle.assemble_gradient(mesh, mid, lam, mu, x)
+        outer, inner, vals = oracle.assemble_hessian(mesh, mid, lam, mu, x)
+        e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner), "Hessian pattern not bit-exact"
+        assert nnz == inner.size and g.size == 2 * mesh.n_nodes
+        if amp == 0.0:
+            assert abs(e) <= 1e-9 and np.abs(g).max() <= 1e-9 * np.abs(vals).max()
+        else:
+            assert abs(e - e_ref) <= TOL * abs(e_ref)
+            assert rel_err(g, g_ref) <= TOL
+        assert rel_err(v, vals) <= TOL
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_hessian_lin_property(eng, oracle, order):
+    """tests/test_assembler.cpp:12-64: the Hessian of the LinearElasticity energy, assembled through the nonlinear
+    interface with the pattern reused, equals the stiffness matrix of the linear assembler to 1e-8 at zero and at nine
+    random displacements."""
+    mesh = M.square_tris(8, order, jitter=0.2, seed=3)
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+    eng.assemble_linear()
+    n = 2 * mesh.n_nodes
+    rp, ci, v = eng.get_linear_csr()
+    import scipy.sparse as sp
+    K = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    rng = np.random.default_rng(0)
+    prp, pci = eng.get_pattern()
+    for rand in range(10):
+        x = np.zeros(n) if rand == 0 else rng.uniform(-1, 1, n)
+        H = sp.csr_matrix((eng.hessian(x), pci, prp), shape=(n, n))
+        assert abs(H - K).max() <= 1e-8 * max(1.0, abs(K).max())
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_elastic_form_derivatives(eng, oracle, order):
+    """tests/test_form_derivatives.cpp:84-143, 200-227: finite differences of the NeoHookean energy against its gradient,
+    and of the gradient against the Hessian, at x = 0 and nine random x / 100."""
+    mesh = M.square_tris(6, order, jitter=0.2, seed=4)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = 2 * mesh.n_nodes
+    rng = np.random.default_rng(1)
+    prp, pci = eng.get_pattern()
+    import scipy.sparse as sp
+    step = 1e-6
+    for rand in range(10):
+        x = np.zeros(n) if rand == 0 else rng.uniform(-1, 1, n) / 100
+        g = eng.gradient(x)
+        H = sp.csr_matrix((eng.hessian(x), pci, prp), shape=(n, n))
+        d = rng.standard_normal(n)
+        d /= np.linalg.norm(d)
+        fd_g = (eng.energy(x + step * d) - eng.energy(x - step * d)) / (2 * step)
+        assert abs(fd_g - g @ d) <= 1e-6 * max(1.0, np.linalg.norm(g))
+        fd_h = (eng.gradient(x + step * d) - eng.gradient(x - step * d)) / (2 * step)
+        assert np.linalg.norm(fd_h - H @ d) <= 1e-6 * np.linalg.norm(H @ d)
+
+
+@pytest.mark.parametrize("case", ["laplace_p1", "elastic_p2", "neohookean_p2"])
+def test_reduced_matrix_and_cg(eng, oracle, case):
+    if case == "laplace_p1":
+        mesh, model, bs = M.square_tris(12, 1), E.LAPLACIAN, 1
+    elif case == "elastic_p2":
+        mesh, model, bs = M.square_tris(8, 2), E.LINEAR_ELASTICITY, 2
+    else:
+        mesh, model, bs = M.square_tris(8, 2, jitter=0.1), E.NEOHOOKEAN, 2
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    _setup(eng, mesh, model, lam, mu)
+    n = mesh.n_nodes * bs
+    if model == E.NEOHOOKEAN:
+        x = M.seeded_displacement(mesh, 2, 1e-3)
+        eng.hessian(x, fetch=False)
+        full = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+    else:
+        eng.assemble_linear()
+        full = oracle.assemble_linear(mesh, model, lam, mu)
+    bd = M.boundary_dofs(mesh, bs, "x0" if bs == 2 else "all")
+    eng.set_dirichlet(bd)
+    red = oracle.full_to_reduced_matrix(full, bd)
+    rp, ci, v = eng.get_reduced_csr()
+    assert np.array_equal(rp, red[0].astype(np.int64)) and np.array_equal(ci, red[1])
+    assert rel_err(v, red[2]) <= TOL
+    keep = np.setdiff1d(np.arange(n), bd)
+    b_full = np.random.default_rng(5).standard_normal(n)
+    xr, it_ref, _ = oracle.cg(red, b_full[keep], jacobi=True, max_iter=2000, tol=1e-12)
+    xg, it, _ = eng.cg(b_full, None, E.PRECOND_JACOBI, 2000, 1e-12)
+    assert abs(it - it_ref) <= 2, (it, it_ref)
+    assert not xg[bd].any()
+    A = csc_to_scipy(red, keep.size)
+    assert np.linalg.norm(A @ xg[keep] - b_full[keep]) <= 1e-10 * np.linalg.norm(b_full[keep])
+    assert np.linalg.norm(xg[keep] - xr) <= 1e-8 * np.linalg.norm(xr)
+    # the product itself
+    xv = np.random.default_rng(6).standard_normal(n)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert rel_err(eng.spmv(xv), csc_to_scipy(full, n) @ xv) <= 1e-12
+
+
+def test_large_mesh_takes_the_slice_ordered_product(eng, oracle):
+    """More than 65536 nodes: the CG keeps its products in slice order (the path the small meshes above never take)."""
+    mesh = M.square_tris(140, 2)  # 281^2 = 78 961 nodes
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = 2 * mesh.n_nodes
+    x = M.seeded_displacement(mesh, 2, 1e-5)
+    assert abs(eng.energy(x) - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x, n_threads=8)) <= TOL * abs(eng.energy(x))
+    assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x, n_threads=8)) <= TOL
+    v = eng.hessian(x)
+    full = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x, n_threads=8)
+    assert rel_err(v, full[2]) <= TOL
+    bd = M.boundary_dofs(mesh, 2, "x0")
+    eng.set_dirichlet(bd)
+    red = oracle.full_to_reduced_matrix(full, bd)
+    keep = np.setdiff1d(np.arange(n), bd)
+    b = np.random.default_rng(7).standard_normal(n)
+    xr, it_ref, _ = oracle.cg(red, b[keep], jacobi=True, max_iter=300, tol=1e-12)
+    xg, it, _ = eng.cg(b, None, E.PRECOND_JACOBI, 300, 1e-12)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert it == it_ref == 300  # the iteration limit: the iterates after the same number of steps
+    assert np.linalg.norm(xg[keep] - xr) <= 1e-8 * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("case", ["neohookean_p2", "neohookean_p1_large_load", "linear_elasticity_p2"])
+def test_newton_solve_matches_oracle(eng, oracle, case):
+    if case == "neohookean_p2":
+        mesh, model, load = M.square_tris(6, 2, jitter=0.1), E.NEOHOOKEAN, -50.0
+    elif case == "neohookean_p1_large_load":
+        mesh, model, load = M.square_tris(8, 1, jitter=0.1), E.NEOHOOKEAN, -1500.0
+    else:
+        mesh, model, load = M.square_tris(4, 2), E.LINEAR_ELASTICITY, -50.0
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    _setup(eng, mesh, model, lam, mu)
+    n = mesh.n_nodes * 2
+    bnd = M.boundary_dofs(mesh, 2, "x0")
+    eng.set_dirichlet(bnd)
+    rhs = np.zeros(n)
+    rhs[1::2] = load / mesh.n_nodes
+    x_ref, info_ref = oracle.newton_solve(mesh, model, lam, mu, rhs, bnd, np.zeros(n), n_threads=4)
+    x, info = eng.newton_solve(np.zeros(n), rhs)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert info["status"] == info_ref["status"] and info["status"] in (2, 3)
+    assert info["iterations"] == info_ref["iterations"] >= 2
+    assert abs(info["line_search_iterations"] - info_ref["line_search_iterations"]) <= 1
+    assert abs(info["cg_iterations"] - info_ref["cg_iterations"]) <= max(2 * info["iterations"], 0.03 * info_ref["cg_iterations"])
+    assert np.abs(x - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
+    assert abs(info["energy"] - info_ref["energy"]) <= 1e-9 * abs(info_ref["energy"])
+    assert not x[bnd].any()
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem"])
+@pytest.mark.parametrize("size", [1, 2])
+def test_mass_matrix_and_body_force(eng, oracle, name, size):
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    _setup(eng, mesh, E.LAPLACIAN if size == 1 else E.LINEAR_ELASTICITY, lam, mu)
+    rng = np.random.default_rng(8)
+    for rho in (1.7, rng.uniform(0.5, 2.0, mesh.n_el)):
+        eng.assemble_mass(rho)
+        rp, ci, v = eng.get_linear_csr()
+        ref = oracle.assemble_mass(mesh, size, rho)
+        assert np.array_equal(rp, ref[0].astype(np.int64)) and np.array_equal(ci, ref[1])
+        assert rel_err(v, ref[2]) <= TOL
+        force = np.array([0.3, -9.81])[:size]
+        assert rel_err(eng.assemble_rhs(force, rho), oracle.assemble_rhs(mesh, size, force, rho)) <= TOL
+    pts = eng.quadrature_points()
+    assert pts.shape[2] == 2 and rel_err(pts, oracle.quadrature_points(mesh)) <= TOL
+    f_pts = np.stack([np.sin(pts[..., 0]), np.cos(pts[..., 1])], axis=-1)[..., :size].copy()
+    assert rel_err(eng.assemble_rhs_pointwise(f_pts, 1.3), oracle.assemble_rhs_pointwise(mesh, size, f_pts, 1.3)) <= TOL
+    assert rel_err(eng.mass_quadrature_points(), oracle.mass_quadrature_points(mesh)) <= TOL
+
+
+def test_per_element_and_per_point_materials(eng, oracle):
+    mesh = MESHES["p2_jitter_polyfem"]()
+    rng = np.random.default_rng(9)
+    lam0, mu0 = oracle.lame(1e5, 0.3, 2)
+    for shape in ((mesh.n_el,), (mesh.n_el, 4)):
+        lam, mu = lam0 * rng.uniform(0.5, 2, shape), mu0 * rng.uniform(0.5, 2, shape)
+        _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+        eng.assemble_linear()
+        rp, ci, v = eng.get_linear_csr()
+        ref = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+        assert np.array_equal(ci, ref[1]) and rel_err(v, ref[2]) <= TOL
+        _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+        x = M.seeded_displacement(mesh, 2, 2e-3)
+        assert abs(eng.energy(x) - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= TOL * abs(eng.energy(x))
+        assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= TOL
+        assert rel_err(eng.hessian(x), oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]) <= TOL
+
+
+def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
+    mesh = MESHES["p2_aligned"]()
+    eng.set_mesh(mesh)
+    with pytest.raises(E.PfxError):
+        eng.set_material(E.SAINT_VENANT, 1.0, 1.0)  # 2-D: Laplacian, LinearElasticity, NeoHookean
+    with pytest.raises(E.PfxError):
+        eng.set_material(E.NEOHOOKEAN, 1.0, 1.0, dim=3)  # dim must match the mesh
+    eng.set_material(E.NEOHOOKEAN, 1.0, 1.0)
+    eng.build_pattern()
+    x = M.seeded_displacement(mesh, 2, 1e-3)
+    with pytest.raises(E.PfxError):
+        eng.hessian(x, project_to_psd=True)
+    with pytest.raises(E.PfxError):
+        eng.amg_setup()
+    # a tetrahedral mesh with dim = 2 is refused as well
+    eng.set_mesh(M.cube_tets(2, 1))
+    with pytest.raises(E.PfxError):
+        eng.set_material(E.NEOHOOKEAN, 1.0, 1.0, dim=2)

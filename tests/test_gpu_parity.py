@@ -979,8 +979,11 @@ def test_error_behaviour_of_the_abi(oracle):
             e2.build_pattern()
         assert ei.value.code == -1
         e2.set_mesh(mesh)
-        with pytest.raises(E.PfxError) as ei:  # 2-D is not implemented
+        with pytest.raises(E.PfxError) as ei:  # dim = 2 belongs to triangle meshes
             e2.set_material(E.LINEAR_ELASTICITY, 1.0, 1.0, dim=2)
+        assert ei.value.code == -1 and "dim" in str(ei.value)
+        with pytest.raises(E.PfxError) as ei:  # there is no 4-D
+            e2.set_material(E.LINEAR_ELASTICITY, 1.0, 1.0, dim=4)
         assert ei.value.code == -3
         with pytest.raises(E.PfxError) as ei:  # one value per element required
             e2.set_material(E.NEOHOOKEAN, np.ones(mesh.n_el - 1), np.ones(mesh.n_el - 1))

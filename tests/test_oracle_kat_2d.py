@@ -1,0 +1,203 @@
+"""CPU tests of the oracle's 2-D (triangle) branches against what the reference's own tests hold for them:
+
+  tests/test_bases.cpp:60-171   hand-written P1 / P2 triangle closed forms (values and gradients), used by the test cases
+                                P1_2d / P2_2d (:628-688) at the points of an order-12 rule with margin 1e-10;
+  tests/test_bases.cpp:19-38    node tables of the linear / quadratic triangle, and the Kronecker property (Pk_2d :690-714);
+  tests/test_quadrature.cpp     weight sums (0.5 for the triangle) and points inside the reference element;
+and the two property tests the reference runs on 2-D meshes, re-created on seeded triangle meshes:
+  tests/test_assembler.cpp:12-64 (hessian_lin), tests/test_form_derivatives.cpp:84-143, 200-227 (finite differences).
+The NeoHookean dim == 2 branches are also checked against the dim == 3 branches on the plane-strain embedding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from polyfem_amd import mesh as M
+from tests.helpers import csc_to_scipy
+
+
+def _lin_tri(i, p):
+    u, v = p[:2]
+    return [1 - u - v, u, v][i]
+
+
+def _lin_tri_grad(i):
+    return [(-1, -1), (1, 0), (0, 1)][i]
+
+
+def _quad_tri(i, p):
+    u, v = p[:2]
+    return [(1 - u - v) * (1 - 2 * u - 2 * v), u * (2 * u - 1), v * (2 * v - 1), 4 * u * (1 - u - v), 4 * u * v, 4 * v * (1 - u - v)][i]
+
+
+def _quad_tri_grad(i, p):
+    u, v = p[:2]
+    return [(4 * u + 4 * v - 3,) * 2, (4 * u - 1, 0), (0, 4 * v - 1), (4 - 8 * u - 4 * v, -4 * u), (4 * v, 4 * u), (-4 * v, 4 - 4 * u - 8 * v)][i]
+
+
+def test_triangle_bases_match_reference_closed_forms(oracle):
+    pts, _ = oracle.tri_quadrature(5)
+    rng = np.random.default_rng(0)
+    extra = rng.dirichlet((1, 1, 1), 20)[:, :2]
+    for p in np.vstack([pts, extra]):
+        p3 = (p[0], p[1], 0.0)
+        for i in range(3):
+            assert abs(oracle.basis_value(oracle.P1TRI, i, p3) - _lin_tri(i, p)) < 1e-10
+            assert np.abs(oracle.basis_grad(oracle.P1TRI, i, p3)[:2] - _lin_tri_grad(i)).max() < 1e-10
+        for i in range(6):
+            assert abs(oracle.basis_value(oracle.P2TRI, i, p3) - _quad_tri(i, p)) < 1e-10
+            g = oracle.basis_grad(oracle.P2TRI, i, p3)
+            assert np.abs(g[:2] - _quad_tri_grad(i, p)).max() < 1e-10 and g[2] == 0.0
+
+
+def test_triangle_node_tables_and_kronecker(oracle):
+    lin = np.array([(0, 0), (1, 0), (0, 1)], dtype=float)
+    quad = np.array([(0, 0), (2, 0), (0, 2), (1, 0), (1, 1), (0, 1)], dtype=float) / 2
+    assert np.abs(oracle.basis_nodes(oracle.P1TRI)[:, :2] - lin).max() < 1e-10
+    assert np.abs(oracle.basis_nodes(oracle.P2TRI)[:, :2] - quad).max() < 1e-10
+    for kind in (oracle.P1TRI, oracle.P2TRI):
+        nodes = oracle.basis_nodes(kind)
+        for i in range(len(nodes)):
+            for j in range(len(nodes)):
+                assert abs(oracle.basis_value(kind, i, nodes[j]) - (1.0 if i == j else 0.0)) < 1e-12
+
+
+def test_triangle_quadrature(oracle):
+    expect = {1: 1, 2: 3, 3: 4, 4: 6, 5: 7}
+    for order, n in expect.items():
+        pts, w = oracle.tri_quadrature(order)
+        assert len(w) == n and abs(w.sum() - 0.5) < 1e-14
+        assert pts.min() >= 0 and pts.max() <= 1 and (pts.sum(axis=1) <= 1 + 1e-14).all()
+        # exactness: integral of x^a y^b over the reference triangle = a! b! / (a+b+2)!
+        from math import factorial as f
+        for a in range(order + 1):
+            for b in range(order + 1 - a):
+                assert abs((w * pts[:, 0] ** a * pts[:, 1] ** b).sum() - f(a) * f(b) / f(a + b + 2)) < 1e-14
+    # rules the assemblers pick (basis/FEBasis2d.cpp:797-798): stiffness 2(p-1)+1, mass 2p+1
+    assert len(oracle.quadrature(oracle.P1TRI)[1]) == 1 and len(oracle.quadrature(oracle.P2TRI)[1]) == 4
+    assert len(oracle.mass_quadrature(oracle.P1TRI)[1]) == 4 and len(oracle.mass_quadrature(oracle.P2TRI)[1]) == 7
+
+
+def test_mesh_generator_and_geometry(oracle):
+    for order in (1, 2):
+        for numbering in ("lattice", "polyfem"):
+            m = M.square_tris(5, order, numbering=numbering, jitter=0.2, seed=3, scale=(2.0, 0.5))
+            assert m.n_el == 50 and m.n_nodes == (5 * order + 1) ** 2 and m.xyz.shape[1] == 2
+            assert sorted(np.unique(m.conn)) == list(range(m.n_nodes))
+            area = 0.0
+            for e in range(m.n_el):
+                v = oracle.compute_vals(m, e)
+                assert (v["det"] > 0).all()
+                area += (v["det"] * v["w"]).sum()
+                # jac_it is the transposed inverse of the Jacobian of the affine map
+                x = m.xyz[m.gconn[e]]
+                J = np.array([x[1] - x[0], x[2] - x[0]])  # rows: d/dxi, d/deta
+                assert np.abs(v["jac_it"][0][:2, :2] - np.linalg.inv(J).T).max() < 1e-12 * np.abs(np.linalg.inv(J)).max()
+            assert abs(area - 1.0) < 1e-13
+            assert np.abs(M.node_positions(m)[m.conn[:, :3]] - m.xyz[m.gconn]).max() == 0
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_hessian_lin_property_oracle(oracle, order):
+    m = M.square_tris(6, order, jitter=0.2, seed=1)
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    n = 2 * m.n_nodes
+    K = csc_to_scipy(oracle.assemble_linear(m, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    rng = np.random.default_rng(2)
+    for rand in range(4):
+        x = np.zeros(n) if rand == 0 else rng.uniform(-1, 1, n)
+        H = csc_to_scipy(oracle.assemble_hessian(m, oracle.LINEAR_ELASTICITY, lam, mu, x), n)
+        assert abs(H - K).max() <= 1e-8 * abs(K).max()
+        g = oracle.assemble_gradient(m, oracle.LINEAR_ELASTICITY, lam, mu, x)
+        assert np.abs(g - K @ x).max() <= 1e-10 * max(1.0, np.abs(K @ x).max())
+        assert abs(oracle.assemble_energy(m, oracle.LINEAR_ELASTICITY, lam, mu, x) - 0.5 * x @ (K @ x)) <= 1e-10 * max(1.0, abs(x @ (K @ x)))
+    # rigid translations and the linearised rotation are in the kernel of K
+    pos = M.node_positions(m)
+    for mode in (np.tile([1.0, 0.0], m.n_nodes), np.tile([0.0, 1.0], m.n_nodes), np.stack([-pos[:, 1], pos[:, 0]], axis=1).reshape(-1)):
+        assert np.abs(K @ mode).max() <= 1e-9 * abs(K).max()
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_neohookean_fd_oracle(oracle, order):
+    m = M.square_tris(4, order, jitter=0.2, seed=5)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    n = 2 * m.n_nodes
+    rng = np.random.default_rng(3)
+    for rand in range(3):
+        x = np.zeros(n) if rand == 0 else rng.uniform(-1, 1, n) / 100
+        g = oracle.assemble_gradient(m, oracle.NEOHOOKEAN, lam, mu, x)
+        H = csc_to_scipy(oracle.assemble_hessian(m, oracle.NEOHOOKEAN, lam, mu, x), n)
+        assert abs(H - H.T).max() <= 1e-10 * abs(H).max()
+        d = rng.standard_normal(n)
+        d /= np.linalg.norm(d)
+        h = 1e-6
+        fd = (oracle.assemble_energy(m, oracle.NEOHOOKEAN, lam, mu, x + h * d) - oracle.assemble_energy(m, oracle.NEOHOOKEAN, lam, mu, x - h * d)) / (2 * h)
+        assert abs(fd - g @ d) <= 1e-6 * max(1.0, np.linalg.norm(g))
+        fdh = (oracle.assemble_gradient(m, oracle.NEOHOOKEAN, lam, mu, x + h * d) - oracle.assemble_gradient(m, oracle.NEOHOOKEAN, lam, mu, x - h * d)) / (2 * h)
+        assert np.linalg.norm(fdh - H @ d) <= 1e-6 * np.linalg.norm(H @ d)
+
+
+def test_neohookean_2d_branches_equal_the_plane_embedding_of_the_3d_ones(oracle):
+    """F = [[F2, 0], [0, 1]] has the determinant, the in-plane cofactors and the in-plane second derivatives of F2: the
+    dim == 3 local routines, fed the displacements padded with a zero component, must reproduce the dim == 2 ones on the
+    in-plane entries."""
+    L = oracle.lib()
+    L.pfo_local_neohookean_energy_2d.restype = C.c_double
+    m = M.square_tris(3, 2, jitter=0.2, seed=7)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    om = oracle.OMesh(m)
+    q = oracle.Quad()
+    assert L.pfo_element_quadrature(m.kind, -1, C.byref(q)) == 0
+    rng = np.random.default_rng(4)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for e in range(m.n_el):
+        v = oracle.Vals()
+        L.pfo_compute_vals(C.byref(om.s), C.c_int64(e), C.byref(q), C.byref(v))
+        da = np.array([v.det[k] * q.w[k] for k in range(q.n_pts)])
+        ld2 = rng.uniform(-0.02, 0.02, (6, 2))
+        ld3 = np.ascontiguousarray(np.hstack([ld2, np.zeros((6, 1))]))
+        ld2 = np.ascontiguousarray(ld2)
+        e2 = L.pfo_local_neohookean_energy_2d(C.byref(v), dp(da), dp(ld2), C.c_double(lam), C.c_double(mu))
+        e3 = L.pfo_local_neohookean_energy(C.byref(v), dp(da), dp(ld3), C.c_double(lam), C.c_double(mu))
+        assert abs(e2 - e3) <= 1e-12 * max(abs(e2), 1e-3)
+        g2, g3 = np.zeros(12), np.zeros(18)
+        L.pfo_local_neohookean_grad_2d(C.byref(v), dp(da), dp(ld2), C.c_double(lam), C.c_double(mu), dp(g2))
+        L.pfo_local_neohookean_grad(C.byref(v), dp(da), dp(ld3), C.c_double(lam), C.c_double(mu), dp(g3))
+        assert np.abs(g2.reshape(6, 2) - g3.reshape(6, 3)[:, :2]).max() <= 1e-12 * np.abs(g2).max()
+        h2, h3 = np.zeros((12, 12)), np.zeros((18, 18))
+        L.pfo_local_neohookean_hessian_2d(C.byref(v), dp(da), dp(ld2), C.c_double(lam), C.c_double(mu), dp(h2))
+        L.pfo_local_neohookean_hessian(C.byref(v), dp(da), dp(ld3), C.c_double(lam), C.c_double(mu), dp(h3))
+        idx = np.array([3 * i + d for i in range(6) for d in range(2)])
+        assert np.abs(h2 - h3[np.ix_(idx, idx)]).max() <= 1e-12 * np.abs(h2).max()
+
+
+def test_linear_pattern_drops_exact_zeros_2d(oracle):
+    """On the axis-aligned mesh many local values are exact zeros and are absent from the reference's matrix
+    (Assembler.cpp:170-173): the value-dependent pattern is smaller than the structural one."""
+    m = M.square_tris(6, 2)
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    lin = oracle.assemble_linear(m, oracle.LINEAR_ELASTICITY, lam, mu)
+    full = oracle.assemble_hessian(m, oracle.LINEAR_ELASTICITY, lam, mu, np.zeros(2 * m.n_nodes))
+    assert lin[1].size < full[1].size
+    assert np.abs(csc_to_scipy(lin, 2 * m.n_nodes) - csc_to_scipy(full, 2 * m.n_nodes)).max() <= 1e-9 * np.abs(full[2]).max()
+
+
+def test_newton_mass_rhs_2d_oracle(oracle):
+    m = M.square_tris(5, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    n = 2 * m.n_nodes
+    bnd = M.boundary_dofs(m, 2, "x0")
+    rhs = oracle.assemble_rhs(m, 2, np.array([0.0, -30.0]), 1.0)
+    Mm = csc_to_scipy(oracle.assemble_mass(m, 2, 2.0), n)
+    assert abs(Mm.sum() - 2 * 2.0 * 1.0) < 1e-12  # density * area, once per component
+    assert abs(rhs[1::2].sum() + 30.0) < 1e-12 and abs(rhs[0::2]).max() == 0
+    x, info = oracle.newton_solve(m, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, np.zeros(n))
+    assert info["status"] in (2, 3) and info["iterations"] >= 2
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    g = oracle.assemble_gradient(m, oracle.NEOHOOKEAN, lam, mu, x) - rhs
+    assert np.linalg.norm(g[free]) <= 1e-7 * np.linalg.norm(rhs)
+    # models the 2-D branches do not cover are refused
+    with pytest.raises(AssertionError):
+        oracle.assemble_gradient(m, oracle.SAINT_VENANT, lam, mu, x)
