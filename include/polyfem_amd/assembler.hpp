@@ -12,7 +12,7 @@
 //
 // Error behaviour follows the reference: failures surface as std::runtime_error (the Newton solver catches exactly
 // that around factorize/solve, SparseNewtonDescentSolver.tpp:135-150).  Element sets the engine does not implement
-// (non-conforming bases with global().size() != 1, mixed element types, 2-D) are rejected with std::runtime_error
+// (non-conforming bases with global().size() != 1, mixed element types) are rejected with std::runtime_error
 // instead of being computed somewhere else: there is no CPU fallback.
 #pragma once
 
@@ -189,8 +189,13 @@ namespace polyfem_amd
 				kind = PFX_Q1HEX;
 			else if (n_loc == 27 && n_gloc == 8)
 				kind = PFX_Q2HEX;
+			else if (n_loc == 3 && n_gloc == 3)
+				kind = PFX_P1TRI;
+			else if (n_loc == 6 && n_gloc == 3)
+				kind = PFX_P2TRI;
 			else
-				throw std::runtime_error("polyfem_amd: unsupported element (P1/P2 tets and Q1/Q2 hexes on linear geometry only)");
+				throw std::runtime_error("polyfem_amd: unsupported element (P1/P2 tets, Q1/Q2 hexes and P1/P2 triangles on linear geometry only)");
+			const int gdim = (n_gloc == 3) ? 2 : 3; // coordinates per geometry node
 			const int64_t n_el = (int64_t)bases.size();
 			std::vector<int32_t> conn((size_t)n_el * n_loc), gconn((size_t)n_el * n_gloc);
 			int64_t n_gnodes = 0;
@@ -215,13 +220,13 @@ namespace polyfem_amd
 						n_gnodes = g[0].index + 1;
 				}
 			}
-			std::vector<double> xyz((size_t)n_gnodes * 3, 0.0);
+			std::vector<double> xyz((size_t)n_gnodes * gdim, 0.0);
 			for (int64_t e = 0; e < n_el; ++e)
 				for (int j = 0; j < n_gloc; ++j)
 				{
 					const auto &g = gbases[e].bases[j].global()[0];
-					for (int c = 0; c < 3; ++c)
-						xyz[(size_t)g.index * 3 + c] = g.node[c];
+					for (int c = 0; c < gdim; ++c)
+						xyz[(size_t)g.index * gdim + c] = g.node[c];
 				}
 			check(pfx_set_mesh(h, kind, n_el, n_basis, n_gnodes, conn.data(), gconn.data(), xyz.data(), -1));
 			bound_bs = 0;
@@ -256,14 +261,15 @@ namespace polyfem_amd
 			int size() const { return size_; }
 			void set_size(int s)
 			{
-				if (s != 3)
-					throw std::runtime_error("polyfem_amd: only 3-D elasticity is implemented");
+				if (s != 3 && s != 2)
+					throw std::runtime_error("polyfem_amd: elasticity is implemented for size 2 (triangles) and 3");
 				size_ = s;
 			}
-			// LameParameters::add_multimaterial for uniform (E, nu): utils/ElasticityUtils.cpp:203-214
+			// LameParameters::add_multimaterial for uniform (E, nu): utils/ElasticityUtils.cpp:203-214 (convert_to_lambda with
+			// is_volume = size() == 3); call after set_size
 			void set_E_nu(double E, double nu)
 			{
-				lambda = (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+				lambda = size_ == 3 ? (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu)) : (nu * E) / (1.0 - nu * nu);
 				mu = E / (2.0 * (1.0 + nu));
 			}
 			void set_lambda_mu(double l, double m) { lambda = l, mu = m; }
@@ -418,8 +424,8 @@ namespace polyfem_amd
 			int size() const { return size_; }
 			void set_size(int s)
 			{
-				if (s != 1 && s != 3)
-					throw std::runtime_error("polyfem_amd: the mass matrix is implemented for size 1 and 3");
+				if (s != 1 && s != 2 && s != 3)
+					throw std::runtime_error("polyfem_amd: the mass matrix is implemented for size 1, 2 and 3");
 				size_ = s;
 			}
 			// the block size decides the layout of the device pattern: bound like the stiffness of the same size
@@ -436,8 +442,10 @@ namespace polyfem_amd
 						  const std::vector<basis::ElementBases> &gbases, const AssemblyValsCache &, StiffnessMatrix &stiffness,
 						  const bool is_mass = false) const
 			{
-				if (!is_volume)
-					throw std::runtime_error("polyfem_amd: only 3-D problems are implemented");
+				// is_volume = the mesh is 3-D (State::assemble_stiffness_mat, State.cpp:1091); otherwise a triangle mesh, size() == 2
+				const int dim = is_volume ? 3 : 2;
+				if (local_assembler_.size() != 1 && local_assembler_.size() != dim)
+					throw std::runtime_error("polyfem_amd: the local assembler's size() does not match is_volume");
 				Context &c = Context::instance();
 				if constexpr (std::is_same<LocalAssembler, Mass>::value)
 				{
@@ -445,7 +453,7 @@ namespace polyfem_amd
 						throw std::runtime_error("polyfem_amd: Assembler<Mass>::assemble is called with is_mass = true");
 					if (!local_assembler_.density_e.empty() && local_assembler_.density_e.size() != bases.size())
 						throw std::runtime_error("polyfem_amd: one density per element expected");
-					c.bind(bases, gbases, n_basis, local_assembler_.model_for_binding(), 3, 1.0, 1.0);
+					c.bind(bases, gbases, n_basis, local_assembler_.model_for_binding(), dim, 1.0, 1.0);
 					c.check(pfx_assemble_mass(c.h, local_assembler_.density, local_assembler_.density_e.empty() ? nullptr : local_assembler_.density_e.data()));
 				}
 				else if constexpr (std::is_same<LocalAssembler, HookeLinearElasticity>::value)
@@ -463,7 +471,7 @@ namespace polyfem_amd
 				{
 					if (is_mass)
 						throw std::runtime_error("polyfem_amd: is_mass = true belongs to Assembler<Mass>");
-					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
+					c.bind(bases, gbases, n_basis, LocalAssembler::model, dim, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
 					c.check(pfx_assemble_linear(c.h));
 				}
 				int64_t nnz = 0;
@@ -501,7 +509,7 @@ namespace polyfem_amd
 			double assemble(const bool is_volume, const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases,
 							const AssemblyValsCache &, const double /*dt*/, const VectorXd &displacement, const VectorXd & /*displacement_prev*/) const
 			{
-				Context &c = bound(is_volume, bases, gbases, (int)displacement.size() / 3);
+				Context &c = bound(is_volume, bases, gbases, (int)displacement.size() / local_assembler_.size());
 				double e = 0;
 				c.check(pfx_energy(c.h, displacement.data(), &e));
 				return e;
@@ -546,18 +554,19 @@ namespace polyfem_amd
 		private:
 			Context &bound(bool is_volume, const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, int n_basis) const
 			{
-				if (!is_volume)
-					throw std::runtime_error("polyfem_amd: only 3-D problems are implemented");
+				const int dim = is_volume ? 3 : 2;
+				if (local_assembler_.size() != dim)
+					throw std::runtime_error("polyfem_amd: the local assembler's size() does not match is_volume");
 				Context &c = Context::instance();
 				if constexpr (std::is_same<LocalAssembler, MultiModel>::value)
 				{
 					if (local_assembler_.models.size() != bases.size())
 						throw std::runtime_error("polyfem_amd: MultiModel needs one model per element (init_multimodels)");
-					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e,
+					c.bind(bases, gbases, n_basis, LocalAssembler::model, dim, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e,
 						   &local_assembler_.models, local_assembler_.version);
 				}
 				else
-					c.bind(bases, gbases, n_basis, LocalAssembler::model, 3, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
+					c.bind(bases, gbases, n_basis, LocalAssembler::model, dim, local_assembler_.lambda, local_assembler_.mu, &local_assembler_.lambda_e, &local_assembler_.mu_e);
 				if constexpr (std::is_same<LocalAssembler, SaintVenantElasticity>::value)
 					if (local_assembler_.has_tensor)
 					{

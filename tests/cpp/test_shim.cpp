@@ -60,6 +60,46 @@ static void build_p2_cube(int n, std::vector<basis::ElementBases> &bases, std::v
 				}
 }
 
+// n x n cells, two triangles each, P2 bases on the P1 geometry (local node order of autogen/auto_p_bases.cpp:275-284);
+// the reference's own assembler tests run on 2-D triangle meshes (tests/test_assembler.cpp:12-64)
+static void build_p2_square(int n, std::vector<basis::ElementBases> &bases, std::vector<basis::ElementBases> &gbases, int &n_basis)
+{
+	static const int tris[2][3][2] = {{{0, 0}, {1, 0}, {1, 1}}, {{0, 0}, {1, 1}, {0, 1}}};
+	static const int edges[3][2] = {{0, 1}, {1, 2}, {2, 0}};
+	const int L = 2 * n + 1, nv = n + 1;
+	n_basis = L * L;
+	for (int ky = 0; ky < n; ++ky)
+		for (int kx = 0; kx < n; ++kx)
+			for (int t = 0; t < 2; ++t)
+			{
+				basis::ElementBases b, g;
+				b.bases.resize(6);
+				g.bases.resize(3);
+				int lat[6][2];
+				for (int k = 0; k < 3; ++k)
+				{
+					const int vx = kx + tris[t][k][0], vy = ky + tris[t][k][1];
+					lat[k][0] = 2 * vx, lat[k][1] = 2 * vy;
+					basis::Local2Global l2g;
+					l2g.index = vx + nv * vy;
+					// a sheared square, so that no element is axis-aligned
+					l2g.node[0] = (double)vx / n + 0.2 * vy / n, l2g.node[1] = (double)vy / n;
+					g.bases[k].global_.push_back(l2g);
+				}
+				for (int k = 0; k < 3; ++k)
+					for (int c = 0; c < 2; ++c)
+						lat[3 + k][c] = (lat[edges[k][0]][c] + lat[edges[k][1]][c]) / 2;
+				for (int k = 0; k < 6; ++k)
+				{
+					basis::Local2Global l2g;
+					l2g.index = lat[k][0] + L * lat[k][1];
+					b.bases[k].global_.push_back(l2g);
+				}
+				bases.push_back(b);
+				gbases.push_back(g);
+			}
+}
+
 #define REQUIRE(c)                                                    \
 	do                                                                \
 	{                                                                 \
@@ -505,6 +545,110 @@ int main()
 		newton.minimize(problem, xs);
 		REQUIRE(newton.solver_info.status == PFX_NEWTON_F_DELTA || newton.solver_info.status == PFX_NEWTON_GRAD_NORM);
 		std::printf("transient ok: %d + %d newton iterations\n", its[0], its[1]);
+	}
+	// ---- 2-D: the reference's "hessian_lin" (tests/test_assembler.cpp:12-64) and the finite-difference test of the
+	// elastic form (tests/test_form_derivatives.cpp:84-143, 200-227) on a triangle mesh, is_volume = false, size() == 2
+	{
+		std::vector<basis::ElementBases> b2, g2;
+		int nb2 = 0;
+		build_p2_square(6, b2, g2, nb2);
+		const int N2 = 2 * nb2;
+		assembler::Assembler<assembler::LinearElasticity> lin2;
+		lin2.local_assembler().set_size(2);
+		lin2.local_assembler().set_E_nu(1e5, 0.3);
+		StiffnessMatrix K2;
+		lin2.assemble(false, nb2, b2, g2, cache, K2);
+		REQUIRE(K2.rows() == N2 && K2.nonZeros() > 0);
+		assembler::NLAssembler<assembler::LinearElasticity> nll2;
+		nll2.local_assembler().set_size(2);
+		nll2.local_assembler().set_E_nu(1e5, 0.3);
+		utils::SpareMatrixCache cache_lin2;
+		VectorXd x2(N2, 0.0);
+		for (int rand = 0; rand < 10; ++rand)
+		{
+			if (rand > 0)
+				for (auto &v : x2)
+					v = 2.0 * std::rand() / RAND_MAX - 1.0;
+			StiffnessMatrix Hl;
+			nll2.assemble_hessian(false, nb2, false, b2, g2, cache, 0.0, x2, x2, cache_lin2, Hl);
+			// compare as dense rows: K2 holds the value-dependent pattern, Hl the structural one
+			double diff = 0, scale = 0;
+			std::vector<double> row(N2);
+			for (int j = 0; j < N2; ++j)
+			{
+				std::fill(row.begin(), row.end(), 0.0);
+				for (int64_t k = Hl.outer[j]; k < Hl.outer[j + 1]; ++k)
+					row[Hl.inner[k]] += Hl.values[k];
+				for (int64_t k = K2.outer[j]; k < K2.outer[j + 1]; ++k)
+					row[K2.inner[k]] -= K2.values[k], scale = std::fmax(scale, std::fabs(K2.values[k]));
+				for (double v : row)
+					diff = std::fmax(diff, std::fabs(v));
+			}
+			REQUIRE(diff <= 1e-8 * scale);
+		}
+		assembler::NLAssembler<assembler::NeoHookeanElasticity> nl2;
+		nl2.local_assembler().set_size(2);
+		nl2.local_assembler().set_E_nu(2e4, 0.3);
+		utils::SpareMatrixCache cache_neo2;
+		for (auto &v : x2)
+			v = (2.0 * std::rand() / RAND_MAX - 1.0) / 100;
+		VectorXd g2v, d2(N2), xp2(N2), xm2(N2), gp, gm;
+		StiffnessMatrix H2;
+		nl2.assemble_grad(false, nb2, b2, g2, cache, 0.0, x2, x2, g2v);
+		nl2.assemble_hessian(false, nb2, false, b2, g2, cache, 0.0, x2, x2, cache_neo2, H2);
+		REQUIRE((int)g2v.size() == N2 && H2.rows() == N2);
+		double dn = 0;
+		for (auto &v : d2)
+			v = (double)std::rand() / RAND_MAX - 0.5, dn += v * v;
+		for (auto &v : d2)
+			v /= std::sqrt(dn);
+		const double h2 = 1e-6;
+		for (int i = 0; i < N2; ++i)
+			xp2[i] = x2[i] + h2 * d2[i], xm2[i] = x2[i] - h2 * d2[i];
+		const double fd2 = (nl2.assemble(false, b2, g2, cache, 0.0, xp2, xp2) - nl2.assemble(false, b2, g2, cache, 0.0, xm2, xm2)) / (2 * h2);
+		double gd2 = 0, gn = 0;
+		for (int i = 0; i < N2; ++i)
+			gd2 += g2v[i] * d2[i], gn += g2v[i] * g2v[i];
+		REQUIRE(std::fabs(fd2 - gd2) <= 1e-6 * std::fmax(1.0, std::sqrt(gn)));
+		nl2.assemble_grad(false, nb2, b2, g2, cache, 0.0, xp2, xp2, gp);
+		nl2.assemble_grad(false, nb2, b2, g2, cache, 0.0, xm2, xm2, gm);
+		double err = 0, ref = 0;
+		for (int j = 0; j < N2; ++j)
+		{
+			double hd = 0; // H2 is symmetric: column j == row j
+			for (int64_t k = H2.outer[j]; k < H2.outer[j + 1]; ++k)
+				hd += H2.values[k] * d2[H2.inner[k]];
+			const double f = (gp[j] - gm[j]) / (2 * h2);
+			err += (f - hd) * (f - hd), ref += hd * hd;
+		}
+		REQUIRE(std::sqrt(err) <= 1e-6 * std::sqrt(ref));
+		// the Newton direction of that state through the LinearSolver, x = 0 edge fixed
+		auto s2 = polysolve::LinearSolver::create("Eigen::ConjugateGradient", "Eigen::DiagonalPreconditioner");
+		s2->setParameters(2000, 1e-12);
+		std::vector<int> fixed2;
+		for (int i = 0; i < nb2; ++i)
+			if (i % 13 == 0) // lattice x == 0 (13 nodes wide for n = 6)
+				fixed2.push_back(2 * i), fixed2.push_back(2 * i + 1);
+		s2->setDirichlet(fixed2);
+		s2->analyzePattern(H2, H2.rows());
+		s2->factorize(H2);
+		VectorXd r2(N2), dx2;
+		for (int i = 0; i < N2; ++i)
+			r2[i] = -g2v[i];
+		s2->solve(r2, dx2);
+		REQUIRE(s2->solver_error() < 1e-10 && s2->solver_iter() > 0 && s2->uses_resident_matrix());
+		// wrong size() for the mesh is refused, not computed somewhere else
+		bool threw = false;
+		try
+		{
+			nl2.assemble(true, b2, g2, cache, 0.0, x2, x2);
+		}
+		catch (const std::runtime_error &)
+		{
+			threw = true;
+		}
+		REQUIRE(threw);
+		std::printf("2-D ok: %d dofs, cg %d iterations\n", N2, s2->solver_iter());
 	}
 	std::printf("shim ok: nnz(K)=%ld energy=%.6e cg_iters=%d err=%.2e\n", (long)K.nonZeros(), e0, solver->solver_iter(), solver->solver_error());
 	return 0;
