@@ -1,4 +1,4 @@
-"""Volume meshes from Gmsh files, flattened to the layout the assembly engine consumes.
+"""Volume meshes (and 2-D triangle meshes) from Gmsh / OBJ files, flattened to the layout the assembly engine consumes.
 
 Input side of the hot path: what the reference does between reading a mesh and calling its assemblers.
 
@@ -17,6 +17,12 @@ Input side of the hot path: what the reference does between reading a mesh and c
     `numbering="vertices_first"` (default) keeps vertex id = node id and numbers the other primitives in first-touch order
     after them.  Geometry map linear / trilinear on the cell's own vertices.  Tetrahedra with a negative Jacobian are
     re-oriented by swapping two vertices.
+
+  * 2-D: a file whose highest element dimension is 2 and whose elements are triangles gives `cells` with 3 columns
+    (`read_msh`, or `read_obj` for the Wavefront files the reference's 2-D tests load, `tests/test_assembler.cpp:24`);
+    `flatten` keeps the first two coordinates (`mesh/mesh2D/CMesh2D.cpp`), orients every triangle counter-clockwise and
+    numbers the P2 edge nodes in the order (0,1) (1,2) (2,0) of `autogen/auto_p_bases.cpp:275-284`
+    (`basis/FEBasis2d.cpp`).
 
 No reference fixture pins this numbering (the reference's meshes live in the external polyfem-data repository), so
 results on real meshes are comparable to a PolyFEM run only up to a node permutation.
@@ -204,7 +210,7 @@ def _read_binary(raw, path, major):
 
 
 def read_msh(path):
-    """Returns (vertices (n, 3) float64, cells (m, 4 | 8) int32, body_ids (m,) int32)."""
+    """Returns (vertices (n, 3) float64, cells (m, 4 | 8, or 3 for a triangle mesh) int32, body_ids (m,) int32)."""
     with open(path, "rb") as fh:
         raw = fh.read()
     head = raw[:256].split(b"\n")
@@ -241,18 +247,18 @@ def read_msh(path):
     vertices[tag_to_index[tag_arr]] = np.asarray(xyz, dtype=np.float64)
 
     dim = max(b[0] for b in blocks)
-    if dim != 3:
-        raise ValueError(f"{path}: only volume meshes are supported (highest element dimension is {dim})")
+    if dim not in (2, 3):
+        raise ValueError(f"{path}: only volume and triangle meshes are supported (highest element dimension is {dim})")
     cols = None
     cells, body = [], []
     for edim, phys, etype, elems in blocks:
         if edim != dim:
             continue
         nverts = _ELEMENT_TYPES[etype][2]
-        if nverts not in (4, 8):
-            raise ValueError(f"{path}: only tetrahedra and hexahedra are supported (element type {etype})")
+        if (dim == 3 and nverts not in (4, 8)) or (dim == 2 and nverts != 3):
+            raise ValueError(f"{path}: only tetrahedra, hexahedra and triangles are supported (element type {etype})")
         if cols is not None and cols != nverts:
-            raise ValueError(f"{path}: mixed tetrahedra / hexahedra are not supported")
+            raise ValueError(f"{path}: mixed element types are not supported")
         cols = nverts
         for nodes in elems:
             if len(nodes) != _ELEMENT_TYPES[etype][1]:
@@ -267,6 +273,7 @@ def read_msh(path):
 
 def _write_msh_binary(path, vertices, cells, body, etype, version):
     nv, ne = vertices.shape[0], cells.shape[0]
+    edim = 2 if etype == 2 else 3
     with open(path, "wb") as fh:
         fh.write(("$MeshFormat\n%s 1 8\n" % version).encode())
         fh.write(np.array([1], dtype="<i4").tobytes())
@@ -285,7 +292,7 @@ def _write_msh_binary(path, vertices, cells, body, etype, version):
         ids = sorted(set(int(b) for b in body))
         lo, hi = vertices.min(axis=0), vertices.max(axis=0)
         fh.write(b"$Entities\n")
-        fh.write(np.array([0, 0, 0, len(ids)], dtype="<u8").tobytes())
+        fh.write(np.array([0, 0, len(ids), 0] if edim == 2 else [0, 0, 0, len(ids)], dtype="<u8").tobytes())
         for t, b in enumerate(ids):
             fh.write(np.array([t + 1], dtype="<i4").tobytes())
             fh.write(np.concatenate([lo, hi]).astype("<f8").tobytes())
@@ -295,7 +302,7 @@ def _write_msh_binary(path, vertices, cells, body, etype, version):
             fh.write(np.array([0], dtype="<u8").tobytes())
         fh.write(b"\n$EndEntities\n$Nodes\n")
         fh.write(np.array([1, nv, 1, nv], dtype="<u8").tobytes())
-        fh.write(np.array([3, 1, 0], dtype="<i4").tobytes())
+        fh.write(np.array([edim, 1, 0], dtype="<i4").tobytes())
         fh.write(np.array([nv], dtype="<u8").tobytes())
         fh.write(np.arange(1, nv + 1, dtype="<u8").tobytes())
         fh.write(vertices.astype("<f8").tobytes())
@@ -304,7 +311,7 @@ def _write_msh_binary(path, vertices, cells, body, etype, version):
         tag = 1
         for t, b in enumerate(ids):
             sel = np.nonzero(body == b)[0]
-            fh.write(np.array([3, t + 1, etype], dtype="<i4").tobytes())
+            fh.write(np.array([edim, t + 1, etype], dtype="<i4").tobytes())
             fh.write(np.array([sel.size], dtype="<u8").tobytes())
             data = np.concatenate([np.arange(tag, tag + sel.size)[:, None], cells[sel] + 1], axis=1).astype("<u8")
             fh.write(data.tobytes())
@@ -313,11 +320,14 @@ def _write_msh_binary(path, vertices, cells, body, etype, version):
 
 
 def write_msh(path, vertices, cells, body_ids=None, version: str = "2.2", binary: bool = False):
-    """MSH writer (ASCII or binary) for tetrahedra (4 columns) / hexahedra (8 columns); the counterpart of read_msh for
-    tests and for exporting generated meshes."""
+    """MSH writer (ASCII or binary) for tetrahedra (4 columns) / hexahedra (8 columns) / triangles (3 columns; vertices
+    with two coordinates get z = 0); the counterpart of read_msh for tests and for exporting generated meshes."""
     vertices = np.asarray(vertices, dtype=np.float64)
+    if vertices.shape[1] == 2:
+        vertices = np.hstack([vertices, np.zeros((vertices.shape[0], 1))])
     cells = np.asarray(cells)
-    etype = {4: 4, 8: 5}[cells.shape[1]]
+    etype = {4: 4, 8: 5, 3: 2}[cells.shape[1]]
+    edim = 2 if etype == 2 else 3
     body = np.zeros(cells.shape[0], dtype=np.int64) if body_ids is None else np.asarray(body_ids, dtype=np.int64)
     if version not in ("2.2", "4.1"):
         raise ValueError("version must be '2.2' or '4.1'")
@@ -335,11 +345,11 @@ def write_msh(path, vertices, cells, body_ids=None, version: str = "2.2", binary
         elif version == "4.1":
             ids = sorted(set(int(b) for b in body))
             lo, hi = vertices.min(axis=0), vertices.max(axis=0)
-            fh.write("$MeshFormat\n4.1 0 8\n$EndMeshFormat\n$Entities\n0 0 0 %d\n" % len(ids))
+            fh.write("$MeshFormat\n4.1 0 8\n$EndMeshFormat\n$Entities\n%s\n" % ("0 0 %d 0" % len(ids) if edim == 2 else "0 0 0 %d" % len(ids)))
             for t, b in enumerate(ids):
                 fh.write("%d %.17g %.17g %.17g %.17g %.17g %.17g %s 0\n" % (t + 1, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2],
                                                                              ("1 %d" % b) if b != 0 else "0"))
-            fh.write("$EndEntities\n$Nodes\n1 %d 1 %d\n3 1 0 %d\n" % (vertices.shape[0], vertices.shape[0], vertices.shape[0]))
+            fh.write("$EndEntities\n$Nodes\n1 %d 1 %d\n%d 1 0 %d\n" % (vertices.shape[0], vertices.shape[0], edim, vertices.shape[0]))
             for k in range(vertices.shape[0]):
                 fh.write("%d\n" % (k + 1))
             for p in vertices:
@@ -348,7 +358,7 @@ def write_msh(path, vertices, cells, body_ids=None, version: str = "2.2", binary
             tag = 1
             for t, b in enumerate(ids):
                 sel = np.nonzero(body == b)[0]
-                fh.write("3 %d %d %d\n" % (t + 1, etype, sel.size))
+                fh.write("%d %d %d %d\n" % (edim, t + 1, etype, sel.size))
                 for k in sel:
                     fh.write("%d %s\n" % (tag, " ".join(str(int(v) + 1) for v in cells[k])))
                     tag += 1
@@ -420,12 +430,24 @@ def flatten(vertices, cells, order: int = 1, numbering: str = "vertices_first") 
                                         np.stack([cells[:, list(f)] for f in _HEX_FACES], axis=1), cells[:, None, :]]
         kind = M.Q1HEX if order == 1 else M.Q2HEX
         gkind = M.Q1HEX
+    elif cells.shape[1] == 3:
+        vertices = np.ascontiguousarray(vertices[:, :2])
+        p = vertices[cells]
+        a, b = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+        det = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+        if np.any(det == 0):
+            raise ValueError("degenerate triangle")
+        flip = det < 0
+        cells[flip, 1], cells[flip, 2] = cells[flip, 2].copy(), cells[flip, 1].copy()
+        groups = [] if order == 1 else [np.stack([cells[:, list(e)] for e in M._P2_TRI_EDGES], axis=1)]
+        kind = M.P1TRI if order == 1 else M.P2TRI
+        gkind = M.P1TRI
     else:
-        raise ValueError("cells must have 4 (tetrahedra) or 8 (hexahedra) columns")
+        raise ValueError("cells must have 4 (tetrahedra), 8 (hexahedra) or 3 (triangles) columns")
     conn, n_nodes, node_of, tables = _number_primitives(cells, nv, groups, numbering)
     if n_nodes >= 2 ** 31:
         raise ValueError("too many nodes for 32-bit indices")
-    node_xyz = np.zeros((n_nodes, 3))
+    node_xyz = np.zeros((n_nodes, vertices.shape[1]))
     used_v = node_of[:nv] >= 0
     node_xyz[node_of[:nv][used_v]] = vertices[used_v]
     for offset, uniq in tables:  # barycentre of the primitive's vertices (MeshNodes.cpp:166-173)
@@ -435,7 +457,34 @@ def flatten(vertices, cells, order: int = 1, numbering: str = "vertices_first") 
     return M.Mesh(kind, gkind, np.ascontiguousarray(conn.astype(np.int32)), c32, vertices, n_nodes, node_xyz)
 
 
+def read_obj(path):
+    """Triangle mesh from a Wavefront OBJ file (`v x y [z]` and `f a b c` records, 1-based or negative indices, the
+    `a/b/c` forms accepted): what the reference's 2-D tests load (`tests/test_assembler.cpp:24`, `tests/test_form_derivatives.cpp:45`).
+    Returns (vertices (n, 3), cells (m, 3) int32, body_ids (m,) zeros)."""
+    verts, faces = [], []
+    with open(path) as fh:
+        for line in fh:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "v":
+                c = [float(v) for v in t[1:4]]
+                verts.append(c + [0.0] * (3 - len(c)))
+            elif t[0] == "f":
+                ids = [int(v.split("/")[0]) for v in t[1:]]
+                if len(ids) != 3:
+                    raise ValueError(f"{path}: only triangles are supported (face with {len(ids)} vertices)")
+                faces.append(ids)
+    if not verts or not faces:
+        raise ValueError(f"{path}: no vertices or no faces")
+    cells = np.asarray(faces, dtype=np.int64)
+    cells = np.where(cells < 0, cells + len(verts), cells - 1)
+    if cells.min() < 0 or cells.max() >= len(verts):
+        raise ValueError(f"{path}: a face refers to a vertex that is not defined")
+    return np.asarray(verts, dtype=np.float64), np.ascontiguousarray(cells.astype(np.int32)), np.zeros(len(faces), dtype=np.int32)
+
+
 def load(path, order: int = 1, numbering: str = "vertices_first"):
-    """read_msh + flatten; returns (Mesh, body_ids)."""
-    vertices, cells, body = read_msh(path)
+    """read_msh / read_obj + flatten; returns (Mesh, body_ids)."""
+    vertices, cells, body = read_obj(path) if str(path).lower().endswith(".obj") else read_msh(path)
     return flatten(vertices, cells, order, numbering), body

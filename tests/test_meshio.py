@@ -56,8 +56,12 @@ def test_msh_hexes_sparse_tags_and_orientation(tmp_path):
         IO.read_msh(bad)
     surf = tmp_path / "surf.msh"
     surf.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n3\n1 0 0 0\n2 1 0 0\n3 0 1 0\n$EndNodes\n$Elements\n1\n1 2 2 0 0 1 2 3\n$EndElements\n")
+    v, c, b = IO.read_msh(surf)  # a triangle mesh is a 2-D problem
+    assert c.shape == (1, 3) and IO.flatten(v, c, 2).kind == M.P2TRI
+    quad = tmp_path / "quad.msh"
+    quad.write_text("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n4\n1 0 0 0\n2 1 0 0\n3 1 1 0\n4 0 1 0\n$EndNodes\n$Elements\n1\n1 3 2 0 0 1 2 3 4\n$EndElements\n")
     with pytest.raises(ValueError):
-        IO.read_msh(surf)
+        IO.read_msh(quad)  # quadrilaterals are not implemented
 
 
 def test_flattened_file_mesh_assembles_like_the_generated_one(tmp_path, oracle):
@@ -167,5 +171,73 @@ def test_file_mesh_through_the_hip_path(tmp_path, oracle, element, binary):
         outer, inner_idx, vals = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
         assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner_idx)
         assert rel_err(v, vals) <= 1e-12
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("fmt", ["msh2", "msh4", "msh4bin", "obj"])
+def test_triangle_mesh_files(tmp_path, oracle, fmt):
+    """2-D meshes: triangles from MSH (2.2 / 4.1, ASCII / binary) and OBJ files, some of them clockwise in the file; the
+    flattened P2 mesh assembles to the matrix of the generated mesh up to the node permutation."""
+    gen = M.square_tris(4, 2, jitter=0.2, seed=6)
+    src = M.square_tris(4, 1, jitter=0.2, seed=6)
+    cells = src.gconn.copy()
+    cells[::3] = cells[::3][:, [0, 2, 1]]  # clockwise triangles: flatten re-orients them
+    path = tmp_path / ("mesh.obj" if fmt == "obj" else "mesh.msh")
+    if fmt == "obj":
+        with open(path, "w") as fh:
+            fh.write("# test mesh\n")
+            for p in src.xyz:
+                fh.write("v %.17g %.17g 0\n" % (p[0], p[1]))
+            for c in cells:
+                fh.write("f %d/1 %d/1 %d/1\n" % (c[0] + 1, c[1] + 1, c[2] + 1))
+    else:
+        IO.write_msh(path, src.xyz, cells, None, "2.2" if fmt == "msh2" else "4.1", binary=fmt == "msh4bin")
+    mesh, body = IO.load(path, 2)
+    assert mesh.kind == M.P2TRI and mesh.xyz.shape[1] == 2 and body.size == src.n_el and mesh.n_nodes == gen.n_nodes
+    assert np.array_equal(mesh.xyz, src.xyz)
+    # same node set, different numbering: match the nodes by position
+    def key(p):
+        return np.round(p * 1e9).astype(np.int64)
+    a, b = key(M.node_positions(mesh)), key(M.node_positions(gen))
+    ia, ib = np.lexsort(a.T), np.lexsort(b.T)
+    assert np.array_equal(a[ia], b[ib])
+    perm = np.empty(gen.n_nodes, dtype=np.int64)  # perm[node of gen] = node of mesh
+    perm[ib] = ia
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    from tests.helpers import csc_to_scipy
+    n = 2 * gen.n_nodes
+    A = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n).toarray()
+    B = csc_to_scipy(oracle.assemble_linear(gen, oracle.LINEAR_ELASTICITY, lam, mu), n).toarray()
+    dof = (2 * perm[:, None] + np.arange(2)[None]).reshape(-1)
+    assert np.abs(A[np.ix_(dof, dof)] - B).max() <= 1e-12 * np.abs(B).max()
+
+
+@pytest.mark.gpu
+def test_triangle_file_mesh_through_the_hip_path(tmp_path, oracle):
+    """An OBJ triangle mesh (the format of the reference's 2-D test meshes), first-touch numbering, P2, on the HIP path."""
+    from polyfem_amd import engine as E
+    from tests.helpers import rel_err
+    src = M.square_tris(7, 1, jitter=0.25, seed=8)
+    path = tmp_path / "mesh.obj"
+    with open(path, "w") as fh:
+        for p in src.xyz:
+            fh.write("v %.17g %.17g 0\n" % (p[0], p[1]))
+        for c in src.gconn:
+            fh.write("f %d %d %d\n" % (c[0] + 1, c[2] + 1, c[1] + 1))  # clockwise in the file
+    mesh, _ = IO.load(path, 2, numbering="first_touch")
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        lam, mu = oracle.lame(2e4, 0.3, 2)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.build_pattern()
+        x = M.seeded_displacement(mesh, 2, 2e-3)
+        v = eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        outer, inner_idx, vals = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner_idx)
+        assert rel_err(v, vals) <= 1e-12
+        assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= 1e-12
     finally:
         eng.close()
