@@ -43,8 +43,10 @@ enum
  * 2-D problems: triangles with the local node order of autogen/auto_p_bases.cpp:138-144, 275-284 and a P1 geometry
  * map (the (3,2) and (6,2) instantiations of NeoHookeanElasticity.cpp:47-115); dim = 2, two coordinates per geometry
  * node, two displacement components per node.  They support the Laplacian, LinearElasticity (both interfaces) and
- * NeoHookean, uniform / per-element / per-point parameters, mass matrix and right-hand side, the Jacobi-CG and the
- * Newton solver; the other entry points return PFX_ERR_UNSUPPORTED for them. */
+ * NeoHookean, uniform / per-element / per-point parameters, project_to_psd, mass matrix and right-hand side, the
+ * Jacobi-CG, the Newton solver with its inertia and augmented-Lagrangian terms and the implicit-Euler step; the other
+ * entry points (SaintVenant, elasticity tensors, element models, AMG, the partitioned solve) return
+ * PFX_ERR_UNSUPPORTED for them. */
 enum
 {
 	PFX_P1TET = 0,

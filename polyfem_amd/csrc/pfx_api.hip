@@ -630,8 +630,8 @@ extern "C"
 	{
 		if (!ctx || !density_pts)
 			return PFX_ERR_ARG;
-		if (ctx->bs != 3)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 3)");
+		if (ctx->bs < 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 2 or 3)");
 		pfx_status rc = assemble_mass_pointwise_impl(ctx, density_pts, n_el, n_pts);
 		if (rc)
 			return rc;
@@ -1019,8 +1019,8 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
-		if (ctx->bs != 3)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 3)");
+		if (ctx->bs < 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model (block size 2 or 3)");
 		pfx_status rc = pfx_assemble_mass(ctx, density, density_e);
 		if (rc)
 			return rc;
@@ -1078,8 +1078,8 @@ extern "C"
 		}
 		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
-		if (ctx->bs != 3)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs block size 3");
+		if (ctx->bs < 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs a vector-valued model (block size 2 or 3)");
 		ctx->al_weight = weight;
 		ctx->d_al_mass = d_masked_lumped_mass;
 		ctx->d_al_target = d_target;
@@ -1116,7 +1116,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (need_mesh(ctx))
 			return PFX_ERR_ARG;
-		if (ctx->mass_count == 0 || ctx->bs != 3)
+		if (ctx->mass_count == 0 || ctx->bs < 2)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");
 		const int64_t n = ctx->n_dofs();
 		pfx_tmp<double> d;

@@ -816,16 +816,27 @@ namespace
 	pfx_status launch_psd(pfx_ctx *ctx)
 	{
 		pfx_status rc;
-		if (ctx->model == PFX_NEOHOOKEAN)
-			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
+		if constexpr (NGLOC == 3) // triangles: NeoHookean and LinearElasticity, 2 x 2 blocks
+		{
+			if (ctx->model == PFX_NEOHOOKEAN)
+				rc = pfx_launch_project_psd<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
+			else
+				rc = pfx_launch_project_psd<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
+			if (rc)
+				return rc;
+			pfx_launch_assemble_rows<NLOC, 2>(ctx, staged_block<NLOC, 2>{ctx->d_kloc}, false);
+			return PFX_OK;
+		}
+		else if (ctx->model == PFX_NEOHOOKEAN)
+			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
-			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor});
+			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor});
 		else if (ctx->model == PFX_SAINT_VENANT)
-			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
+			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_MULTI_MODEL)
-			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab});
+			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab});
 		else
-			rc = pfx_launch_project_psd<NLOC>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
+			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
 		if (rc)
 			return rc;
 		pfx_launch_assemble_rows<NLOC, 3>(ctx, staged_block<NLOC>{ctx->d_kloc}, false);
@@ -929,9 +940,7 @@ pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx)
 {
 	if (ctx->estate_kind != PFX_ESTATE_NL)
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: element state missing");
-	if (ctx->mesh_dim != 3)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "project_to_psd is implemented for the 3-D element kinds");
-	const int64_t need = ctx->n_el * (int64_t)(ctx->n_loc * (ctx->n_loc + 1) / 2) * 9;
+	const int64_t need = ctx->n_el * (int64_t)(ctx->n_loc * (ctx->n_loc + 1) / 2) * (ctx->bs * ctx->bs);
 	if (ctx->kloc_count < need)
 	{
 		if (pfx_alloc(ctx, &ctx->d_kloc, need))
@@ -952,6 +961,12 @@ pfx_status pfx_launch_rows_nl_psd(pfx_ctx *ctx)
 		break;
 	case PFX_Q2HEX:
 		rc = launch_psd<27, 8, 27>(ctx);
+		break;
+	case PFX_P1TRI:
+		rc = launch_psd<3, 3, 1>(ctx);
+		break;
+	case PFX_P2TRI:
+		rc = launch_psd<6, 3, 4>(ctx);
 		break;
 	default:
 		PFX_FAIL(PFX_ERR_UNSUPPORTED, "Hessian assembly: unsupported element kind");

@@ -54,16 +54,16 @@ namespace
 	}
 
 	// mass[b] = rho phi_i phi_j of node block b, read from the (0,0) entry of the assembled mass matrix
-	__global__ __launch_bounds__(256) void k_capture_mass(const double *__restrict__ values, int64_t n_blocks, double *__restrict__ mass)
+	__global__ __launch_bounds__(256) void k_capture_mass(const double *__restrict__ values, int64_t n_blocks, int bs, double *__restrict__ mass)
 	{
 		for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (int64_t)gridDim.x * blockDim.x)
-			mass[b] = values[b * 9];
+			mass[b] = values[b * (bs * bs)];
 	}
 
-	// md = M v on the rows [0, n_rows), M = mass (x) I_3.  Eight lanes share a node row: they walk the row's blocks side by
+	// md = M v on the rows [0, n_rows), M = mass (x) I_bs (bs = 3, or 2 for triangle meshes).  Eight lanes share a node row: they walk the row's blocks side by
 	// side (mass and column index are read in 64-byte runs) and combine their partial sums with shuffles.
 	__global__ __launch_bounds__(256) void k_mass_apply(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col,
-														const double *__restrict__ mass, const double *__restrict__ v, int64_t n_rows,
+														const double *__restrict__ mass, const double *__restrict__ v, int64_t n_rows, int bs,
 														double *__restrict__ md)
 	{
 		const int sub = threadIdx.x & 7;
@@ -77,11 +77,12 @@ namespace
 				const int64_t b1 = node_ptr[g + 1];
 				for (int64_t b = node_ptr[g] + sub; b < b1; b += 8)
 				{
-					const int64_t c = 3 * (int64_t)node_col[b];
+					const int64_t c = bs * (int64_t)node_col[b];
 					const double m = mass[b];
 					a0 += m * v[c];
 					a1 += m * v[c + 1];
-					a2 += m * v[c + 2];
+					if (bs == 3)
+						a2 += m * v[c + 2];
 				}
 			}
 			for (int o = 4; o > 0; o >>= 1)
@@ -90,8 +91,8 @@ namespace
 				a1 += __shfl_xor(a1, o, 64);
 				a2 += __shfl_xor(a2, o, 64);
 			}
-			if (g < n_rows && sub < 3)
-				md[3 * g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
+			if (g < n_rows && sub < bs)
+				md[bs * g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
 		}
 	}
 
@@ -104,12 +105,12 @@ namespace
 	}
 
 	// Hessian of the penalty: weight * m on the diagonal (ALForm::second_derivative_unweighted, :70-73); one thread per node
-	__global__ __launch_bounds__(256) void k_al_add_diag(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes,
+	__global__ __launch_bounds__(256) void k_al_add_diag(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ node_col, int64_t n_nodes, int bs,
 														 double alw, const double *__restrict__ m, double *__restrict__ values)
 	{
 		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
 		{
-			const double m0 = m[3 * g], m1 = m[3 * g + 1], m2 = m[3 * g + 2];
+			const double m0 = m[bs * g], m1 = m[bs * g + 1], m2 = bs == 3 ? m[bs * g + 2] : 0.0;
 			if (m0 == 0.0 && m1 == 0.0 && m2 == 0.0)
 				continue;
 			int64_t lo = node_ptr[g], hi = node_ptr[g + 1];
@@ -123,15 +124,17 @@ namespace
 			}
 			if (lo < node_ptr[g + 1] && node_col[lo] == g)
 			{
-				values[lo * 9] += alw * m0;
-				values[lo * 9 + 4] += alw * m1;
-				values[lo * 9 + 8] += alw * m2;
+				const int64_t at = lo * (bs * bs);
+				values[at] += alw * m0;
+				values[at + bs + 1] += alw * m1;
+				if (bs == 3)
+					values[at + 8] += alw * m2;
 			}
 		}
 	}
 
 	// utils::lump_matrix of the mass matrix: row sums on the diagonal; every component of a node gets the node's sum
-	__global__ __launch_bounds__(256) void k_lump_mass(const int64_t *__restrict__ node_ptr, const double *__restrict__ mass, int64_t n_nodes,
+	__global__ __launch_bounds__(256) void k_lump_mass(const int64_t *__restrict__ node_ptr, const double *__restrict__ mass, int64_t n_nodes, int bs,
 													   double *__restrict__ out)
 	{
 		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
@@ -139,19 +142,21 @@ namespace
 			double s = 0.0;
 			for (int64_t b = node_ptr[g]; b < node_ptr[g + 1]; ++b)
 				s += mass[b];
-			out[3 * g] = out[3 * g + 1] = out[3 * g + 2] = s;
+			for (int m = 0; m < bs; ++m)
+				out[bs * g + m] = s;
 		}
 	}
 
 	// Hessian of the transient objective: values = w * values + M (M sits on the diagonal of every node block)
-	__global__ __launch_bounds__(256) void k_add_inertia(double *__restrict__ values, int64_t nnz, double w, const double *__restrict__ mass)
+	__global__ __launch_bounds__(256) void k_add_inertia(double *__restrict__ values, int64_t nnz, int bs, double w, const double *__restrict__ mass)
 	{
+		const int b2 = bs * bs;
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x)
 		{
-			const int64_t b = k / 9;
-			const int r = (int)(k - b * 9);
+			const int64_t b = k / b2;
+			const int r = (int)(k - b * b2);
 			double v = w * values[k];
-			if (r == 0 || r == 4 || r == 8)
+			if (r % (bs + 1) == 0) // diagonal entries of the block
 				v += mass[b];
 			values[k] = v;
 		}
@@ -316,7 +321,7 @@ namespace
 		{
 			hipLaunchKernelGGL(k_step, dim3(NB), dim3(256), 0, ctx->stream, x, xt, -1.0, n, d);
 			// owned rows (all of them on an unpartitioned mesh); d carries a current halo because x and x_tilde do
-			hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, (const double *)d, ctx->n_owned, md);
+			hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, mass, (const double *)d, ctx->n_owned, ctx->bs, md);
 		}
 
 		// a.b, |a + c|^2 (c may be null), max|a|
@@ -598,14 +603,14 @@ static pfx_status newton_impl(pfx_ctx *ctx, pfx_dist *dist, const double *d_rhs,
 	S.partial = S.alq + n, S.scal = S.partial + 3 * NB, S.dbuf = S.scal + 8;
 	if (ctx->inertia_weight > 0.0 && ctx->d_x_tilde && ctx->mass_count > 0)
 	{
-		if (ctx->bs != 3)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs block size 3");
+		if (ctx->bs < 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the inertia term needs a vector-valued model");
 		S.iw = ctx->inertia_weight, S.mass = ctx->d_mass_blk, S.xt = ctx->d_x_tilde;
 	}
 	if (ctx->al_weight > 0.0 && ctx->d_al_mass && ctx->d_al_target)
 	{
-		if (ctx->bs != 3 || dist)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs block size 3 and an unpartitioned mesh");
+		if (ctx->bs < 2 || dist)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "the augmented-Lagrangian term needs a vector-valued model and an unpartitioned mesh");
 		S.alw = ctx->al_weight, S.alm = ctx->d_al_mass, S.alt = ctx->d_al_target;
 	}
 	hipStream_t st = ctx->stream;
@@ -707,12 +712,12 @@ static pfx_status newton_impl(pfx_ctx *ctx, pfx_dist *dist, const double *d_rhs,
 				return finish(rc, ctx->err.c_str());
 			if (S.mass)
 			{
-				hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, st, ctx->d_values, ctx->nnz, S.iw, S.mass);
+				hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, st, ctx->d_values, ctx->nnz, ctx->bs, S.iw, S.mass);
 				ctx->values_gen++;
 			}
 			if (S.alm)
 			{
-				hipLaunchKernelGGL(k_al_add_diag, dim3(NB), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, S.alw, S.alm, ctx->d_values);
+				hipLaunchKernelGGL(k_al_add_diag, dim3(NB), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->n_nodes, ctx->bs, S.alw, S.alm, ctx->d_values);
 				ctx->values_gen++;
 			}
 			ctx->diag_shift = reg_weight;
@@ -822,7 +827,7 @@ pfx_status pfx_capture_mass(pfx_ctx *ctx)
 			return PFX_ERR_HIP;
 		ctx->mass_count = ctx->n_blocks;
 	}
-	hipLaunchKernelGGL(k_capture_mass, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_values, ctx->n_blocks, ctx->d_mass_blk);
+	hipLaunchKernelGGL(k_capture_mass, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_values, ctx->n_blocks, ctx->bs, ctx->d_mass_blk);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
@@ -876,14 +881,14 @@ pfx_status pfx_dist_implicit_euler_run(pfx_dist *dist, double dt, const double *
 // y[owned rows] = M v with the captured mass matrix (v needs a current halo on a partitioned mesh)
 pfx_status pfx_lumped_mass_run(pfx_ctx *ctx, double *d_out)
 {
-	hipLaunchKernelGGL(k_lump_mass, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_mass_blk, ctx->n_nodes, d_out);
+	hipLaunchKernelGGL(k_lump_mass, dim3(NB), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_mass_blk, ctx->n_nodes, ctx->bs, d_out);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
 
 pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y)
 {
-	hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_mass_blk, d_v, ctx->n_owned, d_y);
+	hipLaunchKernelGGL(k_mass_apply, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_node_ptr, ctx->d_node_col, ctx->d_mass_blk, d_v, ctx->n_owned, ctx->bs, d_y);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }
@@ -891,7 +896,7 @@ pfx_status pfx_mass_apply_run(pfx_ctx *ctx, const double *d_v, double *d_y)
 // values = w * values + M on the resident matrix
 pfx_status pfx_add_mass_run(pfx_ctx *ctx, double w)
 {
-	hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_values, ctx->nnz, w, ctx->d_mass_blk);
+	hipLaunchKernelGGL(k_add_inertia, dim3(NB * 8), dim3(256), 0, ctx->stream, ctx->d_values, ctx->nnz, ctx->bs, w, ctx->d_mass_blk);
 	ctx->values_gen++;
 	ctx->have_mask = false;
 	PFX_HIP(hipGetLastError());

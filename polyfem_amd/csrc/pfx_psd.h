@@ -1,7 +1,7 @@
 // pfx_psd.h -- projection of the element Hessians onto the cone of positive semi-definite matrices.
 //
 // Reference: NLAssembler::assemble_hessian with project_to_psd = true (src/polyfem/assembler/Assembler.cpp:554-555)
-// calls ipc::project_to_psd on every local (n_loc*3)^2 matrix: symmetric eigendecomposition, the matrix is returned
+// calls ipc::project_to_psd on every local (n_loc*dim)^2 matrix: symmetric eigendecomposition, the matrix is returned
 // unchanged if its smallest eigenvalue is >= 0, otherwise V max(D, 0) V^T.  The Newton solver switches this on when a
 // plain Newton step fails (SparseNewtonDescentSolver.tpp:105-123, descent strategy 1).  ipc-toolkit and Eigen's
 // SelfAdjointEigenSolver are not part of the reference tree.  Like that solver, the kernel reduces the matrix to
@@ -16,22 +16,22 @@
 //
 // This is the only assembly path that materialises local matrices: one 64-lane workgroup per element builds the local
 // Hessian in LDS from the contribution functor, factorises it there and writes the (projected) blocks of the pairs
-// j <= i to HBM (n_loc(n_loc+1)/2 * 9 doubles per element); the row assembly then reads them through staged_block.
+// j <= i to HBM (n_loc(n_loc+1)/2 * dim^2 doubles per element); the row assembly then reads them through staged_block.
 #pragma once
 #include "pfx_internal.h"
 
-template <int NLOC>
+template <int NLOC, int BS = 3>
 struct staged_block
 {
 	const double *kloc;
 	static constexpr int LDS_DOUBLES = 1;
 	__device__ __forceinline__ void load_tables(double *, int) const {}
-	__device__ __forceinline__ void operator()(const double *, uint32_t e, int i, int j, double (&out)[9]) const
+	__device__ __forceinline__ void operator()(const double *, uint32_t e, int i, int j, double (&out)[BS * BS]) const
 	{
 		constexpr int64_t NPAIR = NLOC * (NLOC + 1) / 2;
-		const double *p = kloc + ((int64_t)e * NPAIR + (i * (i + 1) / 2 + j)) * 9;
+		const double *p = kloc + ((int64_t)e * NPAIR + (i * (i + 1) / 2 + j)) * (BS * BS);
 #pragma unroll
-		for (int k = 0; k < 9; ++k)
+		for (int k = 0; k < BS * BS; ++k)
 			out[k] = p[k];
 	}
 };
@@ -296,12 +296,12 @@ namespace pfx_psd_detail
 	}
 } // namespace pfx_psd_detail
 
-// W: N x LD doubles of dynamic shared memory (N = 3 NLOC, LD = N rounded up to odd)
-template <int NLOC, class Op>
+// W: N x LD doubles of dynamic shared memory (N = BS NLOC, LD = N rounded up to odd); BS = 3, or 2 for the triangles
+template <int NLOC, int BS, class Op>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLOC <= 10 ? 4 : 1, NLOC <= 10 ? 4 : 8))) void k_project_psd(Op op, int64_t n_el, double *__restrict__ kloc)
 {
 	using namespace pfx_psd_detail;
-	constexpr int N = NLOC * 3, NPAIR = NLOC * (NLOC + 1) / 2;
+	constexpr int N = NLOC * BS, NPAIR = NLOC * (NLOC + 1) / 2, B2 = BS * BS;
 	constexpr int R = (N + 63) / 64;                                   // matrix rows per lane
 	constexpr int RW = N <= 16 ? 16 : (N <= 32 ? 32 : 64), PPI = 64 / RW; // elimination pass: lanes laid out as (column slot, row)
 	constexpr int LD = N | 1;                                            // odd row stride: one row per lane without bank conflicts
@@ -329,20 +329,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLOC <= 10 ?
 		for (int q = lane; q < NPAIR; q += 64)
 		{
 			const int i = ij[2 * q], j = ij[2 * q + 1];
-			double b[9];
+			double b[B2];
 			op(optab, (uint32_t)el, i, j, b);
-			for (int m = 0; m < 3; ++m)
-				for (int n = 0; n < 3; ++n)
+			for (int m = 0; m < BS; ++m)
+				for (int n = 0; n < BS; ++n)
 				{
-					W[(3 * i + m) * LD + 3 * j + n] = b[3 * m + n];
-					W[(3 * j + n) * LD + 3 * i + m] = b[3 * m + n];
+					W[(BS * i + m) * LD + BS * j + n] = b[BS * m + n];
+					W[(BS * j + n) * LD + BS * i + m] = b[BS * m + n];
 				}
 		}
 		__syncthreads();
 	};
 	fill();
 	const int row = lane & (RW - 1), slot = lane / RW;
-	double *out = kloc + el * (int64_t)(NPAIR * 9);
+	double *out = kloc + el * (int64_t)(NPAIR * B2);
 	double dloc = 0.0;
 #pragma unroll
 	for (int rr = 0; rr < R; ++rr)
@@ -409,18 +409,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLOC <= 10 ?
 			for (int q = lane; q < NPAIR; q += 64)
 			{
 				const int i = ij[2 * q], j = ij[2 * q + 1];
-				double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+				double b[B2];
+#pragma unroll
+				for (int k = 0; k < B2; ++k)
+					b[k] = 0.0;
 				for (int k = 0; k < N; ++k)
 				{
 					const double l = e[k];
-					const double vi0 = l * W[(3 * i) * LD + k], vi1 = l * W[(3 * i + 1) * LD + k], vi2 = l * W[(3 * i + 2) * LD + k];
-					const double vj0 = W[(3 * j) * LD + k], vj1 = W[(3 * j + 1) * LD + k], vj2 = W[(3 * j + 2) * LD + k];
-					b[0] += vi0 * vj0, b[1] += vi0 * vj1, b[2] += vi0 * vj2;
-					b[3] += vi1 * vj0, b[4] += vi1 * vj1, b[5] += vi1 * vj2;
-					b[6] += vi2 * vj0, b[7] += vi2 * vj1, b[8] += vi2 * vj2;
+					double vi[BS], vj[BS];
+#pragma unroll
+					for (int m = 0; m < BS; ++m)
+						vi[m] = l * W[(BS * i + m) * LD + k], vj[m] = W[(BS * j + m) * LD + k];
+#pragma unroll
+					for (int m = 0; m < BS; ++m)
+#pragma unroll
+						for (int n = 0; n < BS; ++n)
+							b[BS * m + n] += vi[m] * vj[n];
 				}
-				for (int k = 0; k < 9; ++k)
-					out[q * 9 + k] = b[k];
+				for (int k = 0; k < B2; ++k)
+					out[q * B2 + k] = b[k];
 			}
 			return;
 		}
@@ -428,23 +435,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLOC <= 10 ?
 	// the matrix is kept as it is
 	for (int q = lane; q < NPAIR; q += 64)
 	{
-		double b[9];
+		double b[B2];
 		op(optab, (uint32_t)el, ij[2 * q], ij[2 * q + 1], b);
-		for (int k = 0; k < 9; ++k)
-			out[q * 9 + k] = b[k];
+		for (int k = 0; k < B2; ++k)
+			out[q * B2 + k] = b[k];
 	}
 }
 
 // launches k_project_psd for all elements; the matrix lives in dynamic shared memory (more than the 64 KB a kernel may
 // claim statically for 27-node elements)
-template <int NLOC, class Op>
+template <int NLOC, int BS, class Op>
 pfx_status pfx_launch_project_psd(pfx_ctx *ctx, Op op)
 {
-	constexpr int N = NLOC * 3, LD = N | 1;
+	constexpr int N = NLOC * BS, LD = N | 1;
 	const size_t bytes = sizeof(double) * N * LD;
 	if (bytes > 32 * 1024)
-		PFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_project_psd<NLOC, Op>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-	hipLaunchKernelGGL((k_project_psd<NLOC, Op>), dim3((unsigned)ctx->n_el), dim3(64), bytes, ctx->stream, op, ctx->n_el, ctx->d_kloc);
+		PFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_project_psd<NLOC, BS, Op>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	hipLaunchKernelGGL((k_project_psd<NLOC, BS, Op>), dim3((unsigned)ctx->n_el), dim3(64), bytes, ctx->stream, op, ctx->n_el, ctx->d_kloc);
 	PFX_HIP(hipGetLastError());
 	return PFX_OK;
 }

@@ -256,6 +256,125 @@ def test_per_element_and_per_point_materials(eng, oracle):
         assert rel_err(eng.hessian(x), oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "p2_stretched"])
+def test_hessian_project_to_psd(eng, oracle, name):
+    """assemble_hessian(project_to_psd = true) on triangles: (n_loc * 2)^2 element Hessians projected onto the PSD cone
+    (Assembler.cpp:554-555); tolerance 1e-10 of the largest entry (different eigen-solvers, same projection)."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    nnz = _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 2
+    x = np.zeros(n)
+    x[0::2] = -0.35 * mesh.node_xyz[:, 0]
+    x[1::2] = 0.3 * mesh.node_xyz[:, 1]
+    x += M.seeded_displacement(mesh, 2, 2e-3)
+    v = eng.hessian(x)
+    vp = eng.hessian(x, project_to_psd=True)
+    ref = oracle.assemble_hessian_psd(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]
+    plain = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)[2]
+    assert vp.size == nnz == ref.size
+    assert np.abs(plain - ref).max() > 1e-3 * np.abs(plain).max(), "test state is not indefinite anywhere"
+    assert rel_err(v, plain) <= TOL
+    assert np.abs(vp - ref).max() <= 1e-10 * np.abs(ref).max()
+    zero = np.zeros(n)
+    assert np.abs(eng.hessian(zero, project_to_psd=True) - eng.hessian(zero)).max() <= 1e-10 * np.abs(v).max()
+
+
+def test_newton_with_backtracking_and_projected_fallback(eng, oracle):
+    """A load large enough that plain Newton steps fail: the line search halves steps and the solver falls back to the
+    projected Hessian (descent strategy 1), as on the 3-D meshes."""
+    mesh = M.square_tris(6, 1, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 2
+    bnd = M.boundary_dofs(mesh, 2, "x0")
+    eng.set_dirichlet(bnd)
+    rhs = np.zeros(n)
+    rhs[0::2] = -2.5e4 / mesh.n_nodes
+    x_ref, info_ref = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, bnd, np.zeros(n), n_threads=4)
+    x, info = eng.newton_solve(np.zeros(n), rhs)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert info_ref["line_search_iterations"] > 3 * info_ref["iterations"]
+    assert info["iterations"] == info_ref["iterations"] and info["status"] == info_ref["status"]
+    assert abs(info["line_search_iterations"] - info_ref["line_search_iterations"]) <= 0.1 * info_ref["line_search_iterations"]
+    assert np.abs(x - x_ref).max() <= 1e-7 * np.abs(x_ref).max()
+
+
+@pytest.mark.parametrize("model", ["NeoHookean", "LinearElasticity"])
+def test_implicit_euler_steps_match_oracle(eng, oracle, model):
+    """Transient steps (InertiaForm + weighted elastic / body forms, ImplicitEuler) on a triangle mesh against the oracle."""
+    mesh = MESHES["p2_jitter_polyfem"]()
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    mdl = E.MODEL_BY_NAME[model]
+    _setup(eng, mesh, mdl, lam, mu)
+    n = mesh.n_nodes * 2
+    bnd = M.boundary_dofs(mesh, 2, "x0")
+    eng.set_dirichlet(bnd)
+    rho, dt = 1000.0, 0.02
+    rho_e = np.where(np.arange(mesh.n_el) < mesh.n_el // 2, rho, 2.5 * rho)
+    mass = oracle.assemble_mass(mesh, 2, rho_e)
+    force = np.array([3.0, -9.81])
+    rhs = oracle.assemble_rhs(mesh, 2, force, rho_e)
+    eng.inertia_set_mass(rho_e)
+    free = np.ones(n, dtype=bool)
+    free[bnd] = False
+    x = np.zeros(n)
+    v = np.where(free, 0.05 * np.random.default_rng(9).standard_normal(n), 0.0)
+    xo, vo = x.copy(), v.copy()
+    try:
+        for step in range(3):
+            x, v, a, info = eng.implicit_euler_step(dt, x, v, rhs)
+            xo, vo, ao, iref = oracle.implicit_euler_step(mesh, mdl, lam, mu, rhs, bnd, mass, dt, xo, vo)
+            assert info["status"] == iref["status"] and info["status"] in (2, 3)
+            assert info["iterations"] == iref["iterations"] >= 1
+            assert info["line_search_iterations"] == iref["line_search_iterations"]
+            assert abs(info["energy"] - iref["energy"]) <= 1e-9 * abs(iref["energy"])
+            assert np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()
+            assert np.abs(v - vo).max() <= 1e-7 * np.abs(vo).max()
+            assert np.abs(a - ao).max() <= 1e-6 * np.abs(ao).max()
+            assert not x[bnd].any()
+        # lumped mass: row sums of the mass matrix, once per component
+        lumped = eng.lumped_mass()
+        ref = np.asarray(csc_to_scipy(mass, n).sum(axis=1)).reshape(-1)
+        assert rel_err(lumped, ref) <= 1e-12
+    finally:
+        eng.inertia_disable()
+        eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+
+
+def test_augmented_lagrangian_dirichlet(eng, oracle):
+    """ALForm / ALSolver on a triangle mesh: one penalised solve against the oracle (the static penalty is its inertia
+    term with mass w * D and predictor = target), then the loop against the direct constrained solve."""
+    import scipy.sparse as sp
+    mesh = M.square_tris(6, 2, jitter=0.1)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    n = mesh.n_nodes * 2
+    bnd = M.boundary_dofs(mesh, 2, "x0")
+    rhs = np.zeros(n)
+    rhs[1::2] = -40.0 / mesh.n_nodes
+    target = np.zeros(n)
+    target[bnd[1::2]] = 0.02
+    w = 1e6
+    masked = np.zeros(n)
+    masked[bnd] = 1.0
+    eng.al_enable_host(w, masked, target)
+    xs, info = eng.newton_solve(np.zeros(n), rhs)
+    eng.al_disable()
+    d = sp.diags(w * masked).tocsc()
+    d.sort_indices()
+    xr, iref = oracle.newton_solve(mesh, oracle.NEOHOOKEAN, lam, mu, rhs, np.zeros(0, dtype=np.int32), np.zeros(n),
+                                   mass=(d.indptr.astype(np.int32), d.indices.astype(np.int32), d.data), x_tilde=target, weight=1.0)
+    assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+    assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+    xa, ia, used = eng.al_solve(np.zeros(n), rhs, bnd, target[bnd], force_al=True)
+    assert used == [1e6] and np.array_equal(xa[bnd], target[bnd])
+    eng.set_dirichlet(bnd)
+    xd, _ = eng.newton_solve(target.copy(), rhs)
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert np.abs(xa - xd).max() <= 1e-7 * np.abs(xd).max()
+
+
 def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
     mesh = MESHES["p2_aligned"]()
     eng.set_mesh(mesh)
@@ -265,9 +384,6 @@ def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
         eng.set_material(E.NEOHOOKEAN, 1.0, 1.0, dim=3)  # dim must match the mesh
     eng.set_material(E.NEOHOOKEAN, 1.0, 1.0)
     eng.build_pattern()
-    x = M.seeded_displacement(mesh, 2, 1e-3)
-    with pytest.raises(E.PfxError):
-        eng.hessian(x, project_to_psd=True)
     with pytest.raises(E.PfxError):
         eng.amg_setup()
     # a tetrahedral mesh with dim = 2 is refused as well
