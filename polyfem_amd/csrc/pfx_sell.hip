@@ -83,12 +83,16 @@ namespace
 	template <int BS, int JB, int WPB, typename V>
 	__global__ __launch_bounds__(64 * WPB) void k_sell_values(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
 															   const int64_t *__restrict__ slice_base, int64_t n_slices,
-															   const double *__restrict__ blocks, V *__restrict__ out)
+															   const double *__restrict__ blocks, V *__restrict__ out, int xmap)
 	{
 		constexpr int B2 = BS * BS, RUN = JB * B2; // entries per row and pass
 		__shared__ V tile[WPB][JB * SL * B2];
 		const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-		const int64_t s = (int64_t)blockIdx.x * WPB + w;
+		// xmap (the grid is then a multiple of 8): workgroup b runs on XCD b % 8; XCD x takes the contiguous range
+		// [x * per, (x + 1) * per) of the slice groups, per = gridDim.x / 8; groups past the last slice do nothing
+		const int64_t per = gridDim.x / PFX_XCDS;
+		const int64_t blk = xmap ? (int64_t)(blockIdx.x % PFX_XCDS) * per + blockIdx.x / PFX_XCDS : (int64_t)blockIdx.x;
+		const int64_t s = blk * WPB + w;
 		const bool active = s < n_slices;
 		const int64_t base = active ? slice_base[s] : 0;
 		const int len = active ? (int)(slice_base[s + 1] - base) : 0;
@@ -542,19 +546,34 @@ static pfx_status sell_build(pfx_ctx *ctx)
 	return PFX_OK;
 }
 
+// workgroups of the conversion kernel for n slice groups; with the XCD-contiguous mapping the grid is rounded up to a
+// multiple of the number of XCDs (the extra groups lie past the last slice and do nothing)
+static int64_t convert_grid(int64_t n, int xmap)
+{
+	if (n < 1)
+		n = 1;
+	return xmap ? (n + PFX_XCDS - 1) / PFX_XCDS * PFX_XCDS : n;
+}
+
 // makes the solver copy of the matrix current (structure and values)
 // values of the node-block array -> slices (one wave per slice)
-// (measured at 1 M P2 tets: one slot per pass 1.68 ms, two 1.70 ms, four with half the waves 2.40 ms)
 template <typename V>
 static pfx_status sell_convert(pfx_ctx *ctx, V *out)
 {
 #define PFX_CONVERT(BS_, JB_, WPB_)                                                                                                                         \
-	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_, V>), dim3((unsigned)((ctx->sell_slices + WPB_ - 1) / WPB_ > 0 ? (ctx->sell_slices + WPB_ - 1) / WPB_ : 1)), \
-					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, out)
+	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_, V>), dim3((unsigned)convert_grid((ctx->sell_slices + WPB_ - 1) / WPB_, xmap)), \
+					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, out, xmap)
+	// Two slots per pass and two waves per workgroup, workgroups dealt so that every XCD converts one contiguous range of
+	// slices: a pass then reads 144 contiguous bytes per row instead of 72 (a 128-byte line holds 1.8 blocks: with one slot
+	// per pass most lines were fetched twice, the L2 of an XCD being about as large as the lines its resident waves have
+	// open), and the rows that neighbouring slices share lines with are converted on the same XCD.  10 M P2 tets:
+	// 14.76 ms (one slot, four waves, round robin) -> 13.97 (two slots) -> 13.36 (two waves) -> 12.8 ms (contiguous ranges);
+	// three or four slots per pass are slower (16.8 / 20.9 ms: the LDS tile then limits the waves per CU).
+	const int xmap = ctx->bs == 3 ? 1 : 0;
 	if (ctx->bs == 1)
 		PFX_CONVERT(1, 4, 4);
 	else if (ctx->bs == 3)
-		PFX_CONVERT(3, 1, 4);
+		PFX_CONVERT(3, 2, 2);
 	else if (ctx->bs == 2)
 		PFX_CONVERT(2, 2, 4);
 	else
