@@ -392,6 +392,8 @@ extern "C"
 		*out = nullptr;
 		if (!ctx->d_node_ptr)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_dist_create: pfx_build_pattern must be called first");
+		if (ctx->bs == 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_dist_create: the partitioned solve is implemented for block sizes 1 and 3 (2-D problems run on one GPU)");
 		const int64_t n_halo = ctx->n_nodes - ctx->n_owned;
 		static const int64_t zero[1] = {0};
 		if (n_neigh == 0)

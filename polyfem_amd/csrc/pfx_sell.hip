@@ -126,6 +126,90 @@ namespace
 		}
 	}
 
+	// The same conversion for 3 x 3 blocks without the LDS transpose: a lane IS a row of the slice.  It walks its row's blocks
+	// -- 72 contiguous bytes each, so consecutive loads of a lane run through consecutive bytes and every 128-byte line is
+	// used up by the lane that opened it within a few instructions -- and writes its nine entries of a slot exactly where
+	// entry_offset puts them: four 16-byte stores and one 8-byte store (two and one for float) that are contiguous
+	// across the lanes.  The loads are divergent (one line per lane) but ask for few distinct lines per byte.
+	typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+	template <typename V, int U>
+	__global__ __launch_bounds__(64) void k_sell_values_rows3(const int64_t *__restrict__ node_ptr, const int32_t *__restrict__ perm,
+															  const int64_t *__restrict__ slice_base, int64_t n_slices,
+															  const double *__restrict__ blocks, V *__restrict__ out)
+	{
+		const int lane = threadIdx.x;
+		// workgroup b runs on XCD b % 8; XCD x takes the contiguous range [x * per, (x + 1) * per) of the slices
+		const int64_t per = gridDim.x / PFX_XCDS;
+		const int64_t s = (int64_t)(blockIdx.x % PFX_XCDS) * per + blockIdx.x / PFX_XCDS;
+		if (s >= n_slices)
+			return;
+		const int64_t base = slice_base[s];
+		const int len = (int)(slice_base[s + 1] - base);
+		const int g = perm[s * SL + lane];
+		const int64_t b0 = g >= 0 ? node_ptr[g] : 0;
+		const int deg = g >= 0 ? (int)(node_ptr[g + 1] - b0) : 0;
+		const double *src = blocks + b0 * 9;
+		V *o = out + base * (SL * 9);
+		static_assert(U % 2 == 0, "whole 16-byte pieces");
+		for (int j = 0; j < len; j += U)
+		{
+			double v[9 * U];
+			if (j + U <= deg)
+			{
+				const d2u *p = reinterpret_cast<const d2u *>(src + (int64_t)j * 9);
+#pragma unroll
+				for (int q = 0; q < 9 * U / 2; ++q)
+				{
+					const d2u t = p[q];
+					v[2 * q] = t.x, v[2 * q + 1] = t.y;
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int u = 0; u < U; ++u)
+				{
+					const bool have = j + u < deg;
+#pragma unroll
+					for (int q = 0; q < 9; ++q)
+						v[9 * u + q] = have ? src[(int64_t)(j + u) * 9 + q] : 0.0;
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				if (j + u < len)
+				{
+					V *os = o + (int64_t)(j + u) * (SL * 9);
+					const double *w = v + 9 * u;
+					if constexpr (sizeof(V) == 8)
+					{
+						typedef double d2 __attribute__((ext_vector_type(2)));
+						d2 *od = reinterpret_cast<d2 *>(os);
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+						{
+							d2 t;
+							t.x = w[2 * q], t.y = w[2 * q + 1];
+							__builtin_nontemporal_store(t, od + q * 64 + lane);
+						}
+					}
+					else
+					{
+						typedef float f4 __attribute__((ext_vector_type(4)));
+						f4 *of = reinterpret_cast<f4 *>(os);
+#pragma unroll
+						for (int q = 0; q < 2; ++q)
+						{
+							f4 t;
+							t.x = (float)w[4 * q], t.y = (float)w[4 * q + 1], t.z = (float)w[4 * q + 2], t.w = (float)w[4 * q + 3];
+							__builtin_nontemporal_store(t, of + q * 64 + lane);
+						}
+					}
+					__builtin_nontemporal_store((V)w[8], os + 512 + lane);
+				}
+		}
+	}
+
 	// flag[s] = 1 if slice s reads an entry of x that this rank does not own (column node >= n_owned)
 	__global__ __launch_bounds__(256) void k_sell_classify(const int64_t *__restrict__ slice_base, const int32_t *__restrict__ cols,
 															int64_t n_slices, int64_t n_owned, uint8_t *__restrict__ flag)
@@ -563,17 +647,16 @@ static pfx_status sell_convert(pfx_ctx *ctx, V *out)
 #define PFX_CONVERT(BS_, JB_, WPB_)                                                                                                                         \
 	hipLaunchKernelGGL((k_sell_values<BS_, JB_, WPB_, V>), dim3((unsigned)convert_grid((ctx->sell_slices + WPB_ - 1) / WPB_, xmap)), \
 					   dim3(64 * WPB_), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm, ctx->d_sell_base, ctx->sell_slices, ctx->d_values, out, xmap)
-	// Two slots per pass and two waves per workgroup, workgroups dealt so that every XCD converts one contiguous range of
-	// slices: a pass then reads 144 contiguous bytes per row instead of 72 (a 128-byte line holds 1.8 blocks: with one slot
-	// per pass most lines were fetched twice, the L2 of an XCD being about as large as the lines its resident waves have
-	// open), and the rows that neighbouring slices share lines with are converted on the same XCD.  10 M P2 tets:
-	// 14.76 ms (one slot, four waves, round robin) -> 13.97 (two slots) -> 13.36 (two waves) -> 12.8 ms (contiguous ranges);
-	// three or four slots per pass are slower (16.8 / 20.9 ms: the LDS tile then limits the waves per CU).
-	const int xmap = ctx->bs == 3 ? 1 : 0;
+	const int xmap = 0; // (the LDS-transposing kernel serves block sizes 1 and 2, in round-robin order)
 	if (ctx->bs == 1)
 		PFX_CONVERT(1, 4, 4);
 	else if (ctx->bs == 3)
-		PFX_CONVERT(3, 2, 2);
+		// a lane per row, four slots per pass.  10 M P2 tets, double: the LDS transpose took 14.76 ms with one slot per pass
+		// and round-robin slices (74 GB read for 28 GB of blocks: a 128-byte line holds 1.8 blocks and most lines were
+		// fetched twice), 12.8 ms with two slots per pass and contiguous slice ranges per XCD (52 GB read); this kernel
+		// 11.5 / 11.0 / 10.96 ms with 2 / 4 / 8 slots per pass (41 / 35 / 34 GB read)
+		hipLaunchKernelGGL((k_sell_values_rows3<V, 4>), dim3((unsigned)convert_grid(ctx->sell_slices, 1)), dim3(64), 0, ctx->stream, ctx->d_node_ptr, ctx->d_sell_perm,
+						   ctx->d_sell_base, ctx->sell_slices, ctx->d_values, out);
 	else if (ctx->bs == 2)
 		PFX_CONVERT(2, 2, 4);
 	else
