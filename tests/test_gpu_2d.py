@@ -375,6 +375,24 @@ def test_augmented_lagrangian_dirichlet(eng, oracle):
     assert np.abs(xa - xd).max() <= 1e-7 * np.abs(xd).max()
 
 
+def test_neohookean_hip_against_sympy_derivatives(eng):
+    """The HIP energy / gradient / Hessian of one triangle against the symbolic derivatives of the 2-D energy density
+    (tests/golden/sympy/neohookean_sympy_2d.npz): independent of the oracle."""
+    import os
+    from tests.test_oracle_kat_2d import _single_triangle_with_gradient, neohookean_sympy_expected_2d
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sympy", "neohookean_sympy_2d.npz"))
+    lam, mu = float(g["lam"]), float(g["mu"])
+    for F, psi, dpsi, d2psi in zip(g["F"], g["psi"], g["dpsi"], g["d2psi"]):
+        mesh, u = _single_triangle_with_gradient(F)
+        _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+        assert abs(eng.energy(u) - psi / 2.0) <= 1e-12 * max(abs(psi / 2.0), 1e-3 * mu)
+        grad_ref, hess_ref = neohookean_sympy_expected_2d(F, dpsi, d2psi)
+        assert np.abs(eng.gradient(u) - grad_ref).max() <= 1e-12 * max(np.abs(grad_ref).max(), mu)
+        rp, ci = eng.get_pattern()
+        H = csc_to_scipy((rp, ci, eng.hessian(u)), 6).toarray()
+        assert np.abs(H - hess_ref).max() <= 1e-12 * np.abs(hess_ref).max()
+
+
 def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
     mesh = MESHES["p2_aligned"]()
     eng.set_mesh(mesh)

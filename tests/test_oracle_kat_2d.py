@@ -201,3 +201,42 @@ def test_newton_mass_rhs_2d_oracle(oracle):
     # models the 2-D branches do not cover are refused
     with pytest.raises(AssertionError):
         oracle.assemble_gradient(m, oracle.SAINT_VENANT, lam, mu, x)
+
+
+def _single_triangle_with_gradient(F):
+    """The reference triangle with P1 bases and the displacement whose deformation gradient is F (2 x 2)."""
+    xy = np.array([[0, 0], [1, 0], [0, 1]], dtype=float)
+    conn = np.array([[0, 1, 2]], dtype=np.int32)
+    mesh = M.Mesh(M.P1TRI, M.P1TRI, conn, conn.copy(), xy, 3, xy.copy())
+    u = np.zeros((3, 2))
+    u[1:] = (F - np.eye(2)).T  # F = I + sum_i u_i (x) grad phi_i, grad phi_0 = -(1,1), grad phi_j = e_{j-1}
+    return mesh, u.reshape(-1)
+
+
+def neohookean_sympy_expected_2d(F, dpsi, d2psi):
+    """Element gradient and Hessian of the single P1 triangle (area 1/2) from the derivatives of psi w.r.t. F."""
+    g_ref = np.array([[-1, -1], [1, 0], [0, 1]], dtype=float)
+    P = dpsi.reshape(2, 2)
+    C = d2psi.reshape(2, 2, 2, 2)
+    grad = np.einsum("dc,ic->id", P, g_ref).reshape(-1) / 2.0
+    hess = np.einsum("dcef,ic,jf->idje", C, g_ref, g_ref).reshape(6, 6) / 2.0
+    return grad, hess
+
+
+def test_neohookean_2d_against_sympy_derivatives(oracle):
+    """The dim == 2 branches against derivatives obtained by symbolic differentiation of the 2-D energy density (fixture
+    tests/golden/sympy/neohookean_sympy_2d.npz, generator tests/tools/make_neohookean_sympy_golden.py): independent of the
+    restated closed forms."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sympy", "neohookean_sympy_2d.npz"))
+    lam, mu = float(g["lam"]), float(g["mu"])
+    assert abs(lam - oracle.lame(2e4, 0.3, 2)[0]) <= 1e-12 * lam
+    for F, psi, dpsi, d2psi in zip(g["F"], g["psi"], g["dpsi"], g["d2psi"]):
+        mesh, u = _single_triangle_with_gradient(F)
+        e = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, u)
+        assert abs(e - psi / 2.0) <= 1e-12 * max(abs(psi / 2.0), 1e-3 * mu)
+        grad_ref, hess_ref = neohookean_sympy_expected_2d(F, dpsi, d2psi)
+        grad = oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, u)
+        assert np.abs(grad - grad_ref).max() <= 1e-12 * max(np.abs(grad_ref).max(), mu)
+        H = csc_to_scipy(oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, u), 6).toarray()
+        assert np.abs(H - hess_ref).max() <= 1e-12 * np.abs(hess_ref).max()
