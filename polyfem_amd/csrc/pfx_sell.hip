@@ -15,6 +15,7 @@
 // the same data; a pure streaming read of the value array takes 0.50 ms.  Sorting only inside windows keeps the x
 // entries gathered by one slice close together (L2 hits) and the padding below 0.2 %.
 #include "pfx_internal.h"
+#include <cstdio>
 
 #include <rocprim/rocprim.hpp>
 
@@ -680,6 +681,7 @@ static pfx_status sell_convert(pfx_ctx *ctx, V *out)
 #ifndef PFX_PLACEMENT_MIN_BYTES
 #define PFX_PLACEMENT_MIN_BYTES ((size_t)1 << 30)
 #endif
+static float good_ms_of(size_t bytes) { return 3.0f * (float)((double)bytes / (0.74 * 8.0e9)); }
 template <typename V>
 static pfx_status sell_place(pfx_ctx *ctx, V *&array, int64_t count, bool fp32)
 {
@@ -729,11 +731,14 @@ static pfx_status sell_place(pfx_ctx *ctx, V *&array, int64_t count, bool fp32)
 		PFX_HIP(hipEventElapsedTime(ms, e0, e1));
 		return PFX_OK;
 	};
+	static const bool log_tries = getenv("PFX_PLACEMENT_LOG") != nullptr; // one line per candidate on stderr
 	float best = 0;
 	rc = measure(&best);
+	if (log_tries)
+		fprintf(stderr, "[polyfem_amd] placement search (%s, %.1f GB): in place %.3f ms per product, stop below %.3f\n", fp32 ? "float" : "double", bytes / 1e9, best / 3, good_ms_of(bytes) / 3);
 	// three products with the value stream alone at 0.74 of the HBM peak (0.80 with the index and vector bytes of the 3 x 3
 	// double-precision format): as good as it gets, stop looking
-	const float good_ms = 3.0f * (float)((double)bytes / (0.74 * 8.0e9));
+	const float good_ms = good_ms_of(bytes);
 	for (int k = 0; k < tries && !rc && best > good_ms; ++k)
 	{
 		V *cand = nullptr;
@@ -751,6 +756,8 @@ static pfx_status sell_place(pfx_ctx *ctx, V *&array, int64_t count, bool fp32)
 			(void)hipFree(cand);
 			break;
 		}
+		if (log_tries)
+			fprintf(stderr, "[polyfem_amd]   candidate %d: %.3f ms per product (%s)\n", k + 1, ms / 3, ms < best ? "kept" : "dropped");
 		if (ms < best)
 		{
 			best = ms;
