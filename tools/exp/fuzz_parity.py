@@ -76,6 +76,23 @@ for case in range(n_cases):
         strain2 = max(eo / (mu * max(abs(csc_to_scipy(O.assemble_mass(m, 1, 1.0), m.n_nodes).sum()), 1e-300)), 1e-300)
         assert abs(e - eo) <= max(1e-12, 4e-16 / strain2) * abs(eo), ("energy", e, eo, strain2)
         assert rel_err(g, go) <= 1e-12 and rel_err(h, ho[2]) <= 1e-12, ("grad/hess", rel_err(g, go), rel_err(h, ho[2]))
+        # projected Hessian, per-element materials, mass matrix and right-hand side
+        hp = eng.hessian(x, project_to_psd=True)
+        hpo = O.assemble_hessian_psd(m, O.NEOHOOKEAN, lam, mu, x)[2]
+        assert np.abs(hp - hpo).max() <= 1e-9 * np.abs(hpo).max(), ("psd", np.abs(hp - hpo).max() / np.abs(hpo).max())
+        lam_e, mu_e = lam * rng.uniform(0.5, 2, m.n_el), mu * rng.uniform(0.5, 2, m.n_el)
+        eng.set_material(E.NEOHOOKEAN, lam_e, mu_e)
+        assert rel_err(eng.hessian(x), O.assemble_hessian(m, O.NEOHOOKEAN, lam_e, mu_e, x)[2]) <= 1e-12, "per-element hessian"
+        assert rel_err(eng.gradient(x), O.assemble_gradient(m, O.NEOHOOKEAN, lam_e, mu_e, x)) <= 1e-12, "per-element gradient"
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        rho = rng.uniform(0.5, 2, m.n_el)
+        eng.assemble_mass(rho)
+        rpm, cim, vm = eng.get_linear_csr()
+        mo = O.assemble_mass(m, dim, rho)
+        assert np.array_equal(rpm, mo[0].astype(np.int64)) and np.array_equal(cim, mo[1]) and rel_err(vm, mo[2]) <= 1e-12, "mass"
+        f = rng.standard_normal(dim)
+        assert rel_err(eng.assemble_rhs(f, rho), O.assemble_rhs(m, dim, f, rho)) <= 1e-12, "rhs"
+        eng.hessian(x, fetch=False)
         # the bare Hessian of a free (or, with elements removed, disconnected) body is singular, and one-point Q1 hexahedra
         # have hourglass modes: the solver is compared on H + shift I with a shift that makes the system well conditioned
         ndof = m.n_nodes * dim
