@@ -287,3 +287,64 @@ def test_placement_search_changes_nothing_but_where_the_values_lie(monkeypatch):
     assert it0 == it4 and err0 == err4 and np.array_equal(x0, x4)
     assert held0 == held4 and products0 == products4
     assert ita0 == ita4 and erra0 == erra4 and np.array_equal(xa0, xa4)
+
+
+def test_two_million_p2_triangles_properties():
+    """2-D at size (1000^2 cells = 2 M P2 triangles, 4 M nodes, 8 M dofs: the slice-ordered product and the multi-window row
+    groups of the block-size-2 path), through properties the oracle is not needed for: a homogeneous deformation has the
+    energy psi(F) |Omega| exactly (constant integrand) and is in equilibrium in the interior; the Hessian at rest is the
+    linear stiffness matrix, symmetric, with the three rigid modes in its null space; the CG reaches its tolerance and is
+    bitwise repeatable."""
+    mesh = M.square_tris(1000, 2, jitter=0.2, seed=11)
+    assert mesh.n_el == 2_000_000
+    n = 2 * mesh.n_nodes
+    E_, nu = 2e4, 0.3
+    lam, mu = nu * E_ / (1 - nu * nu), E_ / (2 * (1 + nu))
+    eng = E.Engine(0)
+    try:
+        eng.set_mesh(mesh)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.build_pattern()
+        pos = M.node_positions(mesh)
+        F = np.array([[1.07, 0.05], [-0.03, 0.94]])
+        u = (pos @ (F - np.eye(2)).T).reshape(-1)
+        J = np.linalg.det(F)
+        psi = mu / 2 * ((F * F).sum() - 2 - 2 * np.log(J)) + lam / 2 * np.log(J) ** 2
+        e = eng.energy(u)
+        assert abs(e - psi * 1.0) <= 1e-11 * psi, (e, psi)
+        g = eng.gradient(u).reshape(-1, 2)
+        lo, hi = pos.min(axis=0), pos.max(axis=0)
+        interior = np.all((pos > lo + 1e-9) & (pos < hi - 1e-9), axis=1)
+        assert np.abs(g[interior]).max() <= 1e-9 * np.abs(g).max()
+        # the boundary tractions of the homogeneous stress sum to zero
+        assert np.abs(g.sum(axis=0)).max() <= 1e-9 * np.abs(g).sum()
+        # at rest: Hessian == linear stiffness
+        eng.hessian(np.zeros(n), fetch=False)
+        rng = np.random.default_rng(3)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        Hx, Hy = eng.spmv(x), eng.spmv(y)
+        assert abs(y @ Hx - x @ Hy) <= 1e-11 * abs(y @ Hx)
+        scale = np.abs(Hx).max()
+        modes = [np.tile([1.0, 0.0], mesh.n_nodes), np.tile([0.0, 1.0], mesh.n_nodes), np.stack([-pos[:, 1], pos[:, 0]], axis=1).reshape(-1)]
+        for t in modes:
+            assert np.abs(eng.spmv(t)).max() <= 1e-9 * scale
+        eng.set_material(E.LINEAR_ELASTICITY, lam, mu)
+        eng.assemble_linear()
+        assert np.abs(eng.spmv(x) - Hx).max() <= 1e-10 * scale
+        # clamped on x = 0: CG to 1e-8 in the limit of iterations it is given, twice, bit for bit
+        bd = M.boundary_dofs(mesh, 2, "x0")
+        eng.set_dirichlet(bd)
+        b = np.zeros(n)
+        b[1::2] = -1.0 / mesh.n_nodes
+        x1, it1, err1 = eng.cg(b, None, E.PRECOND_JACOBI, 300, 1e-30)
+        x2, it2, err2 = eng.cg(b, None, E.PRECOND_JACOBI, 300, 1e-30)
+        assert it1 == it2 == 300 and np.array_equal(x1, x2) and err1 == err2
+        assert not x1[bd].any() and np.isfinite(x1).all()
+        # the reported residual is the residual of the returned iterate (eng.spmv applies the masked operator)
+        free = np.ones(n, dtype=bool)
+        free[bd] = False
+        r = (b - eng.spmv(x1))[free]
+        assert abs(np.linalg.norm(r) / np.linalg.norm(b[free]) - err1) <= 1e-6 * err1
+        eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    finally:
+        eng.close()
