@@ -502,6 +502,16 @@ namespace polyfem_amd
 			c.check(pfx_assemble_rhs(c.h, force, density.density, density.density_e.empty() ? nullptr : density.density_e.data(), rhs.data()));
 		}
 
+		// the same on a triangle mesh (two force components, rhs[node*2 + c])
+		inline void assemble_body_force(const std::vector<basis::ElementBases> &bases, const std::vector<basis::ElementBases> &gbases, const int n_basis,
+										const double (&force)[2], const Mass &density, VectorXd &rhs)
+		{
+			Context &c = Context::instance();
+			c.bind(bases, gbases, n_basis, PFX_LINEAR_ELASTICITY, 2, 1.0, 1.0);
+			rhs.assign((size_t)n_basis * 2, 0.0);
+			c.check(pfx_assemble_rhs(c.h, force, density.density, density.density_e.empty() ? nullptr : density.density_e.data(), rhs.data()));
+		}
+
 		template <class LocalAssembler>
 		class NLAssembler // assembler/Assembler.hpp:70-118
 		{

@@ -70,10 +70,12 @@ def test_factory():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [3, 2])
 @pytest.mark.parametrize("kind", ["ImplicitEuler", "ImplicitNewmark", "BDF2", "BDF3"])
-def test_transient_solver_matches_oracle(oracle, kind):
+def test_transient_solver_matches_oracle(oracle, kind, dim):
     """Four device-resident time steps of a NeoHookean body under gravity with each integrator; the reference run is
-    the same integrator class on numpy vectors with the oracle's Newton solve of the step objective."""
+    the same integrator class on numpy vectors with the oracle's Newton solve of the step objective.  dim = 2: the same on
+    a triangle mesh."""
     import torch
     from polyfem_amd import engine as E
     from polyfem_amd import mesh as M
@@ -82,13 +84,13 @@ def test_transient_solver_matches_oracle(oracle, kind):
         return {"ImplicitEuler": TI.ImplicitEuler, "ImplicitNewmark": TI.ImplicitNewmark, "BDF2": lambda: TI.BDF(2),
                 "BDF3": lambda: TI.BDF(3)}[kind]()
 
-    mesh = M.cube_tets(3, 2, numbering="polyfem", jitter=0.2, seed=2)
-    lam, mu = oracle.lame(2e4, 0.3)
-    n = mesh.n_nodes * 3
-    bnd = M.boundary_dofs(mesh, 3, "x0")
+    mesh = M.cube_tets(3, 2, numbering="polyfem", jitter=0.2, seed=2) if dim == 3 else M.square_tris(6, 2, numbering="polyfem", jitter=0.2, seed=2)
+    lam, mu = oracle.lame(2e4, 0.3, dim)
+    n = mesh.n_nodes * dim
+    bnd = M.boundary_dofs(mesh, dim, "x0")
     rho, dt = 1000.0, 0.02
-    rhs = oracle.assemble_rhs(mesh, 3, np.array([0.0, 3.0, -9.81]), rho)
-    mass = oracle.assemble_mass(mesh, 3, rho)
+    rhs = oracle.assemble_rhs(mesh, dim, np.array([0.0, 3.0, -9.81])[3 - dim:], rho)
+    mass = oracle.assemble_mass(mesh, dim, rho)
     free = np.ones(n, dtype=bool)
     free[bnd] = False
     v0 = np.where(free, 0.05 * np.random.default_rng(9).standard_normal(n), 0.0)
