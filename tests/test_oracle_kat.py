@@ -747,3 +747,38 @@ def test_per_point_density_oracle(oracle, kind):
     sq = oracle.quadrature_points(mesh)
     r = oracle.assemble_rhs(mesh, 1, [1.0], 1.0 + sq[..., 0])  # the stiffness rule integrates a linear density exactly
     assert abs(r.sum() - 1.5) <= 1e-12
+
+
+def test_energy_against_a_50_digit_evaluation(oracle):
+    """The NeoHookean energy of a one-hexahedron mesh (one quadrature point at the centre, unit Jacobian: F is a closed form of
+    the nodal displacements) against mpmath with 50 digits.  At large strains the oracle agrees to 1e-13; at strains of a few
+    1e-3 the density mu/2 (|F|^2 - 3 - 2 ln J) + lambda/2 ln^2 J is a difference of O(1) terms that leaves O(strain^2), and the
+    double-precision evaluation of the reference's own expression is only good to about 1e-16 / strain^2 -- which is why the
+    GPU tests scale their energy bar with the cancellation on meshes with few quadrature points."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    m = M.cube_hexes(1, 1)
+    lam, mu = oracle.lame(3e5, 0.33)
+    nodes = oracle.basis_nodes(oracle.Q1HEX)
+    rng = np.random.default_rng(5)
+    worst = {}
+    for amp in (2.5e-3, 0.25):
+        for _ in range(8):
+            x = rng.standard_normal(24) * amp
+            e = oracle.assemble_energy(m, oracle.NEOHOOKEAN, lam, mu, x)
+            F = mp.eye(3)
+            for i in range(8):
+                node = int(m.conn[0, i])
+                g = [(1 if nodes[i][c] > 0.5 else -1) * mp.mpf(1) / 4 for c in range(3)]  # grad of the Q1 basis at the centre
+                for d in range(3):
+                    for c in range(3):
+                        F[d, c] += mp.mpf(float(x[3 * node + d])) * g[c]
+            J = mp.det(F)
+            if J <= 0:
+                continue
+            lj = mp.log(J)
+            tr = sum(F[a, b] ** 2 for a in range(3) for b in range(3))
+            exact = mp.mpf(mu) / 2 * (tr - 3 - 2 * lj) + mp.mpf(lam) / 2 * lj * lj
+            worst[amp] = max(worst.get(amp, 0.0), abs(float((mp.mpf(e) - exact) / exact)))
+    assert worst[0.25] <= 1e-13
+    assert 1e-13 < worst[2.5e-3] <= 1e-9  # the cancellation is there, and it is rounding-sized
