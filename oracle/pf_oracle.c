@@ -853,6 +853,57 @@ void pfo_local_hooke(const pfo_vals *v, int i, int j, const double *da, const do
 	}
 }
 
+/* assembler/HookeLinearElasticity.cpp:92-122 (size_ == 2): strain<2>() as above with 2 x 2 matrices, the Voigt strain
+ * (xx, yy, 2 xy) through the 3 x 3 tensor (compute_stress<3>, utils/ElasticityUtils.cpp:469-477), sigma = [[s0, s2], [s2, s1]],
+ * entry jj*2+ii = trace(sigma_i * eps_j).  C: symmetric 3 x 3, row-major. */
+static void hooke_strain_2d(const double *g, int coo, double *eps)
+{
+	double J[4] = {0, 0, 0, 0};
+	J[2 * coo] = g[0], J[2 * coo + 1] = g[1];
+	for (int r = 0; r < 2; ++r)
+		for (int c = 0; c < 2; ++c)
+			eps[2 * r + c] = (J[2 * r + c] + J[2 * c + r]) * 0.5;
+}
+
+void pfo_local_hooke_2d(const pfo_vals *v, int i, int j, const double *da, const double *C, double *res)
+{
+	for (int c = 0; c < 4; ++c)
+		res[c] = 0;
+	for (int k = 0; k < v->n_pts; ++k)
+	{
+		const double *gi = v->grad_t_m[i][k], *gj = v->grad_t_m[j][k];
+		double sigma[2][4], epsj[2][4];
+		for (int coo = 0; coo < 2; ++coo)
+		{
+			double ei[4];
+			hooke_strain_2d(gi, coo, ei);
+			hooke_strain_2d(gj, coo, epsj[coo]);
+			const double e3[3] = {ei[0], ei[3], 2 * ei[1]};
+			double s3[3];
+			for (int a = 0; a < 3; ++a)
+			{
+				double r = 0;
+				for (int b = 0; b < 3; ++b)
+					r += C[a * 3 + b] * e3[b];
+				s3[a] = r;
+			}
+			double *sg = sigma[coo];
+			sg[0] = s3[0], sg[1] = s3[2], sg[2] = s3[2], sg[3] = s3[1];
+		}
+		double res_k[4];
+		for (int ci = 0; ci < 2; ++ci)
+			for (int cj = 0; cj < 2; ++cj)
+			{
+				const double *sg = sigma[ci], *ej = epsj[cj];
+				const double d0 = sg[0] * ej[0] + sg[1] * ej[2];
+				const double d1 = sg[2] * ej[1] + sg[3] * ej[3];
+				res_k[cj * 2 + ci] = d0 + d1;
+			}
+		for (int c = 0; c < 4; ++c)
+			res[c] += res_k[c] * da[k];
+	}
+}
+
 /* F = local_disp^T * grad(p) * jac_it(p) + I ; local_disp is n_loc x 3 (row i = displacement of basis i).
  * NeoHookeanElasticity.cpp:402 / :491 (dense products).  F row-major. */
 static void def_grad_at_id(const pfo_vals *v, int p, const double *local_disp, double *F, double id)
@@ -1170,10 +1221,15 @@ static int mat_model(const pfo_material *mat, int64_t e) { return (mat->model ==
 static double local_linear_elasticity_energy_2d(const pfo_vals *v, const double *da, const double *ld, double lambda, double mu);
 static void local_linear_elasticity_grad_2d(const pfo_vals *v, const double *da, const double *ld, double lambda, double mu, double *G);
 static void local_linear_elasticity_hessian_2d(const pfo_vals *v, const double *da, double lambda, double mu, double *H);
+double pfo_local_saint_venant_energy_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor9);
 static double nl_local_energy(int model, const pfo_vals *v, const double *da, const double *ld, double lambda, double mu)
 {
-	if (v->dim == 2) /* triangles: NeoHookean and LinearElasticity only (checked by the callers) */
+	if (v->dim == 2) /* triangles */
+	{
+		if (model == PFO_SAINT_VENANT)
+			return pfo_local_saint_venant_energy_2d(v, da, ld, lambda, mu, NULL);
 		return model == PFO_NEOHOOKEAN ? pfo_local_neohookean_energy_2d(v, da, ld, lambda, mu) : local_linear_elasticity_energy_2d(v, da, ld, lambda, mu);
+	}
 	if (model == PFO_NEOHOOKEAN)
 		return pfo_local_neohookean_energy(v, da, ld, lambda, mu);
 	if (model == PFO_SAINT_VENANT)
@@ -1508,6 +1564,138 @@ static void local_linear_elasticity_hessian_2d(const pfo_vals *v, const double *
 	free(H3);
 }
 
+/* SaintVenantElasticity with size() == 2 (assembler/SaintVenantElasticity.cpp:215-312, the branch at :284-293): the
+ * 2 x 2 Green strain, the Voigt strain (xx, yy, 2 xy), the 3 x 3 tensor of ElasticityTensor::resize(2)
+ * (utils/ElasticityUtils.cpp:264-274; set_from_lambda_mu :374-384), stress [[s0, s2], [s2, s1]]. */
+static void sv_tensor_2d(double lambda, double mu, double C[3][3])
+{
+	C[0][0] = 2 * mu + lambda, C[0][1] = lambda, C[0][2] = 0;
+	C[1][0] = lambda, C[1][1] = 2 * mu + lambda, C[1][2] = 0;
+	C[2][0] = 0, C[2][1] = 0, C[2][2] = mu;
+}
+static void sv_pick_tensor_2d(const double *tensor9, double lambda, double mu, double C[3][3])
+{
+	if (!tensor9)
+	{
+		sv_tensor_2d(lambda, mu, C);
+		return;
+	}
+	for (int a = 0; a < 3; ++a)
+		for (int b = 0; b < 3; ++b)
+			C[a][b] = tensor9[3 * a + b];
+}
+/* G: the 2 x 2 displacement gradient; strain_from_disp_grad (:15-24) */
+static void sv_strain_stress_2d(const double *G, double C[3][3], double *E, double *S)
+{
+	for (int a = 0; a < 2; ++a)
+		for (int b = 0; b < 2; ++b)
+		{
+			double gtg = 0;
+			for (int k = 0; k < 2; ++k)
+				gtg += G[2 * k + a] * G[2 * k + b];
+			E[2 * a + b] = (gtg + G[2 * a + b] + G[2 * b + a]) * 0.5;
+		}
+	const double eps[3] = {E[0], E[3], 2 * E[1]};
+	double sg[3];
+	for (int j = 0; j < 3; ++j)
+	{
+		double res = C[j][0] * eps[0];
+		for (int k = 1; k < 3; ++k)
+			res += C[j][k] * eps[k];
+		sg[j] = res;
+	}
+	S[0] = sg[0], S[1] = sg[2], S[2] = sg[2], S[3] = sg[1];
+}
+double pfo_local_saint_venant_energy_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor9)
+{
+	double C[3][3], energy = 0;
+	sv_pick_tensor_2d(tensor9, lambda, mu, C);
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double G[4], E[4], S[4];
+		def_grad_at_2d(v, p, local_disp, G, 0.0);
+		sv_strain_stress_2d(G, C, E, S);
+		double tr = 0;
+		for (int a = 0; a < 2; ++a)
+			for (int k = 0; k < 2; ++k)
+				tr += S[2 * a + k] * E[2 * k + a];
+		energy += tr * da[p];
+	}
+	return energy * 0.5;
+}
+/* the derivatives the reference takes with autodiff (:104-143), written out as for the 3-D case: the gradient
+ * contracts the first Piola-Kirchhoff stress F S with the physical basis gradients, the Hessian is
+ * delta_ab G_i^T S G_j + voigt(f_a, G_i)^T C voigt(f_b, G_j) with voigt(f, g) = (f0 g0, f1 g1, f0 g1 + g0 f1) */
+void pfo_local_saint_venant_grad_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor9, double *Gout)
+{
+	double C[3][3];
+	sv_pick_tensor_2d(tensor9, lambda, mu, C);
+	for (int k = 0; k < 2 * v->n_loc; ++k)
+		Gout[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double G[4], F[4], E[4], S[4], P[4];
+		def_grad_at_2d(v, p, local_disp, G, 0.0);
+		sv_strain_stress_2d(G, C, E, S);
+		F[0] = G[0] + 1, F[1] = G[1], F[2] = G[2], F[3] = G[3] + 1;
+		for (int a = 0; a < 2; ++a)
+			for (int b = 0; b < 2; ++b)
+				P[2 * a + b] = F[2 * a] * S[b] + F[2 * a + 1] * S[2 + b];
+		for (int i = 0; i < v->n_loc; ++i)
+		{
+			double Gi[3];
+			phys_grad(v, i, p, Gi);
+			for (int d = 0; d < 2; ++d)
+				Gout[2 * i + d] += (P[2 * d] * Gi[0] + P[2 * d + 1] * Gi[1]) * da[p];
+		}
+	}
+}
+void pfo_local_saint_venant_hessian_2d(const pfo_vals *v, const double *da, const double *local_disp, double lambda, double mu, const double *tensor9, double *H)
+{
+	const int N = 2 * v->n_loc;
+	double C[3][3];
+	sv_pick_tensor_2d(tensor9, lambda, mu, C);
+	for (int k = 0; k < N * N; ++k)
+		H[k] = 0;
+	for (int p = 0; p < v->n_pts; ++p)
+	{
+		double G[4], F[4], E[4], S[4];
+		def_grad_at_2d(v, p, local_disp, G, 0.0);
+		sv_strain_stress_2d(G, C, E, S);
+		F[0] = G[0] + 1, F[1] = G[1], F[2] = G[2], F[3] = G[3] + 1;
+		for (int i = 0; i < v->n_loc; ++i)
+		{
+			double Gi[3];
+			phys_grad(v, i, p, Gi);
+			for (int j = 0; j < v->n_loc; ++j)
+			{
+				double Gj[3];
+				phys_grad(v, j, p, Gj);
+				const double gsg = Gi[0] * (S[0] * Gj[0] + S[1] * Gj[1]) + Gi[1] * (S[2] * Gj[0] + S[3] * Gj[1]);
+				for (int a = 0; a < 2; ++a)
+				{
+					const double *fa = F + 2 * a;
+					const double va[3] = {fa[0] * Gi[0], fa[1] * Gi[1], fa[0] * Gi[1] + Gi[0] * fa[1]};
+					for (int b = 0; b < 2; ++b)
+					{
+						const double *fb = F + 2 * b;
+						const double vb[3] = {fb[0] * Gj[0], fb[1] * Gj[1], fb[0] * Gj[1] + Gj[0] * fb[1]};
+						double acc = (a == b) ? gsg : 0.0;
+						for (int r = 0; r < 3; ++r)
+						{
+							double cv = 0;
+							for (int c = 0; c < 3; ++c)
+								cv += C[r][c] * vb[c];
+							acc += va[r] * cv;
+						}
+						H[(2 * i + a) * N + 2 * j + b] += acc * da[p];
+					}
+				}
+			}
+		}
+	}
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* triplets -> CSC  (Eigen::SparseMatrix::setFromTriplets: duplicates summed in insertion order,     */
 /* explicit zeros kept, inner indices ascending)                                                     */
@@ -1647,7 +1835,7 @@ static double nl_local_energy(int model, const pfo_vals *v, const double *da, co
 static double nl_local_energy_mat(int model, const pfo_vals *v, const double *da, const double *ld, const pfo_material *mat, int64_t e)
 {
 	if (model == PFO_SAINT_VENANT && mat->tensor)
-		return pfo_local_saint_venant_energy_t(v, da, ld, 0, 0, mat->tensor);
+		return v->dim == 2 ? pfo_local_saint_venant_energy_2d(v, da, ld, 0, 0, mat->tensor) : pfo_local_saint_venant_energy_t(v, da, ld, 0, 0, mat->tensor);
 	const int np = mat_points(mat);
 	if (!np)
 		return nl_local_energy(model, v, da, ld, mat_lambda(mat, e), mat_mu(mat, e));
@@ -1665,6 +1853,8 @@ static void nl_local_grad(int model, const pfo_vals *v, const double *da, const 
 	{
 		if (model == PFO_NEOHOOKEAN)
 			pfo_local_neohookean_grad_2d(v, da, ld, lambda, mu, G);
+		else if (model == PFO_SAINT_VENANT)
+			pfo_local_saint_venant_grad_2d(v, da, ld, lambda, mu, NULL, G);
 		else
 			local_linear_elasticity_grad_2d(v, da, ld, lambda, mu, G);
 		return;
@@ -1682,6 +1872,8 @@ static void nl_local_hessian(int model, const pfo_vals *v, const double *da, con
 	{
 		if (model == PFO_NEOHOOKEAN)
 			pfo_local_neohookean_hessian_2d(v, da, ld, lambda, mu, H);
+		else if (model == PFO_SAINT_VENANT)
+			pfo_local_saint_venant_hessian_2d(v, da, ld, lambda, mu, NULL, H);
 		else
 			local_linear_elasticity_hessian_2d(v, da, lambda, mu, H);
 		return;
@@ -1697,7 +1889,10 @@ static void nl_local_grad_mat(int model, const pfo_vals *v, const double *da, co
 {
 	if (model == PFO_SAINT_VENANT && mat->tensor)
 	{
-		pfo_local_saint_venant_grad_t(v, da, ld, 0, 0, mat->tensor, G);
+		if (v->dim == 2)
+			pfo_local_saint_venant_grad_2d(v, da, ld, 0, 0, mat->tensor, G);
+		else
+			pfo_local_saint_venant_grad_t(v, da, ld, 0, 0, mat->tensor, G);
 		return;
 	}
 	const int np = mat_points(mat), N = v->n_loc * v->dim;
@@ -1721,7 +1916,10 @@ static void nl_local_hessian_mat(int model, const pfo_vals *v, const double *da,
 {
 	if (model == PFO_SAINT_VENANT && mat->tensor)
 	{
-		pfo_local_saint_venant_hessian_t(v, da, ld, 0, 0, mat->tensor, H);
+		if (v->dim == 2)
+			pfo_local_saint_venant_hessian_2d(v, da, ld, 0, 0, mat->tensor, H);
+		else
+			pfo_local_saint_venant_hessian_t(v, da, ld, 0, 0, mat->tensor, H);
 		return;
 	}
 	const int np = mat_points(mat), N = v->n_loc * v->dim;
@@ -1745,14 +1943,14 @@ static void nl_local_hessian_mat(int model, const pfo_vals *v, const double *da,
 }
 
 static int block_size(const pfo_material *mat) { return mat->model == PFO_LAPLACIAN ? 1 : mat->dim; }
-/* triangles: Laplacian, LinearElasticity and NeoHookean with dim == 2; every other mesh: dim == 3 */
+/* triangles: dim == 2 (a 2-D elasticity tensor is 3 x 3); every other mesh: dim == 3 */
 static int model_fits_mesh(const pfo_mesh *mesh, const pfo_material *mat)
 {
 	if (!is_tri(mesh->kind))
 		return mat->model == PFO_LAPLACIAN || mat->dim == 3;
 	if (mat->model == PFO_LAPLACIAN)
 		return 1;
-	return mat->dim == 2 && (mat->model == PFO_LINEAR_ELASTICITY || mat->model == PFO_NEOHOOKEAN);
+	return mat->dim == 2;
 }
 
 typedef struct
@@ -1876,11 +2074,13 @@ static void *job_run(void *arg)
 					double sv[9];
 					if (mat->model == PFO_LAPLACIAN)
 						pfo_local_laplacian(v, i, j, da, sv);
+					else if (mat->model == PFO_HOOKE_LINEAR && size == 2)
+						pfo_local_hooke_2d(v, i, j, da, mat->tensor, sv); /* the 3 x 3 tensor; res index jj*2+ii already */
 					else if (mat->model == PFO_HOOKE_LINEAR)
 						pfo_local_hooke(v, i, j, da, mat->tensor, sv);
 					else
 						local_linear_elasticity_mat(v, i, j, da, mat, e, sv);
-					if (size == 2) /* LinearElasticity::assemble with size() == 2: the in-plane entries, index jj*2+ii (the third components of the gradients are zero) */
+					if (size == 2 && mat->model != PFO_HOOKE_LINEAR) /* LinearElasticity::assemble with size() == 2: the in-plane entries, index jj*2+ii (the third components of the gradients are zero) */
 						sv[2] = sv[3], sv[3] = sv[4];
 					for (int n = 0; n < size; ++n)
 						for (int m = 0; m < size; ++m)

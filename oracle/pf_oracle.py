@@ -55,9 +55,8 @@ def make_material(model: int, lam, mu, tensor=None):
         tensor = lam  # (SAINT_VENANT, 6 x 6 tensor, None): the positional form the assemble_* wrappers pass through
     if tensor is not None:
         assert model == SAINT_VENANT
-        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(6, 6)
-        assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
-        return Material(model, 3, 0.0, 0.0, None, None, _dp(t), 0, None), t
+        t = _voigt_tensor(tensor)
+        return Material(model, 3 if t.shape[0] == 6 else 2, 0.0, 0.0, None, None, _dp(t), 0, None), t
     if np.ndim(model) == 1:  # MultiModel: one model id per element
         me = np.ascontiguousarray(model, dtype=np.int32)
         assert np.isin(me, (LINEAR_ELASTICITY, NEOHOOKEAN, SAINT_VENANT)).all()
@@ -65,9 +64,8 @@ def make_material(model: int, lam, mu, tensor=None):
         mat.model_e = me.ctypes.data_as(C.POINTER(C.c_int32))
         return mat, (keep, me)
     if model == HOOKE_LINEAR:
-        t = np.ascontiguousarray(lam, dtype=np.float64).reshape(6, 6)
-        assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
-        return Material(model, 3, 0.0, 0.0, None, None, _dp(t), 0, None), t
+        t = _voigt_tensor(lam)
+        return Material(model, 3 if t.shape[0] == 6 else 2, 0.0, 0.0, None, None, _dp(t), 0, None), t
     if np.ndim(lam) == 0:
         return Material(model, 3, float(lam), float(mu), None, None, None, 0, None), None
     la = np.ascontiguousarray(lam, dtype=np.float64)
@@ -78,6 +76,16 @@ def make_material(model: int, lam, mu, tensor=None):
     return Material(model, 3, float(la.flat[0]), float(ma.flat[0]), _dp(la), _dp(ma), None, per_point, None), (la, ma)
 
 
+def _voigt_tensor(tensor):
+    """The symmetric elasticity tensor in Voigt form: 6 x 6 (xx yy zz yz xz xy) in 3-D, 3 x 3 (xx yy xy) in 2-D
+    (ElasticityTensor::resize, utils/ElasticityUtils.cpp:264-274)."""
+    t = np.ascontiguousarray(tensor, dtype=np.float64)
+    n = {36: 6, 9: 3}[t.size]
+    t = t.reshape(n, n)
+    assert np.array_equal(t, t.T), "the elasticity tensor is symmetric"
+    return t
+
+
 def kind_dim(kind: int) -> int:
     return 2 if kind in (P1TRI, P2TRI) else 3
 
@@ -85,15 +93,35 @@ def kind_dim(kind: int) -> int:
 def _material_for(om, model, lam, mu):
     """make_material with the problem dimension of the mesh (2 for triangles)."""
     mat, keep = make_material(model, lam, mu)
+    if mat.tensor:
+        assert mat.dim == kind_dim(om.s.kind), "a 2-D problem takes a 3 x 3 elasticity tensor, a 3-D problem a 6 x 6 one"
     mat.dim = kind_dim(om.s.kind)
     return mat, keep
 
 
-def elasticity_tensor(lam=None, mu=None, entries=None):
+def elasticity_tensor(lam=None, mu=None, entries=None, dim=3):
     """ElasticityTensor (utils/ElasticityUtils.cpp): set_from_lambda_mu (:372-413) or set_from_entries with the 21
     upper-triangular entries row by row (:298-370), or with the 9 orthotropic constants Ex Ey Ez nuYX nuZX nuZY muYZ muZX
     muXY, which the reference stores as the upper triangle written at :439-455; returns the full symmetric 6 x 6 matrix
-    that ElasticityTensor::operator() (:276-296) reads."""
+    that ElasticityTensor::operator() (:276-296) reads.  dim = 2: the 3 x 3 tensor from (lambda, mu) (:374-384), from 6
+    upper-triangular entries (:313-322) or from the 4 orthotropic constants Ex Ey nuYX muXY (:457-466)."""
+    if dim == 2:
+        t = np.zeros((3, 3))
+        if entries is not None:
+            entries = np.asarray(entries, dtype=np.float64)
+            if entries.size == 4:
+                ex, ey, nyx, mxy = entries
+                t[0, :2] = 1.0 / ex, -nyx / ey
+                t[1, 1] = 1.0 / ey
+                t[2, 2] = 1.0 / mxy
+            else:
+                assert entries.size == 6
+                t[np.triu_indices(3)] = entries
+            return t + np.triu(t, 1).T
+        t[:2, :2] = lam
+        t[0, 0] = t[1, 1] = 2 * mu + lam
+        t[2, 2] = mu
+        return t
     t = np.zeros((6, 6))
     if entries is not None:
         entries = np.asarray(entries, dtype=np.float64)

@@ -172,6 +172,128 @@ def test_neohookean_2d_branches_equal_the_plane_embedding_of_the_3d_ones(oracle)
         assert np.abs(h2 - h3[np.ix_(idx, idx)]).max() <= 1e-12 * np.abs(h2).max()
 
 
+def _aniso_tensor_2d(seed=0):
+    """A symmetric positive definite 3 x 3 elasticity tensor with every entry set."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, (3, 3))
+    return 2e4 * (a @ a.T + 1.5 * np.eye(3))
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("tensor", [False, True])
+def test_saint_venant_fd_oracle_2d(oracle, order, tensor):
+    """The written-out derivatives of the 2-D SaintVenant energy (the reference differentiates compute_energy_aux with
+    autodiff, SaintVenantElasticity.cpp:104-143) against central differences of the energy restated from :215-312."""
+    m = M.square_tris(4, order, jitter=0.2, seed=5)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    a, b = (_aniso_tensor_2d(), None) if tensor else (lam, mu)
+    n = 2 * m.n_nodes
+    rng = np.random.default_rng(3)
+    for rand in range(3):
+        x = np.zeros(n) if rand == 0 else rng.uniform(-1, 1, n) / 20
+        g = oracle.assemble_gradient(m, oracle.SAINT_VENANT, a, b, x)
+        H = csc_to_scipy(oracle.assemble_hessian(m, oracle.SAINT_VENANT, a, b, x), n)
+        assert abs(H - H.T).max() <= 1e-10 * abs(H).max()
+        d = rng.standard_normal(n)
+        d /= np.linalg.norm(d)
+        h = 1e-6
+        fd = (oracle.assemble_energy(m, oracle.SAINT_VENANT, a, b, x + h * d) - oracle.assemble_energy(m, oracle.SAINT_VENANT, a, b, x - h * d)) / (2 * h)
+        assert abs(fd - g @ d) <= 1e-6 * max(1.0, np.linalg.norm(g))
+        fdh = (oracle.assemble_gradient(m, oracle.SAINT_VENANT, a, b, x + h * d) - oracle.assemble_gradient(m, oracle.SAINT_VENANT, a, b, x - h * d)) / (2 * h)
+        assert np.linalg.norm(fdh - H @ d) <= 1e-6 * np.linalg.norm(H @ d)
+    if not tensor:  # the isotropic 3 x 3 tensor of set_from_lambda_mu is the (lambda, mu) material
+        t = oracle.elasticity_tensor(lam, mu, dim=2)
+        assert abs(oracle.assemble_energy(m, oracle.SAINT_VENANT, t, None, x) - oracle.assemble_energy(m, oracle.SAINT_VENANT, lam, mu, x)) == 0
+
+
+def test_saint_venant_2d_equals_the_plane_embedding_of_the_3d_one(oracle):
+    """With F = [[F2, 0], [0, 1]] the Green strain has no out-of-plane entries, so the 3-D routines with the 3 x 3 tensor
+    written into the xx, yy, xy rows and columns of a 6 x 6 one reproduce the 2-D branch on the in-plane entries."""
+    L = oracle.lib()
+    L.pfo_local_saint_venant_energy_2d.restype = C.c_double
+    L.pfo_local_saint_venant_energy_t.restype = C.c_double
+    m = M.square_tris(3, 2, jitter=0.2, seed=7)
+    om = oracle.OMesh(m)
+    q = oracle.Quad()
+    assert L.pfo_element_quadrature(m.kind, -1, C.byref(q)) == 0
+    c3 = _aniso_tensor_2d(1)
+    c6 = np.zeros((6, 6))
+    vo = [0, 1, 5]
+    c6[np.ix_(vo, vo)] = c3
+    rng = np.random.default_rng(4)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    z = C.c_double(0.0)
+    for e in range(m.n_el):
+        v = oracle.Vals()
+        L.pfo_compute_vals(C.byref(om.s), C.c_int64(e), C.byref(q), C.byref(v))
+        da = np.array([v.det[k] * q.w[k] for k in range(q.n_pts)])
+        ld2 = rng.uniform(-0.05, 0.05, (6, 2))
+        ld3 = np.ascontiguousarray(np.hstack([ld2, np.zeros((6, 1))]))
+        ld2 = np.ascontiguousarray(ld2)
+        e2 = L.pfo_local_saint_venant_energy_2d(C.byref(v), dp(da), dp(ld2), z, z, dp(c3))
+        e3 = L.pfo_local_saint_venant_energy_t(C.byref(v), dp(da), dp(ld3), z, z, dp(c6))
+        assert abs(e2 - e3) <= 1e-12 * abs(e2)
+        g2, g3 = np.zeros(12), np.zeros(18)
+        L.pfo_local_saint_venant_grad_2d(C.byref(v), dp(da), dp(ld2), z, z, dp(c3), dp(g2))
+        L.pfo_local_saint_venant_grad_t(C.byref(v), dp(da), dp(ld3), z, z, dp(c6), dp(g3))
+        assert np.abs(g2.reshape(6, 2) - g3.reshape(6, 3)[:, :2]).max() <= 1e-12 * np.abs(g2).max()
+        h2, h3 = np.zeros((12, 12)), np.zeros((18, 18))
+        L.pfo_local_saint_venant_hessian_2d(C.byref(v), dp(da), dp(ld2), z, z, dp(c3), dp(h2))
+        L.pfo_local_saint_venant_hessian_t(C.byref(v), dp(da), dp(ld3), z, z, dp(c6), dp(h3))
+        idx = np.array([3 * i + d for i in range(6) for d in range(2)])
+        assert np.abs(h2 - h3[np.ix_(idx, idx)]).max() <= 1e-12 * np.abs(h2).max()
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_hooke_linear_2d_oracle(oracle, order):
+    """HookeLinearElasticity with size 2 (HookeLinearElasticity.cpp:92-122): with the isotropic tensor it is
+    LinearElasticity; with a general tensor it is the linearisation of SaintVenant with that tensor at rest; the
+    orthotropic and 6-entry forms of set_from_entries fill the 3 x 3 upper triangle."""
+    m = M.square_tris(5, order, jitter=0.2, seed=2)
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    n = 2 * m.n_nodes
+    K = csc_to_scipy(oracle.assemble_linear(m, oracle.HOOKE_LINEAR, oracle.elasticity_tensor(lam, mu, dim=2), None), n)
+    Kle = csc_to_scipy(oracle.assemble_linear(m, oracle.LINEAR_ELASTICITY, lam, mu), n)
+    assert abs(K - Kle).max() <= 1e-12 * abs(Kle).max()
+    t = _aniso_tensor_2d(3)
+    K = csc_to_scipy(oracle.assemble_linear(m, oracle.HOOKE_LINEAR, t, None), n)
+    assert abs(K - K.T).max() <= 1e-12 * abs(K).max()
+    H0 = csc_to_scipy(oracle.assemble_hessian(m, oracle.SAINT_VENANT, t, None, np.zeros(n)), n)
+    assert abs(K - H0).max() <= 1e-12 * abs(K).max()
+    for mode in (np.tile([1.0, 0.0], m.n_nodes), np.tile([0.0, 1.0], m.n_nodes)):
+        assert np.abs(K @ mode).max() <= 1e-9 * abs(K).max()
+    e6 = oracle.elasticity_tensor(entries=[1.0, 2.0, 3.0, 4.0, 5.0, 6.0], dim=2)
+    assert np.array_equal(e6, [[1, 2, 3], [2, 4, 5], [3, 5, 6]])
+    e4 = oracle.elasticity_tensor(entries=[2.0, 4.0, 0.5, 8.0], dim=2)
+    assert np.array_equal(e4, [[0.5, -0.125, 0], [-0.125, 0.25, 0], [0, 0, 0.125]])
+
+
+def test_multi_model_2d_oracle(oracle):
+    """MultiModel (MultiModel.cpp:42-96) on triangles: the energy is the sum over the models of the energy of the elements
+    they own, and the gradient is its derivative."""
+    m = M.square_tris(4, 2, jitter=0.15, seed=9)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    n = 2 * m.n_nodes
+    rng = np.random.default_rng(6)
+    models = rng.choice([oracle.LINEAR_ELASTICITY, oracle.NEOHOOKEAN, oracle.SAINT_VENANT], m.n_el).astype(np.int32)
+    x = rng.uniform(-1, 1, n) / 50
+    total = oracle.assemble_energy(m, models, lam, mu, x)
+    parts = 0.0
+    for mod in (oracle.LINEAR_ELASTICITY, oracle.NEOHOOKEAN, oracle.SAINT_VENANT):
+        sub = M.Mesh(kind=m.kind, gkind=m.gkind, conn=np.ascontiguousarray(m.conn[models == mod]), gconn=np.ascontiguousarray(m.gconn[models == mod]), xyz=m.xyz, n_nodes=m.n_nodes, node_xyz=m.node_xyz)
+        parts += oracle.assemble_energy(sub, mod, lam, mu, x)
+    assert abs(total - parts) <= 1e-12 * abs(total)
+    g = oracle.assemble_gradient(m, models, lam, mu, x)
+    H = csc_to_scipy(oracle.assemble_hessian(m, models, lam, mu, x), n)
+    d = rng.standard_normal(n)
+    d /= np.linalg.norm(d)
+    h = 1e-6
+    fd = (oracle.assemble_energy(m, models, lam, mu, x + h * d) - oracle.assemble_energy(m, models, lam, mu, x - h * d)) / (2 * h)
+    assert abs(fd - g @ d) <= 1e-6 * max(1.0, np.linalg.norm(g))
+    fdh = (oracle.assemble_gradient(m, models, lam, mu, x + h * d) - oracle.assemble_gradient(m, models, lam, mu, x - h * d)) / (2 * h)
+    assert np.linalg.norm(fdh - H @ d) <= 1e-6 * np.linalg.norm(H @ d)
+
+
 def test_linear_pattern_drops_exact_zeros_2d(oracle):
     """On the axis-aligned mesh many local values are exact zeros and are absent from the reference's matrix
     (Assembler.cpp:170-173): the value-dependent pattern is smaller than the structural one."""
@@ -198,9 +320,9 @@ def test_newton_mass_rhs_2d_oracle(oracle):
     free[bnd] = False
     g = oracle.assemble_gradient(m, oracle.NEOHOOKEAN, lam, mu, x) - rhs
     assert np.linalg.norm(g[free]) <= 1e-7 * np.linalg.norm(rhs)
-    # models the 2-D branches do not cover are refused
+    # a 2-D problem takes a 3 x 3 elasticity tensor
     with pytest.raises(AssertionError):
-        oracle.assemble_gradient(m, oracle.SAINT_VENANT, lam, mu, x)
+        oracle.assemble_gradient(m, oracle.SAINT_VENANT, oracle.elasticity_tensor(lam, mu), None, x)
 
 
 def _single_triangle_with_gradient(F):
