@@ -42,11 +42,10 @@ enum
  * autogen/auto_q_bases.cpp:1262-1275,1873-1903; geometry map is P1 (tets) / Q1 (hexes).
  * 2-D problems: triangles with the local node order of autogen/auto_p_bases.cpp:138-144, 275-284 and a P1 geometry
  * map (the (3,2) and (6,2) instantiations of NeoHookeanElasticity.cpp:47-115); dim = 2, two coordinates per geometry
- * node, two displacement components per node.  They support the Laplacian, LinearElasticity (both interfaces) and
- * NeoHookean, uniform / per-element / per-point parameters, project_to_psd, mass matrix and right-hand side, the
- * Jacobi-CG, the Newton solver with its inertia and augmented-Lagrangian terms and the implicit-Euler step; the other
- * entry points (SaintVenant, elasticity tensors, element models, AMG, the partitioned solve) return
- * PFX_ERR_UNSUPPORTED for them. */
+ * node, two displacement components per node.  They support every local assembler below (the size-2 branches of
+ * the reference; an elasticity tensor is then 3 x 3), uniform / per-element / per-point parameters, project_to_psd, mass
+ * matrix and right-hand side, the Jacobi-CG, the Newton solver with its inertia and augmented-Lagrangian terms and the
+ * implicit-Euler step; the AMG preconditioner and the partitioned solve return PFX_ERR_UNSUPPORTED for them. */
 enum
 {
 	PFX_P1TET = 0,
@@ -112,11 +111,13 @@ pfx_status pfx_set_material_per_element(pfx_ctx *ctx, int model, int dim, const 
 pfx_status pfx_set_material_per_point(pfx_ctx *ctx, int model, int dim, const double *lambda, const double *mu, int64_t n_el, int n_pts);
 /* HookeLinearElasticity with its `elasticity_tensor`: the symmetric 6 x 6 tensor in Voigt order xx yy zz yz xz xy,
  * row-major, as ElasticityTensor holds it after set_from_entries / set_from_lambda_mu / set_from_young_poisson
- * (utils/ElasticityUtils.cpp:298-413).  Selects the model PFX_HOOKE_LINEAR (pfx_assemble_linear only). */
+ * (utils/ElasticityUtils.cpp:298-413).  dim = 2 (triangle kinds): the symmetric 3 x 3 tensor in Voigt order xx yy xy,
+ * 9 values row-major (ElasticityTensor::resize(2), :264-274; HookeLinearElasticity.cpp:92-122).  Selects the model
+ * PFX_HOOKE_LINEAR (pfx_assemble_linear only). */
 pfx_status pfx_set_elasticity_tensor(pfx_ctx *ctx, int dim, const double *tensor36);
 /* SaintVenantElasticity with the material's `elasticity_tensor` entries instead of (lambda, mu)
  * (SaintVenantElasticity::add_multimaterial, assembler/SaintVenantElasticity.cpp:42-69; the stress of a point is
- * tensor * Voigt(Green strain), :77-86, :281-307).  Same 6 x 6 layout as pfx_set_elasticity_tensor; selects
+ * tensor * Voigt(Green strain), :77-86, :281-307).  Same layout as pfx_set_elasticity_tensor (6 x 6, or 3 x 3 for dim = 2); selects
  * PFX_SAINT_VENANT for the nonlinear interface (energy, gradient, Hessian, Newton, time steps).  A later
  * pfx_set_material call returns to (lambda, mu). */
 pfx_status pfx_set_saint_venant_tensor(pfx_ctx *ctx, int dim, const double *tensor36);

@@ -286,15 +286,40 @@ namespace polyfem_amd
 		{
 			static constexpr int model = PFX_NEOHOOKEAN;
 		};
-		// utils/ElasticityUtils.hpp ElasticityTensor for size 3: only the upper triangle is ever written or read
-		// (operator() swaps its indices, ElasticityUtils.cpp:276-296), so full() mirrors it.
+		// utils/ElasticityUtils.hpp ElasticityTensor: 6 x 6 for size 3, 3 x 3 (xx yy xy) for size 2 (resize,
+		// ElasticityUtils.cpp:264-274); only the upper triangle is ever written or read (operator() swaps its indices,
+		// :276-296), so full() mirrors it.
 		class ElasticityTensor
 		{
 		public:
+			void resize(const int size)
+			{
+				if (size != 2 && size != 3)
+					throw std::runtime_error("polyfem_amd: the elasticity tensor is defined for size 2 and 3");
+				size_ = size;
+				for (double &v : upper_)
+					v = 0;
+			}
+			int size() const { return size_; }
 			double &operator()(int i, int j) { return i <= j ? upper_[i * 6 + j] : upper_[j * 6 + i]; }
 			double operator()(int i, int j) const { return i <= j ? upper_[i * 6 + j] : upper_[j * 6 + i]; }
 			void set_from_entries(const std::vector<double> &entries) // ElasticityUtils.cpp:298-370
 			{
+				if (size_ == 2)
+				{
+					if (entries.size() == 4)
+					{
+						set_orthotropic(entries[0], entries[1], entries[2], entries[3]);
+						return;
+					}
+					if (entries.size() < 6)
+						throw std::runtime_error("polyfem_amd: the 2-D elasticity tensor takes 6 (or 4 orthotropic) entries");
+					int k = 0;
+					for (int i = 0; i < 3; ++i)
+						for (int j = i; j < 3; ++j)
+							(*this)(i, j) = entries[k++];
+					return;
+				}
 				if (entries.size() == 9)
 				{
 					set_orthotropic(entries[0], entries[1], entries[2], entries[3], entries[4], entries[5], entries[6], entries[7], entries[8]);
@@ -311,6 +336,13 @@ namespace polyfem_amd
 			{
 				for (double &v : upper_)
 					v = 0;
+				if (size_ == 2)
+				{
+					(*this)(0, 0) = (*this)(1, 1) = 2 * mu + lambda;
+					(*this)(0, 1) = lambda;
+					(*this)(2, 2) = mu;
+					return;
+				}
 				for (int i = 0; i < 3; ++i)
 				{
 					(*this)(i, i) = 2 * mu + lambda;
@@ -321,9 +353,17 @@ namespace polyfem_amd
 			}
 			void set_from_young_poisson(const double young, const double nu) // ElasticityUtils.cpp:416-437
 			{
-				const double v = nu, f = young / ((1. + v) * (1. - 2. * v));
 				for (double &x : upper_)
 					x = 0;
+				if (size_ == 2)
+				{
+					const double f2 = young / (1.0 - nu * nu);
+					(*this)(0, 0) = (*this)(1, 1) = 1.0 * f2;
+					(*this)(0, 1) = nu * f2;
+					(*this)(2, 2) = ((1.0 - nu) / 2.0) * f2;
+					return;
+				}
+				const double v = nu, f = young / ((1. + v) * (1. - 2. * v));
 				for (int i = 0; i < 3; ++i)
 				{
 					(*this)(i, i) = (1. - v) * f;
@@ -342,14 +382,26 @@ namespace polyfem_amd
 				(*this)(2, 2) = 1.0 / Ez;
 				(*this)(3, 3) = 1.0 / muYZ, (*this)(4, 4) = 1.0 / muZX, (*this)(5, 5) = 1.0 / muXY;
 			}
+			// ElasticityUtils.cpp:457-466 (size 2)
+			void set_orthotropic(double Ex, double Ey, double nuYX, double muXY)
+			{
+				for (double &x : upper_)
+					x = 0;
+				(*this)(0, 0) = 1.0 / Ex, (*this)(0, 1) = -nuYX / Ey;
+				(*this)(1, 1) = 1.0 / Ey;
+				(*this)(2, 2) = 1.0 / muXY;
+			}
+			// the symmetric n x n matrix, row-major: n = 6 for size 3, 3 for size 2
 			void full(double (&out)[36]) const
 			{
-				for (int i = 0; i < 6; ++i)
-					for (int j = 0; j < 6; ++j)
-						out[i * 6 + j] = (*this)(i, j);
+				const int n = size_ == 2 ? 3 : 6;
+				for (int i = 0; i < n; ++i)
+					for (int j = 0; j < n; ++j)
+						out[i * n + j] = (*this)(i, j);
 			}
 
 		private:
+			int size_ = 3;
 			double upper_[36] = {};
 		};
 		// assembler/SaintVenantElasticity.hpp: (lambda, mu) / (young, nu), or the material's "elasticity_tensor" entries
@@ -357,6 +409,11 @@ namespace polyfem_amd
 		struct SaintVenantElasticity : ElasticBase
 		{
 			static constexpr int model = PFX_SAINT_VENANT;
+			void set_size(int s) // SaintVenantElasticity.cpp:71-75
+			{
+				ElasticBase::set_size(s);
+				tensor_.resize(s);
+			}
 			ElasticityTensor &elasticity_tensor()
 			{
 				has_tensor = true;
@@ -374,12 +431,8 @@ namespace polyfem_amd
 		struct HookeLinearElasticity
 		{
 			static constexpr int model = PFX_HOOKE_LINEAR;
-			int size() const { return 3; }
-			void set_size(int s)
-			{
-				if (s != 3)
-					throw std::runtime_error("polyfem_amd: only 3-D elasticity is implemented");
-			}
+			int size() const { return tensor_.size(); }
+			void set_size(int s) { tensor_.resize(s); } // HookeLinearElasticity.cpp:69-73
 			ElasticityTensor &elasticity_tensor() { return tensor_; }
 			const ElasticityTensor &elasticity_tensor() const { return tensor_; }
 			double lambda = 0, mu = 0;
@@ -460,10 +513,10 @@ namespace polyfem_amd
 				{
 					if (is_mass)
 						throw std::runtime_error("polyfem_amd: is_mass = true belongs to Assembler<Mass>");
-					c.bind(bases, gbases, n_basis, PFX_LINEAR_ELASTICITY, 3, 0.0, 0.0); // mesh and pattern of block size 3
+					c.bind(bases, gbases, n_basis, PFX_LINEAR_ELASTICITY, dim, 0.0, 0.0); // mesh and pattern of block size dim
 					double t[36];
 					local_assembler_.elasticity_tensor().full(t);
-					c.check(pfx_set_elasticity_tensor(c.h, 3, t));
+					c.check(pfx_set_elasticity_tensor(c.h, dim, t));
 					c.bound_model = -1; // the next bind passes its own material again
 					c.check(pfx_assemble_linear(c.h));
 				}
@@ -582,7 +635,7 @@ namespace polyfem_amd
 					{
 						double t[36];
 						local_assembler_.elasticity_tensor().full(t);
-						c.check(pfx_set_saint_venant_tensor(c.h, 3, t));
+						c.check(pfx_set_saint_venant_tensor(c.h, dim, t));
 						c.bound_model = -1; // the next bind passes its own material again
 					}
 				return c;

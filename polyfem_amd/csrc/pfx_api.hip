@@ -2,6 +2,7 @@
 // the host-side sequencing of the kernels.  Reference call sites are cited in the header.
 #include "pfx_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -371,8 +372,6 @@ extern "C"
 			PFX_FAIL(PFX_ERR_ARG, "unknown model (PFX_HOOKE_LINEAR is selected by pfx_set_elasticity_tensor)");
 		if (dim != 3 && dim != 2)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "dim is 3, or 2 for triangle meshes");
-		if (dim == 2 && model != PFX_LAPLACIAN && model != PFX_LINEAR_ELASTICITY && model != PFX_NEOHOOKEAN)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "2-D problems: Laplacian, LinearElasticity and NeoHookean");
 		if (ctx->kind >= 0 && model != PFX_LAPLACIAN && dim != ctx->mesh_dim)
 			PFX_FAIL(PFX_ERR_ARG, "dim does not match the mesh (2 for triangles, 3 otherwise)");
 		const int bs = (model == PFX_LAPLACIAN) ? 1 : dim;
@@ -407,19 +406,32 @@ extern "C"
 	{
 		if (!ctx || !tensor36)
 			return PFX_ERR_ARG;
-		if (dim != 3)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "only dim = 3 is implemented");
-		for (int a = 0; a < 6; ++a)
+		if (dim != 3 && dim != 2)
+			PFX_FAIL(PFX_ERR_UNSUPPORTED, "dim is 3, or 2 for triangle meshes");
+		const int nv = dim == 3 ? 6 : 3;
+		for (int a = 0; a < nv; ++a)
 			for (int b = 0; b < a; ++b)
-				if (tensor36[a * 6 + b] != tensor36[b * 6 + a])
+				if (tensor36[a * nv + b] != tensor36[b * nv + a])
 					PFX_FAIL(PFX_ERR_ARG, "the elasticity tensor must be symmetric");
 		pfx_status rc = pfx_set_material(ctx, PFX_LINEAR_ELASTICITY, dim, 0.0, 0.0);
 		if (rc)
 			return rc;
+		// the kernels read a 6 x 6 tensor; the 3 x 3 one of a 2-D problem (xx yy xy) goes into its xx, yy, xy rows and
+		// columns, zeros elsewhere: the out-of-plane strains of the embedded 2-D problem are zero
+		double full[36] = {};
+		if (dim == 3)
+			std::copy(tensor36, tensor36 + 36, full);
+		else
+		{
+			const int at[3] = {0, 1, 5};
+			for (int a = 0; a < 3; ++a)
+				for (int b = 0; b < 3; ++b)
+					full[at[a] * 6 + at[b]] = tensor36[a * 3 + b];
+		}
 		PFX_HIP(hipSetDevice(ctx->device));
 		if (!ctx->d_tensor && pfx_alloc(ctx, &ctx->d_tensor, 36))
 			return PFX_ERR_HIP;
-		PFX_HIP(hipMemcpyAsync(ctx->d_tensor, tensor36, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
+		PFX_HIP(hipMemcpyAsync(ctx->d_tensor, full, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
 		PFX_HIP(hipStreamSynchronize(ctx->stream));
 		ctx->model = PFX_HOOKE_LINEAR;
 		return PFX_OK;
@@ -431,7 +443,7 @@ extern "C"
 			return PFX_ERR_ARG;
 		if (ctx->n_el <= 0 || n_el != ctx->n_el)
 			PFX_FAIL(PFX_ERR_ARG, "one model per element of the current mesh expected");
-		if (ctx->bs != 3)
+		if (ctx->bs < 2)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_set_material(_per_element) with an elastic model must come first");
 		if (ctx->stvk_tensor || ctx->model == PFX_HOOKE_LINEAR)
 			PFX_FAIL(PFX_ERR_UNSUPPORTED, "element models take their (lambda, mu) from pfx_set_material(_per_element), not an elasticity tensor");

@@ -177,7 +177,10 @@ namespace
 	// (engineering shears) goes through ElasticityTensor::compute_stress (utils/ElasticityUtils.cpp:469-477), and entry
 	// (coo_j * 3 + coo_i) is trace(sigma_i * eps_j).  Every operation of the reference is kept (including the products
 	// with the structural zeros), in its order.
-	template <int NLOC, int NPTS, int SP>
+	// BS = 2 (triangles, HookeLinearElasticity.cpp:92-122): the tensor arrives with the 3 x 3 one of the 2-D problem in its
+	// xx, yy, xy rows and columns and zeros elsewhere, the gradients have a zero third component; every extra term of the
+	// 3-D expressions is then an exact zero added to the 2-D sums, which are formed in the reference's order
+	template <int NLOC, int NPTS, int SP, int BS = 3>
 	struct hooke_block
 	{
 		const double *geo;
@@ -206,7 +209,7 @@ namespace
 					eps[3 * r + c] = (J[3 * r + c] + J[3 * c + r]) * 0.5;
 		}
 
-		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[9]) const
+		__device__ __forceinline__ void operator()(const double *lds, uint32_t e, int i, int j, double (&out)[BS * BS]) const
 		{
 			const double *C = lds + NPTS * NLOC * 3 + NPTS;
 			const double *ge = geo + (int64_t)e * (SP * 10);
@@ -259,11 +262,11 @@ namespace
 					}
 			}
 			// entry (row comp m, col comp n) of block (i,j) is res[n*3+m]  (Assembler.cpp:169,177,182)
-			for (int m = 0; m < 3; ++m)
-				for (int n = 0; n < 3; ++n)
+			for (int m = 0; m < BS; ++m)
+				for (int n = 0; n < BS; ++n)
 				{
 					const double v = res[n * 3 + m];
-					out[m * 3 + n] = fabs(v) < 1e-30 ? 0.0 : v;
+					out[m * BS + n] = fabs(v) < 1e-30 ? 0.0 : v;
 				}
 		}
 	};
@@ -406,8 +409,7 @@ namespace
 		constexpr int DIM = (NGLOC == 3) ? 2 : 3;
 		if (ctx->model == PFX_HOOKE_LINEAR)
 		{
-			if constexpr (DIM == 3)
-				pfx_launch_assemble_rows<NLOC, 3>(ctx, hooke_block<NLOC, NPTS, SP>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, write_mask);
+			pfx_launch_assemble_rows<NLOC, DIM>(ctx, hooke_block<NLOC, NPTS, SP, DIM>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, write_mask);
 		}
 		else if (ctx->bs == 1)
 			pfx_launch_assemble_rows<NLOC, 1>(ctx, linear_block<NLOC, NPTS, 1, SP>{ctx->d_estate, ctx->d_tab, ctx->lambda, ctx->mu, ctx->d_lambda_e, ctx->d_mu_e}, write_mask);

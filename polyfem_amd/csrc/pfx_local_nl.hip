@@ -793,53 +793,36 @@ namespace
 	template <int NLOC, int NGLOC, int NPTS>
 	void launch_rows(pfx_ctx *ctx)
 	{
-		if constexpr (NGLOC == 3) // triangles: NeoHookean and LinearElasticity
-		{
-			if (ctx->model == PFX_NEOHOOKEAN)
-				pfx_launch_assemble_rows<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
-			else
-				pfx_launch_assemble_rows<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
-			return;
-		}
-		else if (ctx->model == PFX_NEOHOOKEAN)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
+		constexpr int BS = (NGLOC == 3) ? 2 : 3; // triangles: 2 x 2 blocks
+		if (ctx->model == PFX_NEOHOOKEAN)
+			pfx_launch_assemble_rows<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab}, false);
 		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, false);
+			pfx_launch_assemble_rows<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor}, false);
 		else if (ctx->model == PFX_SAINT_VENANT)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab}, false);
+			pfx_launch_assemble_rows<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab}, false);
 		else if (ctx->model == PFX_MULTI_MODEL)
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab}, false);
+			pfx_launch_assemble_rows<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab}, false);
 		else
-			pfx_launch_assemble_rows<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
+			pfx_launch_assemble_rows<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab}, false);
 	}
 	template <int NLOC, int NGLOC, int NPTS>
 	pfx_status launch_psd(pfx_ctx *ctx)
 	{
 		pfx_status rc;
-		if constexpr (NGLOC == 3) // triangles: NeoHookean and LinearElasticity, 2 x 2 blocks
-		{
-			if (ctx->model == PFX_NEOHOOKEAN)
-				rc = pfx_launch_project_psd<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
-			else
-				rc = pfx_launch_project_psd<NLOC, 2>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
-			if (rc)
-				return rc;
-			pfx_launch_assemble_rows<NLOC, 2>(ctx, staged_block<NLOC, 2>{ctx->d_kloc}, false);
-			return PFX_OK;
-		}
-		else if (ctx->model == PFX_NEOHOOKEAN)
-			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
+		constexpr int BS = (NGLOC == 3) ? 2 : 3; // triangles: 2 x 2 blocks
+		if (ctx->model == PFX_NEOHOOKEAN)
+			rc = pfx_launch_project_psd<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_NEO>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_SAINT_VENANT && ctx->stvk_tensor)
-			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor});
+			rc = pfx_launch_project_psd<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVKT>{ctx->d_estate, ctx->d_tab, ctx->d_tensor});
 		else if (ctx->model == PFX_SAINT_VENANT)
-			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
+			rc = pfx_launch_project_psd<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_STVK>{ctx->d_estate, ctx->d_tab});
 		else if (ctx->model == PFX_MULTI_MODEL)
-			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab});
+			rc = pfx_launch_project_psd<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_MULTI>{ctx->d_estate, ctx->d_tab});
 		else
-			rc = pfx_launch_project_psd<NLOC, 3>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
+			rc = pfx_launch_project_psd<NLOC, BS>(ctx, nl_block<NLOC, NGLOC, NPTS, M_LINEAR>{ctx->d_estate, ctx->d_tab});
 		if (rc)
 			return rc;
-		pfx_launch_assemble_rows<NLOC, 3>(ctx, staged_block<NLOC>{ctx->d_kloc}, false);
+		pfx_launch_assemble_rows<NLOC, BS>(ctx, staged_block<NLOC, BS>{ctx->d_kloc}, false);
 		return PFX_OK;
 	}
 } // namespace
@@ -880,13 +863,13 @@ pfx_status pfx_launch_local_nl(pfx_ctx *ctx, const double *d_u, bool energy, boo
 			launch<27, 8, 27>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_P1TRI:
-		if (np != 1 || (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY))
+		if (np != 1)
 			ok = false;
 		else
 			launch<3, 3, 1>(ctx, d_u, energy, grad, hess, eloc);
 		break;
 	case PFX_P2TRI:
-		if (np != 4 || (ctx->model != PFX_NEOHOOKEAN && ctx->model != PFX_LINEAR_ELASTICITY))
+		if (np != 4)
 			ok = false;
 		else
 			launch<6, 3, 4>(ctx, d_u, energy, grad, hess, eloc);

@@ -54,10 +54,29 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-def elasticity_tensor(entries=None, lam=None, mu=None, young=None, nu=None):
+def elasticity_tensor(entries=None, lam=None, mu=None, young=None, nu=None, dim=3):
     """The 6 x 6 tensor of the reference's ElasticityTensor for size 3 (utils/ElasticityUtils.cpp): from the 21
     upper-triangular entries row by row (set_from_entries, :298-370), from (lambda, mu) (:372-413) or from
-    (young, nu) (:416-437); the precedence is HookeLinearElasticity::add_multimaterial's (entries, young/nu, lambda/mu)."""
+    (young, nu) (:416-437); the precedence is HookeLinearElasticity::add_multimaterial's (entries, young/nu, lambda/mu).
+    dim = 2: the 3 x 3 tensor of size 2 -- 6 upper-triangular entries (:313-322) or the 4 orthotropic constants Ex Ey nuYX
+    muXY (:457-466), (lambda, mu) (:374-384), (young, nu) (:418-424)."""
+    if dim == 2:
+        t = np.zeros((3, 3))
+        if entries is not None:
+            entries = np.asarray(entries, dtype=np.float64).reshape(-1)
+            if entries.size == 4:
+                ex, ey, nyx, mxy = entries
+                t[0, :2] = 1.0 / ex, -nyx / ey
+                t[1, 1] = 1.0 / ey
+                t[2, 2] = 1.0 / mxy
+            elif entries.size < 6:
+                raise ValueError("6 upper-triangular entries (or the 4 orthotropic constants) expected")
+            else:
+                t[np.triu_indices(3)] = entries[:6]
+            return np.triu(t) + np.triu(t, 1).T
+        if young is not None:
+            return np.array([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, (1.0 - nu) / 2.0]]) * (young / (1.0 - nu * nu))
+        return np.array([[2 * mu + lam, lam, 0.0], [lam, 2 * mu + lam, 0.0], [0.0, 0.0, mu]], dtype=np.float64)
     t = np.zeros((6, 6))
     if entries is not None:
         entries = np.asarray(entries, dtype=np.float64).reshape(-1)
@@ -412,14 +431,22 @@ class Engine:
         x, info = self.newton_solve(x, rhs, **newton_params)
         return x, info, used
 
-    def set_elasticity_tensor(self, tensor, dim: int = 3):
-        """HookeLinearElasticity: symmetric 6 x 6 tensor (Voigt order xx yy zz yz xz xy); linear assembly only."""
-        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(36)
+    def _voigt(self, tensor, dim):
+        dim = self._mesh_dim() if dim is None else int(dim)
+        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(-1)
+        if dim in (2, 3) and t.size != (36 if dim == 3 else 9):
+            raise ValueError("the elasticity tensor is 6 x 6 for dim = 3 and 3 x 3 for dim = 2")
+        return t, dim
+
+    def set_elasticity_tensor(self, tensor, dim=None):
+        """HookeLinearElasticity: symmetric 6 x 6 tensor (Voigt order xx yy zz yz xz xy), or 3 x 3 (xx yy xy) on a
+        triangle mesh; linear assembly only.  dim defaults to the dimension of the mesh."""
+        t, dim = self._voigt(tensor, dim)
         self._ck(self.L.pfx_set_elasticity_tensor(self.h, dim, _d(t)))
 
-    def set_saint_venant_tensor(self, tensor, dim: int = 3):
-        """SaintVenantElasticity with its `elasticity_tensor` (same 6 x 6 layout) instead of (lambda, mu)."""
-        t = np.ascontiguousarray(tensor, dtype=np.float64).reshape(36)
+    def set_saint_venant_tensor(self, tensor, dim=None):
+        """SaintVenantElasticity with its `elasticity_tensor` (same layout) instead of (lambda, mu)."""
+        t, dim = self._voigt(tensor, dim)
         self._ck(self.L.pfx_set_saint_venant_tensor(self.h, dim, _d(t)))
 
     def build_pattern(self) -> int:

@@ -648,6 +648,47 @@ int main()
 			threw = true;
 		}
 		REQUIRE(threw);
+		// size 2 of the tensor models: HookeLinearElasticity with the isotropic 3 x 3 tensor acts like LinearElasticity,
+		// SaintVenant with that tensor and MultiModel with SaintVenant everywhere are SaintVenant with (lambda, mu)
+		{
+			auto apply = [&](const StiffnessMatrix &A, const VectorXd &v) {
+				VectorXd r(N2, 0.0);
+				for (int j = 0; j < N2; ++j)
+					for (int64_t k = A.outer[j]; k < A.outer[j + 1]; ++k)
+						r[j] += A.values[k] * v[A.inner[k]];
+				return r;
+			};
+			const double lam2 = lin2.local_assembler().lambda, mu2 = lin2.local_assembler().mu;
+			assembler::Assembler<assembler::HookeLinearElasticity> hooke2;
+			hooke2.local_assembler().set_size(2);
+			hooke2.local_assembler().elasticity_tensor().set_from_lambda_mu(lam2, mu2);
+			StiffnessMatrix Kh2;
+			hooke2.assemble(false, nb2, b2, g2, cache, Kh2);
+			REQUIRE(Kh2.rows() == N2);
+			const VectorXd a = apply(K2, d2), b = apply(Kh2, d2);
+			double da = 0, na = 0;
+			for (int i = 0; i < N2; ++i)
+				da = std::fmax(da, std::fabs(a[i] - b[i])), na = std::fmax(na, std::fabs(a[i]));
+			REQUIRE(da <= 1e-12 * na);
+			assembler::NLAssembler<assembler::SaintVenantElasticity> sv2, svt2;
+			sv2.local_assembler().set_size(2);
+			sv2.local_assembler().set_lambda_mu(lam2, mu2);
+			svt2.local_assembler().set_size(2);
+			svt2.local_assembler().elasticity_tensor().set_from_lambda_mu(lam2, mu2);
+			const double e_sv = sv2.assemble(false, b2, g2, cache, 0.0, x2, x2);
+			const double e_svt = svt2.assemble(false, b2, g2, cache, 0.0, x2, x2);
+			REQUIRE(e_sv > 0 && std::fabs(e_sv - e_svt) <= 1e-12 * e_sv);
+			assembler::NLAssembler<assembler::MultiModel> mm2;
+			mm2.local_assembler().set_size(2);
+			mm2.local_assembler().set_lambda_mu(lam2, mu2);
+			mm2.local_assembler().init_multimodels(std::vector<std::string>(b2.size(), "SaintVenant"));
+			const double e_mm = mm2.assemble(false, b2, g2, cache, 0.0, x2, x2);
+			REQUIRE(std::fabs(e_sv - e_mm) <= 1e-12 * e_sv);
+			assembler::ElasticityTensor t2;
+			t2.resize(2);
+			t2.set_from_entries({2.0, 4.0, 0.5, 8.0}); // Ex Ey nuYX muXY
+			REQUIRE(t2(0, 0) == 0.5 && t2(1, 0) == -0.125 && t2(1, 1) == 0.25 && t2(2, 2) == 0.125 && t2(0, 2) == 0);
+		}
 		std::printf("2-D ok: %d dofs, cg %d iterations\n", N2, s2->solver_iter());
 	}
 	std::printf("shim ok: nnz(K)=%ld energy=%.6e cg_iters=%d err=%.2e\n", (long)K.nonZeros(), e0, solver->solver_iter(), solver->solver_error());

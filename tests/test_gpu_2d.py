@@ -397,9 +397,9 @@ def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
     mesh = MESHES["p2_aligned"]()
     eng.set_mesh(mesh)
     with pytest.raises(E.PfxError):
-        eng.set_material(E.SAINT_VENANT, 1.0, 1.0)  # 2-D: Laplacian, LinearElasticity, NeoHookean
-    with pytest.raises(E.PfxError):
         eng.set_material(E.NEOHOOKEAN, 1.0, 1.0, dim=3)  # dim must match the mesh
+    with pytest.raises(E.PfxError):
+        eng.set_saint_venant_tensor(np.eye(6), dim=3)
     eng.set_material(E.NEOHOOKEAN, 1.0, 1.0)
     eng.build_pattern()
     with pytest.raises(E.PfxError):
@@ -408,3 +408,157 @@ def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
     eng.set_mesh(M.cube_tets(2, 1))
     with pytest.raises(E.PfxError):
         eng.set_material(E.NEOHOOKEAN, 1.0, 1.0, dim=2)
+
+
+# ---- SaintVenant, elasticity tensors and element models with size 2 ------------------------------------------------
+
+
+def _aniso_tensor_2d(seed=0, scale=2e4):
+    """A symmetric positive definite 3 x 3 elasticity tensor (Voigt xx yy xy) with every entry set."""
+    a = np.random.default_rng(seed).uniform(-1, 1, (3, 3))
+    return scale * (a @ a.T + 1.5 * np.eye(3))
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+@pytest.mark.parametrize("tensor", ["isotropic", "anisotropic"])
+def test_hooke_linear_assembly_2d(eng, oracle, name, tensor):
+    """HookeLinearElasticity::assemble with size_ == 2 (HookeLinearElasticity.cpp:92-122): pattern bit-exact (it depends
+    on the values), values 1e-12."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    Ct = E.elasticity_tensor(lam=lam, mu=mu, dim=2) if tensor == "isotropic" else _aniso_tensor_2d(3)
+    assert np.array_equal(E.elasticity_tensor(lam=lam, mu=mu, dim=2), oracle.elasticity_tensor(lam, mu, dim=2))
+    eng.set_mesh(mesh)
+    eng.set_elasticity_tensor(Ct)
+    eng.build_pattern()
+    eng.assemble_linear()
+    rp, ci, v = eng.get_linear_csr()
+    n = mesh.n_nodes * 2
+    ref = csc_to_scipy(oracle.assemble_linear(mesh, oracle.HOOKE_LINEAR, Ct, None), n).tocsr()
+    ref.sort_indices()
+    assert np.array_equal(rp, ref.indptr), "row_ptr differs from the oracle"
+    assert np.array_equal(ci, ref.indices), "col_idx differs from the oracle"
+    assert rel_err(v, ref.data) <= TOL
+    with pytest.raises(E.PfxError):
+        eng.energy(np.zeros(n))  # a linear assembler only
+    with pytest.raises(E.PfxError):
+        eng.set_elasticity_tensor(Ct + np.triu(np.ones((3, 3)), 1))  # not symmetric
+    with pytest.raises(E.PfxError):
+        eng.set_elasticity_tensor(np.eye(6), dim=3)  # a 3-D tensor on a triangle mesh
+    with pytest.raises(ValueError):
+        eng.set_elasticity_tensor(np.eye(6))
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_aligned", "p2_jitter_polyfem", "p2_stretched"])
+@pytest.mark.parametrize("tensor", [False, True])
+def test_saint_venant_2d(eng, oracle, name, tensor):
+    """SaintVenantElasticity with size() == 2 (SaintVenantElasticity.cpp:215-312, branch :284-293), from (lambda, mu) and
+    from a general 3 x 3 elasticity tensor: energy, gradient, Hessian (plain and project_to_psd) at rest, at a moderate and
+    at a large deformation, per-element parameters, and a Newton solve, against the oracle."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    SV = oracle.SAINT_VENANT
+    nnz = _setup(eng, mesh, E.SAINT_VENANT, lam, mu)
+    n = mesh.n_nodes * 2
+    h = 1.0 / round((mesh.n_el / 2) ** 0.5)
+    if tensor:
+        x = M.seeded_displacement(mesh, 2, 0.1 * h, seed=5)
+        e_iso, g_iso, v_iso = eng.energy(x), eng.gradient(x), eng.hessian(x)
+        eng.set_saint_venant_tensor(E.elasticity_tensor(lam=lam, mu=mu, dim=2))
+        assert abs(eng.energy(x) - e_iso) <= TOL * e_iso
+        assert rel_err(eng.gradient(x), g_iso) <= TOL and rel_err(eng.hessian(x), v_iso) <= TOL
+        a = _aniso_tensor_2d(11)
+        eng.set_saint_venant_tensor(E.elasticity_tensor(entries=a[np.triu_indices(3)], dim=2))
+        b = None
+    else:
+        a, b = lam, mu
+    for amp in (0.0, 1e-2 * h, 0.3 * h):
+        x = M.seeded_displacement(mesh, 2, amp)
+        e_ref = oracle.assemble_energy(mesh, SV, a, b, x)
+        g_ref = oracle.assemble_gradient(mesh, SV, a, b, x)
+        outer, inner, vals = oracle.assemble_hessian(mesh, SV, a, b, x)
+        e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+        rp, ci = eng.get_pattern()
+        assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and nnz == inner.size
+        if amp == 0.0:
+            assert e == 0.0 and e_ref == 0.0 and not g.any()
+        else:
+            assert abs(e - e_ref) <= TOL * abs(e_ref)
+            assert rel_err(g, g_ref) <= TOL
+        assert rel_err(v, vals) <= TOL
+    vp = eng.hessian(x, project_to_psd=True)
+    ref = oracle.assemble_hessian_psd(mesh, SV, a, b, x)
+    assert np.abs(vp - ref[2]).max() <= 1e-10 * np.abs(ref[2]).max()
+    if tensor:
+        with pytest.raises(E.PfxError):
+            eng.set_element_models([E.NEOHOOKEAN] * mesh.n_el)  # element models take (lambda, mu)
+    else:
+        half = np.arange(mesh.n_el) < mesh.n_el // 2
+        l2, m2 = oracle.lame(5e4, 0.2, 2)
+        lam_e, mu_e = np.where(half, lam, l2), np.where(half, mu, m2)
+        eng.set_material(E.SAINT_VENANT, lam_e, mu_e)
+        x = M.seeded_displacement(mesh, 2, 0.1 * h, seed=4)
+        assert abs(eng.energy(x) - oracle.assemble_energy(mesh, SV, lam_e, mu_e, x)) <= TOL * abs(eng.energy(x))
+        assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, SV, lam_e, mu_e, x)) <= TOL
+        assert rel_err(eng.hessian(x), oracle.assemble_hessian(mesh, SV, lam_e, mu_e, x)[2]) <= TOL
+        eng.set_material(E.SAINT_VENANT, lam, mu)
+    bnd = M.boundary_dofs(mesh, 2, "x0")
+    eng.set_dirichlet(bnd)
+    rhs = np.zeros(n)
+    rhs[1::2] = -100.0 / mesh.n_nodes
+    xs, info = eng.newton_solve(np.zeros(n), rhs)
+    xr, iref = oracle.newton_solve(mesh, SV, a, b, rhs, bnd, np.zeros(n))
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+    assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "p2_stretched"])
+def test_multi_model_2d(eng, oracle, name):
+    """MultiModel (assembler/MultiModel.cpp:42-96) on triangles: LinearElasticity / NeoHookean / SaintVenant chosen per
+    element, with uniform and per-element Lame parameters; energy, gradient, Hessian (plain and projected), Newton."""
+    mesh = MESHES[name]()
+    n = mesh.n_nodes * 2
+    h = 1.0 / round((mesh.n_el / 2) ** 0.5)
+    ids = np.array([oracle.NEOHOOKEAN, oracle.SAINT_VENANT, oracle.LINEAR_ELASTICITY])[(np.arange(mesh.n_el) * 7 // 3) % 3]
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    l2, m2 = oracle.lame(5e4, 0.2, 2)
+    half = np.arange(mesh.n_el) % 2 == 0
+    for lam_e, mu_e in ((lam, mu), (np.where(half, lam, l2), np.where(half, mu, m2))):
+        eng.set_mesh(mesh)
+        eng.set_material(E.NEOHOOKEAN, lam_e, mu_e)
+        eng.set_element_models(ids)
+        nnz = eng.build_pattern()
+        for amp in (0.0, 2e-2 * h):
+            x = M.seeded_displacement(mesh, 2, amp, seed=8)
+            e_ref = oracle.assemble_energy(mesh, ids, lam_e, mu_e, x)
+            g_ref = oracle.assemble_gradient(mesh, ids, lam_e, mu_e, x)
+            outer, inner, vals = oracle.assemble_hessian(mesh, ids, lam_e, mu_e, x)
+            e, g, v = eng.energy(x), eng.gradient(x), eng.hessian(x)
+            rp, ci = eng.get_pattern()
+            assert np.array_equal(rp, outer.astype(np.int64)) and np.array_equal(ci, inner) and nnz == inner.size
+            if amp == 0.0:
+                assert abs(e) <= 1e-9 and np.abs(g).max() <= 1e-9 * np.abs(vals).max()
+            else:
+                assert abs(e - e_ref) <= TOL * abs(e_ref)
+                assert rel_err(g, g_ref) <= TOL
+            assert rel_err(v, vals) <= TOL
+        vp = eng.hessian(x, project_to_psd=True)
+        ref = oracle.assemble_hessian_psd(mesh, ids, lam_e, mu_e, x)
+        assert np.abs(vp - ref[2]).max() <= 1e-10 * np.abs(ref[2]).max()
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    eng.set_element_models(["SaintVenant"] * mesh.n_el)
+    e_multi, g_multi = eng.energy(x), eng.gradient(x)
+    eng.set_material(E.SAINT_VENANT, lam, mu)
+    assert abs(e_multi - eng.energy(x)) <= 1e-14 * abs(e_multi) and rel_err(g_multi, eng.gradient(x)) <= 1e-14
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    eng.set_element_models(ids)
+    bnd = M.boundary_dofs(mesh, 2, "x0")
+    eng.set_dirichlet(bnd)
+    rhs = np.zeros(n)
+    rhs[1::2] = -100.0 / mesh.n_nodes
+    xs, info = eng.newton_solve(np.zeros(n), rhs)
+    xr, iref = oracle.newton_solve(mesh, ids, lam, mu, rhs, bnd, np.zeros(n))
+    eng.set_dirichlet(np.zeros(0, dtype=np.int32))
+    assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+    assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
