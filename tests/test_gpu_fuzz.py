@@ -95,3 +95,72 @@ def test_random_numberings_holes_and_jitter(oracle, seed):
             assert np.linalg.norm(xs - xr) <= 1e-8 * np.linalg.norm(xr), tag
     finally:
         eng.close()
+
+
+def _spd_tensor(rng, n, scale):
+    a = rng.uniform(-1, 1, (n, n))
+    return scale * (a @ a.T + 0.5 * n * np.eye(n))
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_meshes_tensor_and_mixed_models(oracle, seed):
+    """The same scrambled meshes through the other local assemblers: HookeLinearElasticity with a random symmetric positive
+    definite tensor (6 x 6, or 3 x 3 on triangles; pattern bit-exact, it depends on the values), SaintVenant from (lambda, mu)
+    or such a tensor, and MultiModel with a random model per element and per-element Lame parameters."""
+    rng = np.random.default_rng(seed)
+    eng = E.Engine(0)
+    try:
+        for case in range(24):
+            kind = int(rng.integers(6))
+            n = int(rng.integers(1, 4))
+            jit = float(rng.choice([0.0, 0.15, 0.3]))
+            if kind < 2:
+                m = M.cube_tets(n, kind + 1, jitter=jit, seed=int(rng.integers(1 << 30)))
+            elif kind < 4:
+                m = M.cube_hexes(min(n, 2), kind - 1)
+            else:
+                m = M.square_tris(n + 1, kind - 3, jitter=jit, seed=int(rng.integers(1 << 30)))
+            m = _scramble(m, rng)
+            dim = M.KIND_DIM[m.kind]
+            ndof = m.n_nodes * dim
+            young = float(rng.uniform(1e3, 1e6))
+            lam, mu = oracle.lame(young, float(rng.uniform(0.1, 0.45)), dim)
+            tag = f"seed {seed} case {case}: {M.KIND_NAME[m.kind]} n={n} elements={m.n_el} nodes={m.n_nodes} jitter={jit}"
+            Ct = _spd_tensor(rng, 6 if dim == 3 else 3, young)
+            eng.set_mesh(m)
+            eng.set_elasticity_tensor(Ct)
+            eng.build_pattern()
+            eng.assemble_linear()
+            rp, ci, v = eng.get_linear_csr()
+            ref = csc_to_scipy(oracle.assemble_linear(m, oracle.HOOKE_LINEAR, Ct, None), ndof).tocsr()
+            ref.sort_indices()
+            assert np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices), tag
+            assert rel_err(v, ref.data) <= 1e-12, tag
+            x = M.seeded_displacement(m, dim, 3e-2 / (n + 1), seed=int(rng.integers(1 << 30)))
+            # SaintVenant: (lambda, mu) or the tensor
+            if rng.random() < 0.5:
+                a, b = lam, mu
+                eng.set_material(E.SAINT_VENANT, lam, mu)
+            else:
+                a, b = Ct, None
+                eng.set_saint_venant_tensor(Ct)
+            lam_e, mu_e = lam * rng.uniform(0.5, 2.0, m.n_el), mu * rng.uniform(0.5, 2.0, m.n_el)
+            ids = rng.choice([oracle.LINEAR_ELASTICITY, oracle.NEOHOOKEAN, oracle.SAINT_VENANT], m.n_el).astype(np.int32)
+            for model, pa, pb in ((oracle.SAINT_VENANT, a, b), (ids, lam_e, mu_e)):
+                if model is ids:
+                    eng.set_material(E.NEOHOOKEAN, lam_e, mu_e)
+                    eng.set_element_models(ids)
+                nnz = eng.build_pattern()
+                e, g, h = eng.energy(x), eng.gradient(x), eng.hessian(x)
+                eo = oracle.assemble_energy(m, model, pa, pb, x)
+                go = oracle.assemble_gradient(m, model, pa, pb, x)
+                ho = oracle.assemble_hessian(m, model, pa, pb, x)
+                rp, ci = eng.get_pattern()
+                assert np.array_equal(rp, ho[0].astype(np.int64)) and np.array_equal(ci, ho[1]) and nnz == ho[1].size, tag
+                assert abs(e - eo) <= 1e-12 * abs(eo), (tag, e, eo)
+                assert rel_err(g, go) <= 1e-12 and rel_err(h, ho[2]) <= 1e-12, tag
+                hp = eng.hessian(x, project_to_psd=True)
+                hpo = oracle.assemble_hessian_psd(m, model, pa, pb, x)
+                assert np.abs(hp - hpo[2]).max() <= 1e-9 * np.abs(hpo[2]).max(), tag
+    finally:
+        eng.close()
