@@ -44,8 +44,8 @@ enum
  * map (the (3,2) and (6,2) instantiations of NeoHookeanElasticity.cpp:47-115); dim = 2, two coordinates per geometry
  * node, two displacement components per node.  They support every local assembler below (the size-2 branches of
  * the reference; an elasticity tensor is then 3 x 3), uniform / per-element / per-point parameters, project_to_psd, mass
- * matrix and right-hand side, the Jacobi-CG, the Newton solver with its inertia and augmented-Lagrangian terms and the
- * implicit-Euler step; the AMG preconditioner and the partitioned solve return PFX_ERR_UNSUPPORTED for them. */
+ * matrix and right-hand side, the Jacobi- and AMG-preconditioned CG, the Newton solver with its inertia and
+ * augmented-Lagrangian terms and the implicit-Euler step; the partitioned solve returns PFX_ERR_UNSUPPORTED for them. */
 enum
 {
 	PFX_P1TET = 0,
@@ -73,7 +73,7 @@ enum
 {
 	PFX_PRECOND_IDENTITY = 0,
 	PFX_PRECOND_JACOBI = 1, /* Eigen::DiagonalPreconditioner, polysolve's default for Eigen::ConjugateGradient */
-	PFX_PRECOND_AMG = 2     /* aggregation multigrid (see the AMG section below): rigid-body modes for block size 3, constants for block size 1 */
+	PFX_PRECOND_AMG = 2     /* aggregation multigrid (see the AMG section below): rigid-body modes for block size 3, constants per component for block sizes 1 and 2 */
 };
 
 /* ---- context ------------------------------------------------------------------------------------------------ */

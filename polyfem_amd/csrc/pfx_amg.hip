@@ -1,5 +1,5 @@
 // pfx_amg.hip -- aggregation multigrid preconditioner for the CG solver (3-D elasticity, block size 3; scalar problems,
-// block size 1).
+// block size 1; 2-D elasticity, block size 2, with the translations as coarse space).
 //
 // Role in the reference: polysolve's algebraic-multigrid solvers ("AMGCL", "Hypre"; /root/reference/CMakeLists.txt:101-102,
 // options input-spec.json:1397-1558: CG with an AMG preconditioner, Chebyshev relaxation, ncycle, max_levels) are what a
@@ -307,43 +307,66 @@ namespace
 		}
 	}
 
-	// ---- scalar problems (block size 1, the Laplacian): one coarse dof per aggregate, piecewise constant interpolation.
-	// Constrained nodes are in no aggregate, so neither lists nor transfers ever see them.
-	__global__ __launch_bounds__(256) void k_galerkin_scalar(const int64_t *__restrict__ cp_ptr, const uint32_t *__restrict__ cp_src, const double *__restrict__ fine_values,
-															  int64_t n_cpairs, double *__restrict__ coarse_values)
+	// ---- piecewise constant interpolation, component by component: BS coarse dofs per aggregate on every level.  Scalar
+	// problems (block size 1, the Laplacian), where the constant is the near-null space, and 2-D elasticity (block size 2),
+	// where the two translations are carried and the rotation is left to the relaxation.  A node whose dofs are all
+	// constrained is in no aggregate; a partly constrained one is, and `fixed` (level 0 only) keeps its constrained dofs out
+	// of the Galerkin sums and of both transfers.  One lane per entry of a coarse block; the sums run in list order.
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_galerkin_const(const int64_t *__restrict__ cp_ptr, const uint32_t *__restrict__ cp_src, const int32_t *__restrict__ cp_row,
+															 const int32_t *__restrict__ node_col, const double *__restrict__ fine_values, const uint8_t *__restrict__ fixed,
+															 int64_t n_cpairs, double *__restrict__ coarse_values)
 	{
-		const int64_t cp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		if (cp >= n_cpairs)
+		constexpr int B2 = BS * BS;
+		const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (t >= n_cpairs * B2)
 			return;
+		const int64_t cp = t / B2;
+		const int q = (int)(t - cp * B2), m = q / BS, n = q - m * BS;
 		double acc = 0;
 		for (int64_t k = cp_ptr[cp]; k < cp_ptr[cp + 1]; ++k)
-			acc += fine_values[cp_src[k]];
-		coarse_values[cp] = acc;
+		{
+			const int64_t blk = cp_src[k];
+			if (fixed && (fixed[(int64_t)cp_row[k] * BS + m] || fixed[(int64_t)node_col[blk] * BS + n]))
+				continue;
+			acc += fine_values[blk * B2 + q];
+		}
+		coarse_values[t] = acc;
 	}
 
-	__global__ __launch_bounds__(256) void k_restrict_scalar(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ b,
-															  const double *__restrict__ t, int64_t n_agg, double *__restrict__ bc)
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_restrict_const(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ b,
+															 const double *__restrict__ t, const uint8_t *__restrict__ fixed, int64_t n_agg, double *__restrict__ bc)
 	{
 		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < n_agg; a += (int64_t)gridDim.x * blockDim.x)
 		{
-			double acc = 0;
+			double acc[BS];
+			for (int m = 0; m < BS; ++m)
+				acc[m] = 0;
 			for (int64_t k = mptr[a]; k < mptr[a + 1]; ++k)
 			{
 				const int64_t v = mlist[k];
-				acc += b[v] - t[v];
+				for (int m = 0; m < BS; ++m)
+					if (!fixed || !fixed[v * BS + m])
+						acc[m] += b[v * BS + m] - t[v * BS + m];
 			}
-			bc[a] = acc;
+			for (int m = 0; m < BS; ++m)
+				bc[a * BS + m] = acc[m];
 		}
 	}
 
-	__global__ __launch_bounds__(256) void k_prolong_scalar(const int32_t *__restrict__ agg, const double *__restrict__ xc, int64_t n_vert, double omega,
-															 double *__restrict__ x)
+	template <int BS>
+	__global__ __launch_bounds__(256) void k_prolong_const(const int32_t *__restrict__ agg, const double *__restrict__ xc, const uint8_t *__restrict__ fixed, int64_t n_vert,
+															double omega, double *__restrict__ x)
 	{
 		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
 		{
 			const int64_t a = agg[v];
-			if (a >= 0)
-				x[v] += omega * xc[a];
+			if (a < 0)
+				continue;
+			for (int m = 0; m < BS; ++m)
+				if (!fixed || !fixed[v * BS + m])
+					x[v * BS + m] += omega * xc[a * BS + m];
 		}
 	}
 
@@ -984,7 +1007,7 @@ namespace
 		hipStream_t st = ctx->stream;
 		const int64_t n_nodes = ctx->n_nodes, n_owned = ctx->n_owned;
 		const int bs = ctx->bs;
-		const bool scalar = bs == 1; // one dof per vertex on every level; else 3 on level 0 and 6 (rigid-body modes) below
+		const bool scalar = bs < 3; // piecewise constants: bs dofs per vertex on every level; else 3 on level 0 and 6 (rigid-body modes) below
 		pfx_status rc;
 
 		// level-0 node positions and the vertices left out of the aggregation
@@ -1034,7 +1057,7 @@ namespace
 		{
 			const bool level0 = level == 0;
 			// every rank takes the same decisions: they are made on the sums over the ranks
-			double gl[2] = {(double)(level0 ? bs * n_owned : (scalar ? n_overt : 6 * n_overt)), (double)n_overt};
+			double gl[2] = {(double)(level0 ? bs * n_owned : (scalar ? bs * n_overt : 6 * n_overt)), (double)n_overt};
 			if ((rc = dist_sum(ctx, dist, gl, 2)))
 				return rc;
 			if ((!level0 && gl[0] <= (double)par.coarsest_dofs) || gl[1] < 2.0 || level + 1 >= par.max_levels || level + 1 >= AMG_MAX_LEVELS)
@@ -1162,7 +1185,7 @@ namespace
 			s->device = ctx->device;
 			s->stream = ctx->stream;
 			s->own_stream = false;
-			s->bs = scalar ? 1 : 3;
+			s->bs = scalar ? bs : 3;
 			s->dim = 3;
 			s->n_owned = scalar ? nc : 2 * nc;
 			s->n_nodes = scalar ? nct : 2 * nct;
@@ -1172,8 +1195,8 @@ namespace
 			C.own_m = true;
 			C.n_vert = nct;
 			C.n_overt = nc;
-			C.n_dofs = scalar ? nct : 6 * nct;
-			C.n_odofs = scalar ? nc : 6 * nc;
+			C.n_dofs = scalar ? bs * nct : 6 * nct;
+			C.n_odofs = scalar ? bs * nc : 6 * nc;
 			C.halo = chalo; // (the lists' device arrays now belong to the level)
 			C.small = s->n_owned <= AMG_SMALL_NODES;
 			if (pfx_alloc(s, &s->d_node_ptr, s->n_nodes + 1) || pfx_alloc(s, &s->d_node_col, s->n_blocks) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nct + 1)
@@ -1296,7 +1319,7 @@ namespace
 		pfx_amg *A = ctx->amg;
 		if (A->dist)
 		{
-			pfx_status rc = level_exchange(ctx, A, L, x, L.m == ctx ? ctx->bs : (ctx->bs == 1 ? 1 : 6));
+			pfx_status rc = level_exchange(ctx, A, L, x, L.m == ctx ? ctx->bs : (ctx->bs < 3 ? ctx->bs : 6));
 			if (rc)
 				return rc;
 		}
@@ -1313,6 +1336,8 @@ namespace
 		const unsigned grid = (unsigned)((s->n_owned * 64 + 255) / 256);
 		if (s->bs == 1)
 			hipLaunchKernelGGL((k_rowwave_spmv<1>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_owned, y);
+		else if (s->bs == 2)
+			hipLaunchKernelGGL((k_rowwave_spmv<2>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_owned, y);
 		else
 			hipLaunchKernelGGL((k_rowwave_spmv<3>), dim3(grid), dim3(256), 0, ctx->stream, s->d_node_ptr, s->d_node_col, s->d_values, x, s->n_owned, y);
 		return PFX_OK;
@@ -1413,8 +1438,13 @@ namespace
 		{
 			pfx_amg_level &F = A->lv[l], &C = A->lv[l + 1];
 			const unsigned grid = (unsigned)((2 * F.n_cpairs * 8 + 255) / 256);
+			// (level 0 reads the caller's unmasked matrix: its constrained dofs are left out here; the coarse matrices have none)
 			if (ctx->bs == 1)
-				hipLaunchKernelGGL(k_galerkin_scalar, dim3((unsigned)((F.n_cpairs + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.m->d_values, F.n_cpairs, C.m->d_values);
+				hipLaunchKernelGGL((k_galerkin_const<1>), dim3((unsigned)((F.n_cpairs + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.m->d_node_col,
+								   F.m->d_values, l == 0 ? fixed : nullptr, F.n_cpairs, C.m->d_values);
+			else if (ctx->bs == 2)
+				hipLaunchKernelGGL((k_galerkin_const<2>), dim3((unsigned)((F.n_cpairs * 4 + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.m->d_node_col,
+								   F.m->d_values, l == 0 ? fixed : nullptr, F.n_cpairs, C.m->d_values);
 			else if (l == 0)
 				hipLaunchKernelGGL((k_galerkin<true>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, (const int64_t *)nullptr, ctx->d_node_col, ctx->d_values, F.d_dvec,
 								   fixed, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
@@ -1460,7 +1490,7 @@ namespace
 				// offset in the global numbering (columns: the global ids of its coarse vertices, those of the halo ones
 				// learned from their owners), the sum over the ranks is the whole matrix, and every rank inverts it.
 				pfx_dist *dist = A->dist;
-				const int per = ctx->bs == 1 ? 1 : 6; // dofs per coarse vertex
+				const int per = ctx->bs < 3 ? ctx->bs : 6; // dofs per coarse vertex
 				double total = (double)L.n_odofs;
 				{
 					pfx_status rc = dist_sum(ctx, dist, &total, 1);
@@ -1517,10 +1547,13 @@ namespace
 				{
 					const int64_t g0 = h_gptr[(size_t)a], deg = h_gptr[(size_t)a + 1] - g0;
 					const int64_t ga = gvert[(size_t)a];
-					if (ctx->bs == 1)
+					if (ctx->bs < 3)
 					{
+						const int cb = ctx->bs;
 						for (int64_t k = 0; k < deg; ++k)
-							M[(size_t)(ga * n + gvert[(size_t)h_gcol[(size_t)(g0 + k)]])] = vals[(size_t)(g0 + k)];
+							for (int m = 0; m < cb; ++m)
+								for (int q = 0; q < cb; ++q)
+									M[(size_t)((ga * cb + m) * n + gvert[(size_t)h_gcol[(size_t)(g0 + k)]] * cb + q)] = vals[(size_t)((g0 + k) * cb * cb + m * cb + q)];
 						continue;
 					}
 					for (int64_t k = 0; k < deg; ++k)
@@ -1672,7 +1705,7 @@ namespace
 		}
 		const bool level0 = l == 0;
 		const int64_t n = level0 ? ctx->n_owned * ctx->bs : L.n_odofs;
-		const bool scalar = ctx->bs == 1;
+		const uint8_t *fixed = (level0 && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
 		relax_vecs v{b, x, level0 ? t0 : L.d_t, L.d_r, L.d_dv, level0 ? dinv0 : L.d_dinv, n};
 		pfx_status rc = amg_relax(ctx, L, v, true);
 		if (rc)
@@ -1681,8 +1714,10 @@ namespace
 		if ((rc = amg_matvec(ctx, L, x, v.t)))
 			return rc;
 		pfx_amg_level &C = A->lv[l + 1];
-		if (scalar)
-			hipLaunchKernelGGL(k_restrict_scalar, dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, L.n_agg, C.d_b);
+		if (ctx->bs == 1)
+			hipLaunchKernelGGL((k_restrict_const<1>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, fixed, L.n_agg, C.d_b);
+		else if (ctx->bs == 2)
+			hipLaunchKernelGGL((k_restrict_const<2>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, fixed, L.n_agg, C.d_b);
 		else if (level0)
 			hipLaunchKernelGGL((k_restrict<true>), dim3(grid_for(L.n_agg * 16)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
 		else
@@ -1702,10 +1737,11 @@ namespace
 				hipLaunchKernelGGL(k_vec_add, dim3(grid_for(C.n_odofs)), dim3(256), 0, st, C.d_x2, C.n_odofs, C.d_x);
 			}
 		}
-		const uint8_t *fixed = (level0 && ctx->n_dirichlet > 0) ? ctx->d_fixed : nullptr;
 		const double omega = ctx->amg_params.coarse_scale;
-		if (scalar)
-			hipLaunchKernelGGL(k_prolong_scalar, dim3(grid_for(level0 ? ctx->n_owned : L.n_overt)), dim3(256), 0, st, L.d_agg, C.d_x, level0 ? ctx->n_owned : L.n_overt, omega, x);
+		if (ctx->bs == 1)
+			hipLaunchKernelGGL((k_prolong_const<1>), dim3(grid_for(level0 ? ctx->n_owned : L.n_overt)), dim3(256), 0, st, L.d_agg, C.d_x, fixed, level0 ? ctx->n_owned : L.n_overt, omega, x);
+		else if (ctx->bs == 2)
+			hipLaunchKernelGGL((k_prolong_const<2>), dim3(grid_for(level0 ? ctx->n_owned : L.n_overt)), dim3(256), 0, st, L.d_agg, C.d_x, fixed, level0 ? ctx->n_owned : L.n_overt, omega, x);
 		else if (level0)
 			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, omega, x);
 		else
@@ -1738,8 +1774,8 @@ void pfx_amg_release(pfx_ctx *ctx)
 // the level-0 operator (n_dofs doubles), scratch_v / scratch_t: two level-0 vectors that may be overwritten
 pfx_status pfx_amg_prepare(pfx_ctx *ctx, double *dinv0, double *scratch_v, double *scratch_t)
 {
-	if (ctx->bs != 3 && ctx->bs != 1)
-		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner is implemented for block sizes 1 and 3");
+	if (ctx->bs < 1 || ctx->bs > 3)
+		PFX_FAIL(PFX_ERR_UNSUPPORTED, "the AMG preconditioner is implemented for block sizes 1, 2 and 3");
 	pfx_status rc = pfx_sell_refresh(ctx);
 	if (rc)
 		return rc;

@@ -20,14 +20,21 @@ def skew(d):
 
 def prolongation(agg, na, pos, level0, fixed=None, scalar=False):
     """Rows: 3 dofs per vertex (level 0) or 6 (translation, rotation); columns: 6 per aggregate.  Scalar problems: one dof
-    per vertex and per aggregate, piecewise constant.  Returns P, centres."""
+    per vertex and per aggregate, piecewise constant; 2-D elasticity: two, constant per component.  Returns P, centres."""
     nv = agg.size
     ok = agg >= 0
     cnt = np.bincount(agg[ok], minlength=na).astype(float)
     c = np.stack([np.bincount(agg[ok], weights=pos[ok, k], minlength=na) / cnt for k in range(3)], axis=1)
     if scalar:
+        # scalar = the number of components per vertex (True: one): piecewise constants, component by component
+        cb = int(scalar)
         v = np.nonzero(ok)[0]
-        return sp.csr_matrix((np.ones(v.size), (v, agg[v])), shape=(nv, na)), c
+        P = sp.csr_matrix((np.ones(v.size), (v, agg[v])), shape=(nv, na))
+        if cb > 1:
+            P = sp.kron(P, sp.identity(cb)).tocsr()
+            if fixed is not None:
+                P = (sp.diags((~fixed).astype(float)) @ P).tocsr()
+        return P, c
     rows, cols, vals = [], [], []
     per = 3 if level0 else 6
     for v in np.nonzero(ok)[0]:

@@ -400,10 +400,6 @@ def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
         eng.set_material(E.NEOHOOKEAN, 1.0, 1.0, dim=3)  # dim must match the mesh
     with pytest.raises(E.PfxError):
         eng.set_saint_venant_tensor(np.eye(6), dim=3)
-    eng.set_material(E.NEOHOOKEAN, 1.0, 1.0)
-    eng.build_pattern()
-    with pytest.raises(E.PfxError):
-        eng.amg_setup()
     # a tetrahedral mesh with dim = 2 is refused as well
     eng.set_mesh(M.cube_tets(2, 1))
     with pytest.raises(E.PfxError):
@@ -562,3 +558,108 @@ def test_multi_model_2d(eng, oracle, name):
     eng.set_dirichlet(np.zeros(0, dtype=np.int32))
     assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
     assert np.abs(xs - xr).max() <= 1e-8 * np.abs(xr).max()
+
+
+# ---- aggregation AMG for 2 x 2 blocks ------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("bc", ["clamped", "roller"])
+def test_amg_2d_matches_mirror(oracle, order, bc):
+    """Block size 2: two coarse dofs per aggregate on every level (the translations; constant interpolation component by
+    component), against the scipy mirror of the same algorithm built from the library's aggregates (one application 1e-10,
+    PCG iterations +-2), against the oracle's matrix (relative residual 1e-10) and against Jacobi-CG.  "roller" fixes only
+    the x component on the x = 0 edge (plus one y dof): partly constrained nodes stay in their aggregates and the
+    constrained dofs stay out of the Galerkin sums and the transfers."""
+    import scipy.sparse as sp
+    import torch
+    from tests import amg_mirror as AM
+    eng = E.Engine(0)
+    try:
+        mesh = M.square_tris(24 if order == 2 else 40, order, jitter=0.1, seed=3)
+        lam, mu = oracle.lame(1e5, 0.3, 2)
+        n = 2 * mesh.n_nodes
+        _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+        eng.assemble_linear()
+        A = csc_to_scipy(oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu), n).tocsr()
+        bd = M.boundary_dofs(mesh, 2, "x0")
+        if bc == "roller":
+            bd = np.concatenate([bd[bd % 2 == 0], bd[bd % 2 == 1][:1]]).astype(np.int32)
+            bd.sort()
+        eng.set_dirichlet(bd)
+        fixed = np.zeros(n, dtype=bool)
+        fixed[bd] = True
+        D = sp.diags((~fixed).astype(float))
+        Am = (D @ A @ D + sp.diags(fixed.astype(float))).tocsr()
+        eng.amg_set_params(coarsest_dofs=40, mixed_precision=0)
+        eng.amg_setup()
+        info = eng.amg_info()
+        aggs = [eng.amg_aggregates(l) for l in range(info["n_levels"] - 1)]
+        assert info["n_levels"] >= 3
+        all_fixed = fixed.reshape(-1, 2).all(axis=1)
+        assert ((aggs[0] >= 0) == ~all_fixed).all()
+        pos = np.hstack([M.node_positions(mesh), np.zeros((mesh.n_nodes, 1))])
+        levels = AM.build(Am, pos, fixed, aggs, info["lambda_max"], ncycle=2, scalar=2)
+        rng = np.random.default_rng(8)
+        r = rng.standard_normal(n)
+        r[fixed] = 0
+        d_r = torch.from_numpy(r).cuda()
+        d_z = torch.zeros_like(d_r)
+        eng.amg_apply_dev(d_r.data_ptr(), d_z.data_ptr())
+        eng.synchronize()
+        z = d_z.cpu().numpy()
+        z_ref = AM.cycle(levels, 0, r)
+        assert np.abs(z - z_ref).max() <= 1e-10 * np.abs(z_ref).max()
+        assert np.all(z[fixed] == 0)
+        b = rng.standard_normal(n)
+        x, it, err = eng.cg(b, None, E.PRECOND_AMG, 1000, 1e-10)
+        bm = np.where(fixed, 0.0, b)
+        _, it_ref, _ = AM.pcg(Am, bm, lambda v: AM.cycle(levels, 0, v), 1e-10, 1000)
+        assert abs(it - it_ref) <= 2 and err <= 1e-10, (it, it_ref, err)
+        assert np.linalg.norm(bm - Am @ x) / np.linalg.norm(bm) <= 1.01e-10
+        _, it_jac, _ = eng.cg(b, None, E.PRECOND_JACOBI, 20000, 1e-10)
+        print("2-D AMG:", order, bc, "levels", info["n_vertices"], "iterations", it, "Jacobi", it_jac)
+        assert it < it_jac / 2, (it, it_jac)
+    finally:
+        eng.close()
+
+
+def test_amg_2d_large_and_newton(oracle):
+    """2 M P1 triangles / 0.5 M P2 triangles (1 M nodes each, 2 M dofs): the AMG-preconditioned CG reaches 1e-10 in a small
+    fraction of the Jacobi iterations, with the single-precision level matrices; and a Newton solve with the AMG-CG as its
+    linear solver reaches the minimiser of the Jacobi-CG one."""
+    import torch
+    for nq, order in ((1000, 1), (500, 2)):
+        mesh = M.square_tris(nq, order)
+        eng = E.Engine(0)
+        try:
+            lam, mu = oracle.lame(1e5, 0.3, 2)
+            _setup(eng, mesh, E.LINEAR_ELASTICITY, lam, mu)
+            eng.set_dirichlet(M.boundary_dofs(mesh, 2, "x0"))
+            eng.assemble_linear()
+            nd = 2 * mesh.n_nodes
+            b = torch.from_numpy(np.random.default_rng(2).standard_normal(nd)).cuda()
+            x = torch.zeros(nd, dtype=torch.float64, device="cuda")
+            it, err = eng.cg_dev(b.data_ptr(), x.data_ptr(), E.PRECOND_AMG, 2000, 1e-10)
+            xj = torch.zeros_like(x)
+            it_j, err_j = eng.cg_dev(b.data_ptr(), xj.data_ptr(), E.PRECOND_JACOBI, 40000, 1e-10)
+            print("2-D AMG large:", nq, order, "iterations", it, err, "Jacobi", it_j, err_j, eng.amg_info()["n_vertices"][:8])
+            assert err <= 1e-10 and err_j <= 1e-10 and it < 300 and it < it_j / 5
+            assert float(torch.linalg.norm(x - xj) / torch.linalg.norm(xj)) < 1e-6
+        finally:
+            eng.close()
+    mesh = M.square_tris(40, 2, jitter=0.1)
+    eng = E.Engine(0)
+    try:
+        lam, mu = oracle.lame(2e4, 0.3, 2)
+        _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+        n = 2 * mesh.n_nodes
+        eng.set_dirichlet(M.boundary_dofs(mesh, 2, "x0"))
+        rhs = np.zeros(n)
+        rhs[1::2] = -40.0 / mesh.n_nodes
+        xa, ia = eng.newton_solve(np.zeros(n), rhs, cg_precond=E.PRECOND_AMG)
+        xj, ij = eng.newton_solve(np.zeros(n), rhs, cg_precond=E.PRECOND_JACOBI)
+        assert ia["status"] == ij["status"] and abs(ia["iterations"] - ij["iterations"]) <= 1
+        assert np.abs(xa - xj).max() <= 1e-7 * np.abs(xj).max()
+    finally:
+        eng.close()
