@@ -45,7 +45,7 @@ enum
  * node, two displacement components per node.  They support every local assembler below (the size-2 branches of
  * the reference; an elasticity tensor is then 3 x 3), uniform / per-element / per-point parameters, project_to_psd, mass
  * matrix and right-hand side, the Jacobi- and AMG-preconditioned CG, the Newton solver with its inertia and
- * augmented-Lagrangian terms and the implicit-Euler step; the partitioned solve returns PFX_ERR_UNSUPPORTED for them. */
+ * augmented-Lagrangian terms, the implicit-Euler step and the partitioned solve (pfx_dist_*). */
 enum
 {
 	PFX_P1TET = 0,

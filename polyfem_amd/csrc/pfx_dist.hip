@@ -392,8 +392,6 @@ extern "C"
 		*out = nullptr;
 		if (!ctx->d_node_ptr)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_dist_create: pfx_build_pattern must be called first");
-		if (ctx->bs == 2)
-			PFX_FAIL(PFX_ERR_UNSUPPORTED, "pfx_dist_create: the partitioned solve is implemented for block sizes 1 and 3 (2-D problems run on one GPU)");
 		const int64_t n_halo = ctx->n_nodes - ctx->n_owned;
 		static const int64_t zero[1] = {0};
 		if (n_neigh == 0)
@@ -500,7 +498,7 @@ extern "C"
 		pfx_ctx *ctx = dist->ctx;
 		if (ctx->kind < 0)
 			DIST_FAIL(PFX_ERR_ARG, "the context holds no mesh");
-		if (ctx->model == PFX_LAPLACIAN || ctx->bs != 3)
+		if (ctx->model == PFX_LAPLACIAN || ctx->bs < 2)
 			DIST_FAIL(PFX_ERR_UNSUPPORTED, "pfx_dist_newton_dev needs an elastic model");
 		if (ctx->d_work_ext)
 			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_newton_dev uses the context's own workspace (clear pfx_cgs_set_workspace first)");
@@ -521,7 +519,7 @@ extern "C"
 		pfx_ctx *ctx = dist->ctx;
 		if (!(dt > 0.0))
 			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_implicit_euler_step_dev: dt must be positive");
-		if (ctx->kind < 0 || ctx->model == PFX_LAPLACIAN || ctx->bs != 3)
+		if (ctx->kind < 0 || ctx->model == PFX_LAPLACIAN || ctx->bs < 2)
 			DIST_FAIL(PFX_ERR_ARG, "pfx_dist_implicit_euler_step_dev needs a mesh and an elastic model");
 		if (ctx->mass_count == 0)
 			DIST_FAIL(PFX_ERR_ARG, "pfx_inertia_set_mass must be called first");

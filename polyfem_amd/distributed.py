@@ -90,9 +90,10 @@ def morton_numbering(node_xyz: np.ndarray, bits: int = 10) -> np.ndarray:
     span = np.where(hi > lo, hi - lo, 1.0)
     q = np.minimum(((p - lo) / span * (1 << bits)).astype(np.uint64), np.uint64((1 << bits) - 1))
     key = np.zeros(p.shape[0], dtype=np.uint64)
+    dim = p.shape[1]  # 3, or 2 for triangle meshes
     for b in range(bits):
-        for c in range(3):
-            key |= ((q[:, c] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + c)
+        for c in range(dim):
+            key |= ((q[:, c] >> np.uint64(b)) & np.uint64(1)) << np.uint64(dim * b + c)
     order = np.argsort(key, kind="stable")
     new_id = np.empty(p.shape[0], dtype=np.int64)
     new_id[order] = np.arange(p.shape[0])
@@ -677,13 +678,16 @@ class DistributedCG:
             free[np.asarray(fixed_dofs, dtype=np.int64)] = 0.0
         owner = np.full(nl, self.comm.rank, dtype=np.int64)
         owner[no:] = np.asarray(self.part.halo_owner, dtype=np.int64)
-        pos = t.from_numpy(np.ascontiguousarray(node_pos, dtype=np.float64)).to(dev)
+        node_pos = np.asarray(node_pos, dtype=np.float64)
+        if node_pos.shape[1] == 2:  # triangle meshes: the plane z = 0
+            node_pos = np.hstack([node_pos, np.zeros((node_pos.shape[0], 1))])
+        pos = t.from_numpy(np.ascontiguousarray(node_pos)).to(dev)
         # centre of every rank's owned nodes (any point would do; the centre keeps the rotations well scaled)
         cen = t.zeros((self.comm.world, 3), dtype=t.float64, device=dev)
         cen[self.comm.rank] = pos[:no].mean(dim=0)
         self.comm.all_reduce_sum(cen)
         self.cs = dict(pos=pos, free=t.from_numpy(free).to(dev).view(nl, bs), owner=t.from_numpy(owner).to(dev), centres=cen,
-                       modes=6 if bs == 3 else 1, einv=None, sources=sorted(set(int(o) for o in owner)))
+                       modes={3: 6, 2: 3, 1: 1}[bs], einv=None, sources=sorted(set(int(o) for o in owner)))
 
     def _cs_modes(self, s, k):
         """Local part (n_local, bs) of mode k of rank s: non-zero on the free dofs of the nodes rank s owns."""
@@ -691,6 +695,14 @@ class DistributedCG:
         sel = (c["owner"] == s).to(t.float64)[:, None]
         if self.bs == 1:
             return sel * c["free"]
+        if self.bs == 2:  # the two translations and the in-plane rotation
+            v = t.zeros((self.n_local, 2), dtype=t.float64, device=c["pos"].device)
+            if k < 2:
+                v[:, k] = 1.0
+            else:
+                d = c["pos"] - c["centres"][s]
+                v[:, 0], v[:, 1] = -d[:, 1], d[:, 0]
+            return v * sel * c["free"]
         if k < 3:
             v = t.zeros((self.n_local, 3), dtype=t.float64, device=c["pos"].device)
             v[:, k] = 1.0
@@ -707,6 +719,8 @@ class DistributedCG:
         if self.bs == 1:
             return yn.sum().reshape(1)
         d = c["pos"][:no] - c["centres"][self.comm.rank]
+        if self.bs == 2:
+            return t.cat([yn.sum(dim=0), (d[:, 0] * yn[:, 1] - d[:, 1] * yn[:, 0]).sum().reshape(1)])
         return t.cat([yn.sum(dim=0), t.cross(d, yn, dim=1).sum(dim=0)])
 
     def _cs_setup(self):

@@ -393,7 +393,7 @@ def test_neohookean_hip_against_sympy_derivatives(eng):
         assert np.abs(H - hess_ref).max() <= 1e-12 * np.abs(hess_ref).max()
 
 
-def test_what_2d_does_not_offer_fails_loudly(eng, oracle):
+def test_dimension_mismatches_fail_loudly(eng, oracle):
     mesh = MESHES["p2_aligned"]()
     eng.set_mesh(mesh)
     with pytest.raises(E.PfxError):

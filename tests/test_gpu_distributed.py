@@ -764,3 +764,124 @@ def test_hierarchy_that_spans_the_ranks_is_the_serial_one_with_the_same_aggregat
         eng.close()
     assert iters <= 1.3 * it_one + 2, (iters, it_one)
     assert iters <= iters_bj, (iters, iters_bj)
+
+
+# ---- 2-D: a triangle mesh over two ranks (2 x 2 blocks) --------------------------------------------------------------
+
+
+def _tri_case():
+    from polyfem_amd import mesh as M
+    mesh = M.square_tris(14, 2, jitter=0.1, seed=4)  # lattice numbering: contiguous node ranges are strips in y
+    n = mesh.n_nodes
+    pos = M.node_positions(mesh)
+    fixed = np.nonzero(np.abs(pos[:, 0]) < 1e-12)[0]
+    fixed_dofs = np.sort((fixed[:, None] * 2 + np.arange(2)[None]).reshape(-1)).astype(np.int32)
+    rhs = np.zeros(2 * n)
+    rhs[1::2] = -60.0 / n
+    lam, mu = 2e4 * 0.3 / (1.0 - 0.09), 2e4 / 2.6
+    return mesh, pos, fixed_dofs, rhs, lam, mu
+
+
+def _tri_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        mesh, pos, fixed_g, rhs_g, lam, mu = _tri_case()
+        n_nodes, bs = mesh.n_nodes, 2
+        bounds = D.owner_ranges(n_nodes, world)
+        part = D.partition(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds, rank, node_xyz=pos)
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        eng.set_mesh(part.mesh)
+        eng.set_material(E.NEOHOOKEAN, lam, mu)
+        eng.build_pattern()
+        eng.set_owned(part.n_owned, part.elem_owned)
+        l2g = part.local_to_global()
+        nl = part.n_local
+        dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
+        g2l = {int(g): i for i, g in enumerate(dof_l2g)}
+        fixed_l = np.array(sorted(g2l[int(g)] for g in fixed_g if int(g) in g2l), dtype=np.int32)
+        rng = np.random.default_rng(7)
+        u_g = rng.standard_normal(n_nodes * bs) * 1e-3
+        b_g = rng.standard_normal(n_nodes * bs)
+        u = torch.from_numpy(u_g[dof_l2g]).to(dev)
+        eng.hessian_dev(u.data_ptr())
+        eng.set_dirichlet(fixed_l)
+        comm = D.Comm()
+        cg = D.DistributedCG(D.HipOps(eng), part, bs, comm, dev)
+        b = torch.from_numpy(b_g[dof_l2g]).to(dev)
+        x = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        iters, err = cg.solve(b, x, E.PRECOND_JACOBI, 3000, 1e-12, check_every=10)
+        x_amg = torch.zeros_like(x)
+        it_amg, err_amg = cg.solve(b, x_amg, E.PRECOND_AMG, 500, 1e-10)
+        torch.cuda.synchronize()
+        assert cg.lib is not None and cg.lib.halo_bytes() == cg.halo.bytes_per_exchange(bs)
+        e_lib = torch.zeros(1, dtype=torch.float64, device=dev)
+        cg.lib.energy(u, e_lib)
+        newton = D.DistributedNewton(D.HipOps(eng), part, bs, comm, dev, fixed_l)
+        xn = torch.zeros(nl * bs, dtype=torch.float64, device=dev)
+        info = newton.solve(xn, torch.from_numpy(rhs_g[dof_l2g]).to(dev), cg_check_every=16)
+        torch.cuda.synchronize()
+        no = part.n_owned * bs
+        out = [None] * world
+        dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no], x_amg.cpu().numpy()[:no], xn.cpu().numpy()[:no]))
+        if rank == 0:
+            xg, xa, xnn = np.zeros(n_nodes * bs), np.zeros(n_nodes * bs), np.zeros(n_nodes * bs)
+            for lo, xv, av, nv in out:
+                xg[lo * bs: lo * bs + xv.size], xa[lo * bs: lo * bs + av.size], xnn[lo * bs: lo * bs + nv.size] = xv, av, nv
+            ret["cg"] = (iters, err, it_amg, err_amg, float(e_lib.item()))
+            ret["x"], ret["x_amg"], ret["x_newton"], ret["info"] = xg, xa, xnn, dict(info)
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_triangle_mesh_over_two_ranks_matches_single_engine(oracle):
+    """2 x 2 blocks through the partitioned path: energy, Jacobi-CG (Eigen order), AMG-CG with the hierarchy that spans the
+    ranks and the Newton solve of two ranks against the single engine on the whole mesh, and the CG against the oracle."""
+    import torch.multiprocessing as mp
+    from polyfem_amd import engine as E
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_tri_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        (iters, err, it_amg, err_amg, energy), xg, xa, xn, info = ret["cg"], ret["x"], ret["x_amg"], ret["x_newton"], ret["info"]
+    mesh, pos, fixed_dofs, rhs, lam, mu = _tri_case()
+    n = 2 * mesh.n_nodes
+    eng = E.Engine(0)
+    eng.set_mesh(mesh)
+    eng.set_material(E.NEOHOOKEAN, lam, mu)
+    eng.build_pattern()
+    rng = np.random.default_rng(7)
+    u = rng.standard_normal(n) * 1e-3
+    b = rng.standard_normal(n)
+    eng.hessian(u, fetch=False)
+    assert abs(energy - eng.energy(u)) <= 1e-12 * abs(energy)
+    assert abs(energy - oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, u)) <= 1e-12 * abs(energy)
+    eng.set_dirichlet(fixed_dofs)
+    x_ref, it_ref, _ = eng.cg(b, None, E.PRECOND_JACOBI, 3000, 1e-12)
+    assert abs(iters - it_ref) <= 2 and err < 1e-11
+    assert np.abs(xg - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+    red = oracle.full_to_reduced_matrix(oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, u, 8), fixed_dofs)
+    keep = np.setdiff1d(np.arange(n), fixed_dofs)
+    x_o, it_o, _ = oracle.cg(red, b[keep], jacobi=True, max_iter=3000, tol=1e-12)
+    assert abs(iters - it_o) <= 2, (iters, it_o)
+    assert np.abs(xg[keep] - x_o).max() <= 1e-8 * np.abs(x_o).max() and not xg[fixed_dofs].any()
+    assert err_amg <= 1e-10 and it_amg < iters / 3, (it_amg, iters)
+    assert np.abs(xa - x_ref).max() <= 1e-6 * np.abs(x_ref).max()
+    x_n, iref = eng.newton_solve(np.zeros(n), rhs)
+    eng.close()
+    assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
+    assert info["line_search_iterations"] == iref["line_search_iterations"]
+    assert np.abs(xn - x_n).max() <= 1e-8 * np.abs(x_n).max()
