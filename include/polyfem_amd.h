@@ -73,7 +73,7 @@ enum
 {
 	PFX_PRECOND_IDENTITY = 0,
 	PFX_PRECOND_JACOBI = 1, /* Eigen::DiagonalPreconditioner, polysolve's default for Eigen::ConjugateGradient */
-	PFX_PRECOND_AMG = 2     /* aggregation multigrid (see the AMG section below): rigid-body modes for block size 3, constants per component for block sizes 1 and 2 */
+	PFX_PRECOND_AMG = 2     /* aggregation multigrid (see the AMG section below): rigid-body modes for block sizes 3 (six) and 2 (three, in the plane), constants for block size 1 */
 };
 
 /* ---- context ------------------------------------------------------------------------------------------------ */

@@ -1,5 +1,5 @@
 // pfx_amg.hip -- aggregation multigrid preconditioner for the CG solver (3-D elasticity, block size 3; scalar problems,
-// block size 1; 2-D elasticity, block size 2, with the translations as coarse space).
+// block size 1; 2-D elasticity, block size 2, with the three rigid-body modes of the plane).
 //
 // Role in the reference: polysolve's algebraic-multigrid solvers ("AMGCL", "Hypre"; /root/reference/CMakeLists.txt:101-102,
 // options input-spec.json:1397-1558: CG with an AMG preconditioner, Chebyshev relaxation, ncycle, max_levels) are what a
@@ -307,9 +307,8 @@ namespace
 		}
 	}
 
-	// ---- piecewise constant interpolation, component by component: BS coarse dofs per aggregate on every level.  Scalar
-	// problems (block size 1, the Laplacian), where the constant is the near-null space, and 2-D elasticity (block size 2),
-	// where the two translations are carried and the rotation is left to the relaxation.  A node whose dofs are all
+	// ---- piecewise constant interpolation, component by component: BS coarse dofs per aggregate on every level (scalar
+	// problems: block size 1, the Laplacian, where the constant is the near-null space).  A node whose dofs are all
 	// constrained is in no aggregate; a partly constrained one is, and `fixed` (level 0 only) keeps its constrained dofs out
 	// of the Galerkin sums and of both transfers.  One lane per entry of a coarse block; the sums run in list order.
 	template <int BS>
@@ -367,6 +366,115 @@ namespace
 			for (int m = 0; m < BS; ++m)
 				if (!fixed || !fixed[v * BS + m])
 					x[v * BS + m] += omega * xc[a * BS + m];
+		}
+	}
+
+	// ---- 2-D elasticity (block size 2): three rigid-body modes per aggregate -- the two translations and the in-plane
+	// rotation about the aggregate's centre -- held as ONE node of block size 3 per aggregate on every coarse level.  With
+	// d the offset of a vertex from its aggregate's centre (z = 0), P_v = [[1, 0, -d_y], [0, 1, d_x]] on level 0 and the same
+	// with the row (0, 0, 1) below it between coarse levels: the plane case of u = T + W x d.
+	// Galerkin product: one lane per coarse pair, C = sum over its fine pairs of P_i^T B_ij P_j in list order.
+	template <bool LEVEL0>
+	__global__ __launch_bounds__(256) void k_galerkin_plane(const int64_t *__restrict__ cp_ptr, const uint32_t *__restrict__ cp_src, const int32_t *__restrict__ cp_row,
+															 const int32_t *__restrict__ node_col, const double *__restrict__ fine_values, const double *__restrict__ dvec,
+															 const uint8_t *__restrict__ fixed, int64_t n_cpairs, double *__restrict__ coarse_values)
+	{
+		constexpr int FR = LEVEL0 ? 2 : 3; // rows / columns of a fine block
+		const int64_t cp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (cp >= n_cpairs)
+			return;
+		double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (int64_t k = cp_ptr[cp]; k < cp_ptr[cp + 1]; ++k)
+		{
+			const int64_t q = cp_src[k];
+			const int64_t i = cp_row[k];
+			const int64_t j = node_col[q];
+			const double dix = dvec[3 * i], diy = dvec[3 * i + 1], djx = dvec[3 * j], djy = dvec[3 * j + 1];
+			double a[FR * FR];
+#pragma unroll
+			for (int z = 0; z < FR * FR; ++z)
+				a[z] = fine_values[q * (FR * FR) + z];
+			if (LEVEL0 && fixed)
+#pragma unroll
+				for (int m = 0; m < 2; ++m)
+#pragma unroll
+					for (int n = 0; n < 2; ++n)
+						if (fixed[2 * i + m] || fixed[2 * j + n])
+							a[2 * m + n] = 0.0;
+			// t = B P_j (FR x 3), then c += P_i^T t
+			double t[FR][3];
+#pragma unroll
+			for (int m = 0; m < FR; ++m)
+			{
+				t[m][0] = a[FR * m];
+				t[m][1] = a[FR * m + 1];
+				t[m][2] = a[FR * m + 1] * djx - a[FR * m] * djy;
+				if (!LEVEL0)
+					t[m][2] += a[FR * m + 2];
+			}
+#pragma unroll
+			for (int n = 0; n < 3; ++n)
+			{
+				c[n] += t[0][n];
+				c[3 + n] += t[1][n];
+				double w = t[1][n] * dix - t[0][n] * diy;
+				if (!LEVEL0)
+					w += t[FR - 1][n];
+				c[6 + n] += w;
+			}
+		}
+#pragma unroll
+		for (int z = 0; z < 9; ++z)
+			coarse_values[cp * 9 + z] = c[z];
+	}
+
+	template <bool LEVEL0>
+	__global__ __launch_bounds__(256) void k_restrict_plane(const int64_t *__restrict__ mptr, const int32_t *__restrict__ mlist, const double *__restrict__ dvec,
+															 const double *__restrict__ b, const double *__restrict__ t, const uint8_t *__restrict__ fixed, int64_t n_agg,
+															 double *__restrict__ bc)
+	{
+		constexpr int FR = LEVEL0 ? 2 : 3;
+		for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < n_agg; a += (int64_t)gridDim.x * blockDim.x)
+		{
+			double T0 = 0, T1 = 0, W = 0;
+			for (int64_t k = mptr[a]; k < mptr[a + 1]; ++k)
+			{
+				const int64_t v = mlist[k];
+				const int64_t o = FR * v;
+				double r0 = b[o] - t[o], r1 = b[o + 1] - t[o + 1];
+				if (LEVEL0 && fixed)
+				{
+					r0 = fixed[o] ? 0.0 : r0;
+					r1 = fixed[o + 1] ? 0.0 : r1;
+				}
+				T0 += r0, T1 += r1;
+				W += dvec[3 * v] * r1 - dvec[3 * v + 1] * r0;
+				if (!LEVEL0)
+					W += b[o + 2] - t[o + 2];
+			}
+			bc[3 * a] = T0, bc[3 * a + 1] = T1, bc[3 * a + 2] = W;
+		}
+	}
+
+	template <bool LEVEL0>
+	__global__ __launch_bounds__(256) void k_prolong_plane(const int32_t *__restrict__ agg, const double *__restrict__ dvec, const double *__restrict__ xc,
+															const uint8_t *__restrict__ fixed, int64_t n_vert, double omega, double *__restrict__ x)
+	{
+		constexpr int FR = LEVEL0 ? 2 : 3;
+		for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_vert; v += (int64_t)gridDim.x * blockDim.x)
+		{
+			const int64_t a = agg[v];
+			if (a < 0)
+				continue;
+			const double T0 = omega * xc[3 * a], T1 = omega * xc[3 * a + 1], W = omega * xc[3 * a + 2];
+			const double u0 = T0 - W * dvec[3 * v + 1], u1 = T1 + W * dvec[3 * v];
+			const int64_t o = FR * v;
+			if (!(LEVEL0 && fixed && fixed[o]))
+				x[o] += u0;
+			if (!(LEVEL0 && fixed && fixed[o + 1]))
+				x[o + 1] += u1;
+			if (!LEVEL0)
+				x[o + 2] += W;
 		}
 	}
 
@@ -819,7 +927,7 @@ namespace
 		}
 	}
 
-	// scalar levels: the coarse matrix has one entry per coarse edge, its pattern is the coarse graph itself
+	// one node per aggregate (scalar and plane problems): the coarse matrix has one block per coarse edge, its pattern is the coarse graph itself
 	__global__ void k_copy_i64(const int64_t *__restrict__ src, int64_t n, int64_t *__restrict__ dst)
 	{
 		for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
@@ -1007,7 +1115,10 @@ namespace
 		hipStream_t st = ctx->stream;
 		const int64_t n_nodes = ctx->n_nodes, n_owned = ctx->n_owned;
 		const int bs = ctx->bs;
-		const bool scalar = bs < 3; // piecewise constants: bs dofs per vertex on every level; else 3 on level 0 and 6 (rigid-body modes) below
+		// dofs of a coarse vertex: the constant (scalar problems), the three rigid-body modes of the plane (block size 2) or
+		// the six of space (block size 3).  Up to three they are one node of that block size; the six are two nodes of block size 3.
+		const int per = bs == 1 ? 1 : bs == 2 ? 3 : 6;
+		const bool scalar = bs == 1, one_node = bs < 3;
 		pfx_status rc;
 
 		// level-0 node positions and the vertices left out of the aggregation
@@ -1022,7 +1133,7 @@ namespace
 			else if (scalar)
 				PFX_HIP(hipMemsetAsync(A->d_pos, 0, sizeof(double) * (size_t)(n_nodes * 3), st));
 			else
-				PFX_FAIL(PFX_ERR_ARG, "the AMG preconditioner of a caller's block-3 matrix needs node positions (pfx_solver_set_node_positions), or analyze with block size 1");
+				PFX_FAIL(PFX_ERR_ARG, "the AMG preconditioner of a caller's block-2 or block-3 matrix needs node positions (pfx_solver_set_node_positions), or analyze with block size 1");
 		}
 		else
 		{
@@ -1057,7 +1168,7 @@ namespace
 		{
 			const bool level0 = level == 0;
 			// every rank takes the same decisions: they are made on the sums over the ranks
-			double gl[2] = {(double)(level0 ? bs * n_owned : (scalar ? bs * n_overt : 6 * n_overt)), (double)n_overt};
+			double gl[2] = {(double)(level0 ? bs * n_owned : per * n_overt), (double)n_overt};
 			if ((rc = dist_sum(ctx, dist, gl, 2)))
 				return rc;
 			if ((!level0 && gl[0] <= (double)par.coarsest_dofs) || gl[1] < 2.0 || level + 1 >= par.max_levels || level + 1 >= AMG_MAX_LEVELS)
@@ -1108,9 +1219,9 @@ namespace
 				if (nc <= 1)
 					break;
 			}
-			// level 0: aggregates of fewer than three nodes cannot carry the rotations; they join their strongest neighbour
+			// level 0: aggregates of fewer than three nodes (two in the plane) cannot carry the rotations; they join their strongest neighbour
 			if (level0 && nc > 1 && !scalar)
-				if ((rc = pfx_graph_merge_small(ctx, n_vert, cur.p, &nc, gq.view(), 3)))
+				if ((rc = pfx_graph_merge_small(ctx, n_vert, cur.p, &nc, gq.view(), bs == 2 ? 2 : 3)))
 					return rc;
 			gq.ptr.reset(), gq.col.reset(), gq.w.reset();
 			m.reset();
@@ -1185,18 +1296,18 @@ namespace
 			s->device = ctx->device;
 			s->stream = ctx->stream;
 			s->own_stream = false;
-			s->bs = scalar ? bs : 3;
+			s->bs = one_node ? per : 3;
 			s->dim = 3;
-			s->n_owned = scalar ? nc : 2 * nc;
-			s->n_nodes = scalar ? nct : 2 * nct;
-			s->n_blocks = scalar ? n_cp : 4 * n_cp;
+			s->n_owned = one_node ? nc : 2 * nc;
+			s->n_nodes = one_node ? nct : 2 * nct;
+			s->n_blocks = one_node ? n_cp : 4 * n_cp;
 			s->nnz = s->n_blocks * s->bs * s->bs;
 			C.m = s;
 			C.own_m = true;
 			C.n_vert = nct;
 			C.n_overt = nc;
-			C.n_dofs = scalar ? bs * nct : 6 * nct;
-			C.n_odofs = scalar ? bs * nc : 6 * nc;
+			C.n_dofs = per * nct;
+			C.n_odofs = per * nc;
 			C.halo = chalo; // (the lists' device arrays now belong to the level)
 			C.small = s->n_owned <= AMG_SMALL_NODES;
 			if (pfx_alloc(s, &s->d_node_ptr, s->n_nodes + 1) || pfx_alloc(s, &s->d_node_col, s->n_blocks) || pfx_alloc(s, &s->d_values, s->nnz + 2) || keep(ctx, &C.d_gptr, gc.ptr.p, nct + 1)
@@ -1207,7 +1318,7 @@ namespace
 				A->lv.push_back(C); // released with the hierarchy
 				return PFX_ERR_HIP;
 			}
-			if (scalar)
+			if (one_node)
 			{
 				hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(nct + 1)), dim3(256), 0, st, C.d_gptr, nct + 1, s->d_node_ptr);
 				PFX_HIP(hipMemcpyAsync(s->d_node_col, C.d_gcol, sizeof(int32_t) * (size_t)n_cp, hipMemcpyDeviceToDevice, st));
@@ -1319,7 +1430,7 @@ namespace
 		pfx_amg *A = ctx->amg;
 		if (A->dist)
 		{
-			pfx_status rc = level_exchange(ctx, A, L, x, L.m == ctx ? ctx->bs : (ctx->bs < 3 ? ctx->bs : 6));
+			pfx_status rc = level_exchange(ctx, A, L, x, L.m == ctx ? ctx->bs : (ctx->bs == 1 ? 1 : ctx->bs == 2 ? 3 : 6));
 			if (rc)
 				return rc;
 		}
@@ -1442,9 +1553,12 @@ namespace
 			if (ctx->bs == 1)
 				hipLaunchKernelGGL((k_galerkin_const<1>), dim3((unsigned)((F.n_cpairs + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.m->d_node_col,
 								   F.m->d_values, l == 0 ? fixed : nullptr, F.n_cpairs, C.m->d_values);
+			else if (ctx->bs == 2 && l == 0)
+				hipLaunchKernelGGL((k_galerkin_plane<true>), dim3((unsigned)((F.n_cpairs + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, ctx->d_node_col,
+								   ctx->d_values, F.d_dvec, fixed, F.n_cpairs, C.m->d_values);
 			else if (ctx->bs == 2)
-				hipLaunchKernelGGL((k_galerkin_const<2>), dim3((unsigned)((F.n_cpairs * 4 + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.m->d_node_col,
-								   F.m->d_values, l == 0 ? fixed : nullptr, F.n_cpairs, C.m->d_values);
+				hipLaunchKernelGGL((k_galerkin_plane<false>), dim3((unsigned)((F.n_cpairs + 255) / 256)), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, F.m->d_node_col,
+								   F.m->d_values, F.d_dvec, (const uint8_t *)nullptr, F.n_cpairs, C.m->d_values);
 			else if (l == 0)
 				hipLaunchKernelGGL((k_galerkin<true>), dim3(grid), dim3(256), 0, st, F.d_cp_ptr, F.d_cp_src, F.d_cp_row, (const int64_t *)nullptr, ctx->d_node_col, ctx->d_values, F.d_dvec,
 								   fixed, C.d_gptr, F.d_cp_arow, F.n_cpairs, C.m->d_values);
@@ -1490,7 +1604,7 @@ namespace
 				// offset in the global numbering (columns: the global ids of its coarse vertices, those of the halo ones
 				// learned from their owners), the sum over the ranks is the whole matrix, and every rank inverts it.
 				pfx_dist *dist = A->dist;
-				const int per = ctx->bs < 3 ? ctx->bs : 6; // dofs per coarse vertex
+				const int per = ctx->bs == 1 ? 1 : ctx->bs == 2 ? 3 : 6; // dofs per coarse vertex
 				double total = (double)L.n_odofs;
 				{
 					pfx_status rc = dist_sum(ctx, dist, &total, 1);
@@ -1549,7 +1663,7 @@ namespace
 					const int64_t ga = gvert[(size_t)a];
 					if (ctx->bs < 3)
 					{
-						const int cb = ctx->bs;
+						const int cb = per; // one node of block size `per` per coarse vertex
 						for (int64_t k = 0; k < deg; ++k)
 							for (int m = 0; m < cb; ++m)
 								for (int q = 0; q < cb; ++q)
@@ -1716,8 +1830,10 @@ namespace
 		pfx_amg_level &C = A->lv[l + 1];
 		if (ctx->bs == 1)
 			hipLaunchKernelGGL((k_restrict_const<1>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, fixed, L.n_agg, C.d_b);
+		else if (ctx->bs == 2 && level0)
+			hipLaunchKernelGGL((k_restrict_plane<true>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, fixed, L.n_agg, C.d_b);
 		else if (ctx->bs == 2)
-			hipLaunchKernelGGL((k_restrict_const<2>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, b, v.t, fixed, L.n_agg, C.d_b);
+			hipLaunchKernelGGL((k_restrict_plane<false>), dim3(grid_for(L.n_agg)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, fixed, L.n_agg, C.d_b);
 		else if (level0)
 			hipLaunchKernelGGL((k_restrict<true>), dim3(grid_for(L.n_agg * 16)), dim3(256), 0, st, L.d_mptr, L.d_mlist, L.d_dvec, b, v.t, L.n_agg, C.d_b);
 		else
@@ -1740,8 +1856,10 @@ namespace
 		const double omega = ctx->amg_params.coarse_scale;
 		if (ctx->bs == 1)
 			hipLaunchKernelGGL((k_prolong_const<1>), dim3(grid_for(level0 ? ctx->n_owned : L.n_overt)), dim3(256), 0, st, L.d_agg, C.d_x, fixed, level0 ? ctx->n_owned : L.n_overt, omega, x);
+		else if (ctx->bs == 2 && level0)
+			hipLaunchKernelGGL((k_prolong_plane<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, omega, x);
 		else if (ctx->bs == 2)
-			hipLaunchKernelGGL((k_prolong_const<2>), dim3(grid_for(level0 ? ctx->n_owned : L.n_overt)), dim3(256), 0, st, L.d_agg, C.d_x, fixed, level0 ? ctx->n_owned : L.n_overt, omega, x);
+			hipLaunchKernelGGL((k_prolong_plane<false>), dim3(grid_for(L.n_overt)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, L.n_overt, omega, x);
 		else if (level0)
 			hipLaunchKernelGGL((k_prolong<true>), dim3(grid_for(ctx->n_owned)), dim3(256), 0, st, L.d_agg, L.d_dvec, C.d_x, fixed, ctx->n_owned, omega, x);
 		else

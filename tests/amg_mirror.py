@@ -18,23 +18,31 @@ def skew(d):
     return np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
 
 
-def prolongation(agg, na, pos, level0, fixed=None, scalar=False):
+def prolongation(agg, na, pos, level0, fixed=None, scalar=False, plane=False):
     """Rows: 3 dofs per vertex (level 0) or 6 (translation, rotation); columns: 6 per aggregate.  Scalar problems: one dof
-    per vertex and per aggregate, piecewise constant; 2-D elasticity: two, constant per component.  Returns P, centres."""
+    per vertex and per aggregate, piecewise constant; plane: the three rigid-body modes of 2-D elasticity.  Returns P, centres."""
     nv = agg.size
     ok = agg >= 0
     cnt = np.bincount(agg[ok], minlength=na).astype(float)
     c = np.stack([np.bincount(agg[ok], weights=pos[ok, k], minlength=na) / cnt for k in range(3)], axis=1)
     if scalar:
-        # scalar = the number of components per vertex (True: one): piecewise constants, component by component
-        cb = int(scalar)
         v = np.nonzero(ok)[0]
-        P = sp.csr_matrix((np.ones(v.size), (v, agg[v])), shape=(nv, na))
-        if cb > 1:
-            P = sp.kron(P, sp.identity(cb)).tocsr()
-            if fixed is not None:
-                P = (sp.diags((~fixed).astype(float)) @ P).tocsr()
-        return P, c
+        return sp.csr_matrix((np.ones(v.size), (v, agg[v])), shape=(nv, na)), c
+    if plane:
+        # 2-D elasticity: rows 2 dofs per vertex (level 0) or 3 (translations, rotation); columns 3 per aggregate
+        rows, cols, vals = [], [], []
+        per = 2 if level0 else 3
+        for v in np.nonzero(ok)[0]:
+            a = agg[v]
+            d = pos[v] - c[a]
+            ent = [(0, 0, 1.0), (1, 1, 1.0), (0, 2, -d[1]), (1, 2, d[0])] + ([] if level0 else [(2, 2, 1.0)])
+            for r, q, val in ent:
+                if val != 0:
+                    rows.append(per * v + r), cols.append(3 * a + q), vals.append(val)
+        P = sp.csr_matrix((vals, (rows, cols)), shape=(per * nv, 3 * na))
+        if fixed is not None:
+            P = sp.diags((~fixed).astype(float)) @ P
+        return P.tocsr(), c
     rows, cols, vals = [], [], []
     per = 3 if level0 else 6
     for v in np.nonzero(ok)[0]:
@@ -58,7 +66,7 @@ class Level:
     pass
 
 
-def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, relax_lower=0.1, ncycle=1, coarse_scale=1.6, scalar=False):
+def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, relax_lower=0.1, ncycle=1, coarse_scale=1.6, scalar=False, plane=False):
     """A_masked: level-0 operator with identity rows/columns on the constrained dofs; aggregates[l]: vertex -> aggregate."""
     levels, A, pos = [], A_masked.tocsr(), np.asarray(node_xyz, dtype=float)
     for l, agg in enumerate(aggregates):
@@ -68,7 +76,7 @@ def build(A_masked, node_xyz, fixed, aggregates, lambda_max, relax_degree=1, rel
         L.dinv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1.0), 1.0)
         L.lmax = lambda_max[l]
         na = int(agg.max()) + 1
-        L.P, centres = prolongation(np.asarray(agg), na, pos, l == 0, fixed if l == 0 else None, scalar)
+        L.P, centres = prolongation(np.asarray(agg), na, pos, l == 0, fixed if l == 0 else None, scalar, plane)
         levels.append(L)
         A = (L.P.T @ A @ L.P).tocsr()
         pos = centres

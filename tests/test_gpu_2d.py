@@ -566,8 +566,8 @@ def test_multi_model_2d(eng, oracle, name):
 @pytest.mark.parametrize("order", [1, 2])
 @pytest.mark.parametrize("bc", ["clamped", "roller"])
 def test_amg_2d_matches_mirror(oracle, order, bc):
-    """Block size 2: two coarse dofs per aggregate on every level (the translations; constant interpolation component by
-    component), against the scipy mirror of the same algorithm built from the library's aggregates (one application 1e-10,
+    """Block size 2: three coarse dofs per aggregate on every level (the rigid-body modes of the plane: two translations and
+    the rotation about the aggregate's centre), against the scipy mirror of the same algorithm built from the library's aggregates (one application 1e-10,
     PCG iterations +-2), against the oracle's matrix (relative residual 1e-10) and against Jacobi-CG.  "roller" fixes only
     the x component on the x = 0 edge (plus one y dof): partly constrained nodes stay in their aggregates and the
     constrained dofs stay out of the Galerkin sums and the transfers."""
@@ -599,7 +599,7 @@ def test_amg_2d_matches_mirror(oracle, order, bc):
         all_fixed = fixed.reshape(-1, 2).all(axis=1)
         assert ((aggs[0] >= 0) == ~all_fixed).all()
         pos = np.hstack([M.node_positions(mesh), np.zeros((mesh.n_nodes, 1))])
-        levels = AM.build(Am, pos, fixed, aggs, info["lambda_max"], ncycle=2, scalar=2)
+        levels = AM.build(Am, pos, fixed, aggs, info["lambda_max"], ncycle=2, plane=True)
         rng = np.random.default_rng(8)
         r = rng.standard_normal(n)
         r[fixed] = 0
