@@ -216,7 +216,8 @@ pfx_status pfx_dirichlet_solve(pfx_ctx *ctx, const double *b, double *x, int pre
  *
  *   pfx_solver_analyze(64)  once per pattern.  block_size 3: entries are grouped into 3 x 3 node blocks (one column index per
  *                           nine values in the solver's block-SELL format; entries missing from a block are explicit
- *                           zeros), n must be a multiple of 3; block_size 1: scalar format; block_size 0: 3 if n is a
+ *                           zeros), n must be a multiple of 3; block_size 2: the same with 2 x 2 node blocks (2-D
+ *                           elasticity), n a multiple of 2; block_size 1: scalar format; block_size 0: 3 if n is a
  *                           multiple of 3 and the blocks hold at most 25 % more entries than A, else 1.  A reduced matrix
  *                           whose constrained dofs are whole nodes, or a stiffness matrix from which a few exact zeros
  *                           were dropped, is blocked.

@@ -85,34 +85,34 @@ namespace
 		}
 	}
 
-	// Node g owns rows 3g .. 3g+2: three-way merge of their (ascending) column lists by column node.
+	// Node g owns rows BS g .. BS g + BS - 1: BS-way merge of their (ascending) column lists by column node.
 	// FILL = false: cnt[g] = number of distinct column nodes.  FILL = true: node_col and the value map of the blocks.
-	template <bool FILL>
+	template <bool FILL, int BS>
 	__global__ void k_ext_blocks(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ ccol, const uint32_t *__restrict__ perm, int64_t n_nodes,
 								 int64_t *__restrict__ cnt, const int64_t *__restrict__ node_ptr, int32_t *__restrict__ node_col, uint32_t *__restrict__ map)
 	{
 		for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_nodes; g += (int64_t)gridDim.x * blockDim.x)
 		{
-			int64_t p[3], e[3];
-			for (int m = 0; m < 3; ++m)
-				p[m] = row_ptr[3 * g + m], e[m] = row_ptr[3 * g + m + 1];
+			int64_t p[BS], e[BS];
+			for (int m = 0; m < BS; ++m)
+				p[m] = row_ptr[BS * g + m], e[m] = row_ptr[BS * g + m + 1];
 			int64_t b = FILL ? node_ptr[g] : 0;
 			for (;;)
 			{
 				int32_t c = INT32_MAX;
-				for (int m = 0; m < 3; ++m)
+				for (int m = 0; m < BS; ++m)
 					if (p[m] < e[m])
 					{
-						const int32_t cm = ccol[p[m]] / 3;
+						const int32_t cm = ccol[p[m]] / BS;
 						c = cm < c ? cm : c;
 					}
 				if (c == INT32_MAX)
 					break;
-				for (int m = 0; m < 3; ++m)
-					while (p[m] < e[m] && ccol[p[m]] / 3 == c)
+				for (int m = 0; m < BS; ++m)
+					while (p[m] < e[m] && ccol[p[m]] / BS == c)
 					{
 						if (FILL)
-							map[b * 9 + m * 3 + (ccol[p[m]] - 3 * c)] = perm[p[m]];
+							map[b * (BS * BS) + m * BS + (ccol[p[m]] - BS * c)] = perm[p[m]];
 						++p[m];
 					}
 				if (FILL)
@@ -205,10 +205,10 @@ namespace
 			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_analyze: this context holds a mesh; a caller's matrix takes a context of its own (pfx_create)");
 		if (n <= 0 || (!outer64 && !outer32) || !inner)
 			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_analyze: empty matrix or null pointer");
-		if (block_size != 0 && block_size != 1 && block_size != 3)
-			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_analyze: block_size is 0 (choose), 1 or 3");
-		if (block_size == 3 && n % 3 != 0)
-			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_analyze: block size 3 needs a multiple of 3 rows");
+		if (block_size < 0 || block_size > 3)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_analyze: block_size is 0 (choose between 1 and 3), 1, 2 or 3");
+		if (block_size > 1 && n % block_size != 0)
+			PFX_FAIL(PFX_ERR_ARG, "pfx_solver_analyze: block size 2 / 3 needs a multiple of 2 / 3 rows");
 		if (n >= ((int64_t)1 << 31) - 1)
 			PFX_FAIL(PFX_ERR_SIZE, "pfx_solver_analyze: the matrix dimension must fit a 32-bit index");
 		// the kernels index device arrays with these values: validate them on the host
@@ -272,13 +272,18 @@ namespace
 
 		int bs = 1;
 		int64_t n_blocks = nnz;
-		if (block_size == 3 || (block_size == 0 && n % 3 == 0))
+		if (block_size == 3 || block_size == 2 || (block_size == 0 && n % 3 == 0))
 		{
-			const int64_t n_nodes = n / 3;
+			const int B = block_size == 2 ? 2 : 3, B2 = B * B;
+			const int64_t n_nodes = n / B;
 			PFX_HIP(d_cnt.alloc((size_t)n_nodes + 1));
 			PFX_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(int64_t) * ((size_t)n_nodes + 1), st));
-			hipLaunchKernelGGL((k_ext_blocks<false>), dim3(grid_for(n_nodes)), dim3(256), 0, st, d_rowptr.p, d_ccol.p, vb.p, n_nodes, d_cnt.p, (const int64_t *)nullptr,
-							   (int32_t *)nullptr, (uint32_t *)nullptr);
+			if (B == 2)
+				hipLaunchKernelGGL((k_ext_blocks<false, 2>), dim3(grid_for(n_nodes)), dim3(256), 0, st, d_rowptr.p, d_ccol.p, vb.p, n_nodes, d_cnt.p, (const int64_t *)nullptr,
+								   (int32_t *)nullptr, (uint32_t *)nullptr);
+			else
+				hipLaunchKernelGGL((k_ext_blocks<false, 3>), dim3(grid_for(n_nodes)), dim3(256), 0, st, d_rowptr.p, d_ccol.p, vb.p, n_nodes, d_cnt.p, (const int64_t *)nullptr,
+								   (int32_t *)nullptr, (uint32_t *)nullptr);
 			if (pfx_alloc(ctx, &ctx->d_node_ptr, n_nodes + 1))
 				return PFX_ERR_HIP;
 			tb = 0;
@@ -288,17 +293,21 @@ namespace
 			int64_t nb = 0;
 			PFX_HIP(hipMemcpyAsync(&nb, ctx->d_node_ptr + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, st));
 			PFX_HIP(hipStreamSynchronize(st));
-			if (block_size == 3 || (double)nb * 9.0 <= 1.25 * (double)nnz)
+			if (block_size >= 2 || (double)nb * 9.0 <= 1.25 * (double)nnz)
 			{
-				bs = 3;
+				bs = B;
 				n_blocks = nb;
-				if (nb * 9 >= (int64_t)PAD * 2) // keeps the 32-bit block indices of the solver copy valid
+				if (nb * B2 >= (int64_t)PAD * 2) // keeps the 32-bit block indices of the solver copy valid
 					PFX_FAIL(PFX_ERR_SIZE, "pfx_solver_analyze: too many blocks");
-				if (pfx_alloc(ctx, &ctx->d_node_col, nb) || pfx_alloc(ctx, &ctx->d_ext_map, nb * 9))
+				if (pfx_alloc(ctx, &ctx->d_node_col, nb) || pfx_alloc(ctx, &ctx->d_ext_map, nb * B2))
 					return PFX_ERR_HIP;
-				PFX_HIP(hipMemsetAsync(ctx->d_ext_map, 0xFF, sizeof(uint32_t) * (size_t)(nb * 9), st));
-				hipLaunchKernelGGL((k_ext_blocks<true>), dim3(grid_for(n_nodes)), dim3(256), 0, st, d_rowptr.p, d_ccol.p, vb.p, n_nodes, (int64_t *)nullptr, ctx->d_node_ptr,
-								   ctx->d_node_col, ctx->d_ext_map);
+				PFX_HIP(hipMemsetAsync(ctx->d_ext_map, 0xFF, sizeof(uint32_t) * (size_t)(nb * B2), st));
+				if (B == 2)
+					hipLaunchKernelGGL((k_ext_blocks<true, 2>), dim3(grid_for(n_nodes)), dim3(256), 0, st, d_rowptr.p, d_ccol.p, vb.p, n_nodes, (int64_t *)nullptr, ctx->d_node_ptr,
+									   ctx->d_node_col, ctx->d_ext_map);
+				else
+					hipLaunchKernelGGL((k_ext_blocks<true, 3>), dim3(grid_for(n_nodes)), dim3(256), 0, st, d_rowptr.p, d_ccol.p, vb.p, n_nodes, (int64_t *)nullptr, ctx->d_node_ptr,
+									   ctx->d_node_col, ctx->d_ext_map);
 			}
 		}
 		if (bs == 1)
@@ -335,7 +344,9 @@ namespace
 		const int init[2] = {0, INT32_MAX};
 		PFX_HIP(hipMemcpyAsync(d_flag.p, init, sizeof(init), hipMemcpyHostToDevice, st));
 		hipLaunchKernelGGL(k_ext_gather, dim3(grid_for(ctx->nnz)), dim3(256), 0, st, ctx->d_ext_map, d_src, ctx->nnz, ctx->d_values, d_flag.p);
-		if (ctx->bs == 3)
+		if (ctx->bs == 2)
+			hipLaunchKernelGGL((k_ext_diag_check<2>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, ctx->n_nodes, d_flag.p, d_flag.p + 1);
+		else if (ctx->bs == 3)
 			hipLaunchKernelGGL((k_ext_diag_check<3>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, ctx->n_nodes, d_flag.p, d_flag.p + 1);
 		else
 			hipLaunchKernelGGL((k_ext_diag_check<1>), dim3(grid_for(ctx->n_nodes)), dim3(256), 0, st, ctx->d_node_ptr, ctx->d_node_col, ctx->d_values, ctx->n_nodes, d_flag.p, d_flag.p + 1);

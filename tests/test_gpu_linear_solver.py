@@ -229,7 +229,9 @@ def test_argument_checks_of_the_solver_entry_points(oracle):
         with pytest.raises(E.PfxError):  # factorize before analyze
             eng.solver_factorize(red[2])
         with pytest.raises(E.PfxError):
-            eng.solver_analyze(n, outer, inner, 2)
+            eng.solver_analyze(n, outer, inner, 4)
+        with pytest.raises(E.PfxError):
+            eng.solver_analyze(n - n % 2 + 1, outer, inner, 2)  # an odd number of rows in 2 x 2 blocks
         bad = inner.copy()
         bad[5] = n
         with pytest.raises(E.PfxError):
@@ -294,5 +296,47 @@ def test_amg_on_a_handed_in_matrix(oracle):
         eng.solver_factorize(red[2])
         with pytest.raises(E.PfxError, match="node positions"):
             eng.cg(b, None, E.PRECOND_AMG, 100, 1e-10)
+    finally:
+        eng.close()
+
+
+def test_two_by_two_blocks_handed_in(oracle):
+    """A 2-D elasticity matrix handed in by value with block_size 2: 2 x 2 node blocks in the solver copy.  The reduced
+    NeoHookean Hessian of a triangle mesh (whole nodes constrained) through Jacobi-CG against the oracle's Eigen-order CG,
+    and through the AMG with node positions (rigid-body modes of the plane) against the scalar layout without them."""
+    mesh = M.square_tris(12, 2, jitter=0.1, seed=2)
+    lam, mu = oracle.lame(2e4, 0.3, 2)
+    n = 2 * mesh.n_nodes
+    x = M.seeded_displacement(mesh, 2, 2e-3)
+    H = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+    bd = M.boundary_dofs(mesh, 2, "x0")
+    red = oracle.full_to_reduced_matrix(H, bd)
+    keep = np.setdiff1d(np.arange(n), bd)
+    b = np.random.default_rng(8).standard_normal(keep.size)
+    S = csc_to_scipy(red, keep.size)
+    x_o, it_o, _ = oracle.cg(red, b, jacobi=True, max_iter=5000, tol=1e-10)
+    eng = E.Engine(0)
+    try:
+        eng.solver_analyze(keep.size, red[0].astype(np.int32), red[1], 2)
+        bs, n_blocks, stored = eng.solver_layout()
+        assert bs == 2 and stored == 4 * n_blocks and stored <= 1.05 * red[1].size
+        eng.solver_factorize(red[2])
+        y = eng.spmv(b)
+        assert np.abs(y - S @ b).max() <= 1e-12 * np.abs(S @ b).max()
+        xs, it, err = eng.cg(b, None, E.PRECOND_JACOBI, 5000, 1e-10)
+        assert abs(it - it_o) <= 2 and np.abs(xs - x_o).max() <= 1e-8 * np.abs(x_o).max(), (it, it_o)
+        with pytest.raises(E.PfxError, match="node positions"):
+            eng.cg(b, None, E.PRECOND_AMG, 100, 1e-10)
+        pos = M.node_positions(mesh)[keep[::2] // 2]
+        eng.solver_set_node_positions(np.hstack([pos, np.zeros((pos.shape[0], 1))]))
+        xa, it_a, err_a = eng.cg(b, None, E.PRECOND_AMG, 500, 1e-10)
+        assert err_a <= 1e-10 and np.linalg.norm(S @ xa - b) <= 1e-9 * np.linalg.norm(b)
+        assert it_a < it_o / 4, (it_a, it_o)
+        # the scalar layout of the same matrix: constants only in the coarse space
+        eng.solver_analyze(keep.size, red[0].astype(np.int32), red[1], 1)
+        eng.solver_factorize(red[2])
+        xb, it_b, err_b = eng.cg(b, None, E.PRECOND_AMG, 2000, 1e-10)
+        print("2 x 2 blocks handed in: Jacobi", it, "AMG (plane modes)", it_a, "AMG (scalar layout)", it_b)
+        assert err_b <= 1e-10 and it_a <= it_b
     finally:
         eng.close()
