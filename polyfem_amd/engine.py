@@ -934,11 +934,14 @@ class _AssemblerBase:
         self.formulation = formulation
         self.engine = engine or Engine(device)
         self.lam, self.mu = 1.0, 1.0
+        self.size = 3
         self._bound = None
 
     def set_size(self, size: int):
-        if size != 3:
-            raise ValueError("only 3-D problems are implemented")
+        """2 for triangle meshes (is_volume = False), 3 otherwise; call before add_multimaterial, as the reference does."""
+        if size not in (2, 3):
+            raise ValueError("elasticity is implemented for size 2 (triangles) and 3")
+        self.size = size
 
     def add_multimaterial(self, index: int, params: dict):
         """LameParameters::add_multimaterial (utils/ElasticityUtils.cpp:519-560) for uniform parameters given
@@ -947,11 +950,18 @@ class _AssemblerBase:
             self.lam, self.mu = float(params["lambda"]), float(params["mu"])
         elif "E" in params and "nu" in params:
             E, nu = float(params["E"]), float(params["nu"])
-            self.lam = (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu))
+            # convert_to_lambda with is_volume = size() == 3 (utils/ElasticityUtils.cpp:203-214)
+            self.lam = (E * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu)) if self.size == 3 else (nu * E) / (1.0 - nu * nu)
             self.mu = E / (2.0 * (1.0 + nu))
         self._bound = None
 
-    def _bind(self, mesh):
+    def _bind(self, mesh, is_volume=True):
+        from . import mesh as _M
+        dim = _M.KIND_DIM[mesh.kind]
+        if bool(is_volume) != (dim == 3):
+            raise ValueError("is_volume does not match the mesh (False for triangle meshes)")
+        if self.formulation != "Laplacian" and self.size != dim:
+            raise ValueError("the local assembler's size() does not match the mesh")
         key = (id(mesh), self.lam, self.mu)
         if self._bound != key:
             self.engine.set_mesh(mesh)
@@ -964,12 +974,12 @@ class Assembler(_AssemblerBase):
     """assembler::Assembler<LocalAssembler> for Laplacian / LinearElasticity."""
 
     def assemble(self, is_volume: bool, n_basis: int, bases, gbases=None, cache=None, is_mass: bool = False) -> StiffnessMatrix:
-        if not is_volume or is_mass:
-            raise NotImplementedError("3-D stiffness assembly only")
+        if is_mass:
+            raise NotImplementedError("is_mass = True belongs to Assembler<Mass>: Engine.assemble_mass")
         mesh = bases
         if n_basis != mesh.n_nodes:
             raise ValueError("n_basis does not match the bases")
-        self._bind(mesh)
+        self._bind(mesh, is_volume)
         self.engine.assemble_linear()
         rp, ci, v = self.engine.get_linear_csr()
         return StiffnessMatrix(int(rp.size - 1), rp, ci, v, resident=(self.engine, self.engine.matrix_generation()))
@@ -979,16 +989,16 @@ class NLAssembler(_AssemblerBase):
     """assembler::NLAssembler<LocalAssembler> for NeoHookean, SaintVenant (and LinearElasticity)."""
 
     def assemble(self, is_volume, bases, gbases, cache, dt, displacement, displacement_prev=None) -> float:
-        self._bind(bases)
+        self._bind(bases, is_volume)
         return self.engine.energy(np.asarray(displacement).reshape(-1))
 
     def assemble_grad(self, is_volume, n_basis, bases, gbases, cache, dt, displacement, displacement_prev=None):
-        self._bind(bases)
+        self._bind(bases, is_volume)
         return self.engine.gradient(np.asarray(displacement).reshape(-1)).reshape(-1, 1)
 
     def assemble_hessian(self, is_volume, n_basis, project_to_psd, bases, gbases, cache, dt, displacement,
                          displacement_prev, mat_cache: SpareMatrixCache) -> StiffnessMatrix:
-        self._bind(bases)
+        self._bind(bases, is_volume)
         if mat_cache.engine is not self.engine or mat_cache.outer is None:
             mat_cache.engine = self.engine
             mat_cache.outer, mat_cache.inner = self.engine.get_pattern()

@@ -663,3 +663,33 @@ def test_amg_2d_large_and_newton(oracle):
         assert np.abs(xa - xj).max() <= 1e-7 * np.abs(xj).max()
     finally:
         eng.close()
+
+
+def test_host_mirror_of_reference_interface_2d(oracle):
+    """tests/test_assembler.cpp:12-64 ("hessian_lin") through the reference-shaped host classes on a triangle mesh:
+    is_volume = False, set_size(2), (E, nu) converted with the plane formula."""
+    mesh = M.square_tris(6, 2, jitter=0.1)
+    asm = E.Assembler("LinearElasticity")
+    asm.set_size(2)
+    asm.add_multimaterial(0, {"E": 1e5, "nu": 0.3})
+    K = asm.assemble(False, mesh.n_nodes, mesh, mesh, None)
+    lam, mu = oracle.lame(1e5, 0.3, 2)
+    assert asm.lam == lam and asm.mu == mu
+    ref = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert K.rows() == mesh.n_nodes * 2 and np.array_equal(K.inner, ref[1]) and rel_err(K.values, ref[2]) <= TOL
+    nl = E.NLAssembler("LinearElasticity", engine=asm.engine)
+    nl.set_size(2)
+    nl.add_multimaterial(0, {"E": 1e5, "nu": 0.3})
+    cache = E.SpareMatrixCache()
+    Kd = K.to_scipy()
+    rng = np.random.default_rng(0)
+    for rand in range(4):
+        x = (np.zeros(K.rows()) if rand == 0 else rng.uniform(-1, 1, K.rows())).reshape(-1, 1)
+        H = nl.assemble_hessian(False, mesh.n_nodes, False, mesh, mesh, None, 0.0, x, x, cache)
+        assert abs(H.to_scipy() - Kd).max() <= 1e-8 * abs(Kd).max()
+    with pytest.raises(ValueError):
+        nl.assemble(True, mesh, mesh, None, 0.0, x, x)  # is_volume = True on a triangle mesh
+    bad = E.NLAssembler("NeoHookean", engine=asm.engine)  # size() left at 3
+    with pytest.raises(ValueError):
+        bad.assemble(False, mesh, mesh, None, 0.0, x, x)
+    asm.engine.close()
