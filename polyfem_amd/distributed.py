@@ -761,6 +761,9 @@ class DistributedCG:
             zn += a[0] * c["free"][:no]
             return
         d = c["pos"][:no] - c["centres"][r]
+        if self.bs == 2:
+            zn += t.stack([a[0] - a[2] * d[:, 1], a[1] + a[2] * d[:, 0]], dim=1) * c["free"][:no]
+            return
         zn += (a[0:3] + t.cross(a[3:6].expand(no, 3), d, dim=1)) * c["free"][:no]
 
     def close(self):

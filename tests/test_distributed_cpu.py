@@ -46,9 +46,11 @@ def _worker(rank, world, port, case, ret):
             mesh, model, bs = M.cube_tets(5, 1), O.LAPLACIAN, 1
         elif case == "elastic_q2":
             mesh, model, bs = M.cube_hexes(2, 2), O.LINEAR_ELASTICITY, 3
+        elif case == "elastic_tri_p2":
+            mesh, model, bs = M.square_tris(6, 2, jitter=0.1), O.LINEAR_ELASTICITY, 2
         else:
             mesh, model, bs = M.cube_tets(3, 2, jitter=0.1), O.LINEAR_ELASTICITY, 3
-        lam, mu = O.lame(1e5, 0.3)
+        lam, mu = O.lame(1e5, 0.3, M.KIND_DIM[mesh.kind])
         bounds = D.owner_ranges(mesh.n_nodes, world)
         part = D.partition(mesh.kind, mesh.conn, mesh.gconn, mesh.xyz, bounds, rank, mesh.node_xyz)
         if slab is not None:
@@ -107,7 +109,7 @@ def _worker(rank, world, port, case, ret):
 
 
 @pytest.mark.parametrize("world,case", [(2, "laplace_p1"), (2, "elastic_p2"), (3, "elastic_p2"), (2, "elastic_q2"), (4, "laplace_p1"),
-                                        (8, "slab_p2"), (8, "morton_p2")])
+                                        (8, "slab_p2"), (8, "morton_p2"), (3, "elastic_tri_p2")])
 def test_distributed_cg_gloo(world, case):
     port = _free_port()
     with mp.Manager() as mgr:
@@ -327,14 +329,28 @@ def _coarse_worker(rank, world, port, bs, ret):
     try:
         from oracle import pf_oracle as O
         from tests.dist_helpers import OracleOps, csc_tuple_to_csr
-        model = O.LINEAR_ELASTICITY if bs == 3 else O.LAPLACIAN
+        model = O.LINEAR_ELASTICITY if bs >= 2 else O.LAPLACIAN
         lam, mu = O.lame(1e5, 0.3)
-        part, bounds, n_nodes = D.slab_part(2, 2, rank, world, 2)  # a bar of 2 x 2 x (2 * world) cells, P2 tets
+        if bs == 2:
+            # a strip of 2 x (4 * world) cells, P2 triangles, lattice numbering (x fastest): the ranks own bands in y
+            strip = M.square_tris(4 * world, 2)
+            keep_el = M.node_positions(strip)[strip.conn[:, :3]][:, :, 0].max(axis=1) <= 2.0 / (4 * world) + 1e-12
+            conn = strip.conn[keep_el]
+            used = np.unique(conn)
+            new_id = np.full(strip.n_nodes, -1, dtype=np.int64)
+            new_id[used] = np.arange(used.size)
+            pos = M.node_positions(strip)[used]
+            lam, mu = O.lame(1e5, 0.3, 2)
+            n_nodes = int(used.size)
+            bounds = D.owner_ranges(n_nodes, world)
+            part = D.partition(strip.kind, new_id[conn].astype(np.int32), strip.gconn[keep_el], strip.xyz, bounds, rank, node_xyz=pos)
+        else:
+            part, bounds, n_nodes = D.slab_part(2, 2, rank, world, 2)  # a bar of 2 x 2 x (2 * world) cells, P2 tets
         nl, no = part.n_local, part.n_owned * bs
         l2g = part.local_to_global()
         dof_l2g = (l2g[:, None] * bs + np.arange(bs)[None]).reshape(-1)
         Kl = csc_tuple_to_csr(O.assemble_linear(part.mesh, model, lam, mu), nl * bs)
-        fixed_nodes = np.nonzero(np.abs(part.mesh.node_xyz[:, 2]) < 1e-12)[0]  # clamped at the first rank's outer face
+        fixed_nodes = np.nonzero(np.abs(part.mesh.node_xyz[:, -1]) < 1e-12)[0]  # clamped at the first rank's outer face (z = 0; y = 0 for the strip)
         fixed_dofs = np.sort((fixed_nodes[:, None] * bs + np.arange(bs)[None]).reshape(-1))
         fixed_l = np.zeros(nl * bs, dtype=bool)
         fixed_l[fixed_dofs] = True
@@ -380,7 +396,7 @@ def _coarse_worker(rank, world, port, bs, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bs", [(4, 3), (6, 3), (4, 1)])
+@pytest.mark.parametrize("world,bs", [(4, 3), (6, 3), (4, 1), (4, 2)])
 def test_coarse_space_over_the_ranks(world, bs):
     """DistributedCG's preconditioned loop (precond = 2) with exact subdomain solves standing in for the per-rank AMG:
     block-Jacobi alone and with the coarse space of the ranks' rigid-body modes (constants for a scalar problem) both
