@@ -65,9 +65,12 @@ namespace
 
 	// entry offset inside one slot of a slice.  Block size 3: entries 0..7 are stored lane-interleaved in 16-byte groups
 	// (two doubles / four floats per group), entry 8 after them, so that a lane fetches its nine entries with 16-byte loads.
+	// Block size 2: the four entries as two such groups of doubles, or one of floats.
 	template <int BS, typename V>
 	__device__ __forceinline__ int entry_offset(int c, int lane)
 	{
+		if (BS == 2)
+			return sizeof(V) == 8 ? (c >> 1) * 128 + lane * 2 + (c & 1) : lane * 4 + c;
 		if (BS == 3)
 		{
 			if (sizeof(V) == 8)
@@ -435,15 +438,31 @@ namespace
 			}
 			else if constexpr (BS == 2)
 			{
-				// 2-D problems: four entries per slot, entry c of the lane's block at c * 64 + lane
+				// 2-D problems: four entries per slot in 16-byte groups (entry_offset): two loads of two doubles, or one of
+				// four floats, per lane and slot; the two entries of x are one 16-byte load
+				typedef double d2 __attribute__((ext_vector_type(2)));
+				typedef double d2x __attribute__((ext_vector_type(2), aligned(8))); // x is the caller's: only its 8-byte alignment is known
+				typedef float f4 __attribute__((ext_vector_type(4)));
 #pragma unroll 4
 				for (int j = 0; j < len; ++j)
 				{
-					const V *vj = v + (int64_t)j * (SL * 4) + lane;
+					const V *vj = v + (int64_t)j * (SL * 4);
 					const int64_t cc = (int64_t)__builtin_nontemporal_load(c + j * SL) * 2;
-					const double x0 = x[cc], x1 = x[cc + 1];
-					a0 += (double)__builtin_nontemporal_load(vj) * x0 + (double)__builtin_nontemporal_load(vj + SL) * x1;
-					a1 += (double)__builtin_nontemporal_load(vj + 2 * SL) * x0 + (double)__builtin_nontemporal_load(vj + 3 * SL) * x1;
+					const d2x xv = *reinterpret_cast<const d2x *>(x + cc);
+					double m0, m1, m2, m3;
+					if constexpr (sizeof(V) == 8)
+					{
+						const d2 p0 = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vj) + lane);
+						const d2 p1 = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(vj + 128) + lane);
+						m0 = p0.x, m1 = p0.y, m2 = p1.x, m3 = p1.y;
+					}
+					else
+					{
+						const f4 p = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(vj) + lane);
+						m0 = p.x, m1 = p.y, m2 = p.z, m3 = p.w;
+					}
+					a0 += m0 * xv.x + m1 * xv.y;
+					a1 += m2 * xv.x + m3 * xv.y;
 				}
 			}
 			else
