@@ -1,4 +1,4 @@
-"""Volume meshes (and 2-D triangle meshes) from Gmsh / OBJ files, flattened to the layout the assembly engine consumes.
+"""Volume meshes (and 2-D triangle meshes) from Gmsh / MEDIT / OBJ files, flattened to the layout the assembly engine consumes.
 
 Input side of the hot path: what the reference does between reading a mesh and calling its assemblers.
 
@@ -484,7 +484,94 @@ def read_obj(path):
     return np.asarray(verts, dtype=np.float64), np.ascontiguousarray(cells.astype(np.int32)), np.zeros(len(faces), dtype=np.int32)
 
 
+_MEDIT_CELLS = {"tetrahedra": (3, 4), "hexahedra": (3, 8), "triangles": (2, 3), "quadrilaterals": (2, 4), "edges": (1, 2),
+                "corners": (0, 1), "requiredvertices": (0, 1), "ridges": (0, 1), "requirededges": (0, 1)}
+
+
+def read_medit(path):
+    """ASCII MEDIT / INRIA `.mesh` file (`MeshVersionFormatted`, `Dimension`, `Vertices`, `Tetrahedra` / `Hexahedra` /
+    `Triangles` sections, 1-based indices, a reference number after every record): the format of most volume meshes the
+    reference is run on.  There it goes through the un-vendored geogram loader (`mesh/Mesh.cpp:172-230` falls through to
+    `GEO::mesh_load`, `mesh/mesh3D/CMesh3D.cpp:86-91`); as for every format but MSH, no body ids come with it (:212-226).
+    The elements of the highest dimension present become `cells`; hexahedra are in the corner order of Gmsh and of the
+    reference.  Returns (vertices (n, 3), cells (m, 4 | 8 | 3) int32, body_ids (m,) zeros)."""
+    with open(path) as fh:
+        tok = []
+        for line in fh:
+            line = line.split("#", 1)[0]
+            tok.extend(line.split())
+    if not tok or tok[0].lower() != "meshversionformatted":
+        raise ValueError(f"{path}: not an ASCII MEDIT mesh file")
+    pos, dim, verts, found = 2, None, None, {}
+    try:
+        while pos < len(tok):
+            key = tok[pos].lower()
+            pos += 1
+            if key == "end":
+                break
+            if key == "dimension":
+                dim = int(tok[pos])
+                pos += 1
+                if dim not in (2, 3):
+                    raise ValueError(f"{path}: Dimension {dim}")
+            elif key == "vertices":
+                if dim is None:
+                    raise ValueError(f"{path}: Vertices before Dimension")
+                n = int(tok[pos])
+                pos += 1
+                a = np.array(tok[pos: pos + n * (dim + 1)], dtype=np.float64).reshape(n, dim + 1)
+                pos += n * (dim + 1)
+                verts = np.zeros((n, 3))
+                verts[:, :dim] = a[:, :dim]
+            elif key in _MEDIT_CELLS:
+                edim, nv = _MEDIT_CELLS[key]
+                n = int(tok[pos])
+                pos += 1
+                width = nv + (0 if key in ("corners", "requiredvertices", "ridges", "requirededges") else 1)
+                a = np.array(tok[pos: pos + n * width], dtype=np.int64).reshape(n, width)
+                pos += n * width
+                if edim >= 2 and n > 0:
+                    found[key] = a[:, :nv] - 1
+            else:
+                raise ValueError(f"{path}: section {tok[pos - 1]} is not supported")
+    except (IndexError, ValueError) as exc:
+        if isinstance(exc, ValueError) and str(exc).startswith(str(path)):
+            raise
+        raise ValueError(f"{path}: truncated or malformed MEDIT file") from exc
+    if verts is None or not found:
+        raise ValueError(f"{path}: no vertices or no elements")
+    top = max(_MEDIT_CELLS[k][0] for k in found)
+    kinds = [k for k in found if _MEDIT_CELLS[k][0] == top]
+    if len(kinds) != 1:
+        raise ValueError(f"{path}: mixed element types are not supported")
+    if kinds[0] == "quadrilaterals":
+        raise ValueError(f"{path}: only tetrahedra, hexahedra and triangles are supported")
+    cells = found[kinds[0]]
+    if cells.min() < 0 or cells.max() >= verts.shape[0]:
+        raise ValueError(f"{path}: an element refers to a vertex that is not defined")
+    return verts, np.ascontiguousarray(cells.astype(np.int32)), np.zeros(cells.shape[0], dtype=np.int32)
+
+
+def write_medit(path, vertices, cells):
+    """Writes tetrahedra, hexahedra or triangles as an ASCII MEDIT file (tests and round trips)."""
+    vertices = np.asarray(vertices, dtype=np.float64)
+    cells = np.asarray(cells)
+    name = {4: "Tetrahedra", 8: "Hexahedra", 3: "Triangles"}[cells.shape[1]]
+    dim = 2 if cells.shape[1] == 3 and vertices.shape[1] == 2 else 3
+    with open(path, "w") as fh:
+        fh.write(f"MeshVersionFormatted 1\nDimension {dim}\nVertices\n{vertices.shape[0]}\n")
+        for v in vertices:
+            fh.write(" ".join(repr(float(c)) for c in v[:dim]) + " 0\n")
+        fh.write(f"{name}\n{cells.shape[0]}\n")
+        for c in cells:
+            fh.write(" ".join(str(int(i) + 1) for i in c) + " 0\n")
+        fh.write("End\n")
+
+
 def load(path, order: int = 1, numbering: str = "vertices_first"):
-    """read_msh / read_obj + flatten; returns (Mesh, body_ids)."""
-    vertices, cells, body = read_obj(path) if str(path).lower().endswith(".obj") else read_msh(path)
+    """read_msh / read_obj / read_medit (by extension: .obj, .mesh, anything else is read as MSH) + flatten; returns
+    (Mesh, body_ids)."""
+    low = str(path).lower()
+    reader = read_obj if low.endswith(".obj") else read_medit if low.endswith(".mesh") else read_msh
+    vertices, cells, body = reader(path)
     return flatten(vertices, cells, order, numbering), body

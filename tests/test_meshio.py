@@ -241,3 +241,54 @@ def test_triangle_file_mesh_through_the_hip_path(tmp_path, oracle):
         assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= 1e-12
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("element", ["tet", "hex", "tri"])
+def test_medit_mesh_files(tmp_path, oracle, element):
+    """ASCII MEDIT `.mesh` files (read by geogram in the reference, un-vendored: parity unpinned): round trip, the same
+    flattened mesh as the MSH path -- and therefore the same oracle matrix --, keywords in any case, `Dimension` on its
+    own line, comments, lower-dimensional sections ignored, rejected inputs."""
+    if element == "tet":
+        base = M.cube_tets(2, 1, jitter=0.1)
+    elif element == "hex":
+        base = M.cube_hexes(2, 1)
+    else:
+        base = M.square_tris(3, 1, jitter=0.1)
+    path = tmp_path / "m.mesh"
+    IO.write_medit(path, base.xyz, base.gconn)
+    v, c, b = IO.read_medit(path)
+    assert np.array_equal(v[:, :base.xyz.shape[1]], base.xyz) and np.array_equal(c, base.gconn) and not b.any()
+    mesh, body = IO.load(path, 2)
+    msh = tmp_path / "m.msh"
+    IO.write_msh(msh, base.xyz, base.gconn, None, "2.2")
+    ref, _ = IO.load(msh, 2)
+    assert mesh.kind == ref.kind and np.array_equal(mesh.conn, ref.conn) and np.array_equal(mesh.gconn, ref.gconn)
+    assert np.array_equal(mesh.xyz, ref.xyz) and body.size == base.n_el
+    dim = M.KIND_DIM[mesh.kind]
+    lam, mu = oracle.lame(1e5, 0.3, dim)
+    a = oracle.assemble_linear(mesh, oracle.LINEAR_ELASTICITY, lam, mu)
+    r = oracle.assemble_linear(ref, oracle.LINEAR_ELASTICITY, lam, mu)
+    assert all(np.array_equal(x, y) for x, y in zip(a, r))
+
+
+def test_medit_variants_and_rejected_inputs(tmp_path):
+    p = tmp_path / "v.mesh"
+    p.write_text("# a comment\nMeshVersionFormatted 2\nDimension\n3\nVertices\n5\n0 0 0 1\n1 0 0 1\n0 1 0 1\n0 0 1 2\n1 1 1 2\n"
+                 "Edges\n1\n1 2 5\nTriangles\n1\n1 2 3 9\nTETRAHEDRA\n2\n1 3 2 4 7\n2 3 4 5 8\nCorners\n1\n1\nEnd\n")
+    v, c, b = IO.read_medit(p)
+    assert v.shape == (5, 3) and np.array_equal(c, [[0, 2, 1, 3], [1, 2, 3, 4]]) and not b.any()
+    m = IO.flatten(v, c, 1)  # the first tetrahedron is inverted in the file
+    q = v[m.gconn]
+    assert np.all(np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0]) > 0)
+    two = tmp_path / "t.mesh"
+    two.write_text("MeshVersionFormatted 1\nDimension 2\nVertices\n3\n0 0 0\n1 0 0\n0 1 0\nTriangles\n1\n1 2 3 0\nEnd\n")
+    v, c, _ = IO.read_medit(two)
+    assert c.shape == (1, 3) and IO.flatten(v, c, 2).kind == M.P2TRI
+    for text in ("$MeshFormat\n2.2 0 8\n", "MeshVersionFormatted 1\nDimension 3\nVertices\n2\n0 0 0 0\n",
+                 "MeshVersionFormatted 1\nDimension 3\nVertices\n1\n0 0 0 0\nTetrahedra\n1\n1 2 3 4 0\nEnd\n",
+                 "MeshVersionFormatted 1\nDimension 2\nVertices\n4\n0 0 0\n1 0 0\n1 1 0\n0 1 0\nQuadrilaterals\n1\n1 2 3 4 0\nEnd\n",
+                 "MeshVersionFormatted 1\nDimension 3\nVertices\n4\n0 0 0 0\n1 0 0 0\n0 1 0 0\n0 0 1 0\nPrisms\n0\nEnd\n"):
+        bad = tmp_path / "bad.mesh"
+        bad.write_text(text)
+        with pytest.raises(ValueError):
+            IO.read_medit(bad)
