@@ -97,6 +97,31 @@ namespace
 		__host__ __device__ static constexpr int f_at(int k) { return affine ? 10 + 12 * k : 22 * k + 10; }
 	};
 
+	// What the NeoHookean row functor reads instead of (J^-T, F): everything in its block that does not depend on the pair
+	// (i, j) is formed once per point by the element kernel.  With g_i = J^-T grad phi_i, cof the cofactor matrix of F:
+	//   g_i . g_j = grad phi_i^T S grad phi_j,        S = jt jt^T (symmetric; its six entries go into the slot of J^-T),
+	//   cof g_i   = M grad phi_i,                     M = cof jt^T (into the slot of F),
+	//   F (g_i x g_j) = (cof g_i) x (cof g_j) / det F (cofactor of the cofactor matrix = det F * F), so c2 is stored divided by det F.
+	// jt is the row-major array with g_i[c] = sum_r grad phi_i[r] * jt[3 r + c].
+	__device__ __forceinline__ void neo_state_header(const double *jt, double *out)
+	{
+		out[0] = jt[0] * jt[0] + jt[1] * jt[1] + jt[2] * jt[2];
+		out[1] = jt[0] * jt[3] + jt[1] * jt[4] + jt[2] * jt[5];
+		out[2] = jt[0] * jt[6] + jt[1] * jt[7] + jt[2] * jt[8];
+		out[3] = jt[3] * jt[3] + jt[4] * jt[4] + jt[5] * jt[5];
+		out[4] = jt[3] * jt[6] + jt[4] * jt[7] + jt[5] * jt[8];
+		out[5] = jt[6] * jt[6] + jt[7] * jt[7] + jt[8] * jt[8];
+		out[6] = out[7] = out[8] = 0.0;
+	}
+	__device__ __forceinline__ void neo_state_point(const double *jt, const double *F, const double *cof, double c0, double c1, double c2, double *out)
+	{
+		for (int a = 0; a < 3; ++a)
+			for (int r = 0; r < 3; ++r)
+				out[3 * a + r] = cof[3 * a] * jt[3 * r] + cof[3 * a + 1] * jt[3 * r + 1] + cof[3 * a + 2] * jt[3 * r + 2];
+		const double J = F[0] * cof[0] + F[1] * cof[1] + F[2] * cof[2];
+		out[9] = c0, out[10] = c1, out[11] = c2 / J;
+	}
+
 	// One quadrature point of the energy density and its derivative: F the deformation gradient (the displacement gradient
 	// for M_LINEAR), da = det J * weight.  dJ receives what the gradient contracts with the physical basis gradients (NeoHookean:
 	// the cofactor matrix of F; otherwise the first Piola-Kirchhoff / Cauchy stress), c0..c2 the coefficients the gradient
@@ -331,8 +356,11 @@ namespace
 				inv3_transposed_det(tmp, jt, &det);
 				if (WH)
 				{
-					for (int q = 0; q < 9; ++q)
-						st[ST::jt_at(k) + q] = jt[q];
+					if (model == M_NEO)
+						neo_state_header(jt, st + ST::jt_at(k));
+					else
+						for (int q = 0; q < 9; ++q)
+							st[ST::jt_at(k) + q] = jt[q];
 					st[ST::jt_at(k) + 9] = (double)model;
 				}
 			}
@@ -356,9 +384,14 @@ namespace
 			en += nl_point<MODEL, DIM>(model, F, lambda, mu, tensor, da, dJ, c0, c1, c2, bad);
 			if (WH)
 			{
-				for (int q = 0; q < 9; ++q)
-					st[ST::f_at(k) + q] = F[q];
-				st[ST::f_at(k) + 9] = c0, st[ST::f_at(k) + 10] = c1, st[ST::f_at(k) + 11] = c2;
+				if (model == M_NEO)
+					neo_state_point(jt, F, dJ, c0, c1, c2, st + ST::f_at(k));
+				else
+				{
+					for (int q = 0; q < 9; ++q)
+						st[ST::f_at(k) + q] = F[q];
+					st[ST::f_at(k) + 9] = c0, st[ST::f_at(k) + 10] = c1, st[ST::f_at(k) + 11] = c2;
+				}
 			}
 			if (WG)
 				for (int i = 0; i < NLOC; ++i)
@@ -484,12 +517,20 @@ namespace
 			if (want_h)
 			{
 				double *st = estate + e * (int64_t)ST::stride;
-				for (int q = 0; q < 9; ++q)
-					st[ST::jt_at(k) + q] = jt[q];
+				if (model == M_NEO)
+				{
+					neo_state_header(jt, st + ST::jt_at(k));
+					neo_state_point(jt, F, dJ, c0, c1, c2, st + ST::f_at(k));
+				}
+				else
+				{
+					for (int q = 0; q < 9; ++q)
+						st[ST::jt_at(k) + q] = jt[q];
+					for (int q = 0; q < 9; ++q)
+						st[ST::f_at(k) + q] = F[q];
+					st[ST::f_at(k) + 9] = c0, st[ST::f_at(k) + 10] = c1, st[ST::f_at(k) + 11] = c2;
+				}
 				st[ST::jt_at(k) + 9] = (double)model; // the tenth slot tells the row functor the element's model
-				for (int q = 0; q < 9; ++q)
-					st[ST::f_at(k) + q] = F[q];
-				st[ST::f_at(k) + 9] = c0, st[ST::f_at(k) + 10] = c1, st[ST::f_at(k) + 11] = c2;
 			}
 		}
 		wave_sync();
@@ -523,6 +564,15 @@ namespace
 #ifndef PFX_NL_UNROLL
 #define PFX_NL_UNROLL 3 // quadrature points per trip of the point loop: more keeps more state loads in flight, and more registers
 #endif
+// NeoHookean reads a state that leaves little arithmetic per point (neo_state_point): one point per trip in 106 registers
+// lets four waves share a SIMD, which pays more than loads kept in flight by one wave (10 M P2 tets: 23.8 ms; three
+// points per trip at three waves 32.9 ms, two at four 28.3 ms, one at five 28.5 ms)
+#ifndef PFX_NEO_UNROLL
+#define PFX_NEO_UNROLL 1
+#endif
+#ifndef PFX_NEO_MINWAVES
+#define PFX_NEO_MINWAVES 4
+#endif
 	template <int NLOC, int NGLOC, int NPTS, int MODEL>
 	struct nl_block
 	{
@@ -530,7 +580,7 @@ namespace
 		const pfx_tables *tab;
 		const double *tensor = nullptr;                                                   // M_STVKT: the 6 x 6 elasticity tensor
 		static constexpr int LDS_DOUBLES = NPTS * NLOC * 3 + (MODEL == M_STVKT ? 36 : 0); // grad[k][i][3], tensor
-		static constexpr int MIN_WAVES = MODEL == M_STVKT ? 2 : PFX_ROWASM_MINWAVES; // the tensor products want the registers of a third wave
+		static constexpr int MIN_WAVES = MODEL == M_STVKT ? 2 : MODEL == M_NEO ? PFX_NEO_MINWAVES : PFX_ROWASM_MINWAVES; // the tensor products want the registers of a third wave
 		static constexpr int BS = (NGLOC == 3) ? 2 : 3; // triangles: the in-plane 2 x 2 part of the block computed below
 
 		__device__ __forceinline__ void load_tables(double *lds, int lane) const
@@ -554,7 +604,7 @@ namespace
 					jt[2 * q] = v.x, jt[2 * q + 1] = v.y;
 				}
 			double b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll(MODEL == M_STVKT ? 1 : MODEL == M_MULTI ? 2 : PFX_NL_UNROLL)
+#pragma unroll(MODEL == M_STVKT ? 1 : MODEL == M_MULTI ? 2 : MODEL == M_NEO ? PFX_NEO_UNROLL : PFX_NL_UNROLL)
 			for (int k = 0; k < NPTS; ++k)
 			{
 				if (!ST::affine)
@@ -570,6 +620,34 @@ namespace
 				}
 				const double a = F[9], c1 = F[10], c2 = F[11];
 				const double *ri = lds + (k * NLOC + i) * 3, *rj = lds + (k * NLOC + j) * 3;
+				const int model = (MODEL == M_MULTI) ? (int)jt[9] : MODEL;
+				if (model == M_NEO)
+				{
+					// the state holds S (jt[0..5]: xx xy xz yy yz zz), M (F[0..8]) and c2 / det F (neo_state_header / _point):
+					// block = a (ri^T S rj) I + c1 (M ri)(M rj)^T - hat(c2 (M ri) x (M rj))
+					const double s0 = jt[0] * rj[0] + jt[1] * rj[1] + jt[2] * rj[2];
+					const double s1 = jt[1] * rj[0] + jt[3] * rj[1] + jt[4] * rj[2];
+					const double s2 = jt[2] * rj[0] + jt[4] * rj[1] + jt[5] * rj[2];
+					const double dot = a * (ri[0] * s0 + ri[1] * s1 + ri[2] * s2);
+					const double vi0 = F[0] * ri[0] + F[1] * ri[1] + F[2] * ri[2];
+					const double vi1 = F[3] * ri[0] + F[4] * ri[1] + F[5] * ri[2];
+					const double vi2 = F[6] * ri[0] + F[7] * ri[1] + F[8] * ri[2];
+					const double wj0 = F[0] * rj[0] + F[1] * rj[1] + F[2] * rj[2];
+					const double wj1 = F[3] * rj[0] + F[4] * rj[1] + F[5] * rj[2];
+					const double wj2 = F[6] * rj[0] + F[7] * rj[1] + F[8] * rj[2];
+					const double t0 = c2 * (vi1 * wj2 - vi2 * wj1), t1 = c2 * (vi2 * wj0 - vi0 * wj2), t2 = c2 * (vi0 * wj1 - vi1 * wj0);
+					const double wi0 = c1 * vi0, wi1 = c1 * vi1, wi2 = c1 * vi2;
+					b[0] += dot + wi0 * wj0;
+					b[1] += wi0 * wj1 + t2;
+					b[2] += wi0 * wj2 - t1;
+					b[3] += wi1 * wj0 - t2;
+					b[4] += dot + wi1 * wj1;
+					b[5] += wi1 * wj2 + t0;
+					b[6] += wi2 * wj0 + t1;
+					b[7] += wi2 * wj1 - t0;
+					b[8] += dot + wi2 * wj2;
+					continue;
+				}
 				double Gi[3], Gj[3];
 				for (int c = 0; c < 3; ++c)
 				{
@@ -577,7 +655,6 @@ namespace
 					Gj[c] = rj[0] * jt[c] + rj[1] * jt[3 + c] + rj[2] * jt[6 + c];
 				}
 				const double dot = a * (Gi[0] * Gj[0] + Gi[1] * Gj[1] + Gi[2] * Gj[2]);
-				const int model = (MODEL == M_MULTI) ? (int)jt[9] : MODEL;
 				if (model == M_LINEAR)
 				{
 					// a = mu da, c1 = lambda da
@@ -658,31 +735,6 @@ namespace
 						}
 					continue;
 				}
-				const double f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
-				// cofactor matrix of F, row-major
-				const double d0 = f4 * f8 - f5 * f7, d1 = f5 * f6 - f3 * f8, d2 = f3 * f7 - f4 * f6;
-				const double d3 = f2 * f7 - f1 * f8, d4 = f0 * f8 - f2 * f6, d5 = f1 * f6 - f0 * f7;
-				const double d6 = f1 * f5 - f2 * f4, d7 = f2 * f3 - f0 * f5, d8 = f0 * f4 - f1 * f3;
-				const double wi0 = c1 * (d0 * Gi[0] + d1 * Gi[1] + d2 * Gi[2]);
-				const double wi1 = c1 * (d3 * Gi[0] + d4 * Gi[1] + d5 * Gi[2]);
-				const double wi2 = c1 * (d6 * Gi[0] + d7 * Gi[1] + d8 * Gi[2]);
-				const double wj0 = d0 * Gj[0] + d1 * Gj[1] + d2 * Gj[2];
-				const double wj1 = d3 * Gj[0] + d4 * Gj[1] + d5 * Gj[2];
-				const double wj2 = d6 * Gj[0] + d7 * Gj[1] + d8 * Gj[2];
-				const double cx = Gi[1] * Gj[2] - Gi[2] * Gj[1], cy = Gi[2] * Gj[0] - Gi[0] * Gj[2], cz = Gi[0] * Gj[1] - Gi[1] * Gj[0];
-				// t = c2 * F (Gi x Gj);  block -= hat(t)
-				const double t0 = c2 * (f0 * cx + f1 * cy + f2 * cz);
-				const double t1 = c2 * (f3 * cx + f4 * cy + f5 * cz);
-				const double t2 = c2 * (f6 * cx + f7 * cy + f8 * cz);
-				b[0] += dot + wi0 * wj0;
-				b[1] += wi0 * wj1 + t2;
-				b[2] += wi0 * wj2 - t1;
-				b[3] += wi1 * wj0 - t2;
-				b[4] += dot + wi1 * wj1;
-				b[5] += wi1 * wj2 + t0;
-				b[6] += wi2 * wj0 + t1;
-				b[7] += wi2 * wj1 - t0;
-				b[8] += dot + wi2 * wj2;
 			}
 			for (int m = 0; m < BS; ++m)
 				for (int n = 0; n < BS; ++n)

@@ -12,5 +12,5 @@ COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -Wno-unu
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off -c pfx_local_linear.hip -o $b/pfx_local_linear.o &
 wait
 others=$(ls *.o | grep -v -e pfx_local_nl.o -e pfx_local_linear.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpfx_$name.so $others $b/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpfx_$name.so $others $b/*.o -L/opt/rocm/lib -lrccl
 echo built variants/libpfx_$name.so
