@@ -1162,3 +1162,28 @@ def test_neohookean_hip_against_sympy_derivatives(eng):
         rp, ci = eng.get_pattern()
         H = csc_to_scipy((rp, ci, eng.hessian(u)), 12).toarray()
         assert np.abs(H - hess_ref).max() <= 1e-12 * np.abs(hess_ref).max()
+
+
+@pytest.mark.parametrize("name", ["p1_jitter", "p2_jitter_polyfem", "q1", "q2"])
+def test_neohookean_hessian_at_large_deformations(eng, oracle, name):
+    """Stretch, shear and bending of up to 30 % plus noise: the row functor builds the NeoHookean block from products the
+    element kernel prepares (J^-1 J^-T, cof(F) J^-T, c2 / det F), whose algebra only shows at deformations far from the
+    identity.  Plain and projected Hessian, gradient and energy against the oracle."""
+    mesh = MESHES[name]()
+    lam, mu = oracle.lame(2e4, 0.4)
+    _setup(eng, mesh, E.NEOHOOKEAN, lam, mu)
+    pos = M.node_positions(mesh)
+    for amp in (0.05, 0.15, 0.3):
+        u = np.zeros((mesh.n_nodes, 3))
+        u[:, 0] = amp * pos[:, 0] + 0.5 * amp * pos[:, 1] ** 2
+        u[:, 1] = -0.3 * amp * pos[:, 1] + amp * np.sin(2 * pos[:, 0])
+        u[:, 2] = 0.7 * amp * pos[:, 2] * pos[:, 0]
+        u += np.random.default_rng(3).standard_normal(u.shape) * amp * 0.02
+        x = u.reshape(-1)
+        ho = oracle.assemble_hessian(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        assert rel_err(eng.hessian(x), ho[2]) <= TOL
+        assert rel_err(eng.gradient(x), oracle.assemble_gradient(mesh, oracle.NEOHOOKEAN, lam, mu, x)) <= TOL
+        e_ref = oracle.assemble_energy(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        assert abs(eng.energy(x) - e_ref) <= TOL * abs(e_ref)
+        hp = oracle.assemble_hessian_psd(mesh, oracle.NEOHOOKEAN, lam, mu, x)
+        assert np.abs(eng.hessian(x, project_to_psd=True) - hp[2]).max() <= 1e-10 * np.abs(hp[2]).max()
