@@ -1231,3 +1231,28 @@ class DistributedImplicitEuler:
             a.div_(dt)
         v.copy_(v_new)
         return info
+
+
+class DistributedTransientSolver:
+    """The transient nonlinear solve with any of the implicit integrators of polyfem_amd.time_integrator (ImplicitEuler,
+    ImplicitNewmark, BDF; time_integrator/ImplicitTimeIntegrator.hpp, state/StateSolveNonlinear.cpp:78-84) over the
+    partition: per step x_tilde from the integrator, a Newton solve of
+    acceleration_scaling * (E(x) - rhs.x) + 1/2 (x - x_tilde)^T M (x - x_tilde) starting at the previous solution, then the
+    integrator's update.  Every vector of the integrator is a local vector [owned | halo]: its updates are pointwise, so
+    halos that are consistent at init stay consistent (the Newton driver returns x with a current halo) and the time
+    stepping itself needs no communication."""
+
+    def __init__(self, newton: DistributedNewton, integrator, rhs=None, **newton_params):
+        self.newton, self.integrator, self.rhs, self.newton_params = newton, integrator, rhs, newton_params
+
+    def step(self, **params):
+        """One time step; returns (x, Newton info).  x is a new local tensor, the integrator's history is updated."""
+        ti = self.integrator
+        x_tilde = ti.x_tilde().contiguous()
+        x = ti.x_prev().clone()
+        par = dict(self.newton_params)
+        par.update(params)
+        info = self.newton.solve(x, self.rhs, x_tilde=x_tilde, weight=ti.acceleration_scaling(), **par)
+        ti.update_quantities(x)
+        return x, info
+

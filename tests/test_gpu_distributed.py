@@ -885,3 +885,111 @@ def test_triangle_mesh_over_two_ranks_matches_single_engine(oracle):
     assert info["status"] == iref["status"] and info["iterations"] == iref["iterations"] >= 2
     assert info["line_search_iterations"] == iref["line_search_iterations"]
     assert np.abs(xn - x_n).max() <= 1e-8 * np.abs(x_n).max()
+
+
+# ---- Newmark and BDF over a partition ---------------------------------------------------------------------------------
+
+
+def _transient_setup(eng, mesh, E):
+    eng.set_mesh(mesh)
+    eng.set_material(E.NEOHOOKEAN, 2e4 * 0.3 / (1.3 * 0.4), 2e4 / 2.6)
+    eng.build_pattern()
+
+
+def _integrator_worker(rank, world, port, kind, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from polyfem_amd import distributed as D
+        from polyfem_amd import engine as E
+        from polyfem_amd import time_integrator as TI
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        part, bounds, n_nodes = D.slab_part(4, 2, rank, world, 2)
+        eng = E.Engine(0)
+        eng.set_stream(stream.cuda_stream)
+        _transient_setup(eng, part.mesh, E)
+        eng.set_owned(part.n_owned, part.elem_owned)
+        rho, dt = 1000.0, 0.02
+        rhs_l = eng.assemble_rhs(np.array([0.0, 3.0, -9.81]), rho)
+        eng.inertia_set_mass(rho)
+        fixed_l, _ = _newton_case(part.n_local, part.mesh.node_xyz)
+        fixed_dofs = np.sort((fixed_l[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32)
+        eng.set_dirichlet(fixed_dofs)
+        l2g = part.local_to_global()
+        dof_l2g = (l2g[:, None] * 3 + np.arange(3)[None]).reshape(-1)
+        v_l = (0.05 * np.random.default_rng(9).standard_normal(n_nodes * 3))[dof_l2g].copy()
+        v_l[fixed_dofs] = 0.0
+        newton = D.DistributedNewton(D.HipOps(eng), part, 3, D.Comm(), dev, fixed_dofs)
+        ti = TI.construct_time_integrator(kind)
+        z = torch.zeros(part.n_local * 3, dtype=torch.float64, device=dev)
+        ti.init(z, torch.from_numpy(v_l).to(dev), z.clone(), dt)
+        solver = D.DistributedTransientSolver(newton, ti, torch.from_numpy(rhs_l).to(dev), cg_check_every=16)
+        infos = []
+        for _ in range(3):
+            x, info = solver.step()
+            infos.append(dict(info))
+        torch.cuda.synchronize()
+        no = part.n_owned * 3
+        out = [None] * world
+        dist.all_gather_object(out, (int(part.lo), x.cpu().numpy()[:no], ti.v_prev().cpu().numpy()[:no], ti.a_prev().cpu().numpy()[:no]))
+        xg, vg, ag = np.zeros(n_nodes * 3), np.zeros(n_nodes * 3), np.zeros(n_nodes * 3)
+        for lo, xv, vv, av in out:
+            xg[lo * 3: lo * 3 + xv.size], vg[lo * 3: lo * 3 + vv.size], ag[lo * 3: lo * 3 + av.size] = xv, vv, av
+        # the halos of the integrator's vectors are those of their owners without any exchange of their own
+        assert np.abs(ti.v_prev().cpu().numpy() - vg[dof_l2g]).max() <= 1e-9 * np.abs(vg).max()
+        if rank == 0:
+            ret["infos"], ret["x"], ret["v"], ret["a"] = infos, xg, vg, ag
+        eng.close()
+        ret[f"ok{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ImplicitNewmark", "BDF2"])
+def test_newmark_and_bdf_over_two_ranks_match_single_engine(kind):
+    """Three steps of ImplicitNewmark / BDF2 (time_integrator/ImplicitNewmark.cpp, BDF.cpp) with the mesh split over two
+    ranks -- every Newton solve inside the library, the integrator's bookkeeping on local vectors -- against the
+    single-engine TransientSolver on the whole mesh."""
+    import torch
+    import torch.multiprocessing as mp
+    from polyfem_amd import distributed as D
+    from polyfem_amd import engine as E
+    from polyfem_amd import time_integrator as TI
+    spec = {"type": "BDF", "steps": 2} if kind == "BDF2" else kind
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_integrator_worker, args=(world, _free_port(), spec, ret), nprocs=world, join=True)
+        assert all(ret.get(f"ok{r}") for r in range(world))
+        infos, xg, vg, ag = ret["infos"], ret["x"], ret["v"], ret["a"]
+    part, bounds, n_nodes = D.slab_part(4, 4, 0, 1, 2)
+    eng = E.Engine(0)
+    _transient_setup(eng, part.mesh, E)
+    rho, dt = 1000.0, 0.02
+    rhs = eng.assemble_rhs(np.array([0.0, 3.0, -9.81]), rho)
+    eng.inertia_set_mass(rho)
+    fixed, _ = _newton_case(n_nodes, part.mesh.node_xyz)
+    fixed_dofs = np.sort((fixed[:, None] * 3 + np.arange(3)[None]).reshape(-1)).astype(np.int32)
+    eng.set_dirichlet(fixed_dofs)
+    v = 0.05 * np.random.default_rng(9).standard_normal(n_nodes * 3)
+    v[fixed_dofs] = 0.0
+    dev = torch.device("cuda", 0)
+    ti = TI.construct_time_integrator(spec)
+    z = torch.zeros(n_nodes * 3, dtype=torch.float64, device=dev)
+    ti.init(z, torch.from_numpy(v).to(dev), z.clone(), dt)
+    solver = TI.TransientSolver(eng, ti, torch.from_numpy(rhs).to(dev))
+    for step in range(3):
+        x, iref = solver.step()
+        assert infos[step]["status"] == iref["status"] and infos[step]["iterations"] == iref["iterations"], (step, infos[step], iref)
+    x, vr, ar = x.cpu().numpy(), ti.v_prev().cpu().numpy(), ti.a_prev().cpu().numpy()
+    eng.close()
+    assert np.abs(xg - x).max() <= 1e-8 * np.abs(x).max()
+    assert np.abs(vg - vr).max() <= 1e-7 * np.abs(vr).max()
+    assert np.abs(ag - ar).max() <= 1e-6 * np.abs(ar).max()
+
